@@ -1,0 +1,83 @@
+/* rapiddoc_mi355 - C ABI of the MI355X-native page-inference engine (gfx950).
+ *
+ * Drop-in boundary for RapidDoc's per-page neural forward passes.  Each entry point replaces what one
+ * `InferSession.__call__` of the reference does (paths relative to the RapidDoc source tree):
+ *
+ *   rd_det_forward       <- OCR det session:   rapid_doc/model/ocr/torch.py:171-192 (`maps`),
+ *                           called from rapid_doc/model/ocr/rapid_ocr.py:528 (`text_detector.session`)
+ *   rd_rec_forward       <- OCR rec session:   rapid_doc/model/ocr/torch.py:171-192 (`softmax(ctc_logits)`),
+ *                           called from rapid_doc/model/ocr/rapid_ocr.py:443 (`text_recognizer.session`), plus the
+ *                           argmax/max half of rapidocr's CTCLabelDecode (rapid_ocr.py:444-449)
+ *   rd_backbone_forward  <- the PPHGNetV2-B4 backbone inside the PP-DocLayout ONNX graph:
+ *                           rapid_doc/model/layout/rapid_layout_self/inference_engine/onnxruntime/main.py:61-78
+ *                           (network definition: .../formula/rapid_formula_self/networks/backbones/rec_pphgnetv2.py:1445-1477)
+ *   rd_preproc_resize_norm <- PPPreProcess: .../model_handler/pp_doclayout/pre_process.py:22-42
+ *   rd_load_weights      <- `_load_state_dict` + `load_state_dict`: rapid_doc/model/ocr/torch.py:82-110
+ *
+ * Conventions: every pointer named *_dev is a DEVICE pointer on the handle's GPU (PyTorch-ROCm
+ * `tensor.data_ptr()` works); images are NCHW float32 exactly like the numpy arrays the reference hands to
+ * its sessions; `stream` is a hipStream_t passed as void* (NULL = default stream); functions return 0 on
+ * success, non-zero on failure with the message in rd_last_error(handle).  `ws_dev` may be NULL, in which
+ * case the handle owns (and grows) its own workspace.  One handle = one network on one device; a handle is
+ * not thread-safe, different handles are independent.  There is no CPU fallback: rd_create fails if no
+ * HIP device is present.
+ */
+#ifndef RAPIDDOC_MI355_H
+#define RAPIDDOC_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rd_handle rd_handle;
+
+/* rd_rec_forward flags */
+#define RD_REC_UNFUSED_CTC 1  /* materialise logits, then row statistics (validation path)              */
+#define RD_REC_WANT_SOFTMAX 2 /* also write softmax probabilities [B,T,C] (the reference session output) */
+#define RD_REC_WANT_LOGITS 4  /* also write raw logits [B,T,C]                                          */
+
+const char* rd_version(void);
+/* model_kind: "ppocrv6_det" | "ppocrv6_rec" | "pphgnetv2_b4".  NULL on failure -> rd_create_error(). */
+rd_handle* rd_create(int device_id, const char* model_kind);
+const char* rd_create_error(void);
+void rd_destroy(rd_handle* h);
+const char* rd_last_error(rd_handle* h);
+
+/* HOST pointer to a .safetensors byte image using the reference's tensor names (a leading "model." is ignored). */
+int rd_load_weights(rd_handle* h, const void* safetensors_image, size_t nbytes);
+
+/* bytes of device workspace one call with this geometry needs (H is ignored for rec: always 48) */
+int rd_query_workspace(rd_handle* h, int B, int H, int W, int flags, size_t* ws_bytes);
+
+/* PP-OCRv6 det: x [B,3,H,W] (H, W multiples of 32) -> DB probability map [B,1,H,W] */
+int rd_det_forward(rd_handle* h, const float* x_nchw_dev, int B, int H, int W, float* prob_b1hw_dev, void* ws_dev,
+                   size_t ws_bytes, void* stream);
+
+/* PP-OCRv6 rec: x [B,3,48,W] (W multiple of 8) -> per time step (T = W/8) argmax class and its softmax
+ * probability; full_btc_dev is only written with RD_REC_WANT_SOFTMAX / RD_REC_WANT_LOGITS (else may be NULL). */
+int rd_rec_forward(rd_handle* h, const float* x_nchw_dev, int B, int W, int32_t* idx_bt_dev, float* prob_bt_dev,
+                   float* full_btc_dev, int flags, void* ws_dev, size_t ws_bytes, void* stream);
+int rd_rec_num_classes(rd_handle* h);
+
+/* PPHGNetV2-B4 (PP-DocLayout backbone): x [B,3,H,W] -> 4 NCHW feature maps, strides 4/8/16/32,
+ * channels 128/512/1024/2048. */
+int rd_backbone_forward(rd_handle* h, const float* x_nchw_dev, int B, int H, int W, float* const feats_dev[4],
+                        void* ws_dev, size_t ws_bytes, void* stream);
+
+/* u8 HWC (3 channels) device image -> resize to OHxOW -> (v*scale - mean[c]) / std[c] -> CHW float32.
+ * interp: 1 bilinear, 2 bicubic (a = -0.75, result rounded/saturated to u8 range like an 8-bit resize). */
+int rd_preproc_resize_norm(int device_id, const uint8_t* hwc_u8_dev, int H, int W, int OH, int OW, const float mean[3],
+                           const float std[3], float scale, int interp, int swap_rb, float* out_chw_dev, void* stream);
+
+/* per-op HIP-event timing of the NEXT forward calls; rd_profile_json returns the last call's table as a JSON
+ * array [{"name","kind","cfg","flops","bytes","ms"}, ...] owned by the handle. */
+int rd_set_profiling(rd_handle* h, int on);
+const char* rd_profile_json(rd_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

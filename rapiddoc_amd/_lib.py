@@ -1,0 +1,49 @@
+"""ctypes binding of librapiddoc_mi355.so (include/rapiddoc_mi355.h).  No fallback: if the library is
+missing or no MI355X is visible, importing callers get a loud error."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "librapiddoc_mi355.so"
+_lib = None
+
+SYMBOLS = {
+    "rd_version": (C.c_char_p, []),
+    "rd_create": (C.c_void_p, [C.c_int, C.c_char_p]),
+    "rd_create_error": (C.c_char_p, []),
+    "rd_destroy": (None, [C.c_void_p]),
+    "rd_last_error": (C.c_char_p, [C.c_void_p]),
+    "rd_load_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rd_query_workspace": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "rd_det_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rd_rec_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rd_rec_num_classes": (C.c_int, [C.c_void_p]),
+    "rd_backbone_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rd_preproc_resize_norm": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "rd_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "rd_profile_json": (C.c_char_p, [C.c_void_p]),
+}
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises NativeLibraryError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise NativeLibraryError(
+            f"{LIB_PATH} is missing - build it with `python -m rapiddoc_amd.build` (hipcc, gfx950). "
+            "rapiddoc_amd has no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError = a symbol of include/rapiddoc_mi355.h is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

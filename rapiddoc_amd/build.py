@@ -1,0 +1,62 @@
+"""Build recipe for librapiddoc_mi355.so (hipcc, gfx950 only, in-tree so the .so travels to the GPU box)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+OUT = PKG / "librapiddoc_mi355.so"
+SOURCES = ["kernels_conv.hip", "kernels_misc.hip", "kernels_ctc.hip", "engine.cpp", "models.cpp", "api.cpp"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-x", "hip"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (ROCm 7.x required)")
+
+
+def needs_build() -> bool:
+    if not OUT.exists():
+        return True
+    t = OUT.stat().st_mtime
+    deps = list(CSRC.glob("*")) + [PKG.parent / "include" / "rapiddoc_mi355.h", Path(__file__)]
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> Path:
+    if not force and not needs_build():
+        return OUT
+    hipcc = _hipcc()
+    objdir = PKG / "build"
+    objdir.mkdir(exist_ok=True)
+
+    def compile_one(src: str) -> Path:
+        obj = objdir / (src + ".o")
+        cmd = [hipcc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(OUT)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"built {OUT} ({OUT.stat().st_size/1e6:.1f} MB)")
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

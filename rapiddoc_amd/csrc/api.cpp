@@ -1,0 +1,118 @@
+// extern "C" surface of librapiddoc_mi355.so - see include/rapiddoc_mi355.h for the contract.
+#include "../../include/rapiddoc_mi355.h"
+
+#include <mutex>
+#include <string>
+
+#include "engine.h"
+
+struct rd_handle {
+    rd::Engine* eng = nullptr;
+    std::string err;
+    std::string prof;
+};
+
+static thread_local std::string g_create_err;
+
+template <typename F>
+static int guarded(rd_handle* h, F&& f) {
+    if (!h || !h->eng) return 2;
+    try {
+        f();
+        h->err.clear();
+        return 0;
+    } catch (const std::exception& e) {
+        h->err = e.what();
+        return 1;
+    }
+}
+
+extern "C" {
+
+const char* rd_version(void) { return "rapiddoc_mi355 0.1 (gfx950, fp32 MFMA)"; }
+
+rd_handle* rd_create(int device_id, const char* model_kind) {
+    try {
+        if (!model_kind) throw rd::Error("model_kind is NULL");
+        auto* h = new rd_handle();
+        h->eng = new rd::Engine(device_id, model_kind);
+        g_create_err.clear();
+        return h;
+    } catch (const std::exception& e) {
+        g_create_err = e.what();
+        return nullptr;
+    }
+}
+const char* rd_create_error(void) { return g_create_err.c_str(); }
+
+void rd_destroy(rd_handle* h) {
+    if (!h) return;
+    delete h->eng;
+    delete h;
+}
+const char* rd_last_error(rd_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int rd_load_weights(rd_handle* h, const void* img, size_t nbytes) {
+    return guarded(h, [&] { h->eng->load_weights(img, nbytes); });
+}
+
+int rd_query_workspace(rd_handle* h, int B, int H, int W, int flags, size_t* ws_bytes) {
+    return guarded(h, [&] {
+        RD_CHECK(ws_bytes, "ws_bytes is NULL");
+        if (h->eng->kind() == "ppocrv6_rec") H = 48;
+        *ws_bytes = h->eng->workspace_bytes(B, H, W, flags);
+    });
+}
+
+int rd_det_forward(rd_handle* h, const float* x, int B, int H, int W, float* prob, void* ws, size_t ws_bytes, void* stream) {
+    return guarded(h, [&] {
+        RD_CHECK(h->eng->kind() == "ppocrv6_det", "handle is not a ppocrv6_det model");
+        RD_CHECK(x && prob && B > 0, "null input/output");
+        h->eng->run(B, H, W, 0, {(void*)x, (void*)prob}, ws, ws_bytes, (hipStream_t)stream);
+    });
+}
+
+int rd_rec_forward(rd_handle* h, const float* x, int B, int W, int32_t* idx, float* prob, float* full, int flags, void* ws,
+                   size_t ws_bytes, void* stream) {
+    return guarded(h, [&] {
+        RD_CHECK(h->eng->kind() == "ppocrv6_rec", "handle is not a ppocrv6_rec model");
+        RD_CHECK(x && idx && prob && B > 0, "null input/output");
+        if (flags & (RD_REC_WANT_SOFTMAX | RD_REC_WANT_LOGITS)) RD_CHECK(full, "full_btc_dev is NULL");
+        RD_CHECK(!((flags & RD_REC_WANT_SOFTMAX) && (flags & RD_REC_WANT_LOGITS)), "choose softmax OR logits");
+        h->eng->run(B, 48, W, flags, {(void*)x, (void*)idx, (void*)prob, (void*)full}, ws, ws_bytes, (hipStream_t)stream);
+    });
+}
+int rd_rec_num_classes(rd_handle* h) { return (h && h->eng) ? h->eng->n_classes() : -1; }
+
+int rd_backbone_forward(rd_handle* h, const float* x, int B, int H, int W, float* const feats[4], void* ws, size_t ws_bytes,
+                        void* stream) {
+    return guarded(h, [&] {
+        RD_CHECK(h->eng->kind() == "pphgnetv2_b4", "handle is not a pphgnetv2_b4 model");
+        RD_CHECK(x && feats && feats[0] && feats[1] && feats[2] && feats[3], "null input/output");
+        h->eng->run(B, H, W, 0, {(void*)x, (void*)feats[0], (void*)feats[1], (void*)feats[2], (void*)feats[3]}, ws, ws_bytes,
+                    (hipStream_t)stream);
+    });
+}
+
+int rd_preproc_resize_norm(int device_id, const uint8_t* src, int H, int W, int OH, int OW, const float mean[3],
+                           const float std[3], float scale, int interp, int swap_rb, float* out, void* stream) {
+    if (!src || !out || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || (interp != 1 && interp != 2)) return 1;
+    if (hipSetDevice(device_id) != hipSuccess) return 1;
+    rd::PreprocParams p{};
+    p.src = src; p.H = H; p.W = W; p.dst = out; p.OH = OH; p.OW = OW;
+    for (int i = 0; i < 3; ++i) { p.mean[i] = mean ? mean[i] : 0.f; p.inv_std[i] = 1.f / (std ? std[i] : 1.f); }
+    p.scale = scale; p.interp = interp; p.swap_rb = swap_rb;
+    rd::launch_preproc_resize_norm(p, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int rd_set_profiling(rd_handle* h, int on) {
+    return guarded(h, [&] { h->eng->set_profiling(on != 0); });
+}
+const char* rd_profile_json(rd_handle* h) {
+    if (!h || !h->eng) return "[]";
+    h->prof = h->eng->profile_json();
+    return h->prof.c_str();
+}
+
+}  // extern "C"

@@ -1,0 +1,909 @@
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <sstream>
+
+namespace rd {
+
+// =================================================================================================
+// safetensors image -> WeightStore.  Format: u64 LE header length, JSON header
+// {"name": {"dtype": "F32", "shape": [...], "data_offsets": [b, e]}, "__metadata__": {...}}, raw data.
+// (what the reference loads with safetensors.torch.load_file, rapid_doc/model/ocr/torch.py:93-110)
+// =================================================================================================
+namespace {
+struct JsonCur {
+    const char* p;
+    const char* end;
+    void ws() {
+        while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p;
+    }
+    bool eat(char c) {
+        ws();
+        if (p < end && *p == c) { ++p; return true; }
+        return false;
+    }
+    void expect(char c) {
+        if (!eat(c)) throw Error(std::string("safetensors header: expected '") + c + "'");
+    }
+    std::string str() {
+        ws();
+        if (p >= end || *p != '"') throw Error("safetensors header: expected string");
+        ++p;
+        std::string out;
+        while (p < end && *p != '"') {
+            if (*p == '\\' && p + 1 < end) {
+                ++p;
+                switch (*p) {
+                    case 'n': out += '\n'; break;
+                    case 't': out += '\t'; break;
+                    case 'u': out += '?'; p += 4; break;
+                    default: out += *p;
+                }
+                ++p;
+            } else {
+                out += *p++;
+            }
+        }
+        if (p >= end) throw Error("safetensors header: unterminated string");
+        ++p;
+        return out;
+    }
+    int64_t integer() {
+        ws();
+        bool neg = false;
+        if (p < end && *p == '-') { neg = true; ++p; }
+        if (p >= end || *p < '0' || *p > '9') throw Error("safetensors header: expected integer");
+        int64_t v = 0;
+        while (p < end && *p >= '0' && *p <= '9') v = v * 10 + (*p++ - '0');
+        return neg ? -v : v;
+    }
+    void skip_value() {
+        ws();
+        if (p >= end) throw Error("safetensors header: truncated");
+        if (*p == '"') { str(); return; }
+        if (*p == '{') {
+            ++p;
+            if (eat('}')) return;
+            do { str(); expect(':'); skip_value(); } while (eat(','));
+            expect('}');
+            return;
+        }
+        if (*p == '[') {
+            ++p;
+            if (eat(']')) return;
+            do { skip_value(); } while (eat(','));
+            expect(']');
+            return;
+        }
+        while (p < end && *p != ',' && *p != '}' && *p != ']') ++p;
+    }
+};
+size_t dtype_size(const std::string& d) {
+    if (d == "F32" || d == "I32" || d == "U32") return 4;
+    if (d == "F64" || d == "I64" || d == "U64") return 8;
+    if (d == "F16" || d == "BF16" || d == "I16" || d == "U16") return 2;
+    if (d == "U8" || d == "I8" || d == "BOOL") return 1;
+    throw Error("safetensors: unsupported dtype " + d);
+}
+}  // namespace
+
+void WeightStore::load_safetensors(const void* blob, size_t nbytes) {
+    RD_CHECK(blob && nbytes >= 8, "weights: empty image");
+    uint64_t hlen = 0;
+    std::memcpy(&hlen, blob, 8);
+    RD_CHECK(hlen > 0 && 8 + hlen <= nbytes, "weights: bad safetensors header length");
+    blob_.assign((const uint8_t*)blob, (const uint8_t*)blob + nbytes);
+    map_.clear();
+    const uint8_t* base = blob_.data() + 8 + hlen;
+    const size_t data_bytes = nbytes - 8 - hlen;
+    JsonCur c{(const char*)blob_.data() + 8, (const char*)blob_.data() + 8 + hlen};
+    c.expect('{');
+    if (!c.eat('}')) {
+        do {
+            std::string name = c.str();
+            c.expect(':');
+            if (name == "__metadata__") { c.skip_value(); continue; }
+            HostTensor t;
+            int64_t b = -1, e = -1;
+            c.expect('{');
+            do {
+                std::string k = c.str();
+                c.expect(':');
+                if (k == "dtype") t.dtype = c.str();
+                else if (k == "shape") {
+                    c.expect('[');
+                    if (!c.eat(']')) {
+                        do { t.shape.push_back(c.integer()); } while (c.eat(','));
+                        c.expect(']');
+                    }
+                } else if (k == "data_offsets") {
+                    c.expect('[');
+                    b = c.integer();
+                    c.expect(',');
+                    e = c.integer();
+                    c.expect(']');
+                } else c.skip_value();
+            } while (c.eat(','));
+            c.expect('}');
+            RD_CHECK(b >= 0 && e >= b && (size_t)e <= data_bytes, "weights: tensor offsets out of range: " + name);
+            RD_CHECK((size_t)(e - b) == t.numel() * dtype_size(t.dtype), "weights: tensor byte size mismatch: " + name);
+            t.data = base + b;
+            t.nbytes = (size_t)(e - b);
+            if (name.rfind("model.", 0) == 0) name = name.substr(6);  // reference torch.py:105-110
+            map_[name] = std::move(t);
+        } while (c.eat(','));
+        c.expect('}');
+    }
+    RD_CHECK(!map_.empty(), "weights: no tensors in image");
+}
+
+const HostTensor& WeightStore::get(const std::string& name) const {
+    auto it = map_.find(name);
+    if (it == map_.end()) throw Error("weights: missing tensor '" + name + "'");
+    if (it->second.dtype != "F32") throw Error("weights: tensor '" + name + "' is " + it->second.dtype + ", expected F32");
+    return it->second;
+}
+
+// =================================================================================================
+ParamBlock::~ParamBlock() {
+    if (dev_) (void)hipFree(dev_);
+}
+size_t ParamBlock::add(const std::string& key, const std::vector<float>& v) {
+    RD_CHECK(!dev_, "ParamBlock: add after upload");
+    auto it = off_.find(key);
+    if (it != off_.end()) return it->second;
+    size_t off = (host_.size() + 63) & ~size_t(63);  // 256-byte aligned
+    host_.resize(off + v.size(), 0.f);
+    std::copy(v.begin(), v.end(), host_.begin() + off);
+    off_[key] = off;
+    return off;
+}
+void ParamBlock::upload() {
+    if (dev_) { (void)hipFree(dev_); dev_ = nullptr; }
+    size_t n = std::max<size_t>(host_.size(), 64) + 64;
+    RD_HIP(hipMalloc((void**)&dev_, n * sizeof(float)));
+    RD_HIP(hipMemcpy(dev_, host_.data(), host_.size() * sizeof(float), hipMemcpyHostToDevice));
+}
+const float* ParamBlock::ptr(const std::string& key) const {
+    auto it = off_.find(key);
+    if (it == off_.end()) throw Error("params: missing folded tensor '" + key + "'");
+    RD_CHECK(dev_, "params: not uploaded");
+    return dev_ + it->second;
+}
+
+// =================================================================================================
+// Builder: memory
+// =================================================================================================
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+TView Builder::alloc(int n, int h, int w, int c) {
+    RD_CHECK(n > 0 && h > 0 && w > 0 && c > 0, "alloc: empty tensor");
+    Buf b;
+    b.n = n; b.h = h; b.w = w; b.c = c;
+    b.bytes = align_up((size_t)n * h * w * c * sizeof(float), 256);
+    b.live = true;
+    // first fit
+    size_t found = blocks_.size();
+    for (size_t i = 0; i < blocks_.size(); ++i)
+        if (blocks_[i].free && blocks_[i].size >= b.bytes) { found = i; break; }
+    if (found == blocks_.size()) {
+        // grow: extend a trailing free block or append
+        if (!blocks_.empty() && blocks_.back().free) {
+            blocks_.back().size = b.bytes;
+            found = blocks_.size() - 1;
+        } else {
+            size_t off = blocks_.empty() ? 0 : blocks_.back().off + blocks_.back().size;
+            blocks_.push_back({off, b.bytes, true});
+            found = blocks_.size() - 1;
+        }
+    }
+    Block& blk = blocks_[found];
+    if (blk.size > b.bytes) {
+        Block rest{blk.off + b.bytes, blk.size - b.bytes, true};
+        blk.size = b.bytes;
+        blocks_.insert(blocks_.begin() + found + 1, rest);
+    }
+    blocks_[found].free = false;
+    b.off = blocks_[found].off;
+    plan_->arena_bytes = std::max(plan_->arena_bytes, blocks_.back().off + blocks_.back().size);
+    plan_->bufs.push_back(b);
+    TView v;
+    v.buf = (int)plan_->bufs.size() - 1;
+    v.coff = 0; v.n = n; v.h = h; v.w = w; v.c = c;
+    return v;
+}
+TView Builder::alloc_raw(size_t nfloats) { return alloc(1, 1, 1, (int)align_up(nfloats, 4)); }
+
+TView Builder::external(int slot, int n, int h, int w, int c) {
+    Buf b;
+    b.n = n; b.h = h; b.w = w; b.c = c;
+    b.external = slot;
+    b.live = true;
+    plan_->bufs.push_back(b);
+    TView v;
+    v.buf = (int)plan_->bufs.size() - 1;
+    v.n = n; v.h = h; v.w = w; v.c = c;
+    return v;
+}
+TView Builder::slice(const TView& v, int coff, int c) const {
+    RD_CHECK(coff >= 0 && coff + c <= v.c, "slice out of range");
+    TView s = v;
+    s.coff = v.coff + coff;
+    s.c = c;
+    return s;
+}
+TView Builder::reshape(const TView& v, int n, int h, int w) const {
+    RD_CHECK((long)n * h * w == v.pixels(), "reshape: pixel count mismatch");
+    TView s = v;
+    s.n = n; s.h = h; s.w = w;
+    return s;
+}
+void Builder::release(const TView& v) {
+    Buf& b = plan_->bufs[v.buf];
+    if (b.external >= 0 || !b.live) return;
+    b.live = false;
+    for (size_t i = 0; i < blocks_.size(); ++i) {
+        if (blocks_[i].off == b.off && !blocks_[i].free) {
+            blocks_[i].free = true;
+            if (i + 1 < blocks_.size() && blocks_[i + 1].free) {
+                blocks_[i].size += blocks_[i + 1].size;
+                blocks_.erase(blocks_.begin() + i + 1);
+            }
+            if (i > 0 && blocks_[i - 1].free) {
+                blocks_[i - 1].size += blocks_[i].size;
+                blocks_.erase(blocks_.begin() + i);
+            }
+            return;
+        }
+    }
+}
+
+int Builder::weight_dim(const std::string& name, int d) const {
+    const HostTensor& t = ws_->get(name);
+    RD_CHECK(d < (int)t.shape.size(), "weight_dim: rank");
+    return (int)t.shape[d];
+}
+
+// BatchNorm (eval) as y = x*scale + shift, eps = 1e-5 (nn.BatchNorm2d default)
+std::vector<float> Builder::bn_scale_shift(const std::string& bn, int c, std::vector<float>& shift) const {
+    std::vector<float> scale(c, 1.f);
+    shift.assign(c, 0.f);
+    if (bn.empty()) return scale;
+    const float* g = ws_->get(bn + ".weight").f32();
+    const float* b = ws_->get(bn + ".bias").f32();
+    const float* m = ws_->get(bn + ".running_mean").f32();
+    const float* v = ws_->get(bn + ".running_var").f32();
+    RD_CHECK((int)ws_->get(bn + ".weight").numel() == c, "BN channel mismatch: " + bn);
+    for (int i = 0; i < c; ++i) {
+        const double s = (double)g[i] / std::sqrt((double)v[i] + 1e-5);
+        scale[i] = (float)s;
+        shift[i] = (float)((double)b[i] - (double)m[i] * s);
+    }
+    return scale;
+}
+
+static inline int out_dim(int in, int k, int s, int p0, int p1) { return (in + p0 + p1 - k) / s + 1; }
+
+// =================================================================================================
+// Builder: layers
+// =================================================================================================
+TView Builder::conv(const std::string& wname, const std::string& bname, const std::string& bn, const TView& x,
+                    const ConvGeom& g, int act, const TView* out, const TView* res, const TView* ascale) {
+    const HostTensor& w = ws_->get(wname);
+    RD_CHECK(w.shape.size() == 4 || w.shape.size() == 2, "conv weight rank: " + wname);
+    const int cout = (int)w.shape[0], cin = (int)w.shape[1];
+    const int kh = w.shape.size() == 4 ? (int)w.shape[2] : 1, kw = w.shape.size() == 4 ? (int)w.shape[3] : 1;
+    RD_CHECK(kh == g.kh && kw == g.kw, "conv kernel size mismatch: " + wname);
+    RD_CHECK(cin == x.c, "conv Cin mismatch: " + wname + " expects " + std::to_string(cin) + " got " + std::to_string(x.c));
+    RD_CHECK(cin % 4 == 0, "conv_igemm needs Cin % 4 == 0: " + wname);
+    const int oh = out_dim(x.h, kh, g.sh, g.pt, g.pb), ow = out_dim(x.w, kw, g.sw, g.pl, g.pr);
+    TView y = out ? *out : alloc(x.n, oh, ow, cout);
+    RD_CHECK(y.n == x.n && y.h == oh && y.w == ow && y.c == cout, "conv output view mismatch: " + wname);
+    if (res) RD_CHECK(res->n == y.n && res->h == oh && res->w == ow && res->c == cout, "conv residual mismatch: " + wname);
+    const int K = kh * kw * cin;
+    const std::string key = wname + "|" + bn;
+    if (!planning()) {
+        if (!pb_->has(key + "#w")) {
+            std::vector<float> shift;
+            std::vector<float> scale = bn_scale_shift(bn, cout, shift);
+            std::vector<float> wf((size_t)cout * K);
+            const float* src = w.f32();
+            for (int co = 0; co < cout; ++co)
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int a = 0; a < kh; ++a)
+                        for (int b = 0; b < kw; ++b)
+                            wf[(size_t)co * K + (a * kw + b) * cin + ci] =
+                                src[(((size_t)co * cin + ci) * kh + a) * kw + b] * scale[co];
+            std::vector<float> bias(cout, 0.f);
+            bool any_bias = !bn.empty();
+            if (!bname.empty()) {
+                const float* bs = ws_->get(bname).f32();
+                for (int co = 0; co < cout; ++co) bias[co] = bs[co] * scale[co];
+                any_bias = true;
+            }
+            for (int co = 0; co < cout; ++co) bias[co] += shift[co];
+            pb_->add(key + "#w", wf);
+            if (any_bias) pb_->add(key + "#b", bias);
+        }
+        return y;
+    }
+    ConvParams p{};
+    p.xld = plan_->ld(x);
+    p.N = x.n; p.H = x.h; p.W = x.w; p.Cin = cin;
+    p.w = pb_->ptr(key + "#w");
+    p.bias = pb_->has(key + "#b") ? pb_->ptr(key + "#b") : nullptr;
+    p.yld = plan_->ld(y);
+    p.OH = oh; p.OW = ow; p.Cout = cout;
+    p.KH = kh; p.KW = kw; p.SH = g.sh; p.SW = g.sw; p.PT = g.pt; p.PL = g.pl;
+    p.rld = res ? plan_->ld(*res) : 0;
+    p.act = act;
+    p.out_mode = OUT_NHWC;
+    p.M = x.n * oh * ow; p.K = K; p.Ng = cout;
+    OpRecord r;
+    r.name = wname;
+    r.kind = (kh == 1 && kw == 1) ? "conv1x1" : "conv" + std::to_string(kh) + "x" + std::to_string(kw);
+    r.cfg = conv_igemm_config_name(p);
+    r.flops = 2.0 * p.M * (double)K * cout;
+    r.bytes = 4.0 * ((double)x.pixels() * cin + (double)p.M * cout * (res ? 2 : 1) + (double)cout * K);
+    const TView xv = x, yv = y;
+    const bool has_res = res != nullptr, has_as = ascale != nullptr;
+    const TView rv = res ? *res : TView{}, av = ascale ? *ascale : TView{};
+    r.run = [p, xv, yv, rv, av, has_res, has_as](const Plan& pl, const RunCtx& c) mutable {
+        ConvParams q = p;
+        q.x = pl.vptr(xv, c);
+        q.y = pl.vptr(yv, c);
+        q.res = has_res ? pl.vptr(rv, c) : nullptr;
+        q.ascale = has_as ? pl.vptr(av, c) : nullptr;
+        launch_conv_igemm(q, c.stream);
+    };
+    emit(std::move(r));
+    return y;
+}
+
+TView Builder::linear(const std::string& prefix, const TView& x, int act, const TView* out, const TView* res) {
+    return conv(prefix + ".weight", has_weight(prefix + ".bias") ? prefix + ".bias" : "", "", x, ConvGeom{}, act, out, res);
+}
+
+TView Builder::deconv2x2(const std::string& wname, const std::string& bname, const std::string& bn, const TView& x,
+                         int act, const TView* out) {
+    // nn.ConvTranspose2d(k=2, stride=2): weight [Cin, Cout, 2, 2]  (det_db_head.py:66-72,124-129)
+    const HostTensor& w = ws_->get(wname);
+    RD_CHECK(w.shape.size() == 4 && w.shape[2] == 2 && w.shape[3] == 2, "deconv2x2 weight shape: " + wname);
+    const int cin = (int)w.shape[0], cout = (int)w.shape[1];
+    RD_CHECK(cin == x.c && cin % 4 == 0, "deconv Cin mismatch: " + wname);
+    TView y = out ? *out : alloc(x.n, 2 * x.h, 2 * x.w, cout);
+    RD_CHECK(y.h == 2 * x.h && y.w == 2 * x.w && y.c == cout, "deconv output view mismatch");
+    const std::string key = wname + "|" + bn + "|T";
+    if (!planning()) {
+        if (!pb_->has(key + "#w")) {
+            std::vector<float> shift;
+            std::vector<float> scale = bn_scale_shift(bn, cout, shift);
+            std::vector<float> wf((size_t)4 * cout * cin);
+            const float* src = w.f32();
+            for (int ci = 0; ci < cin; ++ci)
+                for (int co = 0; co < cout; ++co)
+                    for (int dy = 0; dy < 2; ++dy)
+                        for (int dx = 0; dx < 2; ++dx)
+                            wf[((size_t)(dy * 2 + dx) * cout + co) * cin + ci] =
+                                src[(((size_t)ci * cout + co) * 2 + dy) * 2 + dx] * scale[co];
+            std::vector<float> bias(cout, 0.f);
+            if (!bname.empty()) {
+                const float* bs = ws_->get(bname).f32();
+                for (int co = 0; co < cout; ++co) bias[co] = bs[co] * scale[co];
+            }
+            for (int co = 0; co < cout; ++co) bias[co] += shift[co];
+            pb_->add(key + "#w", wf);
+            pb_->add(key + "#b", bias);
+        }
+        return y;
+    }
+    ConvParams p{};
+    p.xld = plan_->ld(x);
+    p.N = x.n; p.H = x.h; p.W = x.w; p.Cin = cin;
+    p.w = pb_->ptr(key + "#w");
+    p.bias = pb_->ptr(key + "#b");
+    p.yld = plan_->ld(y);
+    p.OH = x.h; p.OW = x.w; p.Cout = cout;
+    p.KH = p.KW = p.SH = p.SW = 1;
+    p.act = act;
+    p.out_mode = OUT_DECONV2X2;
+    p.M = x.n * x.h * x.w; p.K = cin; p.Ng = 4 * cout;
+    OpRecord r;
+    r.name = wname;
+    r.kind = "deconv2x2";
+    r.cfg = conv_igemm_config_name(p);
+    r.flops = 2.0 * p.M * (double)cin * 4 * cout;
+    r.bytes = 4.0 * ((double)p.M * cin + (double)p.M * 4 * cout);
+    const TView xv = x, yv = y;
+    r.run = [p, xv, yv](const Plan& pl, const RunCtx& c) {
+        ConvParams q = p;
+        q.x = pl.vptr(xv, c);
+        q.y = pl.vptr(yv, c);
+        launch_conv_igemm(q, c.stream);
+    };
+    emit(std::move(r));
+    return y;
+}
+
+TView Builder::stem3x3s2(const std::string& wname, const std::string& bn, const TView& xin, int act) {
+    // xin: external NCHW image described as n, h, w with c = 3 (addressed as planes by the kernel)
+    const HostTensor& w = ws_->get(wname);
+    RD_CHECK(w.shape.size() == 4 && w.shape[1] == 3 && w.shape[2] == 3 && w.shape[3] == 3, "stem weight shape");
+    const int cout = (int)w.shape[0];
+    RD_CHECK(cout % 8 == 0, "stem Cout % 8");
+    const int oh = out_dim(xin.h, 3, 2, 1, 1), ow = out_dim(xin.w, 3, 2, 1, 1);
+    TView y = alloc(xin.n, oh, ow, cout);
+    const std::string key = wname + "|" + bn + "|stem";
+    if (!planning()) {
+        if (!pb_->has(key + "#w")) {
+            std::vector<float> shift;
+            std::vector<float> scale = bn_scale_shift(bn, cout, shift);
+            std::vector<float> wf((size_t)27 * cout);
+            const float* src = w.f32();
+            for (int co = 0; co < cout; ++co)
+                for (int ci = 0; ci < 3; ++ci)
+                    for (int a = 0; a < 3; ++a)
+                        for (int b = 0; b < 3; ++b)
+                            wf[(size_t)((a * 3 + b) * 3 + ci) * cout + co] = src[(((size_t)co * 3 + ci) * 3 + a) * 3 + b] * scale[co];
+            pb_->add(key + "#w", wf);
+            pb_->add(key + "#b", shift);
+        }
+        return y;
+    }
+    StemParams p{};
+    p.N = xin.n; p.H = xin.h; p.W = xin.w;
+    p.w = pb_->ptr(key + "#w");
+    p.bias = pb_->ptr(key + "#b");
+    p.yld = plan_->ld(y);
+    p.OH = oh; p.OW = ow; p.Cout = cout;
+    p.act = act;
+    OpRecord r;
+    r.name = wname;
+    r.kind = "stem3x3s2";
+    r.flops = 2.0 * xin.n * oh * ow * 27.0 * cout;
+    r.bytes = 4.0 * ((double)xin.n * 3 * xin.h * xin.w + (double)xin.n * oh * ow * cout);
+    const TView xv = xin, yv = y;
+    r.run = [p, xv, yv](const Plan& pl, const RunCtx& c) {
+        StemParams q = p;
+        q.x = pl.vptr(xv, c);
+        q.y = pl.vptr(yv, c);
+        launch_stem_conv3x3s2(q, c.stream);
+    };
+    emit(std::move(r));
+    return y;
+}
+
+TView Builder::dwconv(const std::string& wname, const std::string& bname, const std::string& bn, const TView& x,
+                      const ConvGeom& g, int act, const TView* out, const TView* res) {
+    const HostTensor& w = ws_->get(wname);
+    RD_CHECK(w.shape.size() == 4 && w.shape[1] == 1, "depthwise weight shape: " + wname);
+    const int c = (int)w.shape[0], kh = (int)w.shape[2], kw = (int)w.shape[3];
+    RD_CHECK(c == x.c && c % 4 == 0, "depthwise channel mismatch: " + wname);
+    RD_CHECK(kh == g.kh && kw == g.kw, "depthwise kernel mismatch: " + wname);
+    const int oh = out_dim(x.h, kh, g.sh, g.pt, g.pb), ow = out_dim(x.w, kw, g.sw, g.pl, g.pr);
+    TView y = out ? *out : alloc(x.n, oh, ow, c);
+    RD_CHECK(y.h == oh && y.w == ow && y.c == c, "depthwise output view mismatch: " + wname);
+    const std::string key = wname + "|" + bn + "|dw";
+    if (!planning()) {
+        if (!pb_->has(key + "#w")) {
+            std::vector<float> shift;
+            std::vector<float> scale = bn_scale_shift(bn, c, shift);
+            std::vector<float> wf((size_t)kh * kw * c);
+            const float* src = w.f32();
+            for (int ch = 0; ch < c; ++ch)
+                for (int t = 0; t < kh * kw; ++t) wf[(size_t)t * c + ch] = src[(size_t)ch * kh * kw + t] * scale[ch];
+            std::vector<float> bias(c, 0.f);
+            if (!bname.empty()) {
+                const float* bs = ws_->get(bname).f32();
+                for (int ch = 0; ch < c; ++ch) bias[ch] = bs[ch] * scale[ch];
+            }
+            for (int ch = 0; ch < c; ++ch) bias[ch] += shift[ch];
+            pb_->add(key + "#w", wf);
+            pb_->add(key + "#b", bias);
+        }
+        return y;
+    }
+    DwParams p{};
+    p.xld = plan_->ld(x);
+    p.N = x.n; p.H = x.h; p.W = x.w; p.C = c;
+    p.w = pb_->ptr(key + "#w");
+    p.bias = pb_->ptr(key + "#b");
+    p.yld = plan_->ld(y);
+    p.OH = oh; p.OW = ow; p.KH = kh; p.KW = kw; p.SH = g.sh; p.SW = g.sw; p.PT = g.pt; p.PL = g.pl;
+    p.act = act;
+    p.rld = res ? plan_->ld(*res) : 0;
+    OpRecord r;
+    r.name = wname;
+    r.kind = "dwconv" + std::to_string(kh) + "x" + std::to_string(kw);
+    r.flops = 2.0 * x.n * oh * ow * (double)c * kh * kw;
+    r.bytes = 4.0 * ((double)x.pixels() * c + (double)x.n * oh * ow * c * (res ? 2 : 1));
+    const TView xv = x, yv = y;
+    const bool has_res = res != nullptr;
+    const TView rv = res ? *res : TView{};
+    r.run = [p, xv, yv, rv, has_res](const Plan& pl, const RunCtx& cx) {
+        DwParams q = p;
+        q.x = pl.vptr(xv, cx);
+        q.y = pl.vptr(yv, cx);
+        q.res = has_res ? pl.vptr(rv, cx) : nullptr;
+        launch_dwconv(q, cx.stream);
+    };
+    emit(std::move(r));
+    return y;
+}
+
+void Builder::maxpool2x2s1(const TView& x, const TView& out) {
+    RD_CHECK(out.h == x.h && out.w == x.w && out.c == x.c && x.c % 4 == 0, "maxpool view mismatch");
+    if (!planning()) return;
+    OpRecord r;
+    r.name = "maxpool2x2s1";
+    r.kind = "pool";
+    r.bytes = 8.0 * x.pixels() * x.c;
+    const TView xv = x, yv = out;
+    r.run = [xv, yv](const Plan& pl, const RunCtx& c) {
+        launch_maxpool2x2s1(pl.vptr(xv, c), pl.ld(xv), pl.vptr(yv, c), pl.ld(yv), xv.n, xv.h, xv.w, xv.c, c.stream);
+    };
+    emit(std::move(r));
+}
+
+TView Builder::avgpool3x2(const TView& x) {
+    RD_CHECK(x.h >= 3 && x.w >= 2, "avg_pool2d([3,2]): feature map too small");  // rec_lcnetv4.py:309-310
+    TView y = alloc(x.n, (x.h - 3) / 3 + 1, (x.w - 2) / 2 + 1, x.c);
+    if (!planning()) return y;
+    OpRecord r;
+    r.name = "avgpool3x2";
+    r.kind = "pool";
+    r.bytes = 4.0 * (x.pixels() * x.c + y.pixels() * y.c);
+    const TView xv = x, yv = y;
+    r.run = [xv, yv](const Plan& pl, const RunCtx& c) {
+        launch_avgpool3x2(pl.vptr(xv, c), pl.ld(xv), pl.vptr(yv, c), pl.ld(yv), xv.n, xv.h, xv.w, xv.c, c.stream);
+    };
+    emit(std::move(r));
+    return y;
+}
+
+TView Builder::se_gate(const std::string& w1n, const std::string& b1n, const std::string& w2n, const std::string& b2n,
+                       const TView& x, int gate_act) {
+    const HostTensor& w1 = ws_->get(w1n);
+    const int cr = (int)w1.shape[0], c = (int)w1.shape[1];
+    RD_CHECK(c == x.c && c % 4 == 0, "SE channel mismatch: " + w1n);
+    const int hw = x.h * x.w;
+    int chunks = std::max(1, std::min(64, hw / 256));
+    TView partial = alloc_raw((size_t)x.n * chunks * c);
+    TView gate = alloc(x.n, 1, 1, c);
+    if (!planning()) {
+        if (!pb_->has(w1n)) {
+            const HostTensor& w2 = ws_->get(w2n);
+            pb_->add(w1n, std::vector<float>(w1.f32(), w1.f32() + w1.numel()));
+            pb_->add(b1n, std::vector<float>(ws_->get(b1n).f32(), ws_->get(b1n).f32() + cr));
+            pb_->add(w2n, std::vector<float>(w2.f32(), w2.f32() + w2.numel()));
+            pb_->add(b2n, std::vector<float>(ws_->get(b2n).f32(), ws_->get(b2n).f32() + c));
+        }
+        release(partial);
+        return gate;
+    }
+    {
+        OpRecord r;
+        r.name = w1n + ":gap";
+        r.kind = "gap";
+        r.bytes = 4.0 * x.pixels() * c;
+        const TView xv = x, pv = partial;
+        r.run = [xv, pv, hw, c, chunks](const Plan& pl, const RunCtx& cx) {
+            launch_gap_partial(pl.vptr(xv, cx), pl.ld(xv), xv.n, hw, c, pl.vptr(pv, cx), chunks, cx.stream);
+        };
+        emit(std::move(r));
+    }
+    {
+        SeFcParams p{};
+        p.chunks = chunks; p.N = x.n; p.C = c; p.Cr = cr; p.inv_hw = 1.f / (float)hw;
+        p.w1 = pb_->ptr(w1n); p.b1 = pb_->ptr(b1n); p.w2 = pb_->ptr(w2n); p.b2 = pb_->ptr(b2n);
+        p.gate = gate_act;
+        OpRecord r;
+        r.name = w1n + ":fc";
+        r.kind = "se_fc";
+        r.flops = 4.0 * x.n * c * cr;
+        const TView pv = partial, gv = gate;
+        r.run = [p, pv, gv](const Plan& pl, const RunCtx& cx) {
+            SeFcParams q = p;
+            q.partial = pl.vptr(pv, cx);
+            q.scale = pl.vptr(gv, cx);
+            launch_se_fc(q, cx.stream);
+        };
+        emit(std::move(r));
+    }
+    release(partial);
+    return gate;
+}
+
+void Builder::scale(const TView& x, const TView& gate, float alpha, const TView& out) {
+    RD_CHECK(out.h == x.h && out.w == x.w && out.c == x.c && gate.c == x.c, "scale view mismatch");
+    if (!planning()) return;
+    OpRecord r;
+    r.name = "se_scale";
+    r.kind = "scale";
+    r.bytes = 8.0 * x.pixels() * x.c;
+    const TView xv = x, gv = gate, yv = out;
+    r.run = [xv, gv, yv, alpha](const Plan& pl, const RunCtx& c) {
+        launch_scale_channels(pl.vptr(xv, c), pl.ld(xv), pl.vptr(yv, c), pl.ld(yv), pl.vptr(gv, c), alpha, xv.n,
+                              xv.h * xv.w, xv.c, c.stream);
+    };
+    emit(std::move(r));
+}
+
+void Builder::upsample(const TView& x, const TView& out, int f, bool accumulate) {
+    RD_CHECK(out.h == x.h * f && out.w == x.w * f && out.c == x.c && out.n == x.n, "upsample view mismatch");
+    if (!planning()) return;
+    OpRecord r;
+    r.name = accumulate ? "upsample_add" : "upsample_copy";
+    r.kind = "upsample";
+    r.bytes = 4.0 * (x.pixels() * x.c + out.pixels() * out.c * (accumulate ? 2 : 1));
+    const TView xv = x, yv = out;
+    r.run = [xv, yv, f, accumulate](const Plan& pl, const RunCtx& c) {
+        launch_upsample(pl.vptr(xv, c), pl.ld(xv), pl.vptr(yv, c), pl.ld(yv), yv.n, yv.h, yv.w, yv.c, f,
+                        accumulate ? 1 : 0, c.stream);
+    };
+    emit(std::move(r));
+}
+
+TView Builder::layernorm(const std::string& prefix, const TView& x, float eps) {
+    RD_CHECK(x.c <= 512, "layernorm: C <= 512");
+    TView y = alloc(x.n, x.h, x.w, x.c);
+    if (!planning()) {
+        if (!pb_->has(prefix + ".weight")) {
+            const HostTensor& g = ws_->get(prefix + ".weight");
+            const HostTensor& b = ws_->get(prefix + ".bias");
+            RD_CHECK((int)g.numel() == x.c, "layernorm width: " + prefix);
+            pb_->add(prefix + ".weight", std::vector<float>(g.f32(), g.f32() + g.numel()));
+            pb_->add(prefix + ".bias", std::vector<float>(b.f32(), b.f32() + b.numel()));
+        }
+        return y;
+    }
+    const float* g = pb_->ptr(prefix + ".weight");
+    const float* b = pb_->ptr(prefix + ".bias");
+    OpRecord r;
+    r.name = prefix;
+    r.kind = "layernorm";
+    r.bytes = 8.0 * x.pixels() * x.c;
+    const TView xv = x, yv = y;
+    r.run = [xv, yv, g, b, eps](const Plan& pl, const RunCtx& c) {
+        launch_layernorm(pl.vptr(xv, c), pl.ld(xv), pl.vptr(yv, c), pl.ld(yv), g, b, (int)xv.pixels(), xv.c, eps, c.stream);
+    };
+    emit(std::move(r));
+    return y;
+}
+
+TView Builder::attention(const TView& qkv, int B, int T, int heads, int hd) {
+    RD_CHECK(qkv.c == 3 * heads * hd && qkv.coff == 0 && plan_->ld(qkv) == qkv.c, "attention: packed qkv expected");
+    RD_CHECK(hd == 15 || hd == 16 || hd == 32, "attention: head_dim 15/16/32");
+    RD_CHECK((size_t)2 * T * hd * sizeof(float) <= 160 * 1024 - 1024, "attention: sequence too long for LDS");
+    TView o = alloc(qkv.n, qkv.h, qkv.w, heads * hd);
+    if (!planning()) return o;
+    const float sc = 1.0f / std::sqrt((float)hd);
+    OpRecord r;
+    r.name = "self_attn";
+    r.kind = "attention";
+    r.flops = 4.0 * B * heads * (double)T * T * hd;
+    const TView qv = qkv, ov = o;
+    r.run = [qv, ov, B, T, heads, hd, sc](const Plan& pl, const RunCtx& c) {
+        launch_attention(pl.vptr(qv, c), pl.vptr(ov, c), B, T, heads, hd, sc, c.stream);
+    };
+    emit(std::move(r));
+    return o;
+}
+
+TView Builder::add(const TView& a, const TView& b) {
+    RD_CHECK(a.pixels() == b.pixels() && a.c == b.c, "add: shape mismatch");
+    TView y = alloc(a.n, a.h, a.w, a.c);
+    if (!planning()) return y;
+    OpRecord r;
+    r.name = "add";
+    r.kind = "add";
+    r.bytes = 12.0 * a.pixels() * a.c;
+    const TView av = a, bv = b, yv = y;
+    r.run = [av, bv, yv](const Plan& pl, const RunCtx& c) {
+        launch_add(pl.vptr(av, c), pl.ld(av), pl.vptr(bv, c), pl.ld(bv), pl.vptr(yv, c), pl.ld(yv), (int)av.pixels(), av.c, c.stream);
+    };
+    emit(std::move(r));
+    return y;
+}
+
+void Builder::to_nchw(const TView& x, const TView& out_ext) {
+    if (!planning()) return;
+    OpRecord r;
+    r.name = "to_nchw";
+    r.kind = "layout";
+    r.bytes = 8.0 * x.pixels() * x.c;
+    const TView xv = x, yv = out_ext;
+    r.run = [xv, yv](const Plan& pl, const RunCtx& c) {
+        launch_nhwc_to_nchw(pl.vptr(xv, c), pl.ld(xv), pl.vptr(yv, c), xv.n, xv.h, xv.w, xv.c, c.stream);
+    };
+    emit(std::move(r));
+}
+
+void Builder::ctc_stats(const TView& logits, const TView& idx_ext, const TView& prob_ext) {
+    if (!planning()) return;
+    OpRecord r;
+    r.name = "ctc_rowstats";
+    r.kind = "ctc_stats";
+    r.bytes = 8.0 * logits.pixels() * logits.c;
+    const TView lv = logits, iv = idx_ext, pv = prob_ext;
+    r.run = [lv, iv, pv](const Plan& pl, const RunCtx& c) {
+        launch_rowmax_softmax(pl.vptr(lv, c), pl.ld(lv), (int)lv.pixels(), lv.c, (int32_t*)pl.vptr(iv, c), pl.vptr(pv, c), c.stream);
+    };
+    emit(std::move(r));
+}
+
+void Builder::softmax_rows(const TView& logits, const TView& out_ext) {
+    if (!planning()) return;
+    OpRecord r;
+    r.name = "softmax";
+    r.kind = "softmax";
+    r.bytes = 12.0 * logits.pixels() * logits.c;
+    const TView lv = logits, ov = out_ext;
+    r.run = [lv, ov](const Plan& pl, const RunCtx& c) {
+        launch_row_softmax(pl.vptr(lv, c), pl.ld(lv), pl.vptr(ov, c), (int)lv.pixels(), lv.c, c.stream);
+    };
+    emit(std::move(r));
+}
+
+void Builder::ctc_head(const std::string& prefix, const TView& x, const TView& idx_ext, const TView& prob_ext) {
+    const HostTensor& w = ws_->get(prefix + ".weight");
+    const int C = (int)w.shape[0], K = (int)w.shape[1];
+    RD_CHECK(K == x.c && K % 4 == 0, "ctc head width");
+    const int M = (int)x.pixels();
+    const int nsplit = ctc_head_nsplit(M, C);
+    TView part = alloc_raw((size_t)M * nsplit * 4);
+    if (!planning()) {
+        if (!pb_->has(prefix + "|ctc#w")) {
+            // W' [C][128]: columns 0..K-1 = W, column K = bias (the kernel feeds X[:,K] = 1), rest 0
+            RD_CHECK(K < 128, "ctc head: K < 128");
+            const float* bs = ws_->get(prefix + ".bias").f32();
+            std::vector<float> wp((size_t)C * 128, 0.f);
+            for (int c = 0; c < C; ++c) {
+                std::copy(w.f32() + (size_t)c * K, w.f32() + (size_t)(c + 1) * K, wp.begin() + (size_t)c * 128);
+                wp[(size_t)c * 128 + K] = bs[c];
+            }
+            pb_->add(prefix + "|ctc#w", wp);
+        }
+        release(part);
+        return;
+    }
+    CtcParams p{};
+    p.xld = plan_->ld(x);
+    p.w = pb_->ptr(prefix + "|ctc#w");
+    p.bias = nullptr;
+    p.M = M; p.K = K; p.C = C; p.nsplit = nsplit;
+    OpRecord r;
+    r.name = prefix;
+    r.kind = "ctc_head_fused";
+    r.flops = 2.0 * M * (double)K * C;
+    r.bytes = 4.0 * ((double)M * K + (double)C * K);
+    const TView xv = x, pv = part, iv = idx_ext, prv = prob_ext;
+    r.run = [p, xv, pv, iv, prv](const Plan& pl, const RunCtx& c) {
+        CtcParams q = p;
+        q.x = pl.vptr(xv, c);
+        q.part = pl.vptr(pv, c);
+        q.idx = (int32_t*)pl.vptr(iv, c);
+        q.prob = pl.vptr(prv, c);
+        launch_ctc_head(q, c.stream);
+    };
+    emit(std::move(r));
+    release(part);
+}
+
+// =================================================================================================
+// Engine
+// =================================================================================================
+Engine::Engine(int device, const std::string& kind) : device_(device), kind_(kind) {
+    RD_CHECK(kind == "ppocrv6_det" || kind == "ppocrv6_rec" || kind == "pphgnetv2_b4", "unknown model kind '" + kind + "'");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) throw Error("no HIP device available (MI355X required; there is no CPU fallback)");
+    RD_CHECK(device >= 0 && device < count, "device id out of range");
+}
+
+Engine::~Engine() {
+    (void)hipSetDevice(device_);
+    for (auto ev : events_) (void)hipEventDestroy(ev);
+    if (arena_) (void)hipFree(arena_);
+}
+
+void Engine::build(Builder& b, int B, int H, int W, int flags) {
+    if (kind_ == "ppocrv6_det") build_ppocrv6_det(b, B, H, W);
+    else if (kind_ == "ppocrv6_rec") build_ppocrv6_rec(b, B, H, W, flags);
+    else build_pphgnetv2_b4(b, B, H, W);
+}
+
+void Engine::load_weights(const void* blob, size_t nbytes) {
+    RD_HIP(hipSetDevice(device_));
+    RD_CHECK(!loaded_, "weights already loaded for this handle");
+    store_.load_safetensors(blob, nbytes);
+    if (kind_ == "ppocrv6_rec") n_classes_ = (int)store_.get("head.head.weight").shape[0];  // torch.py:112-116
+    Plan dummy;
+    Builder b(Mode::PREPARE, &store_, &params_, &dummy);
+    // smallest legal geometry; only weight names/shapes matter in PREPARE mode
+    if (kind_ == "ppocrv6_rec") build(b, 1, 48, 64, 0), build(b, 1, 48, 64, REC_UNFUSED_CTC);
+    else build(b, 1, 64, 64, 0);
+    params_.upload();
+    loaded_ = true;
+}
+
+const Plan& Engine::plan_for(int B, int H, int W, int flags) {
+    RD_CHECK(loaded_, "weights not loaded");
+    auto key = std::make_tuple(B, H, W, flags);
+    auto it = plans_.find(key);
+    if (it != plans_.end()) return *it->second;
+    if (plans_.size() >= 256) plans_.clear();
+    auto plan = std::make_unique<Plan>();
+    Builder b(Mode::PLAN, &store_, &params_, plan.get());
+    build(b, B, H, W, flags);
+    plan->arena_bytes = (plan->arena_bytes + 255) / 256 * 256;
+    auto& ref = *plan;
+    plans_[key] = std::move(plan);
+    return ref;
+}
+
+void Engine::run(int B, int H, int W, int flags, const std::vector<void*>& ext, void* ws, size_t ws_bytes, hipStream_t s) {
+    RD_HIP(hipSetDevice(device_));
+    const Plan& plan = plan_for(B, H, W, flags);
+    RunCtx ctx;
+    ctx.ext = ext;
+    ctx.stream = s;
+    if (ws) {
+        RD_CHECK(ws_bytes >= plan.arena_bytes, "workspace too small");
+        ctx.arena = (uint8_t*)ws;
+    } else {
+        if (arena_bytes_ < plan.arena_bytes) {
+            RD_HIP(hipStreamSynchronize(s));
+            if (arena_) RD_HIP(hipFree(arena_));
+            arena_ = nullptr;
+            arena_bytes_ = 0;
+            RD_HIP(hipMalloc((void**)&arena_, plan.arena_bytes));
+            arena_bytes_ = plan.arena_bytes;
+        }
+        ctx.arena = arena_;
+    }
+    for (const Buf& b : plan.bufs)
+        if (b.external >= 0) RD_CHECK(b.external < (int)ext.size() && ext[b.external], "missing external buffer");
+    if (!profiling_) {
+        for (const OpRecord& op : plan.ops) op.run(plan, ctx);
+        RD_HIP(hipGetLastError());
+        return;
+    }
+    const size_t need = plan.ops.size() + 1;
+    while (events_.size() < need) {
+        hipEvent_t ev;
+        RD_HIP(hipEventCreate(&ev));
+        events_.push_back(ev);
+    }
+    RD_HIP(hipEventRecord(events_[0], s));
+    for (size_t i = 0; i < plan.ops.size(); ++i) {
+        plan.ops[i].run(plan, ctx);
+        RD_HIP(hipEventRecord(events_[i + 1], s));
+    }
+    RD_HIP(hipEventSynchronize(events_[plan.ops.size()]));
+    RD_HIP(hipGetLastError());
+    profile_.clear();
+    for (size_t i = 0; i < plan.ops.size(); ++i) {
+        float ms = 0.f;
+        RD_HIP(hipEventElapsedTime(&ms, events_[i], events_[i + 1]));
+        const OpRecord& op = plan.ops[i];
+        profile_.push_back({op.name, op.kind, op.cfg, op.flops, op.bytes, ms});
+    }
+}
+
+std::string Engine::profile_json() const {
+    std::ostringstream os;
+    os << "[";
+    for (size_t i = 0; i < profile_.size(); ++i) {
+        const ProfileEntry& e = profile_[i];
+        if (i) os << ",";
+        os << "{\"name\":\"" << e.name << "\",\"kind\":\"" << e.kind << "\",\"cfg\":\"" << e.cfg << "\",\"flops\":" << e.flops
+           << ",\"bytes\":" << e.bytes << ",\"ms\":" << e.ms << "}";
+    }
+    os << "]";
+    return os.str();
+}
+
+}  // namespace rd

@@ -1,0 +1,229 @@
+// Host-side runtime of the MI355X page-inference engine: weight store (safetensors image), folded
+// parameter block, static memory planner, op list ("plan") per input shape, executor with optional
+// per-op HIP-event profiling.  One Engine = one network on one device; not thread-safe.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "rd_kernels.h"
+
+namespace rd {
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+#define RD_CHECK(cond, msg)                                                          \
+    do {                                                                             \
+        if (!(cond)) throw ::rd::Error(std::string(msg) + " [" #cond "]");           \
+    } while (0)
+#define RD_HIP(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess) throw ::rd::Error(std::string(#expr ": ") + hipGetErrorString(_e));          \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::string dtype;
+    const uint8_t* data = nullptr;
+    size_t nbytes = 0;
+    size_t numel() const {
+        size_t n = 1;
+        for (auto d : shape) n *= (size_t)d;
+        return n;
+    }
+    const float* f32() const { return reinterpret_cast<const float*>(data); }
+};
+
+class WeightStore {
+   public:
+    void load_safetensors(const void* blob, size_t nbytes);  // copies the image; strips a leading "model."
+    bool has(const std::string& name) const { return map_.count(name) != 0; }
+    const HostTensor& get(const std::string& name) const;
+    size_t size() const { return map_.size(); }
+    void clear() { map_.clear(); blob_.clear(); blob_.shrink_to_fit(); }
+
+   private:
+    std::vector<uint8_t> blob_;
+    std::unordered_map<std::string, HostTensor> map_;
+};
+
+// Folded, re-laid-out parameters in one device allocation.
+class ParamBlock {
+   public:
+    ~ParamBlock();
+    size_t add(const std::string& key, const std::vector<float>& v);
+    bool has(const std::string& key) const { return off_.count(key) != 0; }
+    void upload();
+    const float* ptr(const std::string& key) const;
+    size_t bytes() const { return host_.size() * sizeof(float); }
+
+   private:
+    std::vector<float> host_;
+    std::unordered_map<std::string, size_t> off_;
+    float* dev_ = nullptr;
+};
+
+// ------------------------------------------------------------------------------------------------
+struct Buf {
+    int n = 0, h = 0, w = 0, c = 0;
+    size_t off = 0, bytes = 0;
+    int external = -1;  // >= 0: slot in the run-time external pointer table
+    bool live = false;
+};
+struct TView {  // channel slice [coff, coff+c) of an NHWC buffer
+    int buf = -1, coff = 0;
+    int n = 0, h = 0, w = 0, c = 0;
+    long pixels() const { return (long)n * h * w; }
+};
+
+struct RunCtx {
+    uint8_t* arena = nullptr;
+    std::vector<void*> ext;
+    hipStream_t stream = nullptr;
+};
+
+struct OpRecord {
+    std::string name, kind, cfg;
+    double flops = 0, bytes = 0;
+    std::function<void(const struct Plan&, const RunCtx&)> run;
+};
+
+struct Plan {
+    std::vector<Buf> bufs;
+    std::vector<OpRecord> ops;
+    size_t arena_bytes = 0;
+    std::vector<TView> outputs;  // model specific
+    float* vptr(const TView& v, const RunCtx& c) const {
+        const Buf& b = bufs[v.buf];
+        uint8_t* base = b.external >= 0 ? (uint8_t*)c.ext[b.external] : c.arena + b.off;
+        return reinterpret_cast<float*>(base) + v.coff;
+    }
+    int ld(const TView& v) const { return bufs[v.buf].c; }
+};
+
+struct ProfileEntry {
+    std::string name, kind, cfg;
+    double flops, bytes;
+    float ms;
+};
+
+enum class Mode { PREPARE, PLAN };
+
+// Network description helper shared by every model builder.  In PREPARE mode it folds weights into the
+// parameter block; in PLAN mode it allocates buffers and records kernel launches for one input shape.
+class Builder {
+   public:
+    Builder(Mode m, const WeightStore* ws, ParamBlock* pb, Plan* plan) : mode_(m), ws_(ws), pb_(pb), plan_(plan) {}
+    Mode mode() const { return mode_; }
+    bool planning() const { return mode_ == Mode::PLAN; }
+
+    // --- memory
+    TView alloc(int n, int h, int w, int c);
+    TView external(int slot, int n, int h, int w, int c);
+    TView slice(const TView& v, int coff, int c) const;
+    TView reshape(const TView& v, int n, int h, int w) const;  // same pixel count, full-width view only
+    void release(const TView& v);
+    TView alloc_raw(size_t nfloats);  // scratch as [1,1,1,n]
+
+    // --- layers.  `key` = reference state-dict prefix of the layer.
+    struct ConvGeom {
+        int kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0, pb = 0, pr = 0;
+    };
+    // conv weight `wname` [Cout,Cin,kh,kw] (+ optional bias `bname`) (+ optional BatchNorm `bn` prefix, folded)
+    TView conv(const std::string& wname, const std::string& bname, const std::string& bn, const TView& x,
+               const ConvGeom& g, int act, const TView* out = nullptr, const TView* res = nullptr,
+               const TView* ascale = nullptr);
+    TView linear(const std::string& prefix, const TView& x, int act, const TView* out = nullptr,
+                 const TView* res = nullptr);
+    TView deconv2x2(const std::string& wname, const std::string& bname, const std::string& bn, const TView& x, int act,
+                    const TView* out = nullptr);
+    TView stem3x3s2(const std::string& wname, const std::string& bn, const TView& x_nchw, int act);
+    TView dwconv(const std::string& wname, const std::string& bname, const std::string& bn, const TView& x,
+                 const ConvGeom& g, int act, const TView* out = nullptr, const TView* res = nullptr);
+    void maxpool2x2s1(const TView& x, const TView& out);
+    TView avgpool3x2(const TView& x);
+    // squeeze-excite gate s[n][c]; `w1/b1/w2/b2` full tensor names
+    TView se_gate(const std::string& w1, const std::string& b1, const std::string& w2, const std::string& b2,
+                  const TView& x, int gate_act);
+    void scale(const TView& x, const TView& gate, float alpha, const TView& out);
+    void upsample(const TView& x, const TView& out, int f, bool accumulate);
+    TView layernorm(const std::string& prefix, const TView& x, float eps);
+    TView attention(const TView& qkv, int B, int T, int heads, int hd);
+    TView add(const TView& a, const TView& b);
+    void to_nchw(const TView& x, const TView& out_ext);
+    void ctc_stats(const TView& logits, const TView& idx_ext, const TView& prob_ext);
+    void softmax_rows(const TView& logits, const TView& out_ext);
+    void ctc_head(const std::string& prefix, const TView& x, const TView& idx_ext, const TView& prob_ext);
+
+    const HostTensor& weight(const std::string& name) const { return ws_->get(name); }
+    bool has_weight(const std::string& name) const { return ws_ && ws_->has(name); }
+    int weight_dim(const std::string& name, int d) const;
+
+   private:
+    void emit(OpRecord&& r) { plan_->ops.push_back(std::move(r)); }
+    std::vector<float> bn_scale_shift(const std::string& bn, int c, std::vector<float>& shift) const;
+    Mode mode_;
+    const WeightStore* ws_;
+    ParamBlock* pb_;
+    Plan* plan_;
+    struct Block { size_t off, size; bool free; };
+    std::vector<Block> blocks_;
+};
+
+// ------------------------------------------------------------------------------------------------
+class Engine {
+   public:
+    explicit Engine(int device, const std::string& kind);
+    ~Engine();
+    const std::string& kind() const { return kind_; }
+    void load_weights(const void* blob, size_t nbytes);
+    bool loaded() const { return loaded_; }
+
+    // shape key -> plan (built lazily, cached)
+    // flags: model-specific plan variants (RD_REC_* bits)
+    const Plan& plan_for(int B, int H, int W, int flags = 0);
+    size_t workspace_bytes(int B, int H, int W, int flags = 0) { return plan_for(B, H, W, flags).arena_bytes; }
+    // run with caller-provided externals (model specific order); ws may be null (internal arena)
+    void run(int B, int H, int W, int flags, const std::vector<void*>& ext, void* ws, size_t ws_bytes, hipStream_t s);
+
+    void set_profiling(bool on) { profiling_ = on; }
+    const std::vector<ProfileEntry>& last_profile() const { return profile_; }
+    std::string profile_json() const;
+    int n_classes() const { return n_classes_; }
+    int device() const { return device_; }
+
+    std::string last_error;
+
+   private:
+    void build(Builder& b, int B, int H, int W, int flags);
+    int device_;
+    std::string kind_;
+    bool loaded_ = false;
+    bool profiling_ = false;
+    int n_classes_ = 0;
+    ParamBlock params_;
+    WeightStore store_;
+    std::map<std::tuple<int, int, int, int>, std::unique_ptr<Plan>> plans_;
+    uint8_t* arena_ = nullptr;
+    size_t arena_bytes_ = 0;
+    std::vector<ProfileEntry> profile_;
+    std::vector<hipEvent_t> events_;
+};
+
+// model builders (models.cpp)
+void build_ppocrv6_det(Builder& b, int B, int H, int W);
+enum RecFlags : int { REC_UNFUSED_CTC = 1, REC_WANT_SOFTMAX = 2, REC_WANT_LOGITS = 4 };
+void build_ppocrv6_rec(Builder& b, int B, int H, int W, int flags);
+void build_pphgnetv2_b4(Builder& b, int B, int H, int W);
+
+}  // namespace rd

@@ -1,0 +1,317 @@
+// Dense convolution as implicit GEMM on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces what onnxruntime / torch do inside `session(...)` for every dense conv / linear layer of
+// PP-OCRv6 det+rec and PPHGNetV2 (reference definitions: rec_lcnetv4.py:87-118, det_db_head.py:52-93,
+// rec_pphgnetv2.py:860-918, necks/rnn.py:252-299).  fp32-in / fp32-accumulate MFMA is bit-for-bit an
+// fmaf chain, which is what the <=1e-3 parity bar of BASELINE.json asks for.
+//
+// Tiling (wave64, CDNA4):
+//   * block = 256 threads = 4 waves, block tile BM x BN (BM = 128, BN in {32,64,96,128}), K step 32
+//   * A = im2col(X) gathered on the fly from NHWC (ci fastest => 16-byte loads), B = W[Ng][K] (the
+//     natural [Cout][kh][kw][Cin] weight layout): both operands are K-contiguous, staged through LDS
+//     as [row][36] (32 + 4 pad floats) so that every ds_read_b128 of an MFMA operand is conflict-free
+//   * one ds_read_b128 feeds 4 MFMAs: lane l holds k = 4*(l>>5)+e of its row for e = 0..3
+//   * register-staged prefetch of the next K tile while the MFMAs of the current one run
+//   * epilogue fused: + bias (BN folded), activation, + residual, strided (channel-slice) store,
+//     or the 2x2/stride-2 transposed-conv scatter
+//   * 1-D grid with a bijective XCD swizzle so that the n-tiles sharing an A panel run on one XCD (L2)
+#include "rd_kernels.h"
+
+namespace rd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int BK = 32;
+static constexpr int BKP = 36;
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return fmaxf(v, 0.f);
+        case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        case ACT_SILU: return v / (1.f + __expf(-v));
+        case ACT_SIGMOID: {
+            float r = 1.f / (1.f + __expf(-v));
+            return (r != r) ? 0.f : r;  // nan_to_num (det_db_head.py:143-144)
+        }
+        case ACT_HSIG: return fminf(fmaxf(v * (1.f / 6.f) + 0.5f, 0.f), 1.f);
+        case ACT_HSIG_PADDLE: return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f);
+        default: return v;
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool IS1X1>
+__global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(ConvParams p, int ntn) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int AL = BM * 8 / NT, BL = BN * 8 / NT;
+    static_assert(AL >= 1 && BL >= 1 && NT == 256, "tile/loader mismatch");
+
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * BKP];
+    float* As = smem;
+    float* Bs = smem + BM * BKP;
+
+    // bijective XCD-aware remap of the linear block id (cdna_hip_programming.md section 5, T1)
+    int tile_m, tile_n;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x;
+        const int xcd = id & 7, j = id >> 3, q = nwg >> 3, r = nwg & 7;
+        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        tile_m = w / ntn;
+        tile_n = w - tile_m * ntn;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x;
+    const int lrow = tid >> 3, lkq = tid & 7;
+    const int K = p.K;
+
+    // ---- per-thread A row bookkeeping (fixed over the K loop)
+    const float* arow[AL];
+    int a_ih0[AL], a_iw0[AL];
+    const float* asc[AL];
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        asc[i] = nullptr;
+        if (m < p.M) {
+            if (IS1X1) {
+                arow[i] = p.x + (size_t)m * p.xld;
+                a_ih0[i] = a_iw0[i] = 0;
+                if (p.ascale) asc[i] = p.ascale + (size_t)(m / (p.OH * p.OW)) * p.Cin;
+            } else {
+                const int ohw = p.OH * p.OW;
+                const int b = m / ohw, rem = m - b * ohw;
+                const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                a_ih0[i] = oh * p.SH - p.PT;
+                a_iw0[i] = ow * p.SW - p.PL;
+                arow[i] = p.x + (size_t)b * p.H * p.W * p.xld;
+            }
+        } else {
+            arow[i] = nullptr;
+            a_ih0[i] = a_iw0[i] = -(1 << 28);
+        }
+    }
+    const float* brow[BL];
+#pragma unroll
+    for (int i = 0; i < BL; ++i) {
+        const int n = n0 + lrow + 32 * i;
+        brow[i] = (n < p.Ng) ? p.w + (size_t)n * K : nullptr;
+    }
+
+    f32x4 areg[AL], breg[BL];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto load_tiles = [&](int k0) {
+        const int k = k0 + 4 * lkq;
+        const bool kvalid = k < K;
+        if (IS1X1) {
+#pragma unroll
+            for (int i = 0; i < AL; ++i) {
+                f32x4 v = zero4;
+                if (kvalid && arow[i]) {
+                    v = *reinterpret_cast<const f32x4*>(arow[i] + k);
+                    if (asc[i]) v *= *reinterpret_cast<const f32x4*>(asc[i] + k);
+                }
+                areg[i] = v;
+            }
+        } else {
+            const int tap = k / p.Cin, ci = k - tap * p.Cin;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+            for (int i = 0; i < AL; ++i) {
+                const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+                f32x4 v = zero4;
+                if (kvalid && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+                    v = *reinterpret_cast<const f32x4*>(arow[i] + ((size_t)ih * p.W + iw) * p.xld + ci);
+                areg[i] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BL; ++i)
+            breg[i] = (kvalid && brow[i]) ? *reinterpret_cast<const f32x4*>(brow[i] + k) : zero4;
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < AL; ++i) *reinterpret_cast<f32x4*>(&As[(lrow + 32 * i) * BKP + 4 * lkq]) = areg[i];
+#pragma unroll
+        for (int i = 0; i < BL; ++i) *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * i) * BKP + 4 * lkq]) = breg[i];
+    };
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int KT = (K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles();
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const bool more = kt + 1 < KT;
+        if (more) load_tiles((kt + 1) * BK);
+        const int kleft = K - kt * BK;
+        const int ng = kleft >= BK ? 4 : (kleft + 7) >> 3;
+        const float* ap = &As[((wm * TM) * 32 + l31) * BKP + 4 * lhi];
+        const float* bp = &Bs[((wn * TN) * 32 + l31) * BKP + 4 * lhi];
+        for (int g = 0; g < ng; ++g) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(ap + i * 32 * BKP + g * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bp + j * 32 * BKP + g * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+
+    // ---- fused epilogue
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + l31;
+        if (n >= p.Ng) continue;
+        int co = n, dy = 0, dx = 0;
+        if (p.out_mode == OUT_DECONV2X2) {
+            const int tap = n / p.Cout;
+            co = n - tap * p.Cout;
+            dy = tap >> 1;
+            dx = tap & 1;
+        }
+        const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + (wm * TM + i) * 32 + 4 * lhi;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                if (m >= p.M) continue;
+                float v = act_apply(acc[i][j][r] + bv, p.act);
+                if (p.out_mode == OUT_NHWC) {
+                    if (p.res) v += p.res[(size_t)m * p.rld + co];
+                    p.y[(size_t)m * p.yld + co] = v;
+                } else {
+                    const int b = m / ohw, rem = m - b * ohw;
+                    const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                    const size_t pix = ((size_t)b * (2 * p.OH) + 2 * oh + dy) * (2 * p.OW) + 2 * ow + dx;
+                    p.y[pix * p.yld + co] = v;
+                }
+            }
+        }
+    }
+}
+
+struct TileCfg { int bn; const char* name; };
+
+static inline TileCfg pick_cfg(const ConvParams& p) {
+    const int n = p.Ng;
+    if (n <= 32) return {32, "128x32"};
+    if (n <= 64) return {64, "128x64"};
+    if (n <= 96) return {96, "128x96"};
+    // fewest padded columns; ties go to the wider tile
+    const int w128 = (n + 127) / 128 * 128, w96 = (n + 95) / 96 * 96;
+    if (w96 < w128) return {96, "128x96"};
+    return {128, "128x128"};
+}
+
+static inline bool is_1x1(const ConvParams& p) {
+    return p.KH == 1 && p.KW == 1 && p.SH == 1 && p.SW == 1 && p.PT == 0 && p.PL == 0 && p.OH == p.H && p.OW == p.W;
+}
+
+const char* conv_igemm_config_name(const ConvParams& p) { return pick_cfg(p).name; }
+
+template <int BM, int BN, int WM, int WN>
+static void launch_cfg(const ConvParams& p, hipStream_t s) {
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.Ng + BN - 1) / BN;
+    dim3 grid(ntm * ntn), block(WM * WN * 64);
+    if (is_1x1(p))
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true>), grid, block, 0, s, p, ntn);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false>), grid, block, 0, s, p, ntn);
+}
+
+void launch_conv_igemm(const ConvParams& p, hipStream_t s) {
+    if (p.M <= 0) return;
+    switch (pick_cfg(p).bn) {
+        case 32: launch_cfg<128, 32, 4, 1>(p, s); break;
+        case 64: launch_cfg<128, 64, 4, 1>(p, s); break;
+        case 96: launch_cfg<128, 96, 4, 1>(p, s); break;
+        default: launch_cfg<128, 128, 2, 2>(p, s); break;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// Stem: 3x3 stride-2 pad-1 conv on the caller's NCHW fp32 image (Cin = 3), BN folded, ReLU.
+// HBM-bound (27 MACs per output value); one thread = one output pixel x CO_T output channels.
+// --------------------------------------------------------------------------------------------------
+template <int CO_T>
+__global__ void __launch_bounds__(256) stem_conv3x3s2_kernel(StemParams p) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];  // [27][Cout] + bias[Cout]
+    const int nw = 27 * p.Cout;
+    for (int i = threadIdx.x; i < nw + p.Cout; i += 256) wsm[i] = i < nw ? p.w[i] : (p.bias ? p.bias[i - nw] : 0.f);
+    __syncthreads();
+    const int groups = p.Cout / CO_T;
+    const long total = (long)p.N * p.OH * p.OW * groups;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int g = idx % groups;
+        long pix = idx / groups;
+        const int ow = pix % p.OW;
+        pix /= p.OW;
+        const int oh = pix % p.OH;
+        const int b = pix / p.OH;
+        float acc[CO_T];
+#pragma unroll
+        for (int c = 0; c < CO_T; ++c) acc[c] = wsm[nw + g * CO_T + c];
+        const float* xb = p.x + (size_t)b * 3 * p.H * p.W;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * 2 - 1 + kh;
+            if ((unsigned)ih >= (unsigned)p.H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * 2 - 1 + kw;
+                if ((unsigned)iw >= (unsigned)p.W) continue;
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const float xv = xb[((size_t)ci * p.H + ih) * p.W + iw];
+                    const float* wr = &wsm[((kh * 3 + kw) * 3 + ci) * p.Cout + g * CO_T];
+#pragma unroll
+                    for (int c = 0; c < CO_T; ++c) acc[c] = fmaf(xv, wr[c], acc[c]);
+                }
+            }
+        }
+        float* yo = p.y + (((size_t)b * p.OH + oh) * p.OW + ow) * p.yld + g * CO_T;
+#pragma unroll
+        for (int c = 0; c < CO_T; c += 4) {
+            f32x4 v = {act_apply(acc[c], p.act), act_apply(acc[c + 1], p.act), act_apply(acc[c + 2], p.act),
+                       act_apply(acc[c + 3], p.act)};
+            *reinterpret_cast<f32x4*>(yo + c) = v;
+        }
+    }
+}
+
+void launch_stem_conv3x3s2(const StemParams& p, hipStream_t s) {
+    constexpr int CO_T = 8;  // every stem here has Cout in {24, 32, 48}
+    const long total = (long)p.N * p.OH * p.OW * (p.Cout / CO_T);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    const size_t sh = (size_t)(28 * p.Cout) * sizeof(float);
+    hipLaunchKernelGGL(stem_conv3x3s2_kernel<CO_T>, dim3(blocks > 0 ? blocks : 1), dim3(256), sh, s, p);
+}
+
+}  // namespace rd

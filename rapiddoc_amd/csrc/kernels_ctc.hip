@@ -1,0 +1,175 @@
+// Fused CTC head for PP-OCRv6 rec:  Linear(120 -> 18710) + per-time-step argmax + softmax max-probability.
+//
+// Replaces `torch.softmax(ctc_logits).cpu().numpy()` (reference rapid_doc/model/ocr/torch.py:186-192, 3 MB of
+// probabilities per 48x320 crop) followed by rapidocr's CTCLabelDecode argmax/max on the host: the
+// [B*T, 18710] logits never leave the chip, only (idx, prob) per time step do.
+//
+// GEMM is computed transposed on the fp32 matrix cores, D[class][token] = W[class][:] . X[token][:], so a
+// lane's 16 accumulator registers of a 32x32 tile are 16 CLASSES of ONE token: the running
+// (max, argmax, sum-exp) update is register-local VALU work, one v_permlane/shuffle (xor 32) merges the two
+// class halves of a wavefront, and a tiny second kernel merges the class splits.
+//   * the bias rides in the padded K column (K=120 -> 128: X[:,120] = 1, W'[:,120] = bias)
+//   * class ranges are split across blocks so that split s runs on XCD s%8: each XCD keeps its ~1.2 MB slice
+//     of W' resident in its private L2 while the token tiles stream past
+#include "rd_kernels.h"
+
+namespace rd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int CT_TOK = 128;   // tokens per block (4 waves x 32)
+static constexpr int CT_CLS = 128;   // classes per iteration (4 MFMA tiles)
+static constexpr int CT_K = 128;     // padded K
+static constexpr int CT_LD = 132;    // LDS row stride (floats): conflict-free ds_read_b128
+
+__global__ void __launch_bounds__(256) ctc_head_kernel(CtcParams p, int cls_per_split) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;
+    float* Ws = smem + CT_TOK * CT_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int split = blockIdx.x % p.nsplit, ttile = blockIdx.x / p.nsplit;
+    const int tok0 = ttile * CT_TOK;
+    const int c_begin = split * cls_per_split;
+    const int c_end = min(p.C, c_begin + cls_per_split);
+    const int nit = (c_end - c_begin + CT_CLS - 1) / CT_CLS;
+    const int lrow = tid >> 5, lkq = tid & 31;  // 8 rows x 32 float4 per pass
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // ---- X tile (tokens), bias column appended
+#pragma unroll 4
+    for (int r = lrow; r < CT_TOK; r += 8) {
+        const int tok = tok0 + r, k = 4 * lkq;
+        f32x4 v = zero4;
+        if (tok < p.M) {
+            if (k < p.K) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)tok * p.xld + k);
+            else if (k == p.K) v[0] = 1.f;
+        }
+        *reinterpret_cast<f32x4*>(&Xs[r * CT_LD + k]) = v;
+    }
+    f32x4 wreg[16];
+    auto load_w = [&](int it) {
+        const int cb = c_begin + it * CT_CLS;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = cb + lrow + 8 * i;
+            wreg[i] = (c < c_end) ? *reinterpret_cast<const f32x4*>(p.w + (size_t)c * CT_K + 4 * lkq) : zero4;
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4*>(&Ws[(lrow + 8 * i) * CT_LD + 4 * lkq]) = wreg[i];
+    };
+    load_w(0);
+    store_w();
+    __syncthreads();
+
+    float m_run = -INFINITY, s_run = 0.f;
+    int i_run = 0;
+    const float* xp = &Xs[(wave * 32 + l31) * CT_LD + 4 * lhi];
+    const float* wp = &Ws[l31 * CT_LD + 4 * lhi];
+    for (int it = 0; it < nit; ++it) {
+        const bool more = it + 1 < nit;
+        if (more) load_w(it + 1);
+        f32x16 acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+#pragma unroll 4
+        for (int g = 0; g < CT_K / 8; ++g) {
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(xp + g * 8);
+            f32x4 af[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) af[ct] = *reinterpret_cast<const f32x4*>(wp + ct * 32 * CT_LD + g * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ct][e], bf[e], acc[ct], 0, 0, 0);
+        }
+        // ---- register-local running (max, argmax, sum-exp) over this lane's 64 classes of its token
+        const int cb = c_begin + it * CT_CLS + 4 * lhi;
+        float lm = -INFINITY;
+        int li = 0;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = cb + ct * 32 + (r & 3) + 8 * (r >> 2);
+                const float v = (c < c_end) ? acc[ct][r] : -INFINITY;
+                acc[ct][r] = v;
+                if (v > lm) { lm = v; li = c; }
+            }
+        const float m_new = fmaxf(m_run, lm);
+        if (m_new > -INFINITY) {
+            float s = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += __expf(acc[ct][r] - m_new);
+            s_run = s_run * __expf(m_run - m_new) + s;
+            if (lm > m_run) i_run = li;
+            m_run = m_new;
+        }
+        __syncthreads();
+        if (more) {
+            store_w();
+            __syncthreads();
+        }
+    }
+    // ---- merge the two class halves of the wavefront (lane l and l^32 hold the same token)
+    const float om = __shfl_xor(m_run, 32, 64), os = __shfl_xor(s_run, 32, 64);
+    const int oi = __shfl_xor(i_run, 32, 64);
+    const float mm = fmaxf(m_run, om);
+    const float ss = s_run * __expf(m_run - mm) + os * __expf(om - mm);
+    const int ii = (om > m_run || (om == m_run && oi < i_run)) ? oi : i_run;
+    const int tok = tok0 + wave * 32 + l31;
+    if (lhi == 0 && tok < p.M) {
+        float* o = p.part + ((size_t)tok * p.nsplit + split) * 4;
+        o[0] = mm;
+        o[1] = ss;
+        o[2] = __int_as_float(ii);
+    }
+}
+
+__global__ void __launch_bounds__(256) ctc_merge_kernel(const float* part, int M, int nsplit, int32_t* idx, float* prob) {
+    const int tok = blockIdx.x * 256 + threadIdx.x;
+    if (tok >= M) return;
+    const float* pr = part + (size_t)tok * nsplit * 4;
+    float m = -INFINITY;
+    int best = 0;
+    for (int s = 0; s < nsplit; ++s) {
+        const float v = pr[s * 4];
+        if (v > m) { m = v; best = __float_as_int(pr[s * 4 + 2]); }
+    }
+    float sum = 0.f;
+    for (int s = 0; s < nsplit; ++s) sum += pr[s * 4 + 1] * __expf(pr[s * 4] - m);
+    idx[tok] = best;
+    prob[tok] = 1.f / sum;
+}
+
+int ctc_head_nsplit(int M, int C) {
+    const int tiles = (M + CT_TOK - 1) / CT_TOK;
+    int ns = 8;
+    while (tiles * ns < 256 && ns < 64 && (C / (ns * 2)) >= CT_CLS) ns *= 2;
+    return ns;
+}
+
+void launch_ctc_head(const CtcParams& p, hipStream_t s) {
+    if (p.M <= 0) return;
+    const int tiles = (p.M + CT_TOK - 1) / CT_TOK;
+    int cps = (p.C + p.nsplit - 1) / p.nsplit;
+    cps = (cps + 3) / 4 * 4;
+    const size_t sh = (size_t)(CT_TOK + CT_CLS) * CT_LD * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)ctc_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ctc_head_kernel, dim3(tiles * p.nsplit), dim3(256), sh, s, p, cps);
+    hipLaunchKernelGGL(ctc_merge_kernel, dim3((p.M + 255) / 256), dim3(256), 0, s, p.part, p.M, p.nsplit, p.idx, p.prob);
+}
+
+}  // namespace rd

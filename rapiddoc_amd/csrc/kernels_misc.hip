@@ -1,0 +1,531 @@
+// HBM-bound kernels of the page-inference hot path: depthwise stencils, pooling, squeeze-excite,
+// nearest upsample (FPN), LayerNorm, the small LightSVTR attention, CTC row statistics, layout
+// conversion at the C-ABI boundary and the image resize+normalise pre-processing.
+// Everything is NHWC fp32 with the channel dimension innermost => 16-byte coalesced accesses.
+#include "rd_kernels.h"
+
+namespace rd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float act1(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return fmaxf(v, 0.f);
+        case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        case ACT_SILU: return v / (1.f + __expf(-v));
+        case ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        case ACT_HSIG: return fminf(fmaxf(v * (1.f / 6.f) + 0.5f, 0.f), 1.f);
+        case ACT_HSIG_PADDLE: return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f);
+        default: return v;
+    }
+}
+__device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
+    f32x4 r = {act1(v[0], act), act1(v[1], act), act1(v[2], act), act1(v[3], act)};
+    return r;
+}
+
+static inline int grid_for(long total, int block = 256, int cap = 16384) {
+    long g = (total + block - 1) / block;
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+// --------------------------------------------------------------------------------------------------
+// Depthwise KHxKW conv (reference: rec_lcnetv4.py:187-206 token conv, db_fpn.py:315-323 7x7,
+// rec_pphgnetv2.py:945-953 light-block k5, necks/rnn.py:343 local 1x7).  One thread = one output pixel
+// x 4 channels; neighbouring threads walk the channel dimension so every tap is a coalesced 16-B load
+// and the taps of neighbouring pixels hit in L1/L2.
+// --------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dwconv_kernel(DwParams p) {
+    const int c4n = p.C >> 2;
+    const long total = (long)p.N * p.OH * p.OW * c4n;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % c4n) << 2;
+        long pix = idx / c4n;
+        const int ow = pix % p.OW;
+        const long t = pix / p.OW;
+        const int oh = t % p.OH;
+        const int b = t / p.OH;
+        f32x4 acc = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* xb = p.x + (size_t)b * p.H * p.W * p.xld + c;
+        const int ih0 = oh * p.SH - p.PT, iw0 = ow * p.SW - p.PL;
+        for (int kh = 0; kh < p.KH; ++kh) {
+            const int ih = ih0 + kh;
+            if ((unsigned)ih >= (unsigned)p.H) continue;
+            for (int kw = 0; kw < p.KW; ++kw) {
+                const int iw = iw0 + kw;
+                if ((unsigned)iw >= (unsigned)p.W) continue;
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + ((size_t)ih * p.W + iw) * p.xld);
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(p.w + (size_t)(kh * p.KW + kw) * p.C + c);
+                acc += xv * wv;
+            }
+        }
+        acc = act4(acc, p.act);
+        if (p.res) acc += *reinterpret_cast<const f32x4*>(p.res + (size_t)pix * p.rld + c);
+        *reinterpret_cast<f32x4*>(p.y + (size_t)pix * p.yld + c) = acc;
+    }
+}
+void launch_dwconv(const DwParams& p, hipStream_t s) {
+    const long total = (long)p.N * p.OH * p.OW * (p.C >> 2);
+    hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for(total)), dim3(256), 0, s, p);
+}
+
+// --------------------------------------------------------------------------------------------------
+// Pools
+// --------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) maxpool2x2s1_kernel(const float* x, int xld, float* y, int yld, int N, int H,
+                                                           int W, int C) {
+    // F.pad(x,(0,1,0,1)) then MaxPool2d(2, stride 1, ceil) (rec_lcnetv4.py:161-166; rec_pphgnetv2.py:962-976):
+    // the padding is ZERO, so the border takes max(.., 0).
+    const int c4n = C >> 2;
+    const long total = (long)N * H * W * c4n;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % c4n) << 2;
+        const long pix = idx / c4n;
+        const int w = pix % W;
+        const int h = (pix / W) % H;
+        const float* xp = x + (size_t)pix * xld + c;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 v = *reinterpret_cast<const f32x4*>(xp);
+        const f32x4 r = (w + 1 < W) ? *reinterpret_cast<const f32x4*>(xp + xld) : z;
+        const f32x4 d = (h + 1 < H) ? *reinterpret_cast<const f32x4*>(xp + (size_t)W * xld) : z;
+        const f32x4 rd_ = (w + 1 < W && h + 1 < H) ? *reinterpret_cast<const f32x4*>(xp + (size_t)(W + 1) * xld) : z;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(fmaxf(v[i], r[i]), fmaxf(d[i], rd_[i]));
+        *reinterpret_cast<f32x4*>(y + (size_t)pix * yld + c) = v;
+    }
+}
+void launch_maxpool2x2s1(const float* x, int xld, float* y, int yld, int N, int H, int W, int C, hipStream_t s) {
+    const long total = (long)N * H * W * (C >> 2);
+    hipLaunchKernelGGL(maxpool2x2s1_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, xld, y, yld, N, H, W, C);
+}
+
+__global__ void __launch_bounds__(256) avgpool3x2_kernel(const float* x, int xld, float* y, int yld, int N, int H,
+                                                         int W, int C, int OH, int OW) {
+    const int c4n = C >> 2;
+    const long total = (long)N * OH * OW * c4n;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % c4n) << 2;
+        const long pix = idx / c4n;
+        const int ow = pix % OW;
+        const int oh = (pix / OW) % OH;
+        const int b = pix / ((long)OW * OH);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 2; ++kw)
+                acc += *reinterpret_cast<const f32x4*>(
+                    x + (((size_t)b * H + oh * 3 + kh) * W + ow * 2 + kw) * xld + c);
+        acc *= (1.f / 6.f);
+        *reinterpret_cast<f32x4*>(y + (size_t)pix * yld + c) = acc;
+    }
+}
+void launch_avgpool3x2(const float* x, int xld, float* y, int yld, int N, int H, int W, int C, hipStream_t s) {
+    const int OH = (H - 3) / 3 + 1, OW = (W - 2) / 2 + 1;
+    const long total = (long)N * OH * OW * (C >> 2);
+    hipLaunchKernelGGL(avgpool3x2_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, xld, y, yld, N, H, W, C, OH, OW);
+}
+
+// --------------------------------------------------------------------------------------------------
+// Squeeze-excite (rec_lcnetv4.py:120-142; db_fpn.py:288-308)
+// --------------------------------------------------------------------------------------------------
+// partial[n][chunk][c] = sum over the chunk's pixels; fixed summation order => run-to-run deterministic
+__global__ void __launch_bounds__(256) gap_partial_kernel(const float* x, int xld, int HW, int C, float* partial,
+                                                          int chunks) {
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int per = (HW + chunks - 1) / chunks;
+    const int p0 = chunk * per, p1 = min(HW, p0 + per);
+    const int c4n = C >> 2;
+    __shared__ f32x4 red[256];
+    // threads: tc = channel quad, tr = pixel lane
+    const int lanes_c = c4n < 256 ? c4n : 256;
+    const int rows = 256 / lanes_c;
+    const int tc = threadIdx.x % lanes_c, tr = threadIdx.x / lanes_c;
+    for (int cbase = 0; cbase < c4n; cbase += lanes_c) {  // uniform trip count (barriers inside)
+        const int cq = cbase + tc;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (tr < rows && cq < c4n)
+            for (int pidx = p0 + tr; pidx < p1; pidx += rows)
+                acc += *reinterpret_cast<const f32x4*>(x + ((size_t)n * HW + pidx) * xld + (cq << 2));
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (tr == 0 && cq < c4n) {
+            for (int r = 1; r < rows; ++r) acc += red[r * lanes_c + tc];
+            *reinterpret_cast<f32x4*>(partial + ((size_t)n * chunks + chunk) * C + (cq << 2)) = acc;
+        }
+        __syncthreads();
+    }
+}
+void launch_gap_partial(const float* x, int xld, int N, int HW, int C, float* partial, int chunks, hipStream_t s) {
+    hipLaunchKernelGGL(gap_partial_kernel, dim3(chunks, N), dim3(256), 0, s, x, xld, HW, C, partial, chunks);
+}
+
+__global__ void __launch_bounds__(256) se_fc_kernel(SeFcParams p) {
+    extern __shared__ float sm[];  // mean[C] + hid[Cr]
+    float* mean = sm;
+    float* hid = sm + p.C;
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < p.C; c += 256) {
+        float s = 0.f;
+        for (int k = 0; k < p.chunks; ++k) s += p.partial[((size_t)n * p.chunks + k) * p.C + c];
+        mean[c] = s * p.inv_hw;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < p.Cr; r += 256) {
+        float s = p.b1[r];
+        const float* w = p.w1 + (size_t)r * p.C;
+        for (int c = 0; c < p.C; ++c) s = fmaf(w[c], mean[c], s);
+        hid[r] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.C; c += 256) {
+        float s = p.b2[c];
+        const float* w = p.w2 + (size_t)c * p.Cr;
+        for (int r = 0; r < p.Cr; ++r) s = fmaf(w[r], hid[r], s);
+        p.scale[(size_t)n * p.C + c] = act1(s, p.gate);
+    }
+}
+void launch_se_fc(const SeFcParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(se_fc_kernel, dim3(p.N), dim3(256), (p.C + p.Cr) * sizeof(float), s, p);
+}
+
+__global__ void __launch_bounds__(256) scale_channels_kernel(const float* x, int xld, float* y, int yld,
+                                                             const float* scale, float alpha, int HW, int C,
+                                                             long total) {
+    const int c4n = C >> 2;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % c4n) << 2;
+        const long pix = idx / c4n;
+        const int n = pix / HW;
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)pix * xld + c);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + (size_t)n * C + c);
+        v *= (sc + alpha);
+        *reinterpret_cast<f32x4*>(y + (size_t)pix * yld + c) = v;
+    }
+}
+void launch_scale_channels(const float* x, int xld, float* y, int yld, const float* scale, float alpha, int N, int HW,
+                           int C, hipStream_t s) {
+    const long total = (long)N * HW * (C >> 2);
+    hipLaunchKernelGGL(scale_channels_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, xld, y, yld, scale, alpha, HW,
+                       C, total);
+}
+
+// --------------------------------------------------------------------------------------------------
+// nearest upsample (+ accumulate) - RepLKFPN top-down path and concat (db_fpn.py:395-415)
+// --------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) upsample_kernel(const float* x, int xld, float* y, int yld, int H, int W, int C,
+                                                       int f, int accumulate, long total) {
+    // H, W are the OUTPUT dims; input is H/f x W/f
+    const int c4n = C >> 2;
+    const int IH = H / f, IW = W / f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % c4n) << 2;
+        const long pix = idx / c4n;
+        const int w = pix % W;
+        const int h = (pix / W) % H;
+        const int n = pix / ((long)W * H);
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * IH + h / f) * IW + w / f) * xld + c);
+        float* yp = y + (size_t)pix * yld + c;
+        if (accumulate) v += *reinterpret_cast<const f32x4*>(yp);
+        *reinterpret_cast<f32x4*>(yp) = v;
+    }
+}
+void launch_upsample(const float* x, int xld, float* y, int yld, int N, int H, int W, int C, int f, int accumulate,
+                     hipStream_t s) {
+    const long total = (long)N * H * W * (C >> 2);
+    hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, xld, y, yld, H, W, C, f, accumulate,
+                       total);
+}
+
+__global__ void __launch_bounds__(256) add_kernel(const float* a, int ald, const float* b, int bld, float* y, int yld,
+                                                  int C, long total) {
+    const int c4n = C >> 2;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % c4n) << 2;
+        const long m = idx / c4n;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a + (size_t)m * ald + c) +
+                        *reinterpret_cast<const f32x4*>(b + (size_t)m * bld + c);
+        *reinterpret_cast<f32x4*>(y + (size_t)m * yld + c) = v;
+    }
+}
+void launch_add(const float* a, int ald, const float* b, int bld, float* y, int yld, int M, int C, hipStream_t s) {
+    const long total = (long)M * (C >> 2);
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(total)), dim3(256), 0, s, a, ald, b, bld, y, yld, C, total);
+}
+
+// --------------------------------------------------------------------------------------------------
+// LayerNorm over the channel dimension: one wavefront per token (necks/rnn.py:306-318,363)
+// --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* x, int xld, float* y, int yld, const float* g,
+                                                        const float* b, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * xld;
+    float v[8];  // C <= 512
+    float s = 0.f;
+    int cnt = 0;
+    for (int c = lane; c < C; c += 64) {
+        v[cnt] = xr[c];
+        s += v[cnt++];
+    }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+    for (int i = 0; i < cnt; ++i) {
+        const float d = v[i] - mean;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+    float* yr = y + (size_t)row * yld;
+    cnt = 0;
+    for (int c = lane; c < C; c += 64) yr[c] = (v[cnt++] - mean) * rstd * g[c] + b[c];
+}
+void launch_layernorm(const float* x, int xld, float* y, int yld, const float* g, const float* b, int M, int C,
+                      float eps, hipStream_t s) {
+    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, xld, y, yld, g, b, M, C, eps);
+}
+
+// --------------------------------------------------------------------------------------------------
+// LightSVTR global self-attention (necks/rnn.py:238-271): heads=8, head_dim=15, T = W/8 (<= 1024).
+// One block per (sequence, head): K and V live in LDS, each thread owns query rows, two passes
+// (row max, then exp/sum/PV) exactly like a max-subtracted softmax.
+// --------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ void __launch_bounds__(256) attention_kernel(const float* qkv, float* o, int T, int heads, float scale) {
+    extern __shared__ float sm[];
+    float* Ks = sm;               // [T][HD]
+    float* Vs = sm + (size_t)T * HD;
+    const int b = blockIdx.x, h = blockIdx.y;
+    const int C = heads * HD;
+    const float* base = qkv + (size_t)b * T * 3 * C;
+    for (int i = threadIdx.x; i < T * HD; i += 256) {
+        const int t = i / HD, d = i - t * HD;
+        Ks[i] = base[(size_t)t * 3 * C + C + h * HD + d];
+        Vs[i] = base[(size_t)t * 3 * C + 2 * C + h * HD + d];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) {
+        float q[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) q[d] = base[(size_t)t * 3 * C + h * HD + d] * scale;
+        float mx = -INFINITY;
+        for (int j = 0; j < T; ++j) {
+            float sdot = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) sdot = fmaf(q[d], Ks[j * HD + d], sdot);
+            mx = fmaxf(mx, sdot);
+        }
+        float l = 0.f, acc[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+        for (int j = 0; j < T; ++j) {
+            float sdot = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) sdot = fmaf(q[d], Ks[j * HD + d], sdot);
+            const float e = __expf(sdot - mx);
+            l += e;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] = fmaf(e, Vs[j * HD + d], acc[d]);
+        }
+        const float inv = 1.f / l;
+        float* op = o + ((size_t)b * T + t) * C + h * HD;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) op[d] = acc[d] * inv;
+    }
+}
+void launch_attention(const float* qkv, float* o, int B, int T, int heads, int hd, float scale, hipStream_t s) {
+    const size_t sh = (size_t)2 * T * hd * sizeof(float);
+    if (hd == 15)
+        hipLaunchKernelGGL(attention_kernel<15>, dim3(B, heads), dim3(256), sh, s, qkv, o, T, heads, scale);
+    else if (hd == 16)
+        hipLaunchKernelGGL(attention_kernel<16>, dim3(B, heads), dim3(256), sh, s, qkv, o, T, heads, scale);
+    else if (hd == 32)
+        hipLaunchKernelGGL(attention_kernel<32>, dim3(B, heads), dim3(256), sh, s, qkv, o, T, heads, scale);
+}
+
+// --------------------------------------------------------------------------------------------------
+// CTC row statistics over materialised logits (used for validation and for the reference-shaped
+// softmax output; the production path is the fused kernel in kernels_ctc.hip)
+// --------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rowmax_softmax_kernel(const float* z, int ld, int M, int C, int32_t* idx,
+                                                             float* prob) {
+    const int row = blockIdx.x;
+    const float* zr = z + (size_t)row * ld;
+    float mx = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float v = zr[c];
+        if (v > mx) { mx = v; mi = c; }
+    }
+    __shared__ float smx[256];
+    __shared__ int smi[256];
+    __shared__ float ssum[256];
+    smx[threadIdx.x] = mx;
+    smi[threadIdx.x] = mi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const float a = smx[threadIdx.x], b = smx[threadIdx.x + o];
+            const int ia = smi[threadIdx.x], ib = smi[threadIdx.x + o];
+            if (b > a || (b == a && ib < ia)) { smx[threadIdx.x] = b; smi[threadIdx.x] = ib; }
+        }
+        __syncthreads();
+    }
+    const float gmx = smx[0];
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) s += __expf(zr[c] - gmx);
+    ssum[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) ssum[threadIdx.x] += ssum[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        idx[row] = smi[0];
+        prob[row] = 1.f / ssum[0];
+    }
+}
+void launch_rowmax_softmax(const float* logits, int ld, int M, int C, int32_t* idx, float* prob, hipStream_t s) {
+    if (M > 0) hipLaunchKernelGGL(rowmax_softmax_kernel, dim3(M), dim3(256), 0, s, logits, ld, M, C, idx, prob);
+}
+
+__global__ void __launch_bounds__(256) row_softmax_kernel(const float* z, int ld, float* out, int C) {
+    const int row = blockIdx.x;
+    const float* zr = z + (size_t)row * ld;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < C; c += 256) mx = fmaxf(mx, zr[c]);
+    __shared__ float red[4];
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) s += __expf(zr[c] - mx);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
+    float* orow = out + (size_t)row * C;
+    for (int c = threadIdx.x; c < C; c += 256) orow[c] = __expf(zr[c] - mx) * inv;
+}
+void launch_row_softmax(const float* logits, int ld, float* out, int M, int C, hipStream_t s) {
+    if (M > 0) hipLaunchKernelGGL(row_softmax_kernel, dim3(M), dim3(256), 0, s, logits, ld, out, C);
+}
+
+// --------------------------------------------------------------------------------------------------
+// Layout conversion at the boundary (the reference seam is NCHW numpy: inference_engine/base.py)
+// --------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const float* x, int xld, float* y, int HW, int C) {
+    // tile transpose through LDS: 32 pixels x 32 channels
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int pp = p0 + r, c = c0 + tx;
+        tile[r][tx] = (pp < HW && c < C) ? x[((size_t)n * HW + pp) * xld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, pp = p0 + tx;
+        if (c < C && pp < HW) y[((size_t)n * C + c) * HW + pp] = tile[tx][r];
+    }
+}
+void launch_nhwc_to_nchw(const float* x, int xld, float* y, int N, int H, int W, int C, hipStream_t s) {
+    const int HW = H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((HW + 31) / 32, (C + 31) / 32, N), dim3(256), 0, s, x, xld, y, HW, C);
+}
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* x, float* y, int yld, int HW, int C) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, pp = p0 + tx;
+        tile[r][tx] = (pp < HW && c < C) ? x[((size_t)n * C + c) * HW + pp] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int pp = p0 + r, c = c0 + tx;
+        if (c < C && pp < HW) y[((size_t)n * HW + pp) * yld + c] = tile[tx][r];
+    }
+}
+void launch_nchw_to_nhwc(const float* x, float* y, int yld, int N, int C, int H, int W, hipStream_t s) {
+    const int HW = H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + 31) / 32, (C + 31) / 32, N), dim3(256), 0, s, x, y, yld, HW, C);
+}
+
+// --------------------------------------------------------------------------------------------------
+// Pre-processing: u8 HWC page -> resized, normalised NCHW fp32 plane set.
+// interp 1: bilinear with half-pixel centres; interp 2: bicubic a = -0.75 (the OpenCV INTER_CUBIC kernel
+// the reference asks for in pp_doclayout/pre_process.py:35) evaluated in fp32 (cv2's 8-bit path uses
+// 11-bit fixed-point coefficients and rounds to u8 - see DESIGN.md).
+// --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cubic_coeffs(float t, float* w) {
+    const float A = -0.75f;
+    w[0] = ((A * (t + 1.f) - 5.f * A) * (t + 1.f) + 8.f * A) * (t + 1.f) - 4.f * A;
+    w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+    w[2] = ((A + 2.f) * (1.f - t) - (A + 3.f)) * (1.f - t) * (1.f - t) + 1.f;
+    w[3] = 1.f - w[0] - w[1] - w[2];
+}
+__global__ void __launch_bounds__(256) preproc_kernel(PreprocParams p) {
+    const long total = (long)p.OH * p.OW;
+    const float sy = (float)p.H / p.OH, sx = (float)p.W / p.OW;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int ox = idx % p.OW, oy = idx / p.OW;
+        const float fy = (oy + 0.5f) * sy - 0.5f, fx = (ox + 0.5f) * sx - 0.5f;
+        float out[3] = {0.f, 0.f, 0.f};
+        if (p.interp == 2) {
+            const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+            float wy[4], wx[4];
+            cubic_coeffs(fy - iy, wy);
+            cubic_coeffs(fx - ix, wx);
+            for (int a = 0; a < 4; ++a) {
+                const int yy = min(max(iy - 1 + a, 0), p.H - 1);
+                for (int b = 0; b < 4; ++b) {
+                    const int xx = min(max(ix - 1 + b, 0), p.W - 1);
+                    const uint8_t* px = p.src + ((size_t)yy * p.W + xx) * 3;
+                    const float w = wy[a] * wx[b];
+                    out[0] = fmaf(w, (float)px[0], out[0]);
+                    out[1] = fmaf(w, (float)px[1], out[1]);
+                    out[2] = fmaf(w, (float)px[2], out[2]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) out[c] = fminf(fmaxf(rintf(out[c]), 0.f), 255.f);  // saturate_cast<uchar>
+        } else {
+            const float cy = fminf(fmaxf(fy, 0.f), (float)(p.H - 1)), cx = fminf(fmaxf(fx, 0.f), (float)(p.W - 1));
+            const int y0 = (int)cy, x0 = (int)cx;
+            const int y1 = min(y0 + 1, p.H - 1), x1 = min(x0 + 1, p.W - 1);
+            const float ty = cy - y0, tx = cx - x0;
+            for (int c = 0; c < 3; ++c) {
+                const float v00 = p.src[((size_t)y0 * p.W + x0) * 3 + c], v01 = p.src[((size_t)y0 * p.W + x1) * 3 + c];
+                const float v10 = p.src[((size_t)y1 * p.W + x0) * 3 + c], v11 = p.src[((size_t)y1 * p.W + x1) * 3 + c];
+                out[c] = (v00 * (1.f - tx) + v01 * tx) * (1.f - ty) + (v10 * (1.f - tx) + v11 * tx) * ty;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int sc = p.swap_rb ? 2 - c : c;
+            p.dst[(size_t)c * total + idx] = (out[sc] * p.scale - p.mean[c]) * p.inv_std[c];
+        }
+    }
+}
+void launch_preproc_resize_norm(const PreprocParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(preproc_kernel, dim3(grid_for((long)p.OH * p.OW)), dim3(256), 0, s, p);
+}
+
+}  // namespace rd

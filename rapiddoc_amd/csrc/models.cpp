@@ -1,0 +1,336 @@
+// Network topologies of the page hot path, written against the reference's state-dict names so the
+// shipped .safetensors load unchanged.  Reference definitions (file:line, relative to /root/reference):
+//   PPLCNetV4 ............ rapid_doc/model/ocr/ppocrv6_pytorch/modeling/backbones/rec_lcnetv4.py:7-311
+//   RepLKFPN ............. .../necks/db_fpn.py:288-415
+//   DBHead (ppocrv6) ..... .../heads/det_db_head.py:52-149
+//   LightSVTR ............ .../necks/rnn.py:225-379
+//   MultiHead CTC branch . .../heads/rec_multi_head.py:43-75
+//   PPHGNetV2-B4 (det) ... rapid_doc/model/formula/rapid_formula_self/networks/backbones/rec_pphgnetv2.py:860-1477
+#include "engine.h"
+
+namespace rd {
+
+using G = Builder::ConvGeom;
+
+static G geom(int k, int s = 1) {
+    G g;
+    g.kh = g.kw = k;
+    g.sh = g.sw = s;
+    g.pt = g.pl = g.pb = g.pr = (k - 1) / 2;
+    return g;
+}
+static G geom_same_even(int k) {  // padding='same' with an even kernel / explicit F.pad(0,1,0,1): pad right+bottom only
+    G g;
+    g.kh = g.kw = k;
+    g.pt = g.pl = (k - 1) / 2;
+    g.pb = g.pr = (k - 1) - (k - 1) / 2;
+    return g;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// PPLCNetV4
+// ---------------------------------------------------------------------------------------------------
+struct LcBlockCfg { int k, cin, cout, sh, sw; bool se; };
+
+static TView lc_stem(Builder& b, const std::string& p, const TView& x_nchw, int c1, int c2) {
+    auto cw = [&](const char* n) { return p + "." + n + ".convolution.weight"; };
+    auto bn = [&](const char* n) { return p + "." + n + ".normalization"; };
+    TView e = b.stem3x3s2(cw("stem1"), bn("stem1"), x_nchw, ACT_RELU);                 // H/2, c1
+    TView a = b.conv(cw("stem2a"), "", bn("stem2a"), e, geom_same_even(2), ACT_RELU);  // c1/2
+    TView cat = b.alloc(e.n, e.h, e.w, 2 * c1);
+    TView cat_pool = b.slice(cat, 0, c1), cat_b = b.slice(cat, c1, c1);
+    b.maxpool2x2s1(e, cat_pool);
+    b.conv(cw("stem2b"), "", bn("stem2b"), a, geom_same_even(2), ACT_RELU, &cat_b);
+    b.release(e);
+    b.release(a);
+    TView s3 = b.conv(cw("stem3"), "", bn("stem3"), cat, geom(3, 2), ACT_RELU);
+    b.release(cat);
+    TView s4 = b.conv(cw("stem4"), "", bn("stem4"), s3, geom(1), ACT_RELU);
+    b.release(s3);
+    (void)c2;
+    return s4;
+}
+
+static TView lc_block(Builder& b, const std::string& p, const TView& x, const LcBlockCfg& c) {
+    const bool rep = c.sh == 1 && c.sw == 1 && c.cin == c.cout;
+    G g = geom(c.k);
+    g.sh = c.sh;
+    g.sw = c.sw;
+    TView t;
+    if (rep) t = b.dwconv(p + ".token_conv.weight", p + ".token_conv.bias", "", x, g, ACT_NONE);
+    else t = b.dwconv(p + ".token_conv.convolution.weight", "", p + ".token_conv.normalization", x, g, ACT_NONE);
+    if (c.se) {
+        const std::string s = p + ".token_squeeze_excitation.convolutions.";
+        TView gate = b.se_gate(s + "0.weight", s + "0.bias", s + "2.weight", s + "2.bias", t, ACT_HSIG);
+        b.scale(t, gate, 0.f, t);
+        b.release(gate);
+    }
+    TView m = b.conv(p + ".channel_conv1.convolution.weight", "", p + ".channel_conv1.normalization", t, geom(1), ACT_GELU);
+    TView o = b.conv(p + ".channel_conv2.convolution.weight", "", p + ".channel_conv2.normalization", m, geom(1), ACT_NONE,
+                     nullptr, rep ? &t : nullptr);
+    b.release(m);
+    b.release(t);
+    return o;
+}
+
+static const std::vector<std::vector<LcBlockCfg>> kDetSmall = {
+    {{3, 48, 48, 1, 1, true}, {3, 48, 48, 1, 1, false}},
+    {{3, 48, 96, 2, 2, false}, {3, 96, 96, 1, 1, true}, {3, 96, 96, 1, 1, false}},
+    {{3, 96, 192, 2, 2, false}, {3, 192, 192, 1, 1, true}, {3, 192, 192, 1, 1, false}, {3, 192, 192, 1, 1, true},
+     {3, 192, 192, 1, 1, false}},
+    {{3, 192, 384, 2, 2, false}, {3, 384, 384, 1, 1, true}, {3, 384, 384, 1, 1, false}},
+};
+static const std::vector<std::vector<LcBlockCfg>> kRecSmall = {
+    {{3, 96, 96, 1, 1, true}},
+    {{3, 96, 96, 1, 1, false}, {3, 96, 96, 1, 1, false}},
+    {{3, 96, 192, 2, 1, false}, {3, 192, 192, 1, 1, true}, {3, 192, 192, 1, 1, false}, {3, 192, 192, 1, 1, true},
+     {3, 192, 192, 1, 1, false}, {3, 192, 192, 1, 1, true}, {3, 192, 192, 1, 1, false}},
+    {{3, 192, 384, 2, 1, false}, {3, 384, 384, 1, 1, true}, {3, 384, 384, 1, 1, false}},
+};
+
+// returns the 4 stage outputs; the caller releases them
+static std::vector<TView> lcnetv4(Builder& b, const TView& x_nchw, const std::vector<std::vector<LcBlockCfg>>& cfg,
+                                  int c1, int c2, bool keep_all) {
+    const std::string enc = "backbone.encoder";
+    TView h = lc_stem(b, enc + ".convolution", x_nchw, c1, c2);
+    std::vector<TView> feats;
+    for (size_t si = 0; si < cfg.size(); ++si) {
+        for (size_t bi = 0; bi < cfg[si].size(); ++bi) {
+            TView o = lc_block(b, enc + ".blocks." + std::to_string(si) + ".blocks." + std::to_string(bi), h, cfg[si][bi]);
+            const bool is_feat = !feats.empty() && feats.back().buf == h.buf;
+            if (!is_feat) b.release(h);
+            h = o;
+        }
+        if (keep_all || si + 1 == cfg.size()) feats.push_back(h);
+    }
+    return feats;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// PP-OCRv6 det small.   ext[0] = x NCHW [B,3,H,W];  ext[1] = prob map [B,1,H,W]
+// ---------------------------------------------------------------------------------------------------
+void build_ppocrv6_det(Builder& b, int B, int H, int W) {
+    RD_CHECK(H % 32 == 0 && W % 32 == 0 && H >= 32 && W >= 32, "det input H, W must be multiples of 32");
+    TView x = b.external(0, B, H, W, 3);
+    TView out = b.external(1, B, H, W, 1);
+    std::vector<TView> f = lcnetv4(b, x, kDetSmall, 24, 48, true);
+
+    // RepLKFPN
+    std::vector<TView> fused(4);
+    for (int i = 0; i < 4; ++i) {
+        const std::string p = "neck.insert_conv." + std::to_string(i);
+        TView y = b.conv(p + ".in_conv.weight", "", "", f[i], geom(1), ACT_NONE);
+        b.release(f[i]);
+        const std::string s = p + ".squeeze_excitation_block.";
+        TView gate = b.se_gate(s + "conv1.weight", s + "conv1.bias", s + "conv2.weight", s + "conv2.bias", y, ACT_HSIG_PADDLE);
+        b.scale(y, gate, 1.f, y);  // y + y*s
+        b.release(gate);
+        fused[i] = y;
+    }
+    for (int i = 2; i >= 0; --i) b.upsample(fused[i + 1], fused[i], 2, true);
+    TView cat = b.alloc(B, H / 4, W / 4, 96);
+    for (int i = 0; i < 4; ++i) {
+        const std::string p = "neck.input_conv." + std::to_string(i);
+        TView d = b.dwconv(p + ".depthwise_convolution.weight", p + ".depthwise_convolution.bias", "", fused[i], geom(7), ACT_NONE);
+        b.release(fused[i]);
+        TView z = b.conv(p + ".pointwise_convolution.weight", "", "", d, geom(1), ACT_NONE);
+        b.release(d);
+        const std::string s = p + ".squeeze_excitation_module.";
+        TView gate = b.se_gate(s + "conv1.weight", s + "conv1.bias", s + "conv2.weight", s + "conv2.bias", z, ACT_HSIG_PADDLE);
+        TView slot = b.slice(cat, 24 * (3 - i), 24);  // cat(processed[::-1]) : deepest level first (db_fpn.py:415)
+        if (i == 0) {
+            b.scale(z, gate, 1.f, slot);
+        } else {
+            b.scale(z, gate, 1.f, z);
+            b.upsample(z, slot, 1 << i, false);
+        }
+        b.release(gate);
+        b.release(z);
+    }
+    // DBHead v6
+    TView c = b.conv("head.conv_down.convolution.weight", "", "head.conv_down.norm", cat, geom(3), ACT_RELU);
+    b.release(cat);
+    TView u = b.deconv2x2("head.conv_up.convolution.weight", "head.conv_up.convolution.bias", "head.conv_up.norm", c, ACT_RELU);
+    b.release(c);
+    b.deconv2x2("head.conv_final.weight", "head.conv_final.bias", "", u, ACT_SIGMOID, &out);
+    b.release(u);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// PP-OCRv6 rec small.  ext[0] = x NCHW [B,3,48,W]; ext[1] = idx i32 [B*T]; ext[2] = prob f32 [B*T];
+// ext[3] = optional [B,T,C] softmax probabilities or raw logits (flags)
+// ---------------------------------------------------------------------------------------------------
+void build_ppocrv6_rec(Builder& b, int B, int H, int W, int flags) {
+    RD_CHECK(H == 48, "rec input height must be 48");
+    RD_CHECK(W % 8 == 0 && W >= 16, "rec input width must be a multiple of 8 (>= 16)");
+    TView x = b.external(0, B, H, W, 3);
+    std::vector<TView> f = lcnetv4(b, x, kRecSmall, 48, 96, false);
+    TView pooled = b.avgpool3x2(f[0]);  // [B,1,W/8,384]
+    b.release(f[0]);
+    const int T = pooled.w;
+    RD_CHECK(pooled.h == 1, "rec: pooled height");
+
+    const std::string e = "head.encoder";
+    auto cw = [&](int i) { return e + ".conv_block." + std::to_string(i) + ".convolution.weight"; };
+    auto cbn = [&](int i) { return e + ".conv_block." + std::to_string(i) + ".normalization"; };
+    TView res = b.conv(cw(0), "", cbn(0), pooled, geom(1), ACT_SILU);
+    TView h = b.conv(cw(1), "", cbn(1), pooled, geom(1), ACT_SILU);
+    b.release(pooled);
+    G g17;
+    g17.kh = 1;
+    g17.kw = b.weight_dim(cw(2), 3);
+    g17.pl = g17.pr = g17.kw / 2;
+    TView t = b.dwconv(cw(2), "", cbn(2), h, g17, ACT_SILU, nullptr, &h);  // h + silu(bn(dw(h)))
+    b.release(h);
+    const int C = t.c, heads = 8, hd = C / heads;
+    int depth = 0;
+    while (b.has_weight(e + ".svtr_block." + std::to_string(depth) + ".layer_norm1.weight")) ++depth;
+    for (int d = 0; d < depth; ++d) {
+        const std::string p = e + ".svtr_block." + std::to_string(d);
+        TView y = b.layernorm(p + ".layer_norm1", t, 1e-6f);
+        TView qkv = b.linear(p + ".self_attn.qkv", y, ACT_NONE);
+        b.release(y);
+        TView a = b.attention(qkv, B, T, heads, hd);
+        b.release(qkv);
+        TView t2 = b.linear(p + ".self_attn.projection", a, ACT_NONE, nullptr, &t);
+        b.release(a);
+        b.release(t);
+        TView y2 = b.layernorm(p + ".layer_norm2", t2, 1e-6f);
+        TView m = b.linear(p + ".mlp.fc1", y2, ACT_SILU);
+        b.release(y2);
+        t = b.linear(p + ".mlp.fc2", m, ACT_NONE, nullptr, &t2);
+        b.release(m);
+        b.release(t2);
+    }
+    TView n = b.layernorm(e + ".norm", t, 1e-6f);
+    b.release(t);
+    TView seq = b.add(n, res);  // [B,1,T,120]
+    b.release(n);
+    b.release(res);
+
+    const int ncls = b.weight_dim("head.head.weight", 0);
+    TView idx = b.external(1, B, 1, T, 1), prob = b.external(2, B, 1, T, 1);
+    const bool want_full = (flags & (REC_WANT_SOFTMAX | REC_WANT_LOGITS)) != 0;
+    if ((flags & REC_UNFUSED_CTC) || want_full) {
+        if (flags & REC_WANT_LOGITS) {
+            TView lg = b.external(3, B, 1, T, ncls);
+            b.linear("head.head", seq, ACT_NONE, &lg);
+            b.ctc_stats(lg, idx, prob);
+        } else {
+            TView lg = b.linear("head.head", seq, ACT_NONE);
+            b.ctc_stats(lg, idx, prob);
+            if (flags & REC_WANT_SOFTMAX) {
+                TView sm = b.external(3, B, 1, T, ncls);
+                b.softmax_rows(lg, sm);
+            }
+            b.release(lg);
+        }
+    } else {
+        b.ctc_head("head.head", seq, idx, prob);
+    }
+    b.release(seq);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// PPHGNetV2-B4 (det=True): the PP-DocLayout-L / plus-L / V2 / V3 backbone.
+// ext[0] = x NCHW [B,3,H,W]; ext[1..4] = stage outputs NCHW (strides 4/8/16/32; 128/512/1024/2048 ch)
+// ---------------------------------------------------------------------------------------------------
+struct HgStageCfg { int cin, mid, cout, blocks; bool down, light; int k, layers; };
+static const HgStageCfg kB4Det[4] = {
+    {48, 48, 128, 1, false, false, 3, 6},
+    {128, 96, 512, 1, true, false, 3, 6},
+    {512, 192, 1024, 3, true, true, 5, 6},
+    {1024, 384, 2048, 1, true, true, 5, 6},
+};
+
+void build_pphgnetv2_b4(Builder& b, int B, int H, int W) {
+    RD_CHECK(H % 32 == 0 && W % 32 == 0 && H >= 64 && W >= 64, "backbone input H, W must be multiples of 32 (>= 64)");
+    TView x = b.external(0, B, H, W, 3);
+    auto cw = [&](const std::string& p) { return p + ".conv.weight"; };
+    auto bn = [&](const std::string& p) { return p + ".bn"; };
+    // stem (StemBlock, rec_pphgnetv2.py:979-1056)
+    TView e = b.stem3x3s2(cw("stem.stem1"), bn("stem.stem1"), x, ACT_RELU);  // 32 @ H/2
+    TView a = b.conv(cw("stem.stem2a"), "", bn("stem.stem2a"), e, geom_same_even(2), ACT_RELU);
+    TView cat = b.alloc(B, e.h, e.w, 2 * e.c);
+    TView cat_pool = b.slice(cat, 0, e.c), cat_b = b.slice(cat, e.c, e.c);
+    b.maxpool2x2s1(e, cat_pool);
+    b.conv(cw("stem.stem2b"), "", bn("stem.stem2b"), a, geom_same_even(2), ACT_RELU, &cat_b);
+    b.release(e);
+    b.release(a);
+    TView s3 = b.conv(cw("stem.stem3"), "", bn("stem.stem3"), cat, geom(3, 2), ACT_RELU);
+    b.release(cat);
+
+    // stage inputs are produced straight into channel slot 0 of the stage's dense-concat buffer
+    TView cur;         // current block input (a slice of `cur_cat`)
+    TView cur_cat;     // its concat buffer
+    auto new_cat = [&](int n, int h, int w, const HgStageCfg& c, int cin) {
+        return b.alloc(n, h, w, cin + c.layers * c.mid);
+    };
+    {
+        const HgStageCfg& c = kB4Det[0];
+        cur_cat = new_cat(B, s3.h, s3.w, c, c.cin);
+        cur = b.slice(cur_cat, 0, c.cin);
+        b.conv(cw("stem.stem4"), "", bn("stem.stem4"), s3, geom(1), ACT_RELU, &cur);
+        b.release(s3);
+    }
+    for (int si = 0; si < 4; ++si) {
+        const HgStageCfg& c = kB4Det[si];
+        const std::string sp = "stages." + std::to_string(si);
+        if (c.down) {
+            // depthwise 3x3 stride 2 + BN, no activation (HGV2_Stage.downsample)
+            G g = geom(3, 2);
+            const int oh = (cur.h + 2 - 3) / 2 + 1, ow = (cur.w + 2 - 3) / 2 + 1;
+            TView ncat = new_cat(B, oh, ow, c, c.cin);
+            TView nin = b.slice(ncat, 0, c.cin);
+            b.dwconv(cw(sp + ".downsample"), "", bn(sp + ".downsample"), cur, g, ACT_NONE, &nin);
+            b.release(cur_cat);
+            cur_cat = ncat;
+            cur = nin;
+        }
+        for (int bi = 0; bi < c.blocks; ++bi) {
+            const std::string bp = sp + ".blocks." + std::to_string(bi);
+            const int cin = bi == 0 ? c.cin : c.cout;
+            TView prev = cur;
+            for (int li = 0; li < c.layers; ++li) {
+                const std::string lp = bp + ".layers." + std::to_string(li);
+                TView slot = b.slice(cur_cat, cin + li * c.mid, c.mid);
+                if (c.light) {
+                    TView t = b.conv(cw(lp + ".conv1"), "", bn(lp + ".conv1"), prev, geom(1), ACT_NONE);
+                    b.dwconv(cw(lp + ".conv2"), "", bn(lp + ".conv2"), t, geom(c.k), ACT_RELU, &slot);
+                    b.release(t);
+                } else {
+                    b.conv(cw(lp), "", bn(lp), prev, geom(c.k), ACT_RELU, &slot);
+                }
+                prev = slot;
+            }
+            TView full = b.slice(cur_cat, 0, cin + c.layers * c.mid);
+            TView sq = b.conv(cw(bp + ".aggregation_squeeze_conv"), "", bn(bp + ".aggregation_squeeze_conv"), full, geom(1), ACT_RELU);
+            // destination of the block output: slot 0 of the next consumer's concat buffer
+            const bool last_block = bi + 1 == c.blocks;
+            TView ncat, nout;
+            if (!last_block) {
+                ncat = new_cat(B, cur.h, cur.w, c, c.cout);
+                nout = b.slice(ncat, 0, c.cout);
+            } else if (si + 1 < 4 ) {
+                // next stage downsamples from here: a plain buffer is enough
+                ncat = b.alloc(B, cur.h, cur.w, c.cout);
+                nout = ncat;
+            } else {
+                ncat = b.alloc(B, cur.h, cur.w, c.cout);
+                nout = ncat;
+            }
+            const bool identity = bi > 0;
+            b.conv(cw(bp + ".aggregation_excitation_conv"), "", bn(bp + ".aggregation_excitation_conv"), sq, geom(1), ACT_RELU,
+                   &nout, identity ? &cur : nullptr);
+            b.release(sq);
+            b.release(cur_cat);
+            cur_cat = ncat;
+            cur = nout;
+        }
+        TView o = b.external(1 + si, B, cur.h, cur.w, c.cout);
+        b.to_nchw(cur, o);
+    }
+    b.release(cur_cat);
+}
+
+}  // namespace rd

@@ -1,0 +1,118 @@
+// Kernel launch interface of the MI355X page-inference engine (gfx950 only).
+// All activations are NHWC fp32; a "view" is (base pointer, channel stride ld) so that channel
+// slices of a wider buffer (concat-free dense blocks, FPN concat) are addressed without copies.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace rd {
+
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_SIGMOID = 4, ACT_HSIG = 5, ACT_HSIG_PADDLE = 6 };
+enum OutMode : int { OUT_NHWC = 0, OUT_DECONV2X2 = 1 };
+
+// Dense convolution as implicit GEMM on fp32 MFMA:  Y[M, Ng] = im2col(X)[M, K] * W[Ng, K]^T
+//   M = N*OH*OW, K = KH*KW*Cin (ci fastest), Ng = Cout (OUT_NHWC) or 4*Cout (OUT_DECONV2X2).
+struct ConvParams {
+    const float* x; int xld;
+    int N, H, W, Cin;
+    const float* w;      // [Ng][K]
+    const float* bias;   // [Cout] or nullptr (BN already folded into w / bias)
+    float* y; int yld;
+    int OH, OW, Cout;
+    int KH, KW, SH, SW, PT, PL;
+    const float* res; int rld;      // added after the activation, same geometry as y
+    const float* ascale;            // optional [N][Cin] multiplier applied to X rows on load (1x1 only)
+    int act, out_mode;
+    int M, K, Ng;
+};
+void launch_conv_igemm(const ConvParams& p, hipStream_t s);
+// a short human-readable tag of the tile configuration chosen for p (for the per-op profile)
+const char* conv_igemm_config_name(const ConvParams& p);
+
+// First conv of a network: 3x3 stride 2 pad 1, Cin = 3, reads the caller's NCHW (or NHWC u8/f32) image.
+struct StemParams {
+    const float* x;   // NCHW f32 [N,3,H,W]
+    int N, H, W;
+    const float* w;   // [27][Cout] (kh,kw,ci major; co fastest)
+    const float* bias;
+    float* y; int yld; int OH, OW, Cout;
+    int act;
+};
+void launch_stem_conv3x3s2(const StemParams& p, hipStream_t s);
+
+struct DwParams {
+    const float* x; int xld;
+    int N, H, W, C;
+    const float* w;     // [KH*KW][C]
+    const float* bias;  // [C]
+    float* y; int yld;
+    int OH, OW, KH, KW, SH, SW, PT, PL;
+    int act;
+    const float* res; int rld;  // added after activation
+    float* gap_partial;         // optional [N][gap_chunks][C] partial sums of the OUTPUT (SE fusion), or nullptr
+    int gap_chunks;
+};
+void launch_dwconv(const DwParams& p, hipStream_t s);
+
+// 2x2 stride-1 max-pool over an input zero-padded by one pixel on the right/bottom (stem branch b)
+void launch_maxpool2x2s1(const float* x, int xld, float* y, int yld, int N, int H, int W, int C, hipStream_t s);
+// avg_pool2d(kernel (3,2), stride (3,2)) - rec height collapse
+void launch_avgpool3x2(const float* x, int xld, float* y, int yld, int N, int H, int W, int C, hipStream_t s);
+
+// Squeeze-excite: deterministic two-stage global average pool, tiny FCs, then y = x * (alpha + s)
+void launch_gap_partial(const float* x, int xld, int N, int HW, int C, float* partial, int chunks, hipStream_t s);
+struct SeFcParams {
+    const float* partial; int chunks; int N, C, Cr; float inv_hw;
+    const float* w1; const float* b1;  // [Cr][C], [Cr]
+    const float* w2; const float* b2;  // [C][Cr], [C]
+    int gate;                          // ACT_HSIG (x/6+.5) or ACT_HSIG_PADDLE (.2x+.5)
+    float* scale;                      // [N][C]
+};
+void launch_se_fc(const SeFcParams& p, hipStream_t s);
+void launch_scale_channels(const float* x, int xld, float* y, int yld, const float* scale, float alpha,
+                           int N, int HW, int C, hipStream_t s);
+
+// y[n,h,w,:] (+)= x[n,h/f,w/f,:]   (nearest-neighbour upsample by integer factor f)
+void launch_upsample(const float* x, int xld, float* y, int yld, int N, int H, int W, int C, int f, int accumulate,
+                     hipStream_t s);
+
+void launch_layernorm(const float* x, int xld, float* y, int yld, const float* g, const float* b, int M, int C,
+                      float eps, hipStream_t s);
+// qkv: [B*T][3*heads*hd] (q|k|v, head-major) -> o: [B*T][heads*hd]
+void launch_attention(const float* qkv, float* o, int B, int T, int heads, int hd, float scale, hipStream_t s);
+
+// y = a + b (same geometry, views)
+void launch_add(const float* a, int ald, const float* b, int bld, float* y, int yld, int M, int C, hipStream_t s);
+
+// CTC head statistics from logits: idx[m] = argmax_c z[m][c], prob[m] = 1 / sum_c exp(z[m][c]-max)
+void launch_rowmax_softmax(const float* logits, int ld, int M, int C, int32_t* idx, float* prob, hipStream_t s);
+// full softmax (only when the caller asks for the reference-shaped [B,T,C] probabilities)
+void launch_row_softmax(const float* logits, int ld, float* out, int M, int C, hipStream_t s);
+// Fused CTC head: logits are never materialised.
+struct CtcParams {
+    const float* x; int xld;   // [M][K]
+    const float* w;            // [C][K]
+    const float* bias;         // [C]
+    int M, K, C;
+    float* part;               // workspace [M][nsplit][4] (max, sumexp, idx, pad)
+    int nsplit;
+    int32_t* idx; float* prob;
+};
+void launch_ctc_head(const CtcParams& p, hipStream_t s);
+int ctc_head_nsplit(int M, int C);
+
+// layout conversion at the C-ABI boundary
+void launch_nhwc_to_nchw(const float* x, int xld, float* y, int N, int H, int W, int C, hipStream_t s);
+void launch_nchw_to_nhwc(const float* x, float* y, int yld, int N, int C, int H, int W, hipStream_t s);
+
+// image pre-processing: u8 HWC -> bilinear/bicubic resize -> (v*scale - mean)/std -> NCHW f32
+struct PreprocParams {
+    const uint8_t* src; int H, W;      // HWC, 3 channels
+    float* dst; int OH, OW;            // [3][OH][OW] plane of one batch element
+    float mean[3], inv_std[3]; float scale;
+    int interp;                         // 1 = bilinear, 2 = bicubic (a=-0.75, OpenCV convention)
+    int swap_rb;
+};
+void launch_preproc_resize_norm(const PreprocParams& p, hipStream_t s);
+
+}  // namespace rd

@@ -1,0 +1,139 @@
+"""Thin Python handle over the C-ABI: PyTorch-ROCm tensors provide device memory and the stream, the
+library does all the arithmetic."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+from typing import Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib, weights as W
+
+REC_UNFUSED_CTC, REC_WANT_SOFTMAX, REC_WANT_LOGITS = 1, 2, 4
+KINDS = ("ppocrv6_det", "ppocrv6_rec", "pphgnetv2_b4")
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class RdEngine:
+    """One network on one GPU (`rd_handle`)."""
+
+    def __init__(self, kind: str, device: int = 0):
+        if kind not in KINDS:
+            raise ValueError(f"kind must be one of {KINDS}")
+        if not torch.cuda.is_available():
+            raise EngineError("no ROCm device visible: rapiddoc_amd runs on MI355X only (no CPU fallback)")
+        self._l = _lib.load()
+        self.kind, self.device = kind, device
+        self._h = self._l.rd_create(device, kind.encode())
+        if not self._h:
+            raise EngineError(self._l.rd_create_error().decode())
+        self._tdev = torch.device("cuda", device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.rd_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise EngineError(self._l.rd_last_error(self._h).decode())
+
+    # ------------------------------------------------------------------ weights
+    def load_weights(self, src: Union[bytes, str, Dict[str, np.ndarray]]):
+        """`src`: path to / bytes of a .safetensors file, or a name->ndarray state dict."""
+        if isinstance(src, dict):
+            blob = W.to_safetensors_bytes({k: np.asarray(v) for k, v in src.items()}, skip_int=True)
+        elif isinstance(src, (bytes, bytearray)):
+            blob = bytes(src)
+        else:
+            blob = open(src, "rb").read()
+        buf = C.create_string_buffer(blob, len(blob))
+        self._chk(self._l.rd_load_weights(self._h, buf, len(blob)))
+        return self
+
+    @property
+    def num_classes(self) -> int:
+        return self._l.rd_rec_num_classes(self._h)
+
+    def workspace_bytes(self, B: int, H: int, W_: int, flags: int = 0) -> int:
+        n = C.c_size_t(0)
+        self._chk(self._l.rd_query_workspace(self._h, B, H, W_, flags, C.byref(n)))
+        return n.value
+
+    # ------------------------------------------------------------------ forwards
+    def _prep(self, x: torch.Tensor) -> torch.Tensor:
+        if x.device.type != "cuda":
+            x = x.to(self._tdev, non_blocking=True)
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.contiguous().float()
+        return x
+
+    def det_forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = self._prep(x)
+        B, Cc, H, W_ = x.shape
+        out = torch.empty((B, 1, H, W_), dtype=torch.float32, device=x.device)
+        self._chk(self._l.rd_det_forward(self._h, x.data_ptr(), B, H, W_, out.data_ptr(), None, 0, _stream_ptr()))
+        return out
+
+    def rec_forward(self, x: torch.Tensor, flags: int = 0) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+        x = self._prep(x)
+        B, Cc, H, W_ = x.shape
+        if H != 48:
+            raise EngineError("rec input height must be 48")
+        T = W_ // 8
+        idx = torch.empty((B, T), dtype=torch.int32, device=x.device)
+        prob = torch.empty((B, T), dtype=torch.float32, device=x.device)
+        full = None
+        if flags & (REC_WANT_SOFTMAX | REC_WANT_LOGITS):
+            full = torch.empty((B, T, self.num_classes), dtype=torch.float32, device=x.device)
+        self._chk(self._l.rd_rec_forward(self._h, x.data_ptr(), B, W_, idx.data_ptr(), prob.data_ptr(),
+                                         full.data_ptr() if full is not None else None, flags, None, 0, _stream_ptr()))
+        return idx, prob, full
+
+    def backbone_forward(self, x: torch.Tensor) -> List[torch.Tensor]:
+        x = self._prep(x)
+        B, Cc, H, W_ = x.shape
+        chans = (128, 512, 1024, 2048)
+        feats = [torch.empty((B, c, H // s, W_ // s), dtype=torch.float32, device=x.device)
+                 for c, s in zip(chans, (4, 8, 16, 32))]
+        arr = (C.c_void_p * 4)(*[f.data_ptr() for f in feats])
+        self._chk(self._l.rd_backbone_forward(self._h, x.data_ptr(), B, H, W_, arr, None, 0, _stream_ptr()))
+        return feats
+
+    # ------------------------------------------------------------------ profiling
+    def set_profiling(self, on: bool):
+        self._chk(self._l.rd_set_profiling(self._h, 1 if on else 0))
+
+    def profile(self) -> List[dict]:
+        return json.loads(self._l.rd_profile_json(self._h).decode())
+
+
+def preproc_resize_norm(img_u8_hwc: torch.Tensor, out_hw: Tuple[int, int], mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0),
+                        scale: float = 1.0 / 255.0, interp: int = 2, swap_rb: bool = False,
+                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """u8 HWC device image -> normalised CHW float32 (PPPreProcess, pp_doclayout/pre_process.py:22-42)."""
+    lib = _lib.load()
+    assert img_u8_hwc.is_cuda and img_u8_hwc.dtype == torch.uint8 and img_u8_hwc.is_contiguous()
+    H, W_, ch = img_u8_hwc.shape
+    assert ch == 3
+    OH, OW = out_hw
+    if out is None:
+        out = torch.empty((3, OH, OW), dtype=torch.float32, device=img_u8_hwc.device)
+    m = (C.c_float * 3)(*mean)
+    s = (C.c_float * 3)(*std)
+    rc = lib.rd_preproc_resize_norm(img_u8_hwc.device.index or 0, img_u8_hwc.data_ptr(), H, W_, OH, OW, m, s, scale,
+                                    interp, 1 if swap_rb else 0, out.data_ptr(), _stream_ptr())
+    if rc != 0:
+        raise EngineError("rd_preproc_resize_norm failed")
+    return out
