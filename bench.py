@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Headline benchmark: pages/s of the page hot path (layout backbone + OCR det + OCR rec) on synthetic pages.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of 32 synthetic 1684x1191 pages per GPU (BASELINE.json
+configs[1]): PPHGNetV2-B4 backbone @800x800 (the PP-DocLayout-L/V2/V3 backbone; neck/decoder are ONNX-only and
+absent), PP-OCRv6-small det @960x704, PP-OCRv6-small rec on the 45 text lines of every page, fused
+CTC argmax, host CTC decode.  Pages are resident in HBM as u8 when the timed region starts; weights are
+seed-0 synthetic (no checkpoints exist offline) - throughput is weight independent.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from collections import defaultdict
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+PAGES_PER_GPU = 32
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+
+
+def load_states():
+    from rapiddoc_amd import weights as W
+    g = ROOT / "tests" / "golden"
+    return {k: W.synth_state_dict(W.load_manifest(g / f"manifest_{k}.json"), 0)
+            for k in ("ppocrv6_det", "ppocrv6_rec", "pphgnetv2_b4")}
+
+
+def cpu_baseline(states, threads):
+    """The oracle (CPU restatement of the reference networks, oracle/nets.py) on the host cores, bounded sample:
+    one page worth of layout-backbone + det, and 6 of its 45 rec crops (scaled by 45/6)."""
+    from oracle import nets as O
+    torch.set_num_threads(threads)
+    rng = np.random.default_rng(0)
+    st = {k: O.as_torch_state(v) for k, v in states.items()}
+    xb = torch.from_numpy(rng.uniform(0, 1, (1, 3, 800, 800)).astype(np.float32))
+    xd = torch.from_numpy(rng.standard_normal((1, 3, 960, 704)).astype(np.float32))
+    xr = torch.from_numpy(rng.uniform(-1, 1, (6, 3, 48, 1088)).astype(np.float32))
+    with torch.no_grad():
+        def timed(fn, reps):
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            return (time.perf_counter() - t0) / reps
+        t_b4 = timed(lambda: O.pphgnetv2_features(st["pphgnetv2_b4"], xb), 1)
+        t_det = timed(lambda: O.det_forward(st["ppocrv6_det"], xd), 2)
+        t_rec = timed(lambda: O.ctc_greedy_stats(O.rec_forward(st["ppocrv6_rec"], xr)), 1)
+    t_page = t_b4 + t_det + t_rec * 45.0 / 6.0
+    return {"value": round(1.0 / t_page, 4), "unit": "pages/s", "cores": threads, "kind": "port",
+            "sample": "torch-CPU fp32 oracle (oracle/nets.py): 1 page = B4 backbone 1x3x800x800 (%.2fs) + det 1x3x960x704 (%.2fs) "
+                      "+ rec 6x3x48x1088 (%.2fs) scaled x45/6" % (t_b4, t_det, t_rec)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pages", type=int, default=PAGES_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-profile", type=str, default="")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    from rapiddoc_amd import build as rd_build
+    if not rd_build.OUT.exists():
+        if rank == 0:
+            rd_build.build()
+        if dist:
+            dist.barrier()
+    from rapiddoc_amd.pages import synth_batch
+    from rapiddoc_amd.pipeline import PagePipeline, boxes_to_quads
+    from rapiddoc_amd.dist import gather_page_results
+
+    states = load_states()
+    pipe = PagePipeline(states, device=local_rank)
+    P = args.pages
+    pages_np, boxes = synth_batch(rank * P, P)
+    pages = torch.from_numpy(pages_np).cuda()
+    quads = [boxes_to_quads(b) for b in boxes]
+
+    def step():
+        res = pipe.run_batch(pages, quads)
+        payload = [(rank * P + i, [(t, s) for _, t, s in r.lines]) for i, r in enumerate(res)]
+        return gather_page_results(payload, dist)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_lines = sum(len(l) for _, l in out)
+
+    # ---- roofline of the dominant kernel: per-op HIP events (recorded by the library on the launch stream)
+    roof = None
+    if rank == 0:
+        for e in (pipe.det, pipe.rec, pipe.layout):
+            e.set_profiling(True)
+            e.profile_log = []
+        pipe.run_batch(pages, quads)
+        torch.cuda.synchronize()
+        agg = defaultdict(lambda: [0.0, 0.0, 0.0, 0])
+        tot_ms = 0.0
+        for e in (pipe.det, pipe.rec, pipe.layout):
+            for op in e.profile_log:
+                name = op["kind"]
+                if op["kind"].startswith(("conv", "deconv")):
+                    name = "conv_igemm_kernel<%s,%s>" % (op["cfg"], "1x1" if op["kind"] == "conv1x1" else "kxk")
+                a = agg[name]
+                a[0] += op["flops"]; a[1] += op["bytes"]; a[2] += op["ms"]; a[3] += 1
+                tot_ms += op["ms"]
+            e.set_profiling(False)
+        mfma = {k: v for k, v in agg.items() if k.startswith("conv_igemm") or k == "ctc_head_fused"}
+        dom = max(mfma, key=lambda k: mfma[k][2])
+        fl, by, ms, n = mfma[dom]
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches_per_step": n,
+                "avg_launch_us": round(ms * 1e3 / n, 2), "avg_gflop_per_launch": round(fl / n / 1e9, 4),
+                "all_mfma_kernels_tflops": round(sum(v[0] for v in mfma.values()) / (sum(v[2] for v in mfma.values()) * 1e-3) / 1e12, 3),
+                "step_kernel_ms": round(tot_ms, 2)}
+        if args.dump_profile:
+            table = sorted(((k, v[3], v[2], v[0] / 1e9, v[1] / 1e6) for k, v in agg.items()), key=lambda r: -r[2])
+            with open(args.dump_profile, "w") as f:
+                f.write("kernel,launches,total_ms,gflop,algorithmic_MB,TFLOPs,GBs\n")
+                for k, n_, ms_, gf, mb in table:
+                    f.write("%s,%d,%.3f,%.2f,%.1f,%.2f,%.1f\n" % (k, n_, ms_, gf, mb, gf / ms_ if ms_ else 0, mb / ms_ if ms_ else 0))
+
+    if rank == 0:
+        total_pages = P * world * args.steps
+        rec = {
+            "metric": "pages/sec (layout+OCR det/rec)", "value": round(total_pages / dt, 3), "unit": "pages/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "PP-DocLayout backbone (PPHGNetV2-B4 @800x800) + PP-OCRv6-small det (960x704) + rec "
+                                   "(45 lines/page, fused CTC) on %d synthetic 1684x1191 pages per GPU" % P,
+                       "pages_per_gpu": P, "lines_per_step": n_lines, "parallelism": "page-sharded dp%d" % world,
+                       "layout_head": "absent (ONNX-only in the reference; backbone only)",
+                       "det_postprocess": "text-line boxes come from the synthetic page generator"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(states, min(32, os.cpu_count() or 1))
+        print(json.dumps(rec), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

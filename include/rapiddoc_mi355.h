@@ -61,6 +61,8 @@ int rd_det_forward(rd_handle* h, const float* x_nchw_dev, int B, int H, int W, f
 int rd_rec_forward(rd_handle* h, const float* x_nchw_dev, int B, int W, int32_t* idx_bt_dev, float* prob_bt_dev,
                    float* full_btc_dev, int flags, void* ws_dev, size_t ws_bytes, void* stream);
 int rd_rec_num_classes(rd_handle* h);
+/* number of CTC time steps the rec network emits for input width W (stride-2 stem x2, then avg-pool (3,2)) */
+int rd_rec_seq_len(int W);
 
 /* PPHGNetV2-B4 (PP-DocLayout backbone): x [B,3,H,W] -> 4 NCHW feature maps, strides 4/8/16/32,
  * channels 128/512/1024/2048. */
@@ -71,6 +73,21 @@ int rd_backbone_forward(rd_handle* h, const float* x_nchw_dev, int B, int H, int
  * interp: 1 bilinear, 2 bicubic (a = -0.75, result rounded/saturated to u8 range like an 8-bit resize). */
 int rd_preproc_resize_norm(int device_id, const uint8_t* hwc_u8_dev, int H, int W, int OH, int OW, const float mean[3],
                            const float std[3], float scale, int interp, int swap_rb, float* out_chw_dev, void* stream);
+
+/* Text-line crops for one rec batch (replaces per-line cv2.warpPerspective + rapidocr resize_norm_img:
+ * rapid_doc/utils/ocr_utils.py:494-536, rapid_doc/model/ocr/rapid_ocr.py:436-440).  pages_u8_dev: [P][H][W][3];
+ * descs_dev: n device-resident rd_crop_desc; out: [n][3][out_h][out_w_padded] float32, zero right-padded. */
+typedef struct rd_crop_desc {
+    int32_t page;          /* page index in the batch */
+    int32_t out_w;         /* resized width of this line (<= out_w_padded) */
+    float crop_w, crop_h;  /* size of the rectified crop in page pixels */
+    float m[9];            /* crop (x, y, 1) -> page (x, y, w) homography, row-major */
+    int32_t rot90;         /* rotate the crop 90 deg CCW first (tall boxes) */
+    int32_t pad_;
+} rd_crop_desc;
+int rd_crop_resize_norm_batch(int device_id, const uint8_t* pages_u8_dev, int P, int H, int W,
+                              const rd_crop_desc* descs_dev, int n, int out_h, int out_w_padded, const float mean[3],
+                              const float std[3], float scale, int swap_rb, float* out_nchw_dev, void* stream);
 
 /* per-op HIP-event timing of the NEXT forward calls; rd_profile_json returns the last call's table as a JSON
  * array [{"name","kind","cfg","flops","bytes","ms"}, ...] owned by the handle. */

@@ -20,8 +20,10 @@ SYMBOLS = {
     "rd_det_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rd_rec_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rd_rec_num_classes": (C.c_int, [C.c_void_p]),
+    "rd_rec_seq_len": (C.c_int, [C.c_int]),
     "rd_backbone_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_void_p]),
     "rd_preproc_resize_norm": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "rd_crop_resize_norm_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "rd_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "rd_profile_json": (C.c_char_p, [C.c_void_p]),
 }
@@ -40,6 +42,10 @@ def load():
         raise NativeLibraryError(
             f"{LIB_PATH} is missing - build it with `python -m rapiddoc_amd.build` (hipcc, gfx950). "
             "rapiddoc_amd has no CPU fallback.")
+    # PyTorch-ROCm bundles its own HIP runtime; it must be in the process BEFORE this library is opened so that
+    # both resolve to ONE libamdhip64 (shared streams / device memory).  Opening ours first would pull in
+    # /opt/rocm's copy and leave the process with two runtimes.
+    import torch  # noqa: F401
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError = a symbol of include/rapiddoc_mi355.h is not exported

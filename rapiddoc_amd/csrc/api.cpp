@@ -82,6 +82,11 @@ int rd_rec_forward(rd_handle* h, const float* x, int B, int W, int32_t* idx, flo
         h->eng->run(B, 48, W, flags, {(void*)x, (void*)idx, (void*)prob, (void*)full}, ws, ws_bytes, (hipStream_t)stream);
     });
 }
+int rd_rec_seq_len(int W) {
+    if (W < 16) return 0;
+    const int w1 = (W - 1) / 2 + 1, w2 = (w1 - 1) / 2 + 1;
+    return (w2 - 2) / 2 + 1;
+}
 int rd_rec_num_classes(rd_handle* h) { return (h && h->eng) ? h->eng->n_classes() : -1; }
 
 int rd_backbone_forward(rd_handle* h, const float* x, int B, int H, int W, float* const feats[4], void* ws, size_t ws_bytes,
@@ -103,6 +108,22 @@ int rd_preproc_resize_norm(int device_id, const uint8_t* src, int H, int W, int 
     for (int i = 0; i < 3; ++i) { p.mean[i] = mean ? mean[i] : 0.f; p.inv_std[i] = 1.f / (std ? std[i] : 1.f); }
     p.scale = scale; p.interp = interp; p.swap_rb = swap_rb;
     rd::launch_preproc_resize_norm(p, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int rd_crop_resize_norm_batch(int device_id, const uint8_t* pages, int P, int H, int W, const rd_crop_desc* descs, int n,
+                              int out_h, int out_w_padded, const float mean[3], const float std[3], float scale, int swap_rb,
+                              float* out, void* stream) {
+    static_assert(sizeof(rd_crop_desc) == sizeof(rd::CropDesc), "rd_crop_desc layout");
+    if (!pages || !descs || !out || P <= 0 || n < 0 || out_h <= 0 || out_w_padded <= 0) return 1;
+    if (hipSetDevice(device_id) != hipSuccess) return 1;
+    rd::CropBatchParams p{};
+    p.pages = pages; p.H = H; p.W = W; p.page_stride = (size_t)H * W * 3;
+    p.descs = reinterpret_cast<const rd::CropDesc*>(descs); p.n = n;
+    p.dst = out; p.OH = out_h; p.OWp = out_w_padded;
+    for (int i = 0; i < 3; ++i) { p.mean[i] = mean ? mean[i] : 0.f; p.inv_std[i] = 1.f / (std ? std[i] : 1.f); }
+    p.scale = scale; p.swap_rb = swap_rb;
+    rd::launch_crop_resize_norm_batch(p, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

@@ -528,4 +528,56 @@ void launch_preproc_resize_norm(const PreprocParams& p, hipStream_t s) {
     hipLaunchKernelGGL(preproc_kernel, dim3(grid_for((long)p.OH * p.OW)), dim3(256), 0, s, p);
 }
 
+
+__global__ void __launch_bounds__(256) crop_batch_kernel(CropBatchParams p) {
+    const int i = blockIdx.y;
+    const CropDesc d = p.descs[i];
+    const long plane = (long)p.OH * p.OWp;
+    float* dst = p.dst + (size_t)i * 3 * plane;
+    const uint8_t* src = p.pages + (size_t)d.page * p.page_stride;
+    const float sx = d.rot90 ? d.crop_h / d.out_w : d.crop_w / d.out_w;
+    const float sy = d.rot90 ? d.crop_w / p.OH : d.crop_h / p.OH;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < plane; idx += (long)gridDim.x * 256) {
+        const int ox = idx % p.OWp, oy = idx / p.OWp;
+        float out[3] = {0.f, 0.f, 0.f};
+        const bool inside = ox < d.out_w;
+        if (inside) {
+            // resized-line pixel -> (possibly rotated) crop pixel centre
+            float u = (ox + 0.5f) * sx - 0.5f, v = (oy + 0.5f) * sy - 0.5f;
+            float cx = u, cy = v;
+            if (d.rot90) {  // np.rot90(crop): rotated[r][c] = crop[c][Wc-1-r]
+                cx = d.crop_w - 1.f - v;
+                cy = u;
+            }
+            cx = fminf(fmaxf(cx, 0.f), d.crop_w - 1.f);
+            cy = fminf(fmaxf(cy, 0.f), d.crop_h - 1.f);
+            const float wq = d.m[6] * cx + d.m[7] * cy + d.m[8];
+            float px = (d.m[0] * cx + d.m[1] * cy + d.m[2]) / wq;
+            float py = (d.m[3] * cx + d.m[4] * cy + d.m[5]) / wq;
+            px = fminf(fmaxf(px, 0.f), (float)(p.W - 1));  // BORDER_REPLICATE
+            py = fminf(fmaxf(py, 0.f), (float)(p.H - 1));
+            const int x0 = (int)px, y0 = (int)py;
+            const int x1 = min(x0 + 1, p.W - 1), y1 = min(y0 + 1, p.H - 1);
+            const float tx = px - x0, ty = py - y0;
+            const uint8_t* r0 = src + ((size_t)y0 * p.W) * 3;
+            const uint8_t* r1 = src + ((size_t)y1 * p.W) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float a = r0[x0 * 3 + c], b = r0[x1 * 3 + c], e = r1[x0 * 3 + c], f = r1[x1 * 3 + c];
+                out[c] = (a * (1.f - tx) + b * tx) * (1.f - ty) + (e * (1.f - tx) + f * tx) * ty;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int sc = p.swap_rb ? 2 - c : c;
+            dst[(size_t)c * plane + idx] = inside ? (out[sc] * p.scale - p.mean[c]) * p.inv_std[c] : 0.f;
+        }
+    }
+}
+void launch_crop_resize_norm_batch(const CropBatchParams& p, hipStream_t s) {
+    if (p.n <= 0) return;
+    const long plane = (long)p.OH * p.OWp;
+    hipLaunchKernelGGL(crop_batch_kernel, dim3(grid_for(plane, 256, 64), p.n), dim3(256), 0, s, p);
+}
+
 }  // namespace rd

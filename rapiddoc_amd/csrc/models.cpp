@@ -162,7 +162,7 @@ void build_ppocrv6_det(Builder& b, int B, int H, int W) {
 // ---------------------------------------------------------------------------------------------------
 void build_ppocrv6_rec(Builder& b, int B, int H, int W, int flags) {
     RD_CHECK(H == 48, "rec input height must be 48");
-    RD_CHECK(W % 8 == 0 && W >= 16, "rec input width must be a multiple of 8 (>= 16)");
+    RD_CHECK(W >= 16, "rec input width must be >= 16");
     TView x = b.external(0, B, H, W, 3);
     std::vector<TView> f = lcnetv4(b, x, kRecSmall, 48, 96, false);
     TView pooled = b.avgpool3x2(f[0]);  // [B,1,W/8,384]

@@ -115,4 +115,24 @@ struct PreprocParams {
 };
 void launch_preproc_resize_norm(const PreprocParams& p, hipStream_t s);
 
+// Text-line crops for the recogniser, one launch per rec batch: for crop i, output pixel (ox, oy) of the
+// 48 x out_w[i] resized line maps to crop coordinates, then through the 3x3 matrix m (crop -> page, i.e. the
+// inverse of the reference's cv2.getPerspectiveTransform in utils/ocr_utils.py:494-536) to a bilinear sample
+// of page `page`; columns >= out_w[i] are zero (rapidocr resize_norm_img right-pads with 0).
+struct CropDesc {
+    int32_t page;     // index into the page batch
+    int32_t out_w;    // resized width (<= padded batch width)
+    float crop_w, crop_h;
+    float m[9];
+    int32_t rot90;    // 1: the crop is rotated by 90 deg counter-clockwise first (h/w >= 1.5 rule, ocr_utils.py:531-535)
+    int32_t pad_;
+};
+struct CropBatchParams {
+    const uint8_t* pages; int H, W; size_t page_stride;   // [P][H][W][3] u8
+    const CropDesc* descs; int n;
+    float* dst; int OH, OWp;                               // [n][3][OH][OWp]
+    float mean[3], inv_std[3]; float scale; int swap_rb;
+};
+void launch_crop_resize_norm_batch(const CropBatchParams& p, hipStream_t s);
+
 }  // namespace rd

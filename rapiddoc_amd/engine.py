@@ -37,6 +37,8 @@ class RdEngine:
         if not self._h:
             raise EngineError(self._l.rd_create_error().decode())
         self._tdev = torch.device("cuda", device)
+        self._profiling = False
+        self.profile_log: List[dict] = []
 
     def close(self):
         if getattr(self, "_h", None):
@@ -84,6 +86,7 @@ class RdEngine:
         B, Cc, H, W_ = x.shape
         out = torch.empty((B, 1, H, W_), dtype=torch.float32, device=x.device)
         self._chk(self._l.rd_det_forward(self._h, x.data_ptr(), B, H, W_, out.data_ptr(), None, 0, _stream_ptr()))
+        self._log()
         return out
 
     def rec_forward(self, x: torch.Tensor, flags: int = 0) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
@@ -91,7 +94,7 @@ class RdEngine:
         B, Cc, H, W_ = x.shape
         if H != 48:
             raise EngineError("rec input height must be 48")
-        T = W_ // 8
+        T = self._l.rd_rec_seq_len(W_)
         idx = torch.empty((B, T), dtype=torch.int32, device=x.device)
         prob = torch.empty((B, T), dtype=torch.float32, device=x.device)
         full = None
@@ -99,6 +102,7 @@ class RdEngine:
             full = torch.empty((B, T, self.num_classes), dtype=torch.float32, device=x.device)
         self._chk(self._l.rd_rec_forward(self._h, x.data_ptr(), B, W_, idx.data_ptr(), prob.data_ptr(),
                                          full.data_ptr() if full is not None else None, flags, None, 0, _stream_ptr()))
+        self._log()
         return idx, prob, full
 
     def backbone_forward(self, x: torch.Tensor) -> List[torch.Tensor]:
@@ -109,11 +113,17 @@ class RdEngine:
                  for c, s in zip(chans, (4, 8, 16, 32))]
         arr = (C.c_void_p * 4)(*[f.data_ptr() for f in feats])
         self._chk(self._l.rd_backbone_forward(self._h, x.data_ptr(), B, H, W_, arr, None, 0, _stream_ptr()))
+        self._log()
         return feats
 
     # ------------------------------------------------------------------ profiling
     def set_profiling(self, on: bool):
         self._chk(self._l.rd_set_profiling(self._h, 1 if on else 0))
+        self._profiling = bool(on)
+
+    def _log(self):
+        if self._profiling:
+            self.profile_log.extend(self.profile())
 
     def profile(self) -> List[dict]:
         return json.loads(self._l.rd_profile_json(self._h).decode())

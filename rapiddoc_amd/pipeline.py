@@ -1,0 +1,184 @@
+"""Device-resident page-batch hot path: layout backbone -> OCR det -> line crops -> OCR rec -> CTC decode.
+
+Mirrors the stage order of the reference's `BatchAnalyze.__call__`
+(rapid_doc/backend/pipeline/batch_analyze.py:78-164) for the stages whose networks are readable in the
+reference: page images stay in HBM as u8 HWC, every resize / normalise / crop is a HIP
+kernel, the three forwards run through the C-ABI, and only (idx, prob) per CTC time step and the text-line
+boxes cross PCIe.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, ocr_host
+from .engine import RdEngine, preproc_resize_norm
+
+LAYOUT_SIZE = 800          # PP-DocLayout-L/plus-L/V2/V3 input (pp_doclayout/main.py:17-29)
+DET_LIMIT = 960            # rapidocr Det.limit_side_len (rapid_ocr.py:517-518)
+
+
+class CropDesc(C.Structure):
+    _fields_ = [("page", C.c_int32), ("out_w", C.c_int32), ("crop_w", C.c_float), ("crop_h", C.c_float),
+                ("m", C.c_float * 9), ("rot90", C.c_int32), ("pad_", C.c_int32)]
+
+
+CROP_DTYPE = np.dtype([("page", "<i4"), ("out_w", "<i4"), ("crop_w", "<f4"), ("crop_h", "<f4"), ("m", "<f4", (9,)),
+                       ("rot90", "<i4"), ("pad_", "<i4")])
+assert CROP_DTYPE.itemsize == C.sizeof(CropDesc)
+
+
+def quad_to_crop_matrix(quad: np.ndarray) -> Tuple[np.ndarray, float, float]:
+    """Inverse of the reference's perspective rectification (utils/ocr_utils.py:494-536): returns the 3x3 matrix
+    that maps rectified-crop pixel (x, y, 1) to page coordinates plus the crop size.  `quad`: 4x2 points
+    (tl, tr, br, bl)."""
+    q = np.asarray(quad, dtype=np.float64).reshape(4, 2)
+    cw = max(np.linalg.norm(q[0] - q[1]), np.linalg.norm(q[2] - q[3]))
+    ch = max(np.linalg.norm(q[0] - q[3]), np.linalg.norm(q[1] - q[2]))
+    cw, ch = float(int(cw)), float(int(ch))  # ocr_utils.py:508-519 casts to int
+    cw, ch = max(cw, 1.0), max(ch, 1.0)
+    src = np.array([[0, 0], [cw, 0], [cw, ch], [0, ch]], dtype=np.float64)
+    # solve the homography src -> q (8 unknowns)
+    A, b = [], []
+    for (x, y), (u, v) in zip(src, q):
+        A.append([x, y, 1, 0, 0, 0, -u * x, -u * y]); b.append(u)
+        A.append([0, 0, 0, x, y, 1, -v * x, -v * y]); b.append(v)
+    h = np.linalg.solve(np.asarray(A), np.asarray(b))
+    return np.append(h, 1.0).astype(np.float32), cw, ch
+
+
+def boxes_to_quads(boxes_xyxy: np.ndarray) -> np.ndarray:
+    b = np.asarray(boxes_xyxy, dtype=np.float32).reshape(-1, 4)
+    return np.stack([b[:, [0, 1]], b[:, [2, 1]], b[:, [2, 3]], b[:, [0, 3]]], axis=1)
+
+
+@dataclass
+class PageResult:
+    lines: List[Tuple[np.ndarray, str, float]] = field(default_factory=list)  # (quad 4x2, text, score)
+    layout_feats: Optional[List[torch.Tensor]] = None
+
+
+class PagePipeline:
+    def __init__(self, states: Dict[str, object], device: int = 0, characters: Optional[Sequence[str]] = None,
+                 rec_batch_num: int = 64, rec_width_multiple: int = 32, keep_feats: bool = False):
+        """`states`: {'ppocrv6_det': ..., 'ppocrv6_rec': ..., 'pphgnetv2_b4': ...}, each a .safetensors path,
+        bytes, or name->ndarray dict."""
+        self.device = device
+        self.tdev = torch.device("cuda", device)
+        self.det = RdEngine("ppocrv6_det", device).load_weights(states["ppocrv6_det"])
+        self.rec = RdEngine("ppocrv6_rec", device).load_weights(states["ppocrv6_rec"])
+        self.layout = RdEngine("pphgnetv2_b4", device).load_weights(states["pphgnetv2_b4"]) if "pphgnetv2_b4" in states else None
+        ncls = self.rec.num_classes
+        self.characters = list(characters) if characters is not None else ["blank"] + [chr(0x4E00 + i) for i in range(ncls - 2)] + [" "]
+        assert len(self.characters) == ncls, (len(self.characters), ncls)
+        self.rec_batch_num = rec_batch_num
+        self.rec_width_multiple = rec_width_multiple
+        self.keep_feats = keep_feats
+        self._lib = _lib.load()
+        self.stats: Dict[str, float] = {}
+
+    # ---------------------------------------------------------------- stages
+    def layout_forward(self, pages: torch.Tensor) -> List[torch.Tensor]:
+        P = pages.shape[0]
+        x = torch.empty((P, 3, LAYOUT_SIZE, LAYOUT_SIZE), dtype=torch.float32, device=pages.device)
+        for i in range(P):  # PPPreProcess: INTER_CUBIC resize, /255, mean 0 / std 1 (pre_process.py:14-42)
+            preproc_resize_norm(pages[i], (LAYOUT_SIZE, LAYOUT_SIZE), interp=2, out=x[i])
+        return self.layout.backbone_forward(x)
+
+    def det_forward(self, pages: torch.Tensor) -> Tuple[torch.Tensor, Tuple[int, int]]:
+        P, H, W, _ = pages.shape
+        # 64-px bucket of the page region with its 50-px white margin, then DetPreProcess (analyze_utils.py:129-188)
+        bh, bw = -(-(H + 100) // 64) * 64, -(-(W + 100) // 64) * 64
+        dh, dw = ocr_host.det_resize_shape(bh, bw, DET_LIMIT, "max")
+        x = torch.empty((P, 3, dh, dw), dtype=torch.float32, device=pages.device)
+        for i in range(P):  # BGR, (x/255 - 0.5)/0.5
+            preproc_resize_norm(pages[i], (dh, dw), mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), interp=1, swap_rb=True, out=x[i])
+        return self.det.det_forward(x), (dh, dw)
+
+    def rec_forward_lines(self, pages: torch.Tensor, quads_per_page: Sequence[np.ndarray]):
+        """All text lines of the page batch -> [(text, score)] per page, reference batching order
+        (rapid_ocr.py:404-472) with a GPU-sized rec_batch_num."""
+        P, H, W, _ = pages.shape
+        page_of, mats, cws, chs, rots = [], [], [], [], []
+        for pi, quads in enumerate(quads_per_page):
+            for q in np.asarray(quads, dtype=np.float32).reshape(-1, 4, 2):
+                m, cw, ch = quad_to_crop_matrix(q)
+                rot = 1 if ch / cw >= 1.5 else 0  # ocr_utils.py:531-535 rotates tall crops
+                page_of.append(pi); mats.append(m); cws.append(cw); chs.append(ch); rots.append(rot)
+        n = len(page_of)
+        texts: List[Tuple[str, float]] = [("", 0.0)] * n
+        if n == 0:
+            return [[] for _ in range(P)]
+        cws_a, chs_a, rots_a = np.asarray(cws), np.asarray(chs), np.asarray(rots)
+        eff_w = np.where(rots_a == 1, chs_a, cws_a)
+        eff_h = np.where(rots_a == 1, cws_a, chs_a)
+        ratios = (eff_w / eff_h).tolist()
+        batches = ocr_host.rec_batches(ratios, self.rec_batch_num, width_multiple=self.rec_width_multiple)
+        descs = np.zeros(n, dtype=CROP_DTYPE)
+        order_all = np.concatenate([c for c, _ in batches])
+        pos = 0
+        for chunk, wpad in batches:
+            for i in chunk:
+                d = descs[pos]
+                d["page"] = page_of[i]
+                d["out_w"] = ocr_host.rec_resized_width(eff_w[i], eff_h[i], wpad)
+                d["crop_w"], d["crop_h"] = cws[i], chs[i]
+                d["m"] = mats[i]
+                d["rot90"] = rots[i]
+                pos += 1
+        descs_dev = torch.from_numpy(descs.view(np.uint8)).to(pages.device, non_blocking=True)
+        mean = (C.c_float * 3)(0.5, 0.5, 0.5)
+        std = (C.c_float * 3)(0.5, 0.5, 0.5)
+        stream = torch.cuda.current_stream().cuda_stream
+        outs = []
+        pos = 0
+        for chunk, wpad in batches:
+            nb = len(chunk)
+            x = torch.empty((nb, 3, ocr_host.REC_IMG_H, wpad), dtype=torch.float32, device=pages.device)
+            rc = self._lib.rd_crop_resize_norm_batch(
+                self.device, pages.data_ptr(), P, H, W, descs_dev.data_ptr() + pos * CROP_DTYPE.itemsize, nb,
+                ocr_host.REC_IMG_H, wpad, mean, std, 1.0 / 255.0, 1, x.data_ptr(), stream)
+            if rc != 0:
+                raise RuntimeError("rd_crop_resize_norm_batch failed")
+            idx, prob, _ = self.rec.rec_forward(x)
+            outs.append((idx, prob))
+            pos += nb
+        # one sync + D2H per batch result (small), then host CTC decode (rapidocr CTCLabelDecode)
+        pos = 0
+        for (chunk, wpad), (idx, prob) in zip(batches, outs):
+            dec = ocr_host.ctc_decode(idx.cpu().numpy(), prob.cpu().numpy(), self.characters)
+            for j, i in enumerate(chunk):
+                t, s = dec[j]
+                texts[i] = (t, ocr_host.format_score(s))
+        per_page: List[List[Tuple[str, float]]] = [[] for _ in range(P)]
+        for i, pi in enumerate(page_of):
+            per_page[pi].append(texts[i])
+        self.stats["rec_lines"] = n
+        self.stats["rec_batches"] = len(batches)
+        return per_page
+
+    # ---------------------------------------------------------------- whole batch
+    def run_batch(self, pages: torch.Tensor, quads_per_page: Optional[Sequence[np.ndarray]] = None) -> List[PageResult]:
+        """pages: [P,H,W,3] uint8 RGB on the GPU.  quads_per_page: text-line quads in page pixels (from the DB
+        post-process of the det map; the synthetic benchmark passes the generator's own line boxes)."""
+        assert pages.is_cuda and pages.dtype == torch.uint8 and pages.dim() == 4
+        P = pages.shape[0]
+        results = [PageResult() for _ in range(P)]
+        if self.layout is not None:
+            feats = self.layout_forward(pages)
+            if self.keep_feats:
+                for i in range(P):
+                    results[i].layout_feats = [f[i] for f in feats]
+        prob_maps, det_hw = self.det_forward(pages)
+        self.last_det = (prob_maps, det_hw)
+        if quads_per_page is None:
+            raise NotImplementedError("DB post-process (det map -> boxes) is not built yet; pass quads_per_page")
+        texts = self.rec_forward_lines(pages, quads_per_page)
+        for i in range(P):
+            qs = np.asarray(quads_per_page[i], dtype=np.float32).reshape(-1, 4, 2)
+            results[i].lines = [(qs[j], t, s) for j, (t, s) in enumerate(texts[i])]
+        return results
