@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--pages", type=int, default=PAGES_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-profile", type=str, default="")
+    ap.add_argument("--rec-batch", type=int, default=64)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,7 +99,7 @@ def main():
     from rapiddoc_amd.dist import gather_page_results
 
     states = load_states()
-    pipe = PagePipeline(states, device=local_rank)
+    pipe = PagePipeline(states, device=local_rank, rec_batch_num=args.rec_batch)
     P = args.pages
     pages_np, boxes = synth_batch(rank * P, P)
     pages = torch.from_numpy(pages_np).cuda()
@@ -158,6 +159,8 @@ def main():
                 "all_mfma_kernels_tflops": round(sum(v[0] for v in mfma.values()) / (sum(v[2] for v in mfma.values()) * 1e-3) / 1e12, 3),
                 "step_kernel_ms": round(tot_ms, 2)}
         if args.dump_profile:
+            with open(args.dump_profile + ".ops.json", "w") as f:
+                json.dump({"det": pipe.det.profile_log, "rec": pipe.rec.profile_log, "layout": pipe.layout.profile_log}, f)
             table = sorted(((k, v[3], v[2], v[0] / 1e9, v[1] / 1e6) for k, v in agg.items()), key=lambda r: -r[2])
             with open(args.dump_profile, "w") as f:
                 f.write("kernel,launches,total_ms,gflop,algorithmic_MB,TFLOPs,GBs\n")

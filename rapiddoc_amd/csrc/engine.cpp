@@ -305,28 +305,7 @@ TView Builder::conv(const std::string& wname, const std::string& bname, const st
     const int K = kh * kw * cin;
     const std::string key = wname + "|" + bn;
     if (!planning()) {
-        if (!pb_->has(key + "#w")) {
-            std::vector<float> shift;
-            std::vector<float> scale = bn_scale_shift(bn, cout, shift);
-            std::vector<float> wf((size_t)cout * K);
-            const float* src = w.f32();
-            for (int co = 0; co < cout; ++co)
-                for (int ci = 0; ci < cin; ++ci)
-                    for (int a = 0; a < kh; ++a)
-                        for (int b = 0; b < kw; ++b)
-                            wf[(size_t)co * K + (a * kw + b) * cin + ci] =
-                                src[(((size_t)co * cin + ci) * kh + a) * kw + b] * scale[co];
-            std::vector<float> bias(cout, 0.f);
-            bool any_bias = !bn.empty();
-            if (!bname.empty()) {
-                const float* bs = ws_->get(bname).f32();
-                for (int co = 0; co < cout; ++co) bias[co] = bs[co] * scale[co];
-                any_bias = true;
-            }
-            for (int co = 0; co < cout; ++co) bias[co] += shift[co];
-            pb_->add(key + "#w", wf);
-            if (any_bias) pb_->add(key + "#b", bias);
-        }
+        fold_conv(wname, bname, bn);
         return y;
     }
     ConvParams p{};
@@ -345,6 +324,7 @@ TView Builder::conv(const std::string& wname, const std::string& bname, const st
     r.name = wname;
     r.kind = (kh == 1 && kw == 1) ? "conv1x1" : "conv" + std::to_string(kh) + "x" + std::to_string(kw);
     r.cfg = conv_igemm_config_name(p);
+    r.shape = "M" + std::to_string(p.M) + "_K" + std::to_string(K) + "_N" + std::to_string(cout);
     r.flops = 2.0 * p.M * (double)K * cout;
     r.bytes = 4.0 * ((double)x.pixels() * cin + (double)p.M * cout * (res ? 2 : 1) + (double)cout * K);
     const TView xv = x, yv = y;
@@ -357,6 +337,75 @@ TView Builder::conv(const std::string& wname, const std::string& bname, const st
         q.res = has_res ? pl.vptr(rv, c) : nullptr;
         q.ascale = has_as ? pl.vptr(av, c) : nullptr;
         launch_conv_igemm(q, c.stream);
+    };
+    emit(std::move(r));
+    return y;
+}
+
+void Builder::fold_conv(const std::string& wname, const std::string& bname, const std::string& bn) {
+    const std::string key = wname + "|" + bn;
+    if (pb_->has(key + "#w")) return;
+    const HostTensor& w = ws_->get(wname);
+    const int cout = (int)w.shape[0], cin = (int)w.shape[1];
+    const int kh = w.shape.size() == 4 ? (int)w.shape[2] : 1, kw = w.shape.size() == 4 ? (int)w.shape[3] : 1;
+    const int K = kh * kw * cin;
+    std::vector<float> shift;
+    std::vector<float> scale = bn_scale_shift(bn, cout, shift);
+    std::vector<float> wf((size_t)cout * K);
+    const float* src = w.f32();
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int a = 0; a < kh; ++a)
+                for (int b = 0; b < kw; ++b)
+                    wf[(size_t)co * K + (a * kw + b) * cin + ci] = src[(((size_t)co * cin + ci) * kh + a) * kw + b] * scale[co];
+    std::vector<float> bias(cout, 0.f);
+    bool any_bias = !bn.empty();
+    if (!bname.empty()) {
+        const float* bs = ws_->get(bname).f32();
+        for (int co = 0; co < cout; ++co) bias[co] = bs[co] * scale[co];
+        any_bias = true;
+    }
+    for (int co = 0; co < cout; ++co) bias[co] += shift[co];
+    pb_->add(key + "#w", wf);
+    if (any_bias) pb_->add(key + "#b", bias);
+}
+
+TView Builder::mixer_fused(const std::string& prefix, const TView& x, const TView* gate) {
+    // prefix.channel_conv1 / channel_conv2 (+ normalization), residual block: out channels == in channels
+    const std::string w1 = prefix + ".channel_conv1.convolution.weight", bn1 = prefix + ".channel_conv1.normalization";
+    const std::string w2 = prefix + ".channel_conv2.convolution.weight", bn2 = prefix + ".channel_conv2.normalization";
+    const int C = x.c;
+    RD_CHECK(mixer_fused_supported(C), "mixer_fused: unsupported width");
+    RD_CHECK(weight_dim(w1, 0) == 2 * C && weight_dim(w1, 1) == C && weight_dim(w2, 0) == C && weight_dim(w2, 1) == 2 * C,
+             "mixer_fused: weight shapes: " + prefix);
+    TView y = alloc(x.n, x.h, x.w, C);
+    if (!planning()) {
+        fold_conv(w1, "", bn1);
+        fold_conv(w2, "", bn2);
+        return y;
+    }
+    MixerParams p{};
+    p.xld = plan_->ld(x);
+    p.yld = plan_->ld(y);
+    p.M = (int)x.pixels(); p.HW = x.h * x.w; p.C = C;
+    p.w1 = pb_->ptr(w1 + "|" + bn1 + "#w"); p.b1 = pb_->ptr(w1 + "|" + bn1 + "#b");
+    p.w2 = pb_->ptr(w2 + "|" + bn2 + "#w"); p.b2 = pb_->ptr(w2 + "|" + bn2 + "#b");
+    OpRecord r;
+    r.name = prefix + ".mixer";
+    r.kind = "mixer_fused";
+    r.cfg = "C" + std::to_string(C);
+    r.shape = "M" + std::to_string(p.M) + "_C" + std::to_string(C);
+    r.flops = 8.0 * p.M * (double)C * C;
+    r.bytes = 8.0 * p.M * C;
+    const TView xv = x, yv = y;
+    const bool has_gate = gate != nullptr;
+    const TView gv = gate ? *gate : TView{};
+    r.run = [p, xv, yv, gv, has_gate](const Plan& pl, const RunCtx& c) {
+        MixerParams q = p;
+        q.x = pl.vptr(xv, c);
+        q.y = pl.vptr(yv, c);
+        q.gate = has_gate ? pl.vptr(gv, c) : nullptr;
+        launch_mixer_fused(q, c.stream);
     };
     emit(std::move(r));
     return y;
@@ -476,7 +525,7 @@ TView Builder::stem3x3s2(const std::string& wname, const std::string& bn, const 
 }
 
 TView Builder::dwconv(const std::string& wname, const std::string& bname, const std::string& bn, const TView& x,
-                      const ConvGeom& g, int act, const TView* out, const TView* res) {
+                      const ConvGeom& g, int act, const TView* out, const TView* res, GapOut* gap) {
     const HostTensor& w = ws_->get(wname);
     RD_CHECK(w.shape.size() == 4 && w.shape[1] == 1, "depthwise weight shape: " + wname);
     const int c = (int)w.shape[0], kh = (int)w.shape[2], kw = (int)w.shape[3];
@@ -486,6 +535,13 @@ TView Builder::dwconv(const std::string& wname, const std::string& bname, const 
     TView y = out ? *out : alloc(x.n, oh, ow, c);
     RD_CHECK(y.h == oh && y.w == ow && y.c == c, "depthwise output view mismatch: " + wname);
     const std::string key = wname + "|" + bn + "|dw";
+    if (gap) {
+        DwParams gp{};
+        gp.N = x.n; gp.H = x.h; gp.W = x.w; gp.C = c; gp.OH = oh; gp.OW = ow;
+        gp.KH = kh; gp.KW = kw; gp.SH = g.sh; gp.SW = g.sw;
+        gap->chunks = dwconv_gap_chunks(gp);
+        if (gap->chunks > 0) gap->partial = alloc_raw((size_t)x.n * gap->chunks * c);
+    }
     if (!planning()) {
         if (!pb_->has(key + "#w")) {
             std::vector<float> shift;
@@ -522,11 +578,14 @@ TView Builder::dwconv(const std::string& wname, const std::string& bname, const 
     const TView xv = x, yv = y;
     const bool has_res = res != nullptr;
     const TView rv = res ? *res : TView{};
-    r.run = [p, xv, yv, rv, has_res](const Plan& pl, const RunCtx& cx) {
+    const bool has_gap = gap && gap->chunks > 0;
+    const TView gpv = has_gap ? gap->partial : TView{};
+    r.run = [p, xv, yv, rv, has_res, has_gap, gpv](const Plan& pl, const RunCtx& cx) {
         DwParams q = p;
         q.x = pl.vptr(xv, cx);
         q.y = pl.vptr(yv, cx);
         q.res = has_res ? pl.vptr(rv, cx) : nullptr;
+        q.gap_partial = has_gap ? pl.vptr(gpv, cx) : nullptr;
         launch_dwconv(q, cx.stream);
     };
     emit(std::move(r));
@@ -564,13 +623,14 @@ TView Builder::avgpool3x2(const TView& x) {
 }
 
 TView Builder::se_gate(const std::string& w1n, const std::string& b1n, const std::string& w2n, const std::string& b2n,
-                       const TView& x, int gate_act) {
+                       const TView& x, int gate_act, const GapOut* pre) {
     const HostTensor& w1 = ws_->get(w1n);
     const int cr = (int)w1.shape[0], c = (int)w1.shape[1];
     RD_CHECK(c == x.c && c % 4 == 0, "SE channel mismatch: " + w1n);
     const int hw = x.h * x.w;
-    int chunks = std::max(1, std::min(64, hw / 256));
-    TView partial = alloc_raw((size_t)x.n * chunks * c);
+    const bool fused_gap = pre && pre->chunks > 0;  // the producing depthwise conv already wrote the partial sums
+    const int chunks = fused_gap ? pre->chunks : std::max(1, std::min(64, hw / 256));
+    TView partial = fused_gap ? pre->partial : alloc_raw((size_t)x.n * chunks * c);
     TView gate = alloc(x.n, 1, 1, c);
     if (!planning()) {
         if (!pb_->has(w1n)) {
@@ -583,7 +643,7 @@ TView Builder::se_gate(const std::string& w1n, const std::string& b1n, const std
         release(partial);
         return gate;
     }
-    {
+    if (!fused_gap) {
         OpRecord r;
         r.name = w1n + ":gap";
         r.kind = "gap";
@@ -795,7 +855,9 @@ void Builder::ctc_head(const std::string& prefix, const TView& x, const TView& i
 // =================================================================================================
 // Engine
 // =================================================================================================
+extern bool g_disable_fused_mixer;
 Engine::Engine(int device, const std::string& kind) : device_(device), kind_(kind) {
+    if (const char* e = getenv("RD_DISABLE_FUSED_MIXER")) g_disable_fused_mixer = e[0] == '1';
     RD_CHECK(kind == "ppocrv6_det" || kind == "ppocrv6_rec" || kind == "pphgnetv2_b4", "unknown model kind '" + kind + "'");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -889,7 +951,7 @@ void Engine::run(int B, int H, int W, int flags, const std::vector<void*>& ext, 
         float ms = 0.f;
         RD_HIP(hipEventElapsedTime(&ms, events_[i], events_[i + 1]));
         const OpRecord& op = plan.ops[i];
-        profile_.push_back({op.name, op.kind, op.cfg, op.flops, op.bytes, ms});
+        profile_.push_back({op.name, op.kind, op.cfg, op.shape, op.flops, op.bytes, ms});
     }
 }
 
@@ -899,7 +961,8 @@ std::string Engine::profile_json() const {
     for (size_t i = 0; i < profile_.size(); ++i) {
         const ProfileEntry& e = profile_[i];
         if (i) os << ",";
-        os << "{\"name\":\"" << e.name << "\",\"kind\":\"" << e.kind << "\",\"cfg\":\"" << e.cfg << "\",\"flops\":" << e.flops
+        os << "{\"name\":\"" << e.name << "\",\"kind\":\"" << e.kind << "\",\"cfg\":\"" << e.cfg << "\",\"shape\":\"" << e.shape
+           << "\",\"flops\":" << e.flops
            << ",\"bytes\":" << e.bytes << ",\"ms\":" << e.ms << "}";
     }
     os << "]";

@@ -93,7 +93,7 @@ struct RunCtx {
 };
 
 struct OpRecord {
-    std::string name, kind, cfg;
+    std::string name, kind, cfg, shape;
     double flops = 0, bytes = 0;
     std::function<void(const struct Plan&, const RunCtx&)> run;
 };
@@ -112,7 +112,7 @@ struct Plan {
 };
 
 struct ProfileEntry {
-    std::string name, kind, cfg;
+    std::string name, kind, cfg, shape;
     double flops, bytes;
     float ms;
 };
@@ -143,18 +143,22 @@ class Builder {
     TView conv(const std::string& wname, const std::string& bname, const std::string& bn, const TView& x,
                const ConvGeom& g, int act, const TView* out = nullptr, const TView* res = nullptr,
                const TView* ascale = nullptr);
+    // fused PPLCNetV4 residual channel mixer (prefix.channel_conv1/2); gate = optional SE gate [N,1,1,C]
+    TView mixer_fused(const std::string& prefix, const TView& x, const TView* gate);
+    void fold_conv(const std::string& wname, const std::string& bname, const std::string& bn);
     TView linear(const std::string& prefix, const TView& x, int act, const TView* out = nullptr,
                  const TView* res = nullptr);
     TView deconv2x2(const std::string& wname, const std::string& bname, const std::string& bn, const TView& x, int act,
                     const TView* out = nullptr);
     TView stem3x3s2(const std::string& wname, const std::string& bn, const TView& x_nchw, int act);
+    struct GapOut { TView partial; int chunks = 0; };  // per-image partial sums of a layer's output (SE pooling)
     TView dwconv(const std::string& wname, const std::string& bname, const std::string& bn, const TView& x,
-                 const ConvGeom& g, int act, const TView* out = nullptr, const TView* res = nullptr);
+                 const ConvGeom& g, int act, const TView* out = nullptr, const TView* res = nullptr, GapOut* gap = nullptr);
     void maxpool2x2s1(const TView& x, const TView& out);
     TView avgpool3x2(const TView& x);
     // squeeze-excite gate s[n][c]; `w1/b1/w2/b2` full tensor names
     TView se_gate(const std::string& w1, const std::string& b1, const std::string& w2, const std::string& b2,
-                  const TView& x, int gate_act);
+                  const TView& x, int gate_act, const GapOut* pre = nullptr);
     void scale(const TView& x, const TView& gate, float alpha, const TView& out);
     void upsample(const TView& x, const TView& out, int f, bool accumulate);
     TView layernorm(const std::string& prefix, const TView& x, float eps);

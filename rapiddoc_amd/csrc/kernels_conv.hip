@@ -17,6 +17,8 @@
 //   * 1-D grid with a bijective XCD swizzle so that the n-tiles sharing an A panel run on one XCD (L2)
 #include "rd_kernels.h"
 
+#include <cstdlib>
+
 namespace rd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -25,10 +27,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static constexpr int BK = 32;
 static constexpr int BKP = 36;
 
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 round-off class): 1 exp + 1 rcp + 7 FMAs instead of
+// libm erff's ~60 instructions.  GELU(x) = x/2 * (1 + erf(x/sqrt2)) as nn.GELU() (approximate='none').
+__device__ __forceinline__ float gelu_fast(float v) {
+    const float z = fabsf(v) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float erfz = 1.f - poly * t * __expf(-z * z);
+    return 0.5f * v * (1.f + copysignf(erfz, v));
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
         case ACT_RELU: return fmaxf(v, 0.f);
-        case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        case ACT_GELU: return gelu_fast(v);
         case ACT_SILU: return v / (1.f + __expf(-v));
         case ACT_SIGMOID: {
             float r = 1.f / (1.f + __expf(-v));
@@ -65,76 +80,79 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(ConvParams p, i
     const int lrow = tid >> 3, lkq = tid & 7;
     const int K = p.K;
 
-    // ---- per-thread A row bookkeeping (fixed over the K loop)
+    // ---- per-thread A row bookkeeping (fixed over the K loop).  Invalid rows / taps / K-tail quads are redirected to
+    // a safe address and zeroed after the load, so that every global load of a K tile is issued unconditionally and
+    // back to back (a conditional load is fenced by its own s_waitcnt and serialises the whole tile fetch).
     const float* arow[AL];
+    bool avalid[AL];
     int a_ih0[AL], a_iw0[AL];
-    const float* asc[AL];
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
         const int m = m0 + lrow + 32 * i;
-        asc[i] = nullptr;
-        if (m < p.M) {
-            if (IS1X1) {
-                arow[i] = p.x + (size_t)m * p.xld;
-                a_ih0[i] = a_iw0[i] = 0;
-                if (p.ascale) asc[i] = p.ascale + (size_t)(m / (p.OH * p.OW)) * p.Cin;
-            } else {
-                const int ohw = p.OH * p.OW;
-                const int b = m / ohw, rem = m - b * ohw;
-                const int oh = rem / p.OW, ow = rem - oh * p.OW;
-                a_ih0[i] = oh * p.SH - p.PT;
-                a_iw0[i] = ow * p.SW - p.PL;
-                arow[i] = p.x + (size_t)b * p.H * p.W * p.xld;
-            }
+        avalid[i] = m < p.M;
+        const int mm = avalid[i] ? m : 0;
+        if (IS1X1) {
+            arow[i] = p.x + (size_t)mm * p.xld;
+            a_ih0[i] = a_iw0[i] = 0;
         } else {
-            arow[i] = nullptr;
-            a_ih0[i] = a_iw0[i] = -(1 << 28);
+            const int ohw = p.OH * p.OW;
+            const int b = mm / ohw, rem = mm - b * ohw;
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            a_ih0[i] = avalid[i] ? oh * p.SH - p.PT : -(1 << 28);
+            a_iw0[i] = ow * p.SW - p.PL;
+            arow[i] = p.x + (size_t)b * p.H * p.W * p.xld;
         }
     }
     const float* brow[BL];
+    bool bvalid[BL];
 #pragma unroll
     for (int i = 0; i < BL; ++i) {
         const int n = n0 + lrow + 32 * i;
-        brow[i] = (n < p.Ng) ? p.w + (size_t)n * K : nullptr;
+        bvalid[i] = n < p.Ng;
+        brow[i] = p.w + (size_t)(bvalid[i] ? n : 0) * K;
     }
 
     f32x4 areg[AL], breg[BL];
+    unsigned amask = 0, bmask = 0;  // validity of the quads in flight; applied when they are written to LDS, so that
+                                    // nothing consumes a load result (and waits for it) before the MFMAs of this tile
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     auto load_tiles = [&](int k0) {
         const int k = k0 + 4 * lkq;
         const bool kvalid = k < K;
+        const int kk = kvalid ? k : 0;
+        amask = bmask = 0;
         if (IS1X1) {
 #pragma unroll
             for (int i = 0; i < AL; ++i) {
-                f32x4 v = zero4;
-                if (kvalid && arow[i]) {
-                    v = *reinterpret_cast<const f32x4*>(arow[i] + k);
-                    if (asc[i]) v *= *reinterpret_cast<const f32x4*>(asc[i] + k);
-                }
-                areg[i] = v;
+                areg[i] = *reinterpret_cast<const f32x4*>(arow[i] + kk);
+                amask |= (unsigned)(kvalid && avalid[i]) << i;
             }
         } else {
-            const int tap = k / p.Cin, ci = k - tap * p.Cin;
+            const int tap = kk / p.Cin, ci = kk - tap * p.Cin;
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
 #pragma unroll
             for (int i = 0; i < AL; ++i) {
                 const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
-                f32x4 v = zero4;
-                if (kvalid && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-                    v = *reinterpret_cast<const f32x4*>(arow[i] + ((size_t)ih * p.W + iw) * p.xld + ci);
-                areg[i] = v;
+                const bool ok = kvalid && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                const size_t off = ok ? ((size_t)ih * p.W + iw) * p.xld + ci : 0;
+                areg[i] = *reinterpret_cast<const f32x4*>(arow[i] + off);
+                amask |= (unsigned)ok << i;
             }
         }
 #pragma unroll
-        for (int i = 0; i < BL; ++i)
-            breg[i] = (kvalid && brow[i]) ? *reinterpret_cast<const f32x4*>(brow[i] + k) : zero4;
+        for (int i = 0; i < BL; ++i) {
+            breg[i] = *reinterpret_cast<const f32x4*>(brow[i] + kk);
+            bmask |= (unsigned)(kvalid && bvalid[i]) << i;
+        }
     };
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int i = 0; i < AL; ++i) *reinterpret_cast<f32x4*>(&As[(lrow + 32 * i) * BKP + 4 * lkq]) = areg[i];
+        for (int i = 0; i < AL; ++i)
+            *reinterpret_cast<f32x4*>(&As[(lrow + 32 * i) * BKP + 4 * lkq]) = ((amask >> i) & 1u) ? areg[i] : zero4;
 #pragma unroll
-        for (int i = 0; i < BL; ++i) *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * i) * BKP + 4 * lkq]) = breg[i];
+        for (int i = 0; i < BL; ++i)
+            *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * i) * BKP + 4 * lkq]) = ((bmask >> i) & 1u) ? breg[i] : zero4;
     };
 
     const int lane = tid & 63, wave = tid >> 6;
@@ -160,7 +178,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(ConvParams p, i
         const int ng = kleft >= BK ? 4 : (kleft + 7) >> 3;
         const float* ap = &As[((wm * TM) * 32 + l31) * BKP + 4 * lhi];
         const float* bp = &Bs[((wn * TN) * 32 + l31) * BKP + 4 * lhi];
-        for (int g = 0; g < ng; ++g) {
+        auto mma_group = [&](int g) {
             f32x4 af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(ap + i * 32 * BKP + g * 8);
@@ -173,7 +191,10 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(ConvParams p, i
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
-        }
+        };
+        // (software-pipelined fragment reads via sched_group_barrier and a plain full unroll both measured 8-15 %
+        //  slower than hipcc's own schedule of this loop at 3 waves/SIMD)
+        for (int g = 0; g < ng; ++g) mma_group(g);
         __syncthreads();
         if (more) {
             store_tiles();

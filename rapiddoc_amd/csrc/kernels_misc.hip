@@ -65,7 +65,113 @@ __global__ void __launch_bounds__(256) dwconv_kernel(DwParams p) {
         *reinterpret_cast<f32x4*>(p.y + (size_t)pix * p.yld + c) = acc;
     }
 }
+// Register-tiled variant: one thread = TW consecutive output pixels of one row x 4 channels.  The input row segment
+// ((TW-1)*SW + KW pixels) is loaded once per kernel row and reused by every tap: 3.75 loads per output for 3x3/s1
+// at TW = 8 instead of 9, which moves the kernel from L1-request-bound towards the HBM roofline.  Optionally emits
+// deterministic per-block partial sums of its OUTPUT for the squeeze-excite global average pool that follows
+// (rec_lcnetv4.py:228-229): partial[n][chunk][c].
+template <int KH, int KW, int SW, int TW>
+__global__ void __launch_bounds__(256) dwconv_tiled_kernel(DwParams p, int c4n, int groups_w, int groups, int gpb) {
+    constexpr int NCOL = (TW - 1) * SW + KW;
+    __shared__ f32x4 red[256];
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int lanes_p = blockDim.x / c4n;           // pixel-group lanes per block
+    const int c4 = threadIdx.x % c4n, pl = threadIdx.x / c4n;
+    const int c = c4 << 2;
+    const float* xb = p.x + (size_t)n * p.H * p.W * p.xld + c;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 bias = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c) : zero4;
+    f32x4 gsum = zero4;
+    const int g_end = min(groups, (chunk + 1) * gpb);
+    for (int g = chunk * gpb + pl; g < g_end; g += lanes_p) {
+        const int oh = g / groups_w, ow0 = (g - oh * groups_w) * TW;
+        f32x4 acc[TW];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) acc[t] = bias;
+        const int ih0 = oh * p.SH - p.PT, iw0 = ow0 * SW - p.PL;
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+            const int ih = ih0 + kh;
+            if ((unsigned)ih >= (unsigned)p.H) continue;
+            const float* xr = xb + (size_t)ih * p.W * p.xld;
+            f32x4 row[NCOL];
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) {
+                const int iw = iw0 + j;
+                row[j] = ((unsigned)iw < (unsigned)p.W) ? *reinterpret_cast<const f32x4*>(xr + (size_t)iw * p.xld) : zero4;
+            }
+#pragma unroll
+            for (int kw = 0; kw < KW; ++kw) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(p.w + (size_t)(kh * KW + kw) * p.C + c);
+#pragma unroll
+                for (int t = 0; t < TW; ++t) acc[t] += row[t * SW + kw] * wv;
+            }
+        }
+        const size_t pix0 = ((size_t)n * p.OH + oh) * p.OW + ow0;
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+            if (ow0 + t < p.OW) {
+                f32x4 v = act4(acc[t], p.act);
+                if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (pix0 + t) * p.rld + c);
+                *reinterpret_cast<f32x4*>(p.y + (pix0 + t) * p.yld + c) = v;
+                gsum += v;
+            }
+        }
+    }
+    if (p.gap_partial) {
+        red[threadIdx.x] = gsum;
+        __syncthreads();
+        if (pl == 0) {
+            for (int r = 1; r < lanes_p; ++r) gsum += red[r * c4n + c4];
+            *reinterpret_cast<f32x4*>(p.gap_partial + ((size_t)n * gridDim.x + chunk) * p.C + c) = gsum;
+        }
+    }
+}
+
+// chunk geometry shared by the launcher and by the planner (which sizes the partial-sum buffer)
+static inline void dw_tiled_geom(const DwParams& p, int TW, int& c4n, int& threads, int& groups_w, int& groups, int& gpb,
+                                 int& chunks) {
+    c4n = p.C >> 2;
+    threads = (256 / c4n) * c4n;
+    groups_w = (p.OW + TW - 1) / TW;
+    groups = p.OH * groups_w;
+    const int lanes_p = threads / c4n;
+    gpb = lanes_p * 4;
+    // enough blocks to fill the chip a few times over, but not so many that the SE partial buffer explodes
+    while ((long)((groups + gpb - 1) / gpb) * p.N > 8192) gpb += lanes_p;
+    chunks = (groups + gpb - 1) / gpb;
+}
+static inline int dw_tiled_tw(const DwParams& p) {
+    if (p.C % 4 != 0 || (p.C >> 2) > 256) return 0;
+    if (p.KH == 3 && p.KW == 3 && (p.SW == 1 || p.SW == 2)) return p.SW == 1 ? 8 : 4;
+    if (p.KH == 5 && p.KW == 5 && p.SW == 1) return 8;
+    if (p.KH == 7 && p.KW == 7 && p.SW == 1) return 8;
+    return 0;
+}
+int dwconv_gap_chunks(const DwParams& p) {
+    const int tw = dw_tiled_tw(p);
+    if (!tw) return 0;
+    int c4n, threads, gw, g, gpb, chunks;
+    dw_tiled_geom(p, tw, c4n, threads, gw, g, gpb, chunks);
+    return chunks;
+}
+
 void launch_dwconv(const DwParams& p, hipStream_t s) {
+    const int tw = dw_tiled_tw(p);
+    if (tw) {
+        int c4n, threads, gw, g, gpb, chunks;
+        dw_tiled_geom(p, tw, c4n, threads, gw, g, gpb, chunks);
+        dim3 grid(chunks, p.N), block(threads);
+        if (p.KH == 3 && p.SW == 1)
+            hipLaunchKernelGGL((dwconv_tiled_kernel<3, 3, 1, 8>), grid, block, 0, s, p, c4n, gw, g, gpb);
+        else if (p.KH == 3)
+            hipLaunchKernelGGL((dwconv_tiled_kernel<3, 3, 2, 4>), grid, block, 0, s, p, c4n, gw, g, gpb);
+        else if (p.KH == 5)
+            hipLaunchKernelGGL((dwconv_tiled_kernel<5, 5, 1, 8>), grid, block, 0, s, p, c4n, gw, g, gpb);
+        else
+            hipLaunchKernelGGL((dwconv_tiled_kernel<7, 7, 1, 8>), grid, block, 0, s, p, c4n, gw, g, gpb);
+        return;
+    }
     const long total = (long)p.N * p.OH * p.OW * (p.C >> 2);
     hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for(total)), dim3(256), 0, s, p);
 }

@@ -31,6 +31,7 @@ static G geom_same_even(int k) {  // padding='same' with an even kernel / explic
 // PPLCNetV4
 // ---------------------------------------------------------------------------------------------------
 struct LcBlockCfg { int k, cin, cout, sh, sw; bool se; };
+bool g_disable_fused_mixer = false;  // RD_DISABLE_FUSED_MIXER=1: A/B switch for parity tests and profiling
 
 static TView lc_stem(Builder& b, const std::string& p, const TView& x_nchw, int c1, int c2) {
     auto cw = [&](const char* n) { return p + "." + n + ".convolution.weight"; };
@@ -57,11 +58,25 @@ static TView lc_block(Builder& b, const std::string& p, const TView& x, const Lc
     g.sh = c.sh;
     g.sw = c.sw;
     TView t;
-    if (rep) t = b.dwconv(p + ".token_conv.weight", p + ".token_conv.bias", "", x, g, ACT_NONE);
-    else t = b.dwconv(p + ".token_conv.convolution.weight", "", p + ".token_conv.normalization", x, g, ACT_NONE);
+    Builder::GapOut gap;  // the depthwise kernel also emits the SE pooling partial sums of its output
+    Builder::GapOut* gp = c.se ? &gap : nullptr;
+    if (rep) t = b.dwconv(p + ".token_conv.weight", p + ".token_conv.bias", "", x, g, ACT_NONE, nullptr, nullptr, gp);
+    else t = b.dwconv(p + ".token_conv.convolution.weight", "", p + ".token_conv.normalization", x, g, ACT_NONE, nullptr, nullptr, gp);
+    TView gate;
+    bool has_gate = false;
     if (c.se) {
         const std::string s = p + ".token_squeeze_excitation.convolutions.";
-        TView gate = b.se_gate(s + "0.weight", s + "0.bias", s + "2.weight", s + "2.bias", t, ACT_HSIG);
+        gate = b.se_gate(s + "0.weight", s + "0.bias", s + "2.weight", s + "2.bias", t, ACT_HSIG, &gap);
+        has_gate = true;
+    }
+    if (rep && mixer_fused_supported(c.cin) && !g_disable_fused_mixer) {
+        // SE gate, expand, GELU, project and the residual add in one kernel; the gated tensor is never written
+        TView o = b.mixer_fused(p, t, has_gate ? &gate : nullptr);
+        if (has_gate) b.release(gate);
+        b.release(t);
+        return o;
+    }
+    if (has_gate) {
         b.scale(t, gate, 0.f, t);
         b.release(gate);
     }

@@ -53,6 +53,9 @@ struct DwParams {
     int gap_chunks;
 };
 void launch_dwconv(const DwParams& p, hipStream_t s);
+// number of per-image partial-sum chunks launch_dwconv writes to p.gap_partial for this geometry (0 = the fused
+// global-average-pool is not available for it)
+int dwconv_gap_chunks(const DwParams& p);
 
 // 2x2 stride-1 max-pool over an input zero-padded by one pixel on the right/bottom (stem branch b)
 void launch_maxpool2x2s1(const float* x, int xld, float* y, int yld, int N, int H, int W, int C, hipStream_t s);
@@ -135,4 +138,20 @@ struct CropBatchParams {
 };
 void launch_crop_resize_norm_batch(const CropBatchParams& p, hipStream_t s);
 
+}  // namespace rd
+
+namespace rd {
+// Fused PPLCNetV4 channel mixer for residual ("rep") blocks (rec_lcnetv4.py:226-236):
+//   X' = X * gate            (optional SE gate, per sample and channel)
+//   Y  = X' + W2 . GELU(W1 . X' + b1) + b2      W1: [2C][C], W2: [C][2C]  (BN folded)
+// The [M][2C] hidden activation never leaves the CU.  C in {48, 96, 192}.
+struct MixerParams {
+    const float* x; int xld;
+    float* y; int yld;
+    int M, HW, C;
+    const float* gate;   // [N][C] or nullptr
+    const float* w1; const float* b1; const float* w2; const float* b2;
+};
+bool mixer_fused_supported(int C);
+void launch_mixer_fused(const MixerParams& p, hipStream_t s);
 }  // namespace rd

@@ -1,0 +1,62 @@
+"""CPU: host-side OCR glue (rapiddoc_amd/ocr_host.py) - known-answer tests minted from the algorithm
+definitions at the reference call sites (rapid_ocr.py:404-472, analyze_utils.py:278-292)."""
+import numpy as np
+
+from rapiddoc_amd import ocr_host as H
+
+
+def test_ctc_decode_known_answers():
+    chars = H.build_characters(["a\n", "b\n", "c\n"])  # blank a b c ' '
+    assert chars == ["blank", "a", "b", "c", " "]
+    idx = np.array([[0, 1, 1, 0, 1, 2, 2, 4, 4, 3, 0],
+                    [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+                    [3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3]])
+    prob = np.tile(np.linspace(0.1, 1.0, 11, dtype=np.float32), (3, 1))
+    out = H.ctc_decode(idx, prob, chars)
+    assert out[0][0] == "aab c"
+    kept = [1, 4, 5, 7, 9]
+    assert abs(out[0][1] - float(np.mean(prob[0][kept]))) < 1e-7
+    assert out[1] == ("", 0.0)
+    assert out[2][0] == "c" and abs(out[2][1] - 0.1) < 1e-7
+
+
+def test_score_formatting():
+    assert H.format_score(0.98765) == 0.988
+    assert H.format_score(0.4994) == 0.499
+
+
+def test_rec_batching_matches_reference_rule():
+    ratios = [10.0, 2.0, 30.0, 6.0, 7.0, 1.0, 12.5]
+    b = H.rec_batches(ratios, rec_batch_num=3)
+    assert [list(c) for c, _ in b] == [[5, 1, 3], [4, 0, 6], [2]]
+    # imgW = int(48 * max(320/48, chunk max))
+    assert [w for _, w in b] == [320, int(48 * 12.5), int(48 * 30.0)]
+    assert H.rec_resized_width(100, 20, 600) == 240
+    assert H.rec_resized_width(1000, 20, 600) == 600
+    b32 = H.rec_batches(ratios, rec_batch_num=3, width_multiple=32)
+    assert all(w % 32 == 0 for _, w in b32)
+
+
+def test_det_resize_shape():
+    assert H.det_resize_shape(1792, 1344) == (960, 704)   # 64-px bucket of a 1684x1191 page + 50 px margins
+    assert H.det_resize_shape(100, 37) == (96, 32)
+    assert H.det_resize_shape(640, 480) == (640, 480)
+
+
+def test_seq_len_matches_oracle_shapes():
+    import torch
+    from oracle import nets as O
+    from rapiddoc_amd import weights as W
+    from pathlib import Path
+    g = Path(__file__).resolve().parent / "golden"
+    st = O.as_torch_state(W.synth_state_dict(W.load_manifest(g / "manifest_ppocrv6_rec.json"), 0))
+    for w in (16, 50, 97, 321):
+        lg = O.rec_forward(st, torch.zeros(1, 3, 48, w))
+        assert lg.shape[1] == H.rec_seq_len(w)
+
+
+def test_synth_pages_are_deterministic():
+    from rapiddoc_amd.pages import synth_page
+    a, ba = synth_page(3)
+    b, bb = synth_page(3)
+    assert (a == b).all() and (ba == bb).all() and a.shape == (1684, 1191, 3) and len(ba) == 45
