@@ -55,13 +55,13 @@ def cpu_baseline(states, threads):
             for _ in range(reps):
                 fn()
             return (time.perf_counter() - t0) / reps
-        t_b4 = timed(lambda: O.pphgnetv2_features(st["pphgnetv2_b4"], xb), 1)
-        t_det = timed(lambda: O.det_forward(st["ppocrv6_det"], xd), 2)
-        t_rec = timed(lambda: O.ctc_greedy_stats(O.rec_forward(st["ppocrv6_rec"], xr)), 1)
+        t_b4 = timed(lambda: O.pphgnetv2_features(st["pphgnetv2_b4"], xb), 20)
+        t_det = timed(lambda: O.det_forward(st["ppocrv6_det"], xd), 40)
+        t_rec = timed(lambda: O.ctc_greedy_stats(O.rec_forward(st["ppocrv6_rec"], xr)), 25)
     t_page = t_b4 + t_det + t_rec * 45.0 / 6.0
     return {"value": round(1.0 / t_page, 4), "unit": "pages/s", "cores": threads, "kind": "port",
-            "sample": "torch-CPU fp32 oracle (oracle/nets.py): 1 page = B4 backbone 1x3x800x800 (%.2fs) + det 1x3x960x704 (%.2fs) "
-                      "+ rec 6x3x48x1088 (%.2fs) scaled x45/6" % (t_b4, t_det, t_rec)}
+            "sample": "torch-CPU fp32 oracle (oracle/nets.py), mean of 20/40/25 runs: 1 page = B4 backbone 1x3x800x800 (%.3fs) + det "
+                      "1x3x960x704 (%.3fs) + rec 6x3x48x1088 (%.3fs) scaled x45/6" % (t_b4, t_det, t_rec)}
 
 
 def main():
@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--pages", type=int, default=PAGES_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-profile", type=str, default="")
-    ap.add_argument("--rec-batch", type=int, default=64)
+    ap.add_argument("--rec-batch", type=int, default=128)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,18 +143,27 @@ def main():
         for e in (pipe.det, pipe.rec, pipe.layout):
             for op in e.profile_log:
                 name = op["kind"]
-                if op["kind"].startswith(("conv", "deconv")):
+                if op["kind"].startswith(("conv", "deconv")):  # name = the HIP kernel instantiation rocprofv3 reports
                     name = "conv_igemm_kernel<%s,%s>" % (op["cfg"], "1x1" if op["kind"] == "conv1x1" else "kxk")
+                elif op["kind"] == "mixer_fused":
+                    name = "lc_mixer_kernel<%s>" % op["cfg"][1:]
+                elif op["kind"] == "ctc_head_fused":
+                    name = "ctc_head_kernel"
                 a = agg[name]
                 a[0] += op["flops"]; a[1] += op["bytes"]; a[2] += op["ms"]; a[3] += 1
                 tot_ms += op["ms"]
             e.set_profiling(False)
-        mfma = {k: v for k, v in agg.items() if k.startswith("conv_igemm") or k == "ctc_head_fused"}
+        mfma = {k: v for k, v in agg.items() if k.startswith(("conv_igemm", "lc_mixer")) or k == "ctc_head_kernel"}
         dom = max(mfma, key=lambda k: mfma[k][2])
         fl, by, ms, n = mfma[dom]
         ach = fl / (ms * 1e-3) / 1e12
+        traffic = None
+        tf = ROOT / "profiles" / "pmc_traffic.json"   # HBM bytes per launch from the last rocprofv3 --pmc passes
+        if tf.exists():
+            traffic = json.loads(tf.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches_per_step": n,
+                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": round(by / n), "launches_per_step": n,
                 "avg_launch_us": round(ms * 1e3 / n, 2), "avg_gflop_per_launch": round(fl / n / 1e9, 4),
                 "all_mfma_kernels_tflops": round(sum(v[0] for v in mfma.values()) / (sum(v[2] for v in mfma.values()) * 1e-3) / 1e12, 3),
                 "step_kernel_ms": round(tot_ms, 2)}

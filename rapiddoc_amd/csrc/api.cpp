@@ -127,6 +127,41 @@ int rd_crop_resize_norm_batch(int device_id, const uint8_t* pages, int P, int H,
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// ---- developer micro-benchmarks (not part of the public header): time one kernel on caller-provided buffers
+float rd_debug_time_mixer(int C, int M, int variant, int iters, float* x, float* y, float* w1, float* b1, float* w2, float* b2) {
+    rd::MixerParams p{};
+    p.x = x; p.xld = C; p.y = y; p.yld = C; p.M = M; p.HW = M; p.C = C; p.gate = nullptr;
+    p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    rd::launch_mixer_debug(p, variant, nullptr);
+    hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters; ++i) rd::launch_mixer_debug(p, variant, nullptr);
+    hipEventRecord(e1, nullptr);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return ms / iters;
+}
+float rd_debug_time_gemm(int M, int K, int N, int act, int iters, float* x, float* w, float* b, float* y) {
+    rd::ConvParams p{};
+    p.x = x; p.xld = K; p.N = 1; p.H = 1; p.W = M; p.Cin = K; p.w = w; p.bias = b; p.y = y; p.yld = N;
+    p.OH = 1; p.OW = M; p.Cout = N; p.KH = p.KW = p.SH = p.SW = 1; p.act = act; p.out_mode = rd::OUT_NHWC;
+    p.M = M; p.K = K; p.Ng = N;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    rd::launch_conv_igemm(p, nullptr);
+    hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters; ++i) rd::launch_conv_igemm(p, nullptr);
+    hipEventRecord(e1, nullptr);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return ms / iters;
+}
+
 int rd_set_profiling(rd_handle* h, int on) {
     return guarded(h, [&] { h->eng->set_profiling(on != 0); });
 }

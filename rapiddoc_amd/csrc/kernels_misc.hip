@@ -84,7 +84,10 @@ __global__ void __launch_bounds__(256) dwconv_tiled_kernel(DwParams p, int c4n, 
     f32x4 gsum = zero4;
     const int g_end = min(groups, (chunk + 1) * gpb);
     for (int g = chunk * gpb + pl; g < g_end; g += lanes_p) {
-        const int oh = g / groups_w, ow0 = (g - oh * groups_w) * TW;
+        // column-major over (row, w-group): a block walks DOWN a strip of columns, so the KH-1 input rows shared by
+        // vertically adjacent outputs are re-read from this CU's L1/L2 instead of by another XCD from HBM
+        const int owg = g / p.OH, oh = g - owg * p.OH;
+        const int ow0 = owg * TW;
         f32x4 acc[TW];
 #pragma unroll
         for (int t = 0; t < TW; ++t) acc[t] = bias;

@@ -34,7 +34,7 @@ __device__ __forceinline__ float gelu_erf(float v) {
     return 0.5f * v * (1.f + copysignf(erfz, v));
 }
 
-template <int C>
+template <int C, int DBG>
 __global__ void __launch_bounds__(256) lc_mixer_kernel(MixerParams p) {
     constexpr int XS = C + 4;              // LDS row stride of X and W1 chunk (conflict-free b128 reads)
     constexpr int NT = C / 32;             // output n-tiles per wave (C = 48 -> 2 tiles, second half-masked)
@@ -114,42 +114,72 @@ __global__ void __launch_bounds__(256) lc_mixer_kernel(MixerParams p) {
     const float* w2p = &W2s[l31 * 36 + 4 * lhi];               // output-channel row (B operand of GEMM2)
     constexpr int NCHUNK = 2 * C / MX_HC;
     for (int j = 0; j < NCHUNK; ++j) {
-        const bool more = j + 1 < NCHUNK;
+        const bool more = (DBG & 2) ? false : (j + 1 < NCHUNK);   // DBG 2: no weight streaming / barriers
         if (more) load_w(j + 1);
-        // GEMM1: Ht = W1c . X^T  (K = C)
+        // GEMM1: Ht = W1c . X^T  (K = C).  One wavefront per SIMD here (LDS-limited), so nothing hides an exposed
+        // ds_read latency: fragments are double-buffered by hand and the scheduler is told to interleave the reads
+        // of group g+1 with the MFMAs of group g.
         f32x16 h;
 #pragma unroll
         for (int r = 0; r < 16; ++r) h[r] = 0.f;
+        if (!(DBG & 4)) {   // DBG 4: skip GEMM1
+            f32x4 a[2], b[2];
+            a[0] = *reinterpret_cast<const f32x4*>(w1p);
+            b[0] = *reinterpret_cast<const f32x4*>(xp);
 #pragma unroll
-        for (int g = 0; g < KG; ++g) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(w1p + g * 8);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(xp + g * 8);
+            for (int g = 0; g < KG; ++g) {
+                if (g + 1 < KG) {
+                    a[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(w1p + (g + 1) * 8);
+                    b[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(xp + (g + 1) * 8);
+                }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) h = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], h, 0, 0, 0);
+                for (int e = 0; e < 4; ++e) h = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][e], b[g & 1][e], h, 0, 0, 0);
+                if (g + 1 < KG) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                }
+            }
         }
         // bias + GELU in registers; register r holds hidden index 8*(r>>2) + 4*lhi + (r&3)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(&B1s[g * 8 + 4 * lhi]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) h[g * 4 + e] = gelu_erf(h[g * 4 + e] + bv[e]);
+            for (int e = 0; e < 4; ++e) h[g * 4 + e] = (DBG & 1) ? h[g * 4 + e] + bv[e] : gelu_erf(h[g * 4 + e] + bv[e]);
         }
-        // GEMM2: Y += H . W2c^T  (K = 32): A = h registers, B = W2s rows
+        // GEMM2: Y += H . W2c^T  (K = 32): A = h registers, B = W2s rows (double-buffered like GEMM1)
+        if (!(DBG & 8)) {   // DBG 8: skip GEMM2
+            f32x4 bf[2][NTT];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 bf[NTT];
+            for (int n = 0; n < NTT; ++n) bf[0][n] = *reinterpret_cast<const f32x4*>(w2p + n * 32 * 36);
 #pragma unroll
-            for (int n = 0; n < NTT; ++n) bf[n] = *reinterpret_cast<const f32x4*>(w2p + n * 32 * 36 + g * 8);
+            for (int g = 0; g < 4; ++g) {
+                if (g + 1 < 4) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                    for (int n = 0; n < NTT; ++n)
+                        bf[(g + 1) & 1][n] = *reinterpret_cast<const f32x4*>(w2p + n * 32 * 36 + (g + 1) * 8);
+                }
 #pragma unroll
-                for (int n = 0; n < NTT; ++n)
-                    yacc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(h[g * 4 + e], bf[n][e], yacc[n], 0, 0, 0);
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int n = 0; n < NTT; ++n)
+                        yacc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(h[g * 4 + e], bf[g & 1][n][e], yacc[n], 0, 0, 0);
+                if (g + 1 < 4) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, NTT, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NTT - 2, 0);
+                }
+            }
         }
-        __syncthreads();
+        if (!(DBG & 2)) __syncthreads();
         if (more) {
             store_w();
             __syncthreads();
+        }
+        if (DBG & 8) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yacc[0][r] += h[r];
         }
     }
     // ---- epilogue: + b2 + residual (the gated X tile is still in LDS), strided store
@@ -175,23 +205,37 @@ static size_t mixer_lds_bytes() {
 
 bool mixer_fused_supported(int C) { return C == 48 || C == 96 || C == 192; }
 
-template <int C>
+template <int C, int DBG>
 static void launch_mixer_c(const MixerParams& p, hipStream_t s) {
     const size_t sh = mixer_lds_bytes<C>();
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)lc_mixer_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute((const void*)lc_mixer_kernel<C, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         attr_set = true;
     }
-    hipLaunchKernelGGL(lc_mixer_kernel<C>, dim3((p.M + MX_BM - 1) / MX_BM), dim3(256), sh, s, p);
+    hipLaunchKernelGGL((lc_mixer_kernel<C, DBG>), dim3((p.M + MX_BM - 1) / MX_BM), dim3(256), sh, s, p);
+}
+
+// ablation variants for tools/microbench.py (numerically meaningless; they only time what is left)
+void launch_mixer_debug(const MixerParams& p, int variant, hipStream_t s) {
+    if (p.C != 192) return;
+    switch (variant) {
+        case 0: launch_mixer_c<192, 0>(p, s); break;
+        case 1: launch_mixer_c<192, 1>(p, s); break;
+        case 2: launch_mixer_c<192, 2>(p, s); break;
+        case 3: launch_mixer_c<192, 3>(p, s); break;
+        case 4: launch_mixer_c<192, 4>(p, s); break;
+        case 8: launch_mixer_c<192, 8>(p, s); break;
+        default: break;
+    }
 }
 
 void launch_mixer_fused(const MixerParams& p, hipStream_t s) {
     if (p.M <= 0) return;
     switch (p.C) {
-        case 48: launch_mixer_c<48>(p, s); break;
-        case 96: launch_mixer_c<96>(p, s); break;
-        case 192: launch_mixer_c<192>(p, s); break;
+        case 48: launch_mixer_c<48, 0>(p, s); break;
+        case 96: launch_mixer_c<96, 0>(p, s); break;
+        case 192: launch_mixer_c<192, 0>(p, s); break;
         default: break;
     }
 }

@@ -154,4 +154,5 @@ struct MixerParams {
 };
 bool mixer_fused_supported(int C);
 void launch_mixer_fused(const MixerParams& p, hipStream_t s);
+void launch_mixer_debug(const MixerParams& p, int variant, hipStream_t s);
 }  // namespace rd

@@ -1,0 +1,93 @@
+"""Drop-in `InferSession` shims for RapidDoc's engine seam (seam S2).
+
+The reference's OCR sessions are callables `session(np.ndarray NCHW float32) -> np.ndarray`
+(rapid_doc/model/ocr/torch.py:171-192) plus `have_key()` / `get_character_list()` (:194-198); rapidocr's
+TextDetector / TextRecognizer only ever touch those three members.  These classes provide exactly that surface on
+top of the C-ABI, so `INTEGRATION.md`'s two-line patch makes the unchanged pipeline run on the MI355X engine.
+
+`Mi355RecSession.__call__` returns the reference-shaped softmax tensor [B,T,C] (strict drop-in);
+`infer_indices` is the fast path that returns only (argmax idx, max prob) per time step - what CTCLabelDecode uses.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from .engine import REC_WANT_SOFTMAX, RdEngine
+
+WeightSrc = Union[str, bytes, Dict[str, np.ndarray]]
+
+
+class _BaseSession:
+    kind = ""
+
+    def __init__(self, weights: WeightSrc, device: int = 0):
+        self.engine = RdEngine(self.kind, device).load_weights(weights)
+        self.device = torch.device("cuda", device)
+
+    @classmethod
+    def from_cfg(cls, cfg) -> "_BaseSession":
+        """Build from a rapidocr-style cfg mapping: `model_path` (.safetensors) and `engine_cfg.gpu_id`."""
+        model_path = cfg.get("model_path") if hasattr(cfg, "get") else cfg["model_path"]
+        eng_cfg = cfg.get("engine_cfg", {}) if hasattr(cfg, "get") else {}
+        gpu_id = int(getattr(eng_cfg, "gpu_id", None) or (eng_cfg.get("gpu_id", 0) if hasattr(eng_cfg, "get") else 0))
+        if Path(str(model_path)).suffix != ".safetensors":
+            raise ValueError("the MI355X engine loads the reference's .safetensors weights (torch.py:93-103)")
+        return cls(str(model_path), gpu_id)
+
+    def _to_dev(self, img: np.ndarray) -> torch.Tensor:
+        x = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32))
+        return x.to(self.device, non_blocking=True)
+
+    # rapidocr InferSession protocol (ocr/torch.py:194-198)
+    def have_key(self, key: str = "character") -> bool:
+        return False
+
+    def get_character_list(self, key: str = "character") -> List[str]:
+        return []
+
+
+class Mi355DetSession(_BaseSession):
+    """PP-OCRv6 det: [B,3,H,W] -> DB probability map [B,1,H,W] (`maps`, ocr/torch.py:183-184)."""
+    kind = "ppocrv6_det"
+
+    def __call__(self, img: np.ndarray) -> np.ndarray:
+        return self.engine.det_forward(self._to_dev(img)).cpu().numpy()
+
+
+class Mi355RecSession(_BaseSession):
+    """PP-OCRv6 rec: [B,3,48,W] -> softmax(ctc_logits) [B,T,C] (ocr/torch.py:185-187)."""
+    kind = "ppocrv6_rec"
+
+    def __call__(self, img: np.ndarray) -> np.ndarray:
+        _, _, full = self.engine.rec_forward(self._to_dev(img), REC_WANT_SOFTMAX)
+        return full.cpu().numpy()
+
+    def infer_indices(self, img: Union[np.ndarray, torch.Tensor]) -> Tuple[np.ndarray, np.ndarray]:
+        x = img if isinstance(img, torch.Tensor) else self._to_dev(img)
+        idx, prob, _ = self.engine.rec_forward(x)
+        return idx.cpu().numpy(), prob.cpu().numpy()
+
+
+class Mi355LayoutBackboneSession(_BaseSession):
+    """PPHGNetV2-B4 backbone of PP-DocLayout-L/plus-L/V2/V3: [B,3,S,S] -> 4 NCHW feature maps."""
+    kind = "pphgnetv2_b4"
+
+    def __call__(self, img: np.ndarray) -> List[np.ndarray]:
+        return [f.cpu().numpy() for f in self.engine.backbone_forward(self._to_dev(img))]
+
+
+def install_into_rapidocr() -> None:
+    """Replace rapidocr's torch engine by the MI355X sessions the same way the reference patches it
+    (rapid_doc/model/ocr/ocr_patch.py:95-105).  Needs the `rapidocr` package of the RapidDoc installation."""
+    import rapidocr.inference_engine.pytorch as rt  # noqa: WPS433 (third-party, only present in a RapidDoc install)
+
+    class _Dispatch:
+        def __new__(cls, cfg):
+            task = str(getattr(cfg, "task_type", cfg.get("task_type", ""))).lower()
+            return (Mi355DetSession if "det" in task else Mi355RecSession).from_cfg(cfg)
+
+    rt.TorchInferSession = _Dispatch

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks / ablations on the GPU box (developer tool):  python tools/microbench.py"""
+import ctypes as C
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from rapiddoc_amd import _lib
+
+lib = _lib.load()
+lib.rd_debug_time_mixer.restype = C.c_float
+lib.rd_debug_time_mixer.argtypes = [C.c_int] * 4 + [C.c_void_p] * 6
+lib.rd_debug_time_gemm.restype = C.c_float
+lib.rd_debug_time_gemm.argtypes = [C.c_int] * 5 + [C.c_void_p] * 4
+
+
+def mixer(C_, M, variant, iters=20):
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.rand((M, C_), device="cuda", generator=g) - 0.5
+    y = torch.empty_like(x)
+    w1 = (torch.rand((2 * C_, C_), device="cuda", generator=g) - 0.5) * 0.1
+    w2 = (torch.rand((C_, 2 * C_), device="cuda", generator=g) - 0.5) * 0.1
+    b1 = torch.zeros(2 * C_, device="cuda")
+    b2 = torch.zeros(C_, device="cuda")
+    ms = lib.rd_debug_time_mixer(C_, M, variant, iters, x.data_ptr(), y.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr())
+    return ms, 8.0 * M * C_ * C_ / ms / 1e9
+
+
+def gemm(M, K, N, act=0, iters=20):
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.rand((M, K), device="cuda", generator=g) - 0.5
+    w = (torch.rand((N, K), device="cuda", generator=g) - 0.5) * 0.1
+    b = torch.zeros(N, device="cuda")
+    y = torch.empty((M, N), device="cuda")
+    ms = lib.rd_debug_time_gemm(M, K, N, act, iters, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr())
+    return ms, 2.0 * M * K * N / ms / 1e9
+
+
+if __name__ == "__main__":
+    names = {0: "full", 1: "no GELU", 2: "no weight stream/barriers", 3: "no GELU, no stream", 4: "GEMM2 only", 8: "GEMM1 only"}
+    for M in (256 * 128, 256 * 128 * 4):
+        for v in (0, 1, 2, 3, 4, 8):
+            ms, tf = mixer(192, M, v)
+            print(f"mixer C=192 M={M:7d} variant {v} ({names[v]:26s}): {ms*1e3:8.1f} us  {tf:6.1f} TF/s(nominal)")
+    for (M, K, N) in ((131072, 192, 384), (131072, 384, 192), (131072, 384, 768), (131072, 768, 384), (81920, 2176, 512),
+                      (131072, 1024, 1024), (32768, 4096, 4096)):
+        for act in (0, 2):
+            ms, tf = gemm(M, K, N, act)
+            print(f"gemm M={M} K={K} N={N} act={act}: {ms*1e3:8.1f} us  {tf:6.1f} TF/s")
