@@ -89,6 +89,18 @@ int rd_crop_resize_norm_batch(int device_id, const uint8_t* pages_u8_dev, int P,
                               const rd_crop_desc* descs_dev, int n, int out_h, int out_w_padded, const float mean[3],
                               const float std[3], float scale, int swap_rb, float* out_nchw_dev, void* stream);
 
+/* DB post-process (HOST pointers, runs on the host like the reference's): probability maps [B][H][W] -> text boxes.
+ * Replaces rapidocr DBPostProcess.__call__ as patched in rapid_doc/model/ocr/ocr_patch.py:223-241 (box_type "quad",
+ * score_mode "fast"), called from rapid_doc/model/ocr/rapid_ocr.py:537-538.  src_hw[b] = (height, width) of the image
+ * the boxes are scaled to.  out[b*max_out + i], i < n_out[b]: corners tl,tr,br,bl in source pixels + score. */
+typedef struct rd_text_box {
+    float pts[8];
+    float score;
+} rd_text_box;
+int rd_db_postprocess(const float* prob_host, int B, int H, int W, const int32_t* src_hw, float thresh, float box_thresh,
+                      float unclip_ratio, int use_dilation, int max_candidates, rd_text_box* out, int max_out,
+                      int32_t* n_out, int n_threads);
+
 /* per-op HIP-event timing of the NEXT forward calls; rd_profile_json returns the last call's table as a JSON
  * array [{"name","kind","cfg","flops","bytes","ms"}, ...] owned by the handle. */
 int rd_set_profiling(rd_handle* h, int on);

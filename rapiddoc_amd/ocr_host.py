@@ -94,3 +94,150 @@ def rec_batches(wh_ratios: Sequence[float], rec_batch_num: int = 6, img_h: int =
 def rec_resized_width(w: float, h: float, wpad: int, img_h: int = REC_IMG_H) -> int:
     """resize_norm_img: resized_w = min(imgW, ceil(imgH * w/h))."""
     return int(min(wpad, math.ceil(img_h * (w / h))))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# DB post-process (C++ in librapiddoc_mi355.so, host side) and the box ordering that follows it
+# ------------------------------------------------------------------------------------------------------------------
+TEXT_BOX_DTYPE = np.dtype([("pts", "<f4", (8,)), ("score", "<f4")])
+
+
+def db_postprocess(prob: np.ndarray, src_hw: Sequence[Tuple[int, int]], thresh: float = 0.3, box_thresh: float = 0.5,
+                   unclip_ratio: float = 1.6, use_dilation: bool = True, max_candidates: int = 1000, max_out: int = 2048,
+                   n_threads: int = 0) -> List[Tuple[np.ndarray, List[float]]]:
+    """prob: [B,H,W] or [B,1,H,W] float32 DB probability maps (host).  Returns per image (boxes [n,4,2] int32 in
+    source pixels ordered tl,tr,br,bl, scores) - the (boxes, scores) pair rapidocr's DBPostProcess returns."""
+    import ctypes as C
+
+    from . import _lib
+    lib = _lib.load()
+    p = np.ascontiguousarray(prob, dtype=np.float32)
+    if p.ndim == 4:
+        p = p[:, 0]
+    B, H, W = p.shape
+    p = np.ascontiguousarray(p)
+    hw = np.ascontiguousarray(np.asarray(src_hw, dtype=np.int32).reshape(B, 2))
+    out = np.zeros((B, max_out), dtype=TEXT_BOX_DTYPE)
+    n = np.zeros(B, dtype=np.int32)
+    rc = lib.rd_db_postprocess(p.ctypes.data, B, H, W, hw.ctypes.data, thresh, box_thresh, unclip_ratio, 1 if use_dilation else 0,
+                               max_candidates, out.ctypes.data, max_out, n.ctypes.data, n_threads)
+    if rc != 0:
+        raise RuntimeError("rd_db_postprocess failed")
+    res = []
+    for b in range(B):
+        k = int(n[b])
+        res.append((out["pts"][b, :k].reshape(k, 4, 2).astype(np.int32), out["score"][b, :k].tolist()))
+    return res
+
+
+def sorted_boxes(dt_boxes: Sequence[np.ndarray]) -> List[np.ndarray]:
+    """Reading order: top-to-bottom, left-to-right, boxes whose top-left y differ by < 10 px count as one row
+    (rapid_doc/utils/ocr_utils.py:105-127)."""
+    boxes = sorted(list(dt_boxes), key=lambda b: (b[0][1], b[0][0]))
+    for i in range(len(boxes) - 1):
+        for j in range(i, -1, -1):
+            if abs(boxes[j + 1][0][1] - boxes[j][0][1]) < 10 and boxes[j + 1][0][0] < boxes[j][0][0]:
+                boxes[j], boxes[j + 1] = boxes[j + 1], boxes[j]
+            else:
+                break
+    return boxes
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Text-box bookkeeping between det and rec (rapid_doc/utils/ocr_utils.py:16-67,130-317,478-485), restated.
+# Checked against the reference functions themselves through tests/golden/boxes_seed*.json.
+# ------------------------------------------------------------------------------------------------------------------
+LINE_WIDTH_TO_HEIGHT_RATIO_THRESHOLD = 4  # ocr_utils.py:13
+
+
+def quad_is_tilted(quad) -> bool:
+    """calculate_is_angle: the diagonal's vertical extent differs from the mean side height by more than 20 %."""
+    p1, p2, p3, p4 = quad
+    height = ((p4[1] - p1[1]) + (p3[1] - p2[1])) / 2
+    return not (0.8 * height <= (p3[1] - p1[1]) <= 1.2 * height)
+
+
+def _quad_to_bbox(q):
+    return [q[0][0], q[0][1], q[1][0], q[2][1]]
+
+
+def _bbox_to_quad(b) -> np.ndarray:
+    x0, y0, x1, y1 = b
+    return np.array([[x0, y0], [x1, y0], [x1, y1], [x0, y1]]).astype("float32")
+
+
+def _y_overlap_exceeds(b1, b2, thr: float) -> bool:
+    ov = max(0, min(b1[3], b2[3]) - max(b1[1], b2[1]))
+    mh = min(b1[3] - b1[1], b2[3] - b2[1])
+    return (ov / mh) > thr if mh > 0 else False
+
+
+def merge_det_boxes(dt_boxes) -> List[np.ndarray]:
+    """Group axis-aligned boxes into lines (y-overlap > 0.6 with the previous box, after sorting by top y) and, for
+    lines wider than 4x their height, fuse horizontally overlapping boxes; tilted boxes pass through at the end."""
+    flat, tilted = [], []
+    for q in dt_boxes:
+        if quad_is_tilted(q):
+            tilted.append(q)
+        else:
+            flat.append(_quad_to_bbox(q))
+    flat.sort(key=lambda b: b[1])
+    lines: List[List[list]] = []
+    for b in flat:
+        if lines and _y_overlap_exceeds(b, lines[-1][-1], 0.6):
+            lines[-1].append(b)
+        else:
+            lines.append([b])
+    out: List[np.ndarray] = []
+    for line in lines:
+        lw = max(b[2] for b in line) - min(b[0] for b in line)
+        lh = max(b[3] for b in line) - min(b[1] for b in line)
+        if lw > lh * LINE_WIDTH_TO_HEIGHT_RATIO_THRESHOLD:
+            merged: List[tuple] = []
+            for b in sorted(line, key=lambda t: t[0]):
+                if merged and not merged[-1][2] < b[0]:
+                    m = merged.pop()
+                    b = (min(m[0], b[0]), min(m[1], b[1]), max(m[2], b[2]), max(m[3], b[3]))
+                merged.append(tuple(b))
+            out.extend(_bbox_to_quad(m) for m in merged)
+        else:
+            out.extend(_bbox_to_quad(b) for b in line)
+    out.extend(tilted)
+    return out
+
+
+def _subtract_intervals(span, masks):
+    masks = sorted([list(m) for m in masks], key=lambda m: m[0])
+    merged: List[list] = []
+    for m in masks:
+        if merged and not merged[-1][1] < m[0]:
+            merged[-1][1] = max(merged[-1][1], m[1])
+        else:
+            merged.append(m)
+    start, end = span
+    res = []
+    for ms, me in merged:
+        if ms > end or me < start:
+            continue
+        if start < ms:
+            res.append([start, ms - 1])
+        start = max(me + 1, start)
+    if start <= end:
+        res.append([start, end])
+    return res
+
+
+def update_det_boxes(dt_boxes, formula_boxes) -> List[np.ndarray]:
+    """Cut text boxes around inline formulas: remove, from every non-tilted text box, the x-ranges of the formula
+    boxes that overlap it vertically by > 0.8 of the smaller height.  formula_boxes: [{'bbox': [x0,y0,x1,y1]}]."""
+    out, tilted = [], []
+    for q in dt_boxes:
+        if quad_is_tilted(q):
+            tilted.append(q)
+            continue
+        tb = _quad_to_bbox(q)
+        masks = [[f["bbox"][0], f["bbox"][2]] for f in formula_boxes if _y_overlap_exceeds(tb, f["bbox"], 0.8)]
+        for x0, x1 in _subtract_intervals([tb[0], tb[2]], masks):
+            out.append(_bbox_to_quad([x0, tb[1], x1, tb[3]]))
+    out.extend(tilted)
+    return out

@@ -107,7 +107,7 @@ class PagePipeline:
         for pi, quads in enumerate(quads_per_page):
             for q in np.asarray(quads, dtype=np.float32).reshape(-1, 4, 2):
                 m, cw, ch = quad_to_crop_matrix(q)
-                rot = 1 if ch / cw >= 1.5 else 0  # ocr_utils.py:531-535 rotates tall crops
+                rot = 1 if ch / cw >= 2.0 else 0  # ocr_utils.py:531-534 rotates crops with h/w >= 2
                 page_of.append(pi); mats.append(m); cws.append(cw); chs.append(ch); rots.append(rot)
         n = len(page_of)
         texts: List[Tuple[str, float]] = [("", 0.0)] * n
@@ -161,24 +161,78 @@ class PagePipeline:
         self.stats["rec_batches"] = len(batches)
         return per_page
 
+    # ---------------------------------------------------------------- det maps -> text-line quads (host)
+    def boxes_from_maps(self, maps_host: np.ndarray, page_hw: Tuple[int, int], box_thresh: float = 0.3,
+                        unclip_ratio: float = 1.8) -> List[np.ndarray]:
+        """DB post-process + reading-order sort + same-line merge (rapid_ocr.py:537-538; analyze_utils.py:196-204).
+        box_thresh 0.3 / unclip 1.8 are the page-OCR settings (backend/pipeline/model_init.py:73)."""
+        P = maps_host.shape[0]
+        res = ocr_host.db_postprocess(maps_host, [page_hw] * P, thresh=0.3, box_thresh=box_thresh, unclip_ratio=unclip_ratio)
+        out = []
+        for boxes, _scores in res:
+            if len(boxes) == 0:
+                out.append(np.zeros((0, 4, 2), np.float32))
+                continue
+            b = ocr_host.sorted_boxes(boxes.astype(np.float32))
+            b = ocr_host.merge_det_boxes(b)
+            out.append(np.asarray(b, dtype=np.float32).reshape(-1, 4, 2))
+        return out
+
     # ---------------------------------------------------------------- whole batch
-    def run_batch(self, pages: torch.Tensor, quads_per_page: Optional[Sequence[np.ndarray]] = None) -> List[PageResult]:
-        """pages: [P,H,W,3] uint8 RGB on the GPU.  quads_per_page: text-line quads in page pixels (from the DB
-        post-process of the det map; the synthetic benchmark passes the generator's own line boxes)."""
+    def run_batch(self, pages: torch.Tensor, quads_per_page: Optional[Sequence[np.ndarray]] = None,
+                  det_maps_override: Optional[torch.Tensor] = None) -> List[PageResult]:
+        """pages: [P,H,W,3] uint8 RGB on the GPU.  Text-line quads come from the DB post-process of the det maps
+        unless `quads_per_page` is given.  `det_maps_override` (benchmark / tests with random weights, whose maps carry
+        no text): device maps [P,1,h,w] that replace the network's output as the post-process input - the det forward
+        still runs."""
         assert pages.is_cuda and pages.dtype == torch.uint8 and pages.dim() == 4
-        P = pages.shape[0]
+        P, H, W, _ = pages.shape
         results = [PageResult() for _ in range(P)]
+        prob_maps, det_hw = self.det_forward(pages)
+        self.last_det = (prob_maps, det_hw)
+        copy_done = None
+        if quads_per_page is None:
+            src = det_maps_override if det_maps_override is not None else prob_maps
+            if getattr(self, "_maps_host", None) is None or self._maps_host.shape != src.shape:
+                self._maps_host = torch.empty(src.shape, dtype=torch.float32, pin_memory=True)
+                self._copy_stream = torch.cuda.Stream(device=pages.device)
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(self._copy_stream):
+                self._copy_stream.wait_event(ready)
+                self._maps_host.copy_(src, non_blocking=True)
+                copy_done = torch.cuda.Event()
+                copy_done.record()
+        # the layout backbone keeps the GPU busy while the host turns the det maps into boxes
         if self.layout is not None:
             feats = self.layout_forward(pages)
             if self.keep_feats:
                 for i in range(P):
                     results[i].layout_feats = [f[i] for f in feats]
-        prob_maps, det_hw = self.det_forward(pages)
-        self.last_det = (prob_maps, det_hw)
         if quads_per_page is None:
-            raise NotImplementedError("DB post-process (det map -> boxes) is not built yet; pass quads_per_page")
+            copy_done.synchronize()
+            quads_per_page = self.boxes_from_maps(self._maps_host.numpy(), (H, W))
         texts = self.rec_forward_lines(pages, quads_per_page)
         for i in range(P):
             qs = np.asarray(quads_per_page[i], dtype=np.float32).reshape(-1, 4, 2)
             results[i].lines = [(qs[j], t, s) for j, (t, s) in enumerate(texts[i])]
         return results
+
+
+def render_text_maps(boxes_per_page: Sequence[np.ndarray], page_hw: Tuple[int, int], map_hw: Tuple[int, int],
+                     device) -> torch.Tensor:
+    """Synthetic DB probability maps for pages whose text-line boxes are known (benchmark helper): 0.9 inside every
+    line box shrunk by 0.32 x its height on every side (so that the post-process' unclip, ratio 1.8, grows the region
+    back to about the original box), 0.02 elsewhere.  Used because random-weight det maps carry no text to find."""
+    H, W = page_hw
+    h, w = map_hw
+    maps = torch.full((len(boxes_per_page), 1, h, w), 0.02, dtype=torch.float32)
+    for i, boxes in enumerate(boxes_per_page):
+        for x0, y0, x1, y1 in np.asarray(boxes, dtype=np.float64).reshape(-1, 4):
+            bw, bh = x1 - x0, y1 - y0
+            d = 0.32 * min(bw, bh)
+            xa, xb = int(round((x0 + d) * w / W)), int(round((x1 - d) * w / W))
+            ya, yb = int(round((y0 + d) * h / H)), int(round((y1 - d) * h / H))
+            if xb > xa and yb > ya:
+                maps[i, 0, ya:yb, xa:xb] = 0.9
+    return maps.to(device)

@@ -137,6 +137,35 @@ def main():
         assert d < 2e-5, d
         np.savez_compressed(HERE / f"b4_seed0_{tag}.npz", x=x, **{f"feat{i}": f.numpy() for i, f in enumerate(feats)})
 
+    # ---------------- host box helpers (pure python in the reference; cv2 stubbed, it is not called by them) ----------
+    import importlib.util
+    import types
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    spec = importlib.util.spec_from_file_location("ref_ocr_utils", REF / "rapid_doc/utils/ocr_utils.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    for seed in range(5):
+        rng = np.random.default_rng(1000 + seed)
+        quads = []
+        for _ in range(40):
+            x0, y0 = rng.integers(0, 900), rng.integers(0, 60) * 14
+            w, h = rng.integers(20, 400), rng.integers(12, 40)
+            q = np.array([[x0, y0], [x0 + w, y0], [x0 + w, y0 + h], [x0, y0 + h]], dtype=np.float32)
+            if rng.random() < 0.15:   # a tilted quad
+                q[1, 1] += h * 1.5; q[2, 1] += h * 1.5
+            quads.append(q)
+        formulas = [{"bbox": [int(a), int(b), int(a + c), int(b + d)]} for a, b, c, d in
+                    zip(rng.integers(0, 900, 12), rng.integers(0, 60, 12) * 14, rng.integers(20, 120, 12), rng.integers(12, 40, 12))]
+        out = {
+            "quads": [q.tolist() for q in quads], "formulas": formulas,
+            "sorted": [np.asarray(b).tolist() for b in ref.sorted_boxes(np.array(quads))],
+            "merged": [np.asarray(b).tolist() for b in ref.merge_det_boxes([q.copy() for q in quads])],
+            "updated": [np.asarray(b).tolist() for b in ref.update_det_boxes([q.copy() for q in quads], formulas)],
+            "is_angle": [bool(ref.calculate_is_angle(q)) for q in quads],
+        }
+        (HERE / f"boxes_seed{seed}.json").write_text(json.dumps(out))
+        print(f"boxes seed {seed}: {len(quads)} quads -> merged {len(out['merged'])}, updated {len(out['updated'])}")
+
     (HERE / "summary.json").write_text(json.dumps(summary, indent=1))
     print(summary)
 

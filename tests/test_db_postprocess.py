@@ -1,0 +1,76 @@
+"""CPU: DB post-process (C++ host code behind the C-ABI) vs analytic known answers and vs the independent
+oracle restatement (oracle/dbpost.py).  Parity with rapidocr/OpenCV itself is unpinned (see the file headers)."""
+import numpy as np
+import pytest
+
+from oracle import dbpost as OD
+from rapiddoc_amd import ocr_host as H
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    from rapiddoc_amd import build as rd_build
+    rd_build.build(verbose=False)
+
+
+def test_axis_aligned_rectangle_known_answer():
+    pred = np.full((320, 640), 0.05, np.float32)
+    pred[50:80, 100:300] = 0.9                       # text blob: x 100..299, y 50..79
+    (boxes, scores), = H.db_postprocess(pred[None], [(320, 640)], box_thresh=0.5, unclip_ratio=1.8)
+    assert len(boxes) == 1
+    # dilation adds one pixel to the right/bottom -> region points x 100..300, y 50..80 -> rect 200 x 30
+    d = 200 * 30 * 1.8 / (2 * 230)
+    exp = np.array([[100 - d, 50 - d], [300 + d, 50 - d], [300 + d, 80 + d], [100 - d, 80 + d]])
+    assert np.abs(boxes[0] - np.round(exp)).max() <= 1
+    inner = 0.9 * 200 * 30 + 0.05 * (201 * 31 - 200 * 30)
+    assert abs(scores[0] - inner / (201 * 31)) < 1e-6
+
+
+def test_scaling_to_source_and_threshold():
+    pred = np.zeros((2, 160, 320), np.float32)
+    pred[0, 40:60, 60:200] = 0.8
+    pred[1, 40:60, 60:200] = 0.45                   # above thresh .3 but below box_thresh .5 -> dropped
+    r0, r1 = H.db_postprocess(pred, [(320, 640), (320, 640)], box_thresh=0.5, unclip_ratio=1.6)
+    assert len(r0[0]) == 1 and len(r1[0]) == 0
+    b = r0[0][0]
+    assert b[0, 0] < 120 and b[2, 0] > 400 and b[0, 1] < 80 and b[2, 1] > 120  # coordinates doubled
+
+
+def _random_map(rng, h, w, n):
+    pred = rng.uniform(0.0, 0.2, (h, w)).astype(np.float32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for _ in range(n):
+        cx, cy = rng.uniform(40, w - 40), rng.uniform(20, h - 20)
+        bw, bh = rng.uniform(30, 120), rng.uniform(8, 20)
+        ang = rng.uniform(-0.5, 0.5)
+        u = (xx - cx) * np.cos(ang) + (yy - cy) * np.sin(ang)
+        v = -(xx - cx) * np.sin(ang) + (yy - cy) * np.cos(ang)
+        pred[(np.abs(u) < bw / 2) & (np.abs(v) < bh / 2)] = rng.uniform(0.6, 0.95)
+    return pred
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_matches_independent_oracle_on_rotated_blobs(seed):
+    rng = np.random.default_rng(seed)
+    pred = _random_map(rng, 192, 384, 7)
+    (boxes, scores), = H.db_postprocess(pred[None], [(384, 768)], box_thresh=0.5, unclip_ratio=1.6)
+    oboxes, oscores = OD.db_postprocess(pred, (384, 768), box_thresh=0.5, unclip_ratio=1.6)
+    assert len(boxes) == len(oboxes) > 0
+    for b, ob, s, os_ in zip(boxes, oboxes, scores, oscores):
+        assert np.abs(b - ob).max() <= 1
+        assert abs(s - os_) < 1e-5
+
+
+def test_empty_and_full_maps():
+    z = np.zeros((1, 64, 64), np.float32)
+    assert H.db_postprocess(z, [(64, 64)])[0][0].shape == (0, 4, 2)
+    o = np.ones((1, 64, 96), np.float32)
+    (b, s), = H.db_postprocess(o, [(64, 96)])
+    assert len(b) == 1 and abs(s[0] - 1.0) < 1e-6
+
+
+def test_sorted_boxes_reading_order():
+    mk = lambda x, y: np.array([[x, y], [x + 50, y], [x + 50, y + 20], [x, y + 20]])
+    boxes = [mk(300, 12), mk(10, 100), mk(20, 8), mk(200, 104)]
+    out = H.sorted_boxes(boxes)
+    assert [int(b[0][0]) for b in out] == [20, 300, 10, 200]

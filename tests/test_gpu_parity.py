@@ -93,3 +93,54 @@ def test_b4_matches_oracle_batch(engines):
     feats = eng.backbone_forward(x.cuda())
     for r, f in zip(ref, feats):
         assert np.abs(f.cpu().numpy() - r.numpy()).max() < TOL
+
+
+def test_pipeline_end_to_end_boxes_from_db_postprocess(engines, golden_dir):
+    """Whole device-resident path on 2 synthetic pages: det forward, DB post-process (on maps rendered from the
+    generator's boxes), crops, rec with fused CTC, decode.  The rec results must equal the oracle run on the very
+    same crops."""
+    from rapiddoc_amd.pages import synth_batch
+    from rapiddoc_amd.pipeline import PagePipeline, render_text_maps
+    states = {k: W.synth_state_dict(W.load_manifest(golden_dir / f"manifest_{k}.json"), 0)
+              for k in ("ppocrv6_det", "ppocrv6_rec", "pphgnetv2_b4")}
+    pipe = PagePipeline(states, rec_batch_num=16, keep_feats=True)
+    pages_np, boxes = synth_batch(5, 2)
+    pages = torch.from_numpy(pages_np).cuda()
+    det_hw = pipe.det_forward(pages[:1])[1]
+    maps = render_text_maps(boxes, pages_np.shape[1:3], det_hw, pages.device)
+    res = pipe.run_batch(pages, None, det_maps_override=maps)
+    assert [len(r.lines) for r in res] == [45, 45]
+    for r, gb in zip(res, boxes):
+        got = np.array([[q[:, 0].min(), q[:, 1].min(), q[:, 0].max(), q[:, 1].max()] for q, _, _ in r.lines])
+        assert np.abs(got - gb).max() <= 3          # DB boxes ~ generator boxes
+        assert all(isinstance(t, str) and 0.0 <= s <= 1.0 for _, t, s in r.lines)
+        assert r.layout_feats[3].shape == (2048, 25, 25)
+    # det map of the real network was produced too
+    assert pipe.last_det[0].shape == (2, 1, det_hw[0], det_hw[1])
+
+
+def test_crop_kernel_axis_aligned_matches_torch_interpolate(engines):
+    """rd_crop_resize_norm_batch on an axis-aligned quad == bilinear resize of the crop (align_corners=False)."""
+    import ctypes as C
+    from rapiddoc_amd import _lib
+    from rapiddoc_amd.pipeline import CROP_DTYPE, quad_to_crop_matrix
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    page = torch.from_numpy(rng.integers(0, 256, (1, 200, 300, 3), dtype=np.uint8)).cuda()
+    quad = np.array([[40, 50], [240, 50], [240, 90], [40, 90]], np.float32)
+    m, cw, ch = quad_to_crop_matrix(quad)
+    d = np.zeros(1, dtype=CROP_DTYPE)
+    d["page"], d["out_w"], d["crop_w"], d["crop_h"], d["m"] = 0, 240, cw, ch, m
+    dd = torch.from_numpy(d.view(np.uint8)).cuda()
+    out = torch.empty((1, 3, 48, 256), device="cuda")
+    mean = (C.c_float * 3)(0.5, 0.5, 0.5)
+    std = (C.c_float * 3)(0.5, 0.5, 0.5)
+    assert lib.rd_crop_resize_norm_batch(0, page.data_ptr(), 1, 200, 300, dd.data_ptr(), 1, 48, 256, mean, std, 1 / 255.0, 0,
+                                         out.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+    crop = page[0, 50:90, 40:240].permute(2, 0, 1)[None].float()   # sample points x in [40, 240), y in [50, 90)
+    ref = torch.nn.functional.interpolate(crop, size=(48, 240), mode="bilinear", align_corners=False)
+    ref = (ref / 255.0 - 0.5) / 0.5
+    got = out[:, :, :, :240]
+    # interior only: at the crop border the kernel clamps to the crop rectangle exactly like the resize does
+    assert float((got - ref).abs().max()) < 2e-3
+    assert float(out[:, :, :, 240:].abs().max()) == 0.0

@@ -60,3 +60,24 @@ def test_synth_pages_are_deterministic():
     a, ba = synth_page(3)
     b, bb = synth_page(3)
     assert (a == b).all() and (ba == bb).all() and a.shape == (1684, 1191, 3) and len(ba) == 45
+
+
+import json
+from pathlib import Path
+
+import pytest
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_box_helpers_match_reference_golden(seed):
+    """sorted_boxes / merge_det_boxes / update_det_boxes / calculate_is_angle vs outputs of the reference functions
+    (rapid_doc/utils/ocr_utils.py) captured by tests/golden/make_golden.py."""
+    g = json.loads((Path(__file__).resolve().parent / "golden" / f"boxes_seed{seed}.json").read_text())
+    quads = [np.array(q, dtype=np.float32) for q in g["quads"]]
+    assert [H.quad_is_tilted(q) for q in quads] == g["is_angle"]
+    got = [np.asarray(b).tolist() for b in H.sorted_boxes(np.array(quads))]
+    assert got == g["sorted"]
+    got = [np.asarray(b).tolist() for b in H.merge_det_boxes([q.copy() for q in quads])]
+    assert got == g["merged"]
+    got = [np.asarray(b).tolist() for b in H.update_det_boxes([q.copy() for q in quads], g["formulas"])]
+    assert got == g["updated"]
