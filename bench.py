@@ -133,6 +133,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_lines = sum(len(l) for _, l in out)
+    host_stats = {k: round(v, 2) for k, v in pipe.stats.items()}
 
     # ---- roofline of the dominant kernel: per-op HIP events (recorded by the library on the launch stream)
     roof = None
@@ -188,7 +189,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "PP-DocLayout backbone (PPHGNetV2-B4 @800x800) + PP-OCRv6-small det (960x704) + rec "
                                    "(45 lines/page, fused CTC) on %d synthetic 1684x1191 pages per GPU" % P,
-                       "pages_per_gpu": P, "lines_per_step": n_lines, "parallelism": "page-sharded dp%d" % world,
+                       "pages_per_gpu": P, "lines_per_step": n_lines, "host_stage_ms": host_stats, "parallelism": "page-sharded dp%d" % world,
                        "layout_head": "absent (ONNX-only in the reference; backbone only)",
                        "det_postprocess": "DB post-process (host C++) runs on maps rendered from the generator's line boxes "
                                           "(random-weight det output has no text); its boxes drive crop+rec"},

@@ -133,15 +133,15 @@ float rd_debug_time_mixer(int C, int M, int variant, int iters, float* x, float*
     p.x = x; p.xld = C; p.y = y; p.yld = C; p.M = M; p.HW = M; p.C = C; p.gate = nullptr;
     p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2;
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     rd::launch_mixer_debug(p, variant, nullptr);
-    hipEventRecord(e0, nullptr);
+    (void)hipEventRecord(e0, nullptr);
     for (int i = 0; i < iters; ++i) rd::launch_mixer_debug(p, variant, nullptr);
-    hipEventRecord(e1, nullptr);
-    hipEventSynchronize(e1);
+    (void)hipEventRecord(e1, nullptr);
+    (void)hipEventSynchronize(e1);
     float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return ms / iters;
 }
 float rd_debug_time_gemm(int M, int K, int N, int act, int iters, float* x, float* w, float* b, float* y) {
@@ -150,15 +150,15 @@ float rd_debug_time_gemm(int M, int K, int N, int act, int iters, float* x, floa
     p.OH = 1; p.OW = M; p.Cout = N; p.KH = p.KW = p.SH = p.SW = 1; p.act = act; p.out_mode = rd::OUT_NHWC;
     p.M = M; p.K = K; p.Ng = N;
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     rd::launch_conv_igemm(p, nullptr);
-    hipEventRecord(e0, nullptr);
+    (void)hipEventRecord(e0, nullptr);
     for (int i = 0; i < iters; ++i) rd::launch_conv_igemm(p, nullptr);
-    hipEventRecord(e1, nullptr);
-    hipEventSynchronize(e1);
+    (void)hipEventRecord(e1, nullptr);
+    (void)hipEventSynchronize(e1);
     float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return ms / iters;
 }
 

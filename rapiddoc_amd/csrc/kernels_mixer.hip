@@ -141,6 +141,8 @@ __global__ void __launch_bounds__(256) lc_mixer_kernel(MixerParams p) {
                 }
             }
         }
+        // (interleaving the GELU of k-group g+1 with GEMM2's MFMAs of group g measured 5 % SLOWER: VALU fillers beside
+        //  dependent fp32 MFMAs cost more than the stall they remove)
         // bias + GELU in registers; register r holds hidden index 8*(r>>2) + 4*lhi + (r&3)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {

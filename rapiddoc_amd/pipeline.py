@@ -8,6 +8,7 @@ boxes cross PCIe.
 """
 from __future__ import annotations
 
+import time
 import ctypes as C
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -49,6 +50,27 @@ def quad_to_crop_matrix(quad: np.ndarray) -> Tuple[np.ndarray, float, float]:
         A.append([0, 0, 0, x, y, 1, -v * x, -v * y]); b.append(v)
     h = np.linalg.solve(np.asarray(A), np.asarray(b))
     return np.append(h, 1.0).astype(np.float32), cw, ch
+
+
+def quads_to_crop_matrices(quads: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Vectorised `quad_to_crop_matrix` for [n,4,2] quads -> ([n,9] float32, crop widths, crop heights)."""
+    q = np.asarray(quads, dtype=np.float64).reshape(-1, 4, 2)
+    n = len(q)
+    cw = np.maximum(np.linalg.norm(q[:, 0] - q[:, 1], axis=1), np.linalg.norm(q[:, 2] - q[:, 3], axis=1))
+    ch = np.maximum(np.linalg.norm(q[:, 0] - q[:, 3], axis=1), np.linalg.norm(q[:, 1] - q[:, 2], axis=1))
+    cw, ch = np.maximum(np.floor(cw), 1.0), np.maximum(np.floor(ch), 1.0)
+    z = np.zeros(n)
+    src = np.stack([np.stack([z, z], 1), np.stack([cw, z], 1), np.stack([cw, ch], 1), np.stack([z, ch], 1)], axis=1)  # [n,4,2]
+    A = np.zeros((n, 8, 8))
+    b = np.zeros((n, 8))
+    x, y, u, v = src[..., 0], src[..., 1], q[..., 0], q[..., 1]
+    A[:, 0::2, 0], A[:, 0::2, 1], A[:, 0::2, 2] = x, y, 1.0
+    A[:, 0::2, 6], A[:, 0::2, 7] = -u * x, -u * y
+    A[:, 1::2, 3], A[:, 1::2, 4], A[:, 1::2, 5] = x, y, 1.0
+    A[:, 1::2, 6], A[:, 1::2, 7] = -v * x, -v * y
+    b[:, 0::2], b[:, 1::2] = u, v
+    h = np.linalg.solve(A, b[..., None])[..., 0]
+    return np.concatenate([h, np.ones((n, 1))], axis=1).astype(np.float32), cw, ch
 
 
 def boxes_to_quads(boxes_xyxy: np.ndarray) -> np.ndarray:
@@ -103,33 +125,30 @@ class PagePipeline:
         """All text lines of the page batch -> [(text, score)] per page, reference batching order
         (rapid_ocr.py:404-472) with a GPU-sized rec_batch_num."""
         P, H, W, _ = pages.shape
-        page_of, mats, cws, chs, rots = [], [], [], [], []
-        for pi, quads in enumerate(quads_per_page):
-            for q in np.asarray(quads, dtype=np.float32).reshape(-1, 4, 2):
-                m, cw, ch = quad_to_crop_matrix(q)
-                rot = 1 if ch / cw >= 2.0 else 0  # ocr_utils.py:531-534 rotates crops with h/w >= 2
-                page_of.append(pi); mats.append(m); cws.append(cw); chs.append(ch); rots.append(rot)
-        n = len(page_of)
-        texts: List[Tuple[str, float]] = [("", 0.0)] * n
+        t0 = time.perf_counter()
+        counts = [len(np.asarray(q).reshape(-1, 4, 2)) for q in quads_per_page]
+        n = int(sum(counts))
         if n == 0:
             return [[] for _ in range(P)]
-        cws_a, chs_a, rots_a = np.asarray(cws), np.asarray(chs), np.asarray(rots)
+        page_of = np.repeat(np.arange(P), counts)
+        quads = np.concatenate([np.asarray(q, dtype=np.float64).reshape(-1, 4, 2) for q in quads_per_page if len(q)], axis=0)
+        mats, cws_a, chs_a = quads_to_crop_matrices(quads)
+        rots_a = (chs_a / cws_a >= 2.0).astype(np.int32)  # ocr_utils.py:531-534 rotates crops with h/w >= 2
+        texts: List[Tuple[str, float]] = [("", 0.0)] * n
         eff_w = np.where(rots_a == 1, chs_a, cws_a)
         eff_h = np.where(rots_a == 1, cws_a, chs_a)
         ratios = (eff_w / eff_h).tolist()
         batches = ocr_host.rec_batches(ratios, self.rec_batch_num, width_multiple=self.rec_width_multiple)
-        descs = np.zeros(n, dtype=CROP_DTYPE)
         order_all = np.concatenate([c for c, _ in batches])
-        pos = 0
-        for chunk, wpad in batches:
-            for i in chunk:
-                d = descs[pos]
-                d["page"] = page_of[i]
-                d["out_w"] = ocr_host.rec_resized_width(eff_w[i], eff_h[i], wpad)
-                d["crop_w"], d["crop_h"] = cws[i], chs[i]
-                d["m"] = mats[i]
-                d["rot90"] = rots[i]
-                pos += 1
+        wpad_all = np.concatenate([np.full(len(c), w) for c, w in batches])
+        descs = np.zeros(n, dtype=CROP_DTYPE)
+        descs["page"] = page_of[order_all]
+        descs["out_w"] = np.minimum(wpad_all, np.ceil(ocr_host.REC_IMG_H * (eff_w / eff_h)[order_all])).astype(np.int32)
+        descs["crop_w"] = cws_a[order_all]
+        descs["crop_h"] = chs_a[order_all]
+        descs["m"] = mats[order_all]
+        descs["rot90"] = rots_a[order_all]
+        self.stats["t_descs_ms"] = (time.perf_counter() - t0) * 1e3
         descs_dev = torch.from_numpy(descs.view(np.uint8)).to(pages.device, non_blocking=True)
         mean = (C.c_float * 3)(0.5, 0.5, 0.5)
         std = (C.c_float * 3)(0.5, 0.5, 0.5)
@@ -147,15 +166,21 @@ class PagePipeline:
             idx, prob, _ = self.rec.rec_forward(x)
             outs.append((idx, prob))
             pos += nb
-        # one sync + D2H per batch result (small), then host CTC decode (rapidocr CTCLabelDecode)
-        pos = 0
+        self.stats["t_rec_enqueue_ms"] = (time.perf_counter() - t0) * 1e3 - self.stats["t_descs_ms"]
+        # D2H per batch result (small) as soon as that batch is done, host CTC decode (rapidocr CTCLabelDecode)
+        # overlaps the GPU work of the batches still in flight
+        t_dec = 0.0
         for (chunk, wpad), (idx, prob) in zip(batches, outs):
-            dec = ocr_host.ctc_decode(idx.cpu().numpy(), prob.cpu().numpy(), self.characters)
+            idx_h, prob_h = idx.cpu().numpy(), prob.cpu().numpy()
+            t1 = time.perf_counter()
+            dec = ocr_host.ctc_decode(idx_h, prob_h, self.characters)
             for j, i in enumerate(chunk):
                 t, s = dec[j]
                 texts[i] = (t, ocr_host.format_score(s))
+            t_dec += time.perf_counter() - t1
+        self.stats["t_decode_ms"] = t_dec * 1e3
         per_page: List[List[Tuple[str, float]]] = [[] for _ in range(P)]
-        for i, pi in enumerate(page_of):
+        for i, pi in enumerate(page_of.tolist()):
             per_page[pi].append(texts[i])
         self.stats["rec_lines"] = n
         self.stats["rec_batches"] = len(batches)
@@ -210,8 +235,12 @@ class PagePipeline:
                 for i in range(P):
                     results[i].layout_feats = [f[i] for f in feats]
         if quads_per_page is None:
+            t0 = time.perf_counter()
             copy_done.synchronize()
+            t1 = time.perf_counter()
             quads_per_page = self.boxes_from_maps(self._maps_host.numpy(), (H, W))
+            self.stats["t_wait_maps_ms"] = (t1 - t0) * 1e3
+            self.stats["t_db_post_ms"] = (time.perf_counter() - t1) * 1e3
         texts = self.rec_forward_lines(pages, quads_per_page)
         for i in range(P):
             qs = np.asarray(quads_per_page[i], dtype=np.float32).reshape(-1, 4, 2)
