@@ -144,16 +144,18 @@ float rd_debug_time_mixer(int C, int M, int variant, int iters, float* x, float*
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return ms / iters;
 }
-float rd_debug_time_gemm(int M, int K, int N, int act, int iters, float* x, float* w, float* b, float* y) {
+float rd_debug_time_gemm(int M, int K, int N, int act, int iters, float* x, float* w, float* b, float* y, void* wh, void* wl) {
     rd::ConvParams p{};
+    p.wh = (const uint16_t*)wh; p.wl = (const uint16_t*)wl;
     p.x = x; p.xld = K; p.N = 1; p.H = 1; p.W = M; p.Cin = K; p.w = w; p.bias = b; p.y = y; p.yld = N;
     p.OH = 1; p.OW = M; p.Cout = N; p.KH = p.KW = p.SH = p.SW = 1; p.act = act; p.out_mode = rd::OUT_NHWC;
     p.M = M; p.K = K; p.Ng = N;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    rd::launch_conv_igemm(p, nullptr);
+    auto go = [&] { if (wh) rd::launch_conv_igemm_h3(p, nullptr); else rd::launch_conv_igemm(p, nullptr); };
+    go();
     (void)hipEventRecord(e0, nullptr);
-    for (int i = 0; i < iters; ++i) rd::launch_conv_igemm(p, nullptr);
+    for (int i = 0; i < iters; ++i) go();
     (void)hipEventRecord(e1, nullptr);
     (void)hipEventSynchronize(e1);
     float ms = 0.f;

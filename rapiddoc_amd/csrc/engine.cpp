@@ -160,6 +160,11 @@ size_t ParamBlock::add(const std::string& key, const std::vector<float>& v) {
     off_[key] = off;
     return off;
 }
+size_t ParamBlock::add_u16(const std::string& key, const std::vector<uint16_t>& v) {
+    std::vector<float> packed((v.size() + 1) / 2, 0.f);
+    std::memcpy(packed.data(), v.data(), v.size() * sizeof(uint16_t));
+    return add(key, packed);
+}
 void ParamBlock::upload() {
     if (dev_) { (void)hipFree(dev_); dev_ = nullptr; }
     size_t n = std::max<size_t>(host_.size(), 64) + 64;
@@ -330,13 +335,20 @@ TView Builder::conv(const std::string& wname, const std::string& bname, const st
     const TView xv = x, yv = y;
     const bool has_res = res != nullptr, has_as = ascale != nullptr;
     const TView rv = res ? *res : TView{}, av = ascale ? *ascale : TView{};
-    r.run = [p, xv, yv, rv, av, has_res, has_as](const Plan& pl, const RunCtx& c) mutable {
+    const bool h3 = h3_;
+    if (h3) {
+        p.wh = reinterpret_cast<const uint16_t*>(pb_->ptr(key + "#wh"));
+        p.wl = reinterpret_cast<const uint16_t*>(pb_->ptr(key + "#wl"));
+        r.cfg += "/h3";
+    }
+    r.run = [p, xv, yv, rv, av, has_res, has_as, h3](const Plan& pl, const RunCtx& c) mutable {
         ConvParams q = p;
         q.x = pl.vptr(xv, c);
         q.y = pl.vptr(yv, c);
         q.res = has_res ? pl.vptr(rv, c) : nullptr;
         q.ascale = has_as ? pl.vptr(av, c) : nullptr;
-        launch_conv_igemm(q, c.stream);
+        if (h3) launch_conv_igemm_h3(q, c.stream);
+        else launch_conv_igemm(q, c.stream);
     };
     emit(std::move(r));
     return y;
@@ -368,6 +380,12 @@ void Builder::fold_conv(const std::string& wname, const std::string& bname, cons
     for (int co = 0; co < cout; ++co) bias[co] += shift[co];
     pb_->add(key + "#w", wf);
     if (any_bias) pb_->add(key + "#b", bias);
+    if (h3_) {
+        std::vector<uint16_t> hi, lo;
+        split_weights_h3(wf.data(), cout, K, hi, lo);
+        pb_->add_u16(key + "#wh", hi);
+        pb_->add_u16(key + "#wl", lo);
+    }
 }
 
 TView Builder::mixer_fused(const std::string& prefix, const TView& x, const TView* gate) {
@@ -445,6 +463,12 @@ TView Builder::deconv2x2(const std::string& wname, const std::string& bname, con
             for (int co = 0; co < cout; ++co) bias[co] += shift[co];
             pb_->add(key + "#w", wf);
             pb_->add(key + "#b", bias);
+            if (h3_) {
+                std::vector<uint16_t> hi, lo;
+                split_weights_h3(wf.data(), 4 * cout, cin, hi, lo);
+                pb_->add_u16(key + "#wh", hi);
+                pb_->add_u16(key + "#wl", lo);
+            }
         }
         return y;
     }
@@ -453,6 +477,10 @@ TView Builder::deconv2x2(const std::string& wname, const std::string& bname, con
     p.N = x.n; p.H = x.h; p.W = x.w; p.Cin = cin;
     p.w = pb_->ptr(key + "#w");
     p.bias = pb_->ptr(key + "#b");
+    if (h3_) {
+        p.wh = reinterpret_cast<const uint16_t*>(pb_->ptr(key + "#wh"));
+        p.wl = reinterpret_cast<const uint16_t*>(pb_->ptr(key + "#wl"));
+    }
     p.yld = plan_->ld(y);
     p.OH = x.h; p.OW = x.w; p.Cout = cout;
     p.KH = p.KW = p.SH = p.SW = 1;
@@ -466,11 +494,13 @@ TView Builder::deconv2x2(const std::string& wname, const std::string& bname, con
     r.flops = 2.0 * p.M * (double)cin * 4 * cout;
     r.bytes = 4.0 * ((double)p.M * cin + (double)p.M * 4 * cout);
     const TView xv = x, yv = y;
-    r.run = [p, xv, yv](const Plan& pl, const RunCtx& c) {
+    const bool h3 = h3_;
+    r.run = [p, xv, yv, h3](const Plan& pl, const RunCtx& c) {
         ConvParams q = p;
         q.x = pl.vptr(xv, c);
         q.y = pl.vptr(yv, c);
-        launch_conv_igemm(q, c.stream);
+        if (h3) launch_conv_igemm_h3(q, c.stream);
+        else launch_conv_igemm(q, c.stream);
     };
     emit(std::move(r));
     return y;
@@ -858,6 +888,7 @@ void Builder::ctc_head(const std::string& prefix, const TView& x, const TView& i
 extern bool g_disable_fused_mixer;
 Engine::Engine(int device, const std::string& kind) : device_(device), kind_(kind) {
     if (const char* e = getenv("RD_DISABLE_FUSED_MIXER")) g_disable_fused_mixer = e[0] == '1';
+    if (const char* e = getenv("RD_PRECISION")) h3_ = std::string(e) == "h3";
     RD_CHECK(kind == "ppocrv6_det" || kind == "ppocrv6_rec" || kind == "pphgnetv2_b4", "unknown model kind '" + kind + "'");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -883,7 +914,7 @@ void Engine::load_weights(const void* blob, size_t nbytes) {
     store_.load_safetensors(blob, nbytes);
     if (kind_ == "ppocrv6_rec") n_classes_ = (int)store_.get("head.head.weight").shape[0];  // torch.py:112-116
     Plan dummy;
-    Builder b(Mode::PREPARE, &store_, &params_, &dummy);
+    Builder b(Mode::PREPARE, &store_, &params_, &dummy, h3_);
     // smallest legal geometry; only weight names/shapes matter in PREPARE mode
     if (kind_ == "ppocrv6_rec") build(b, 1, 48, 64, 0), build(b, 1, 48, 64, REC_UNFUSED_CTC);
     else build(b, 1, 64, 64, 0);
@@ -898,7 +929,7 @@ const Plan& Engine::plan_for(int B, int H, int W, int flags) {
     if (it != plans_.end()) return *it->second;
     if (plans_.size() >= 256) plans_.clear();
     auto plan = std::make_unique<Plan>();
-    Builder b(Mode::PLAN, &store_, &params_, plan.get());
+    Builder b(Mode::PLAN, &store_, &params_, plan.get(), h3_);
     build(b, B, H, W, flags);
     plan->arena_bytes = (plan->arena_bytes + 255) / 256 * 256;
     auto& ref = *plan;

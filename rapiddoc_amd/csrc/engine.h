@@ -62,6 +62,7 @@ class ParamBlock {
    public:
     ~ParamBlock();
     size_t add(const std::string& key, const std::vector<float>& v);
+    size_t add_u16(const std::string& key, const std::vector<uint16_t>& v);  // packed into the same block
     bool has(const std::string& key) const { return off_.count(key) != 0; }
     void upload();
     const float* ptr(const std::string& key) const;
@@ -123,7 +124,9 @@ enum class Mode { PREPARE, PLAN };
 // parameter block; in PLAN mode it allocates buffers and records kernel launches for one input shape.
 class Builder {
    public:
-    Builder(Mode m, const WeightStore* ws, ParamBlock* pb, Plan* plan) : mode_(m), ws_(ws), pb_(pb), plan_(plan) {}
+    Builder(Mode m, const WeightStore* ws, ParamBlock* pb, Plan* plan, bool h3 = false)
+        : mode_(m), ws_(ws), pb_(pb), plan_(plan), h3_(h3) {}
+    bool h3() const { return h3_; }
     Mode mode() const { return mode_; }
     bool planning() const { return mode_ == Mode::PLAN; }
 
@@ -177,6 +180,7 @@ class Builder {
     void emit(OpRecord&& r) { plan_->ops.push_back(std::move(r)); }
     std::vector<float> bn_scale_shift(const std::string& bn, int c, std::vector<float>& shift) const;
     Mode mode_;
+    bool h3_ = false;   // dense layers on the fp16 matrix cores with hi/lo operand splitting (fp32-accurate)
     const WeightStore* ws_;
     ParamBlock* pb_;
     Plan* plan_;
@@ -204,6 +208,7 @@ class Engine {
     const std::vector<ProfileEntry>& last_profile() const { return profile_; }
     std::string profile_json() const;
     int n_classes() const { return n_classes_; }
+    bool h3() const { return h3_; }
     int device() const { return device_; }
 
     std::string last_error;
@@ -214,6 +219,7 @@ class Engine {
     std::string kind_;
     bool loaded_ = false;
     bool profiling_ = false;
+    bool h3_ = false;
     int n_classes_ = 0;
     ParamBlock params_;
     WeightStore store_;

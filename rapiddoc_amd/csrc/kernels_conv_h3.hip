@@ -1,0 +1,310 @@
+// fp32-accurate implicit-GEMM convolution on the 2.5 PFLOP/s fp16 matrix cores ("h3" = 3 half-precision MFMAs per
+// product).  Same geometry, fused epilogue and launch interface as kernels_conv.hip, different arithmetic:
+//
+//   every fp32 operand x is split as  x = hi + lo * 2^-11,  hi = fp16(x),  lo = fp16((x - hi) * 2^11)
+//   (hi carries 11 significand bits, lo the next 11: |x - hi - lo*2^-11| <= 2^-22 |x|; the 2^11 scale keeps lo in
+//   fp16's normal range), and            a*b ~= ah*bh + 2^-11 (ah*bl + al*bh)        (al*bl ~ 2^-22 |ab| dropped)
+//   acc1 += ah*bh,  acc2 += ah*bl + al*bh   with v_mfma_f32_32x32x16_f16 (fp16 products are exact in fp32, fp32
+//   accumulate);  result = acc1 + acc2 * 2^-11.   Per-product relative error <~ 5e-7, i.e. fp32 round-off class,
+//   three orders of magnitude inside the 1e-3 parity budget, at 16/3 the fp32-MFMA rate.
+// Operand range: |x| must stay below 65504 (fp16 max); tiny values degrade gracefully (absolute error < 2e-11).
+//
+// Activations are split on the fly while a K tile is staged into LDS (5 VALU ops per element, hidden under the
+// MFMAs); weights are split once at load time (rd_load_weights) and stored as two fp16 matrices [Ng][Kp].
+#include <vector>
+
+#include "rd_kernels.h"
+
+namespace rd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int HBK = 32;    // K tile (fp32 elements)
+static constexpr int HLD = 40;    // LDS row stride in halfs (64 B data + 16 B pad: conflict-free ds_read_b128)
+
+__device__ __forceinline__ float h3_gelu(float v) {  // erf by A&S 7.1.26, see kernels_conv.hip
+    const float z = fabsf(v) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float erfz = 1.f - poly * t * __expf(-z * z);
+    return 0.5f * v * (1.f + copysignf(erfz, v));
+}
+__device__ __forceinline__ float h3_act(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return fmaxf(v, 0.f);
+        case ACT_GELU: return h3_gelu(v);
+        case ACT_SILU: return v / (1.f + __expf(-v));
+        case ACT_SIGMOID: {
+            float r = 1.f / (1.f + __expf(-v));
+            return (r != r) ? 0.f : r;
+        }
+        case ACT_HSIG: return fminf(fmaxf(v * (1.f / 6.f) + 0.5f, 0.f), 1.f);
+        case ACT_HSIG_PADDLE: return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f);
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const _Float16 h = (_Float16)v[i];
+        hi[i] = h;
+        lo[i] = (_Float16)((v[i] - (float)h) * 2048.f);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool IS1X1>
+__global__ void __launch_bounds__(WM* WN * 64) conv_igemm_h3_kernel(ConvParams p, int ntn) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int AL = BM * 8 / NT, BL = BN * 8 / NT;
+    static_assert(AL >= 1 && BL >= 1 && NT == 256, "tile/loader mismatch");
+
+    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * (BM + BN) * HLD];
+    _Float16* Ah = smem;
+    _Float16* Al = Ah + BM * HLD;
+    _Float16* Bh = Al + BM * HLD;
+    _Float16* Bl = Bh + BN * HLD;
+
+    int tile_m, tile_n;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x;
+        const int xcd = id & 7, j = id >> 3, q = nwg >> 3, r = nwg & 7;
+        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        tile_m = w / ntn;
+        tile_n = w - tile_m * ntn;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x;
+    const int lrow = tid >> 3, lkq = tid & 7;
+    const int K = p.K, Kp = (p.K + 7) & ~7;
+
+    const float* arow[AL];
+    bool avalid[AL];
+    int a_ih0[AL], a_iw0[AL];
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        avalid[i] = m < p.M;
+        const int mm = avalid[i] ? m : 0;
+        if (IS1X1) {
+            arow[i] = p.x + (size_t)mm * p.xld;
+            a_ih0[i] = a_iw0[i] = 0;
+        } else {
+            const int ohw = p.OH * p.OW;
+            const int b = mm / ohw, rem = mm - b * ohw;
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            a_ih0[i] = avalid[i] ? oh * p.SH - p.PT : -(1 << 28);
+            a_iw0[i] = ow * p.SW - p.PL;
+            arow[i] = p.x + (size_t)b * p.H * p.W * p.xld;
+        }
+    }
+    // B loader: BN*8 16-byte pieces (hi then lo), piece t -> (which, row, 8-half column)
+    const _Float16* bsrc[BL];
+    bool bvalid[BL];
+    int b_lds[BL], b_col[BL];
+#pragma unroll
+    for (int i = 0; i < BL; ++i) {
+        const int t = tid + 256 * i;
+        const int which = t / (BN * 4), rem = t - which * (BN * 4);
+        const int r = rem >> 2, c = rem & 3;
+        const int n = n0 + r;
+        bvalid[i] = n < p.Ng;
+        bsrc[i] = reinterpret_cast<const _Float16*>(which ? p.wl : p.wh) + (size_t)(bvalid[i] ? n : 0) * Kp;
+        b_col[i] = c * 8;
+        b_lds[i] = (which ? (int)(Bl - smem) : (int)(Bh - smem)) + r * HLD + c * 8;
+    }
+
+    f32x4 areg[AL];
+    u32x4 breg[BL];
+    unsigned amask = 0, bmask = 0;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const u32x4 zero4u = {0u, 0u, 0u, 0u};
+
+    auto load_tiles = [&](int k0) {
+        const int k = k0 + 4 * lkq;
+        const bool kvalid = k < K;
+        const int kk = kvalid ? k : 0;
+        amask = bmask = 0;
+        if (IS1X1) {
+#pragma unroll
+            for (int i = 0; i < AL; ++i) {
+                areg[i] = *reinterpret_cast<const f32x4*>(arow[i] + kk);
+                amask |= (unsigned)(kvalid && avalid[i]) << i;
+            }
+        } else {
+            const int tap = kk / p.Cin, ci = kk - tap * p.Cin;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+            for (int i = 0; i < AL; ++i) {
+                const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+                const bool ok = kvalid && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                const size_t off = ok ? ((size_t)ih * p.W + iw) * p.xld + ci : 0;
+                areg[i] = *reinterpret_cast<const f32x4*>(arow[i] + off);
+                amask |= (unsigned)ok << i;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BL; ++i) {
+            const int kb = k0 + b_col[i];
+            const bool ok = kb < Kp && bvalid[i];
+            breg[i] = *reinterpret_cast<const u32x4*>(bsrc[i] + (ok ? kb : 0));
+            bmask |= (unsigned)ok << i;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < AL; ++i) {
+            f16x4 hi, lo;
+            split4(((amask >> i) & 1u) ? areg[i] : zero4, hi, lo);
+            const int o = (lrow + 32 * i) * HLD + 4 * lkq;
+            *reinterpret_cast<f16x4*>(&Ah[o]) = hi;
+            *reinterpret_cast<f16x4*>(&Al[o]) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < BL; ++i) *reinterpret_cast<u32x4*>(&smem[b_lds[i]]) = ((bmask >> i) & 1u) ? breg[i] : zero4u;
+    };
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    f32x16 acc1[TM][TN], acc2[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[i][j][r] = acc2[i][j][r] = 0.f;
+
+    const int KT = (K + HBK - 1) / HBK;
+    load_tiles(0);
+    store_tiles();
+    __syncthreads();
+    const int aoff = ((wm * TM) * 32 + l31) * HLD + 8 * lhi;
+    const int boff = ((wn * TN) * 32 + l31) * HLD + 8 * lhi;
+    for (int kt = 0; kt < KT; ++kt) {
+        const bool more = kt + 1 < KT;
+        if (more) load_tiles((kt + 1) * HBK);
+        const int kleft = K - kt * HBK;
+        const int nks = kleft > 16 ? 2 : 1;
+        for (int ks = 0; ks < nks; ++ks) {
+            f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const f16x8*>(&Ah[aoff + i * 32 * HLD + ks * 16]);
+                al[i] = *reinterpret_cast<const f16x8*>(&Al[aoff + i * 32 * HLD + ks * 16]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const f16x8*>(&Bh[boff + j * 32 * HLD + ks * 16]);
+                bl[j] = *reinterpret_cast<const f16x8*>(&Bl[boff + j * 32 * HLD + ks * 16]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc1[i][j], 0, 0, 0);
+                    acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc2[i][j], 0, 0, 0);
+                    acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc2[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (more) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + l31;
+        if (n >= p.Ng) continue;
+        int co = n, dy = 0, dx = 0;
+        if (p.out_mode == OUT_DECONV2X2) {
+            const int tap = n / p.Cout;
+            co = n - tap * p.Cout;
+            dy = tap >> 1;
+            dx = tap & 1;
+        }
+        const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + (wm * TM + i) * 32 + 4 * lhi;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                if (m >= p.M) continue;
+                float v = h3_act(fmaf(acc2[i][j][r], 1.f / 2048.f, acc1[i][j][r]) + bv, p.act);
+                if (p.out_mode == OUT_NHWC) {
+                    if (p.res) v += p.res[(size_t)m * p.rld + co];
+                    p.y[(size_t)m * p.yld + co] = v;
+                } else {
+                    const int b = m / ohw, rem = m - b * ohw;
+                    const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                    const size_t pix = ((size_t)b * (2 * p.OH) + 2 * oh + dy) * (2 * p.OW) + 2 * ow + dx;
+                    p.y[pix * p.yld + co] = v;
+                }
+            }
+        }
+    }
+}
+
+static inline int h3_pick_bn(const ConvParams& p) {
+    const int n = p.Ng;
+    if (n <= 32) return 32;
+    if (n <= 64) return 64;
+    if (n <= 96) return 96;
+    const int w128 = (n + 127) / 128 * 128, w96 = (n + 95) / 96 * 96;
+    return w96 < w128 ? 96 : 128;
+}
+static inline bool h3_is_1x1(const ConvParams& p) {
+    return p.KH == 1 && p.KW == 1 && p.SH == 1 && p.SW == 1 && p.PT == 0 && p.PL == 0 && p.OH == p.H && p.OW == p.W;
+}
+template <int BM, int BN, int WM, int WN>
+static void h3_launch_cfg(const ConvParams& p, hipStream_t s) {
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.Ng + BN - 1) / BN;
+    dim3 grid(ntm * ntn), block(WM * WN * 64);
+    if (h3_is_1x1(p))
+        hipLaunchKernelGGL((conv_igemm_h3_kernel<BM, BN, WM, WN, true>), grid, block, 0, s, p, ntn);
+    else
+        hipLaunchKernelGGL((conv_igemm_h3_kernel<BM, BN, WM, WN, false>), grid, block, 0, s, p, ntn);
+}
+
+void launch_conv_igemm_h3(const ConvParams& p, hipStream_t s) {
+    if (p.M <= 0) return;
+    switch (h3_pick_bn(p)) {
+        case 32: h3_launch_cfg<128, 32, 4, 1>(p, s); break;
+        case 64: h3_launch_cfg<128, 64, 4, 1>(p, s); break;
+        case 96: h3_launch_cfg<128, 96, 4, 1>(p, s); break;
+        default: h3_launch_cfg<128, 128, 2, 2>(p, s); break;
+    }
+}
+
+// host helper: split a weight matrix [rows][K] fp32 into hi/lo fp16 matrices [rows][Kp] (Kp = K rounded up to 8)
+void split_weights_h3(const float* w, int rows, int K, std::vector<uint16_t>& hi, std::vector<uint16_t>& lo) {
+    const int Kp = (K + 7) & ~7;
+    hi.assign((size_t)rows * Kp, 0);
+    lo.assign((size_t)rows * Kp, 0);
+    for (int r = 0; r < rows; ++r)
+        for (int k = 0; k < K; ++k) {
+            const float v = w[(size_t)r * K + k];
+            const _Float16 h = (_Float16)v;
+            const _Float16 l = (_Float16)((v - (float)h) * 2048.f);
+            uint16_t hb, lb;
+            __builtin_memcpy(&hb, &h, 2);
+            __builtin_memcpy(&lb, &l, 2);
+            hi[(size_t)r * Kp + k] = hb;
+            lo[(size_t)r * Kp + k] = lb;
+        }
+}
+
+}  // namespace rd

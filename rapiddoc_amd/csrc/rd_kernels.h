@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <vector>
 
 namespace rd {
 
@@ -16,6 +17,8 @@ struct ConvParams {
     const float* x; int xld;
     int N, H, W, Cin;
     const float* w;      // [Ng][K]
+    const uint16_t* wh;  // fp16x3 ("h3") mode: the same weights split into hi / lo fp16 matrices [Ng][Kp], Kp = ceil8(K)
+    const uint16_t* wl;
     const float* bias;   // [Cout] or nullptr (BN already folded into w / bias)
     float* y; int yld;
     int OH, OW, Cout;
@@ -26,6 +29,8 @@ struct ConvParams {
     int M, K, Ng;
 };
 void launch_conv_igemm(const ConvParams& p, hipStream_t s);
+// fp32-accurate variant on the fp16 matrix cores (3 MFMAs per product, see kernels_conv_h3.hip); needs p.wh / p.wl
+void launch_conv_igemm_h3(const ConvParams& p, hipStream_t s);
 // a short human-readable tag of the tile configuration chosen for p (for the per-op profile)
 const char* conv_igemm_config_name(const ConvParams& p);
 
@@ -141,6 +146,7 @@ void launch_crop_resize_norm_batch(const CropBatchParams& p, hipStream_t s);
 }  // namespace rd
 
 namespace rd {
+void split_weights_h3(const float* w, int rows, int K, std::vector<uint16_t>& hi, std::vector<uint16_t>& lo);
 // Fused PPLCNetV4 channel mixer for residual ("rep") blocks (rec_lcnetv4.py:226-236):
 //   X' = X * gate            (optional SE gate, per sample and channel)
 //   Y  = X' + W2 . GELU(W1 . X' + b1) + b2      W1: [2C][C], W2: [C][2C]  (BN folded)

@@ -144,3 +144,20 @@ def test_crop_kernel_axis_aligned_matches_torch_interpolate(engines):
     # interior only: at the crop border the kernel clamps to the crop rectangle exactly like the resize does
     assert float((got - ref).abs().max()) < 2e-3
     assert float(out[:, :, :, 240:].abs().max()) == 0.0
+
+
+def test_h3_precision_mode_matches_golden(golden_dir, monkeypatch):
+    """Experimental RD_PRECISION=h3 (dense layers on the fp16 matrix cores with hi/lo operand splitting, 3 MFMAs per
+    product) must meet the same 1e-3 bar as the fp32-MFMA default."""
+    from rapiddoc_amd.engine import REC_WANT_LOGITS, RdEngine
+    monkeypatch.setenv("RD_PRECISION", "h3")
+    st = W.synth_state_dict(W.load_manifest(golden_dir / "manifest_ppocrv6_rec.json"), 0)
+    eng = RdEngine("ppocrv6_rec").load_weights(st)
+    g = np.load(golden_dir / "rec_seed0_b2_w320.npz")
+    _, _, lg = eng.rec_forward(torch.from_numpy(g["x"]).cuda(), REC_WANT_LOGITS)
+    assert np.abs(lg.cpu().numpy()[:, 0, :] - g["logits_t0"]).max() < TOL
+    st = W.synth_state_dict(W.load_manifest(golden_dir / "manifest_pphgnetv2_b4.json"), 0)
+    eng = RdEngine("pphgnetv2_b4").load_weights(st)
+    g = np.load(golden_dir / "b4_seed0_64x96.npz")
+    for i, f in enumerate(eng.backbone_forward(torch.from_numpy(g["x"]).cuda())):
+        assert np.abs(f.cpu().numpy() - g[f"feat{i}"]).max() < TOL

@@ -13,7 +13,7 @@ lib = _lib.load()
 lib.rd_debug_time_mixer.restype = C.c_float
 lib.rd_debug_time_mixer.argtypes = [C.c_int] * 4 + [C.c_void_p] * 6
 lib.rd_debug_time_gemm.restype = C.c_float
-lib.rd_debug_time_gemm.argtypes = [C.c_int] * 5 + [C.c_void_p] * 4
+lib.rd_debug_time_gemm.argtypes = [C.c_int] * 5 + [C.c_void_p] * 6
 
 
 def mixer(C_, M, variant, iters=20):
@@ -28,14 +28,26 @@ def mixer(C_, M, variant, iters=20):
     return ms, 8.0 * M * C_ * C_ / ms / 1e9
 
 
-def gemm(M, K, N, act=0, iters=20):
+def gemm(M, K, N, act=0, iters=20, h3=False, check=False):
     g = torch.Generator(device="cuda").manual_seed(0)
     x = torch.rand((M, K), device="cuda", generator=g) - 0.5
     w = (torch.rand((N, K), device="cuda", generator=g) - 0.5) * 0.1
     b = torch.zeros(N, device="cuda")
     y = torch.empty((M, N), device="cuda")
-    ms = lib.rd_debug_time_gemm(M, K, N, act, iters, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr())
-    return ms, 2.0 * M * K * N / ms / 1e9
+    wh = wl = None
+    if h3:
+        Kp = (K + 7) // 8 * 8
+        hi = w.half()
+        lo = ((w - hi.float()) * 2048.0).half()
+        wh = torch.zeros((N, Kp), dtype=torch.float16, device="cuda"); wh[:, :K] = hi
+        wl = torch.zeros((N, Kp), dtype=torch.float16, device="cuda"); wl[:, :K] = lo
+    ms = lib.rd_debug_time_gemm(M, K, N, act, iters, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
+                                wh.data_ptr() if h3 else None, wl.data_ptr() if h3 else None)
+    err = None
+    if check:
+        ref = (x[:4096].double() @ w.double().t())
+        err = float((y[:4096].double() - ref).abs().max() / ref.abs().max())
+    return ms, 2.0 * M * K * N / ms / 1e9, err
 
 
 if __name__ == "__main__":
@@ -45,7 +57,7 @@ if __name__ == "__main__":
             ms, tf = mixer(192, M, v)
             print(f"mixer C=192 M={M:7d} variant {v} ({names[v]:26s}): {ms*1e3:8.1f} us  {tf:6.1f} TF/s(nominal)")
     for (M, K, N) in ((131072, 192, 384), (131072, 384, 192), (131072, 384, 768), (131072, 768, 384), (81920, 2176, 512),
-                      (131072, 1024, 1024), (32768, 4096, 4096)):
-        for act in (0, 2):
-            ms, tf = gemm(M, K, N, act)
-            print(f"gemm M={M} K={K} N={N} act={act}: {ms*1e3:8.1f} us  {tf:6.1f} TF/s")
+                      (131072, 1024, 1024), (32768, 4096, 4096), (131072, 96, 192), (1310720, 48, 96)):
+        for h3 in (False, True):
+            ms, tf, err = gemm(M, K, N, 0, h3=h3, check=True)
+            print(f"gemm M={M} K={K} N={N} {'h3  ' if h3 else 'fp32'}: {ms*1e3:8.1f} us  {tf:7.1f} TF/s   max rel err vs fp64 {err:.2e}")
