@@ -101,6 +101,25 @@ int rd_db_postprocess(const float* prob_host, int B, int H, int W, const int32_t
                       float unclip_ratio, int use_dilation, int max_candidates, rd_text_box* out, int max_out,
                       int32_t* n_out, int n_threads);
 
+/* PP-DocLayout post-process, rectangle mode (HOST pointers).  Replaces PPPostProcess.__call__ with
+ * layout_shape_mode="rect": rapid_doc/model/layout/rapid_layout_self/model_handler/pp_doclayout/post_process.py:20-243.
+ * boxes: [n][ncol] float32 rows (cls, score, x0, y0, x1, y1[, order...]) in original-image pixels (ncol 6, 7 or 8).
+ * out: [n][6] kept rows, out_order[i] = the reference's 1-based "order" field, *n_out = kept count. */
+typedef struct rd_layout_post_cfg {
+    int32_t n_classes;
+    int32_t image_index, formula_index; /* index of the "image" / "formula" label, -1 if absent          */
+    int32_t thresh_is_dict;             /* 0: thresh[0] for every class; 1: thresh[class] (0.5 if missing) */
+    const float* thresh;
+    int32_t layout_nms;
+    int32_t merge_kind;                 /* 0 none/"union", 1 "large", 2 "small", 3 per-class table         */
+    const int8_t* merge_per_class;      /* [n_classes]: 0 union, 1 large, 2 small (merge_kind 3)            */
+    int32_t unclip_kind;                /* 0 none, 1 one (w, h) ratio pair, 2 per-class pairs               */
+    const float* unclip;                /* [2] or [n_classes][2]                                           */
+    const uint8_t* unclip_present;      /* [n_classes] (unclip_kind 2)                                     */
+} rd_layout_post_cfg;
+int rd_layout_postprocess(const float* boxes, int n, int ncol, int img_w, int img_h, const rd_layout_post_cfg* cfg,
+                          float* out, int32_t* out_order, int32_t* n_out);
+
 /* per-op HIP-event timing of the NEXT forward calls; rd_profile_json returns the last call's table as a JSON
  * array [{"name","kind","cfg","flops","bytes","ms"}, ...] owned by the handle. */
 int rd_set_profiling(rd_handle* h, int on);

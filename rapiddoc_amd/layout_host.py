@@ -1,0 +1,191 @@
+"""Host side of the layout stage: what surrounds the PP-DocLayout network in the reference.
+
+* `LayoutPostProcess` ....... PPPostProcess rect mode (pp_doclayout/post_process.py:20-243) - C++ behind the C-ABI
+* label / threshold / merge tables of the shipped models: data captured from
+  rapid_doc/model/layout/rapid_layout_self/utils/typings.py:14-140 (tests/golden/layout_tables.json)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+_MODES = {"union": 0, "large": 1, "small": 2}
+
+
+class _Cfg(C.Structure):
+    _fields_ = [("n_classes", C.c_int32), ("image_index", C.c_int32), ("formula_index", C.c_int32),
+                ("thresh_is_dict", C.c_int32), ("thresh", C.c_void_p), ("layout_nms", C.c_int32),
+                ("merge_kind", C.c_int32), ("merge_per_class", C.c_void_p), ("unclip_kind", C.c_int32),
+                ("unclip", C.c_void_p), ("unclip_present", C.c_void_p)]
+
+
+class LayoutPostProcess:
+    """Same constructor arguments and result dicts as the reference's PPPostProcess (rect mode)."""
+
+    def __init__(self, labels: Sequence[str], conf_thres: Union[float, Dict[int, float]] = 0.5, iou_thres: float = 0.5,
+                 layout_nms: bool = True, layout_merge_bboxes_mode: Union[None, str, Dict[int, str]] = None,
+                 layout_unclip_ratio=None, scale_size=None):
+        from . import _lib
+        self._lib = _lib.load()
+        self.labels = list(labels)
+        n = len(self.labels)
+        cfg = _Cfg()
+        cfg.n_classes = n
+        cfg.image_index = self.labels.index("image") if "image" in self.labels else -1
+        cfg.formula_index = self.labels.index("formula") if "formula" in self.labels else -1
+        if isinstance(conf_thres, dict):
+            self._thresh = np.full(n, 0.5, np.float32)
+            for k, v in conf_thres.items():
+                if 0 <= int(k) < n:
+                    self._thresh[int(k)] = v
+            cfg.thresh_is_dict = 1
+        else:
+            self._thresh = np.array([conf_thres], np.float32)
+            cfg.thresh_is_dict = 0
+        cfg.thresh = self._thresh.ctypes.data
+        cfg.layout_nms = 1 if layout_nms else 0
+        self._merge = np.zeros(max(n, 1), np.int8)
+        if layout_merge_bboxes_mode is None:
+            cfg.merge_kind = 0
+        elif isinstance(layout_merge_bboxes_mode, str):
+            cfg.merge_kind = _MODES[layout_merge_bboxes_mode]
+        else:
+            cfg.merge_kind = 3
+            for k, v in layout_merge_bboxes_mode.items():
+                if 0 <= int(k) < n:
+                    self._merge[int(k)] = _MODES[v]
+        cfg.merge_per_class = self._merge.ctypes.data
+        self._unclip = np.ones((max(n, 1), 2), np.float32)
+        self._present = np.zeros(max(n, 1), np.uint8)
+        if not layout_unclip_ratio:
+            cfg.unclip_kind = 0
+        elif isinstance(layout_unclip_ratio, dict):
+            cfg.unclip_kind = 2
+            for k, (rw, rh) in layout_unclip_ratio.items():
+                if 0 <= int(k) < n:
+                    self._unclip[int(k)] = (rw, rh)
+                    self._present[int(k)] = 1
+        else:
+            r = (layout_unclip_ratio, layout_unclip_ratio) if isinstance(layout_unclip_ratio, float) else tuple(layout_unclip_ratio)
+            assert len(r) == 2, "The length of `layout_unclip_ratio` should be 2."
+            cfg.unclip_kind = 1
+            self._unclip[0] = r
+        cfg.unclip = self._unclip.ctypes.data
+        cfg.unclip_present = self._present.ctypes.data
+        self._cfg = cfg
+
+    def __call__(self, boxes: np.ndarray, img_size: Tuple[int, int], masks=None, layout_shape_mode: Optional[str] = "rect"):
+        """boxes [n, 6|7|8] float32, img_size (width, height).  Returns the reference's list of dicts
+        {cls_id, label, score, coordinate, order}."""
+        if masks is not None and layout_shape_mode != "rect":
+            raise NotImplementedError("polygon output (masks) is not built; use layout_shape_mode='rect'")
+        b = np.ascontiguousarray(boxes, dtype=np.float32)
+        if b.size == 0:
+            return np.array([])
+        n, ncol = b.shape
+        out = np.zeros((n, 6), np.float32)
+        order = np.zeros(n, np.int32)
+        k = C.c_int32(0)
+        rc = self._lib.rd_layout_postprocess(b.ctypes.data, n, ncol, int(img_size[0]), int(img_size[1]), C.byref(self._cfg),
+                                             out.ctypes.data, order.ctypes.data, C.byref(k))
+        if rc != 0:
+            raise ValueError(f"The shape of boxes should be 6, 7 or 8 columns, instead of {ncol}")
+        if k.value == 0:
+            return np.array([]) if not self._any_survivor_possible(b) else []
+        res = []
+        for i in range(k.value):
+            r = out[i]
+            res.append({"cls_id": int(r[0]), "label": self.labels[int(r[0])], "score": float(r[1]),
+                        "coordinate": [float(r[2]), float(r[3]), float(r[4]), float(r[5])], "order": int(order[i])})
+        return res
+
+    @staticmethod
+    def _any_survivor_possible(b) -> bool:
+        return False
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Region bookkeeping after the layout network (rectangle mode), restated from
+#   rapid_doc/backend/utils/utils.py:109-173        filter_overlap_boxes
+#   rapid_doc/utils/model_utils.py:90-124,162-196   crop_img / get_res_list_from_layout_res
+# ------------------------------------------------------------------------------------------------------------------
+_EXCLUSIVE_LABELS = {"image", "seal", "chart"}          # never dropped against a box of another label
+OCR_CATEGORY_IDS = (0, 1, 2, 4, 6, 7, 9)                 # model_utils.py:177
+TABLE_CATEGORY_ID = 5
+FORMULA_CATEGORY_IDS = (8, 13, 14)
+IMAGE_CATEGORY_IDS = (3,)
+
+
+def _rect(det) -> Tuple[float, float, float, float]:
+    p = det["poly"]
+    return p[0], p[1], p[4], p[5]
+
+
+def _overlap_over_smaller(a, b) -> float:
+    iw = max(0, min(a[2], b[2]) - max(a[0], b[0]))
+    ih = max(0, min(a[3], b[3]) - max(a[1], b[1]))
+    inter = float(iw) * float(ih)
+    ref = min(abs((a[2] - a[0]) * (a[3] - a[1])), abs((b[2] - b[0]) * (b[3] - b[1])))
+    return 0.0 if ref == 0 else inter / ref
+
+
+def filter_overlap_boxes(layout_dets: Sequence[dict], use_custom_ocr: bool = False) -> List[dict]:
+    """Drop 'reference' boxes, boxes thinner than 6 px, and - for pairs overlapping by > 0.7 of the smaller box - the
+    smaller one (image / seal / chart are only compared with their own label; inline formulas are only touched in
+    custom-OCR mode, where an overlap > 0.5 removes the formula).  Rectangle mode (no polygon_points)."""
+    boxes = [dict(d) for d in layout_dets if d["original_label"] != "reference"]
+    dropped = set()
+    for i in range(len(boxes)):
+        ri = _rect(boxes[i])
+        if ri[2] - ri[0] < 6 or ri[3] - ri[1] < 6:
+            dropped.add(i)
+        li = boxes[i]["original_label"]
+        for j in range(i + 1, len(boxes)):
+            if i in dropped or j in dropped:
+                continue
+            rj = _rect(boxes[j])
+            lj = boxes[j]["original_label"]
+            ov = _overlap_over_smaller(ri, rj)
+            if li == "inline_formula" or lj == "inline_formula":
+                if not use_custom_ocr:
+                    continue
+                if ov > 0.5:
+                    if li == "inline_formula":
+                        dropped.add(i)
+                    if lj == "inline_formula":
+                        dropped.add(j)
+                    continue
+            if ov > 0.7:
+                if ({li, lj} & _EXCLUSIVE_LABELS) and li != lj:
+                    continue
+                ai = abs((ri[2] - ri[0]) * (ri[3] - ri[1]))
+                aj = abs((rj[2] - rj[0]) * (rj[3] - rj[1]))
+                dropped.add(j if ai >= aj else i)
+    return [b for k, b in enumerate(boxes) if k not in dropped]
+
+
+def split_regions(layout_dets: Sequence[dict]) -> Tuple[List[dict], List[dict], List[dict]]:
+    """(ocr regions, table regions, formula regions with 'bbox') - get_res_list_from_layout_res without the
+    image-in-table bookkeeping."""
+    ocr, tables, formulas = [], [], []
+    for d in layout_dets:
+        cid = int(d["category_id"])
+        if cid in FORMULA_CATEGORY_IDS:
+            d = dict(d)
+            p = d["poly"]
+            d["bbox"] = [int(p[0]), int(p[1]), int(p[4]), int(p[5])]
+            formulas.append(d)
+        elif cid in OCR_CATEGORY_IDS:
+            ocr.append(d)
+        elif cid == TABLE_CATEGORY_ID:
+            tables.append(d)
+    return ocr, tables, formulas
+
+
+def crop_geometry(det: dict, paste_x: int = 0, paste_y: int = 0) -> List[int]:
+    """crop_img's `useful_list`: [paste_x, paste_y, xmin, ymin, xmax, ymax, new_w, new_h] (white margin of paste_x/y)."""
+    p = det["poly"]
+    x0, y0, x1, y1 = int(p[0]), int(p[1]), int(p[4]), int(p[5])
+    return [paste_x, paste_y, x0, y0, x1, y1, x1 - x0 + 2 * paste_x, y1 - y0 + 2 * paste_y]

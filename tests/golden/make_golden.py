@@ -166,6 +166,127 @@ def main():
         (HERE / f"boxes_seed{seed}.json").write_text(json.dumps(out))
         print(f"boxes seed {seed}: {len(quads)} quads -> merged {len(out['merged'])}, updated {len(out['updated'])}")
 
+    # ---------------- layout post-process (PPPostProcess, rect mode; cv2 stubbed - the rect branch never calls it) -------
+    spec = importlib.util.spec_from_file_location(
+        "ref_layout_post", REF / "rapid_doc/model/layout/rapid_layout_self/model_handler/pp_doclayout/post_process.py")
+    refpp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(refpp)
+    # the per-class tables are plain dict literals in typings.py (the module itself has package-relative imports)
+    import ast
+    tree = ast.parse((REF / "rapid_doc/model/layout/rapid_layout_self/utils/typings.py").read_text())
+    lits = {}
+    for node in tree.body:
+        if isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Name) and isinstance(node.value, ast.Dict):
+            try:
+                lits[node.targets[0].id] = ast.literal_eval(node.value)
+            except ValueError:
+                pass
+    v2_merge = {int(k): v for k, v in lits["PP_DOCLAYOUTV2_layout_merge_bboxes_mode"].items()}
+    plus_merge = {int(k): v for k, v in lits["PP_DOCLAYOUT_PLUS_L_layout_merge_bboxes_mode"].items()}
+    l_thresh = {int(k): float(v) for k, v in lits["PP_DOCLAYOUT_L_Threshold"].items()}
+    (HERE / "layout_tables.json").write_text(json.dumps(
+        {"PP_DOCLAYOUTV2_layout_merge_bboxes_mode": v2_merge, "PP_DOCLAYOUT_PLUS_L_layout_merge_bboxes_mode": plus_merge,
+         "PP_DOCLAYOUT_L_Threshold": l_thresh}))
+    W_, H_ = 1191, 1684
+    cases = [
+        dict(ncol=6, ncls=11, labels_img=1, labels_formula=7, thr=0.5, merge=None, unclip=None),
+        dict(ncol=6, ncls=20, labels_img=1, labels_formula=7, thr=l_thresh, merge=plus_merge, unclip=[1.0, 1.0]),
+        dict(ncol=7, ncls=25, labels_img=14, labels_formula=None, thr=0.3, merge=v2_merge, unclip=[1.0, 1.0]),
+        dict(ncol=8, ncls=25, labels_img=14, labels_formula=5, thr=0.3, merge="large", unclip={3: (1.1, 1.2), 14: (0.9, 1.0), 22: (1.0, 1.05)}),
+        dict(ncol=6, ncls=12, labels_img=None, labels_formula=3, thr=0.2, merge="small", unclip=1.05),
+        dict(ncol=6, ncls=25, labels_img=14, labels_formula=None, thr=0.95, merge=v2_merge, unclip=[1.0, 1.0]),
+    ]
+    for ci, cs in enumerate(cases):
+        rng = np.random.default_rng(2000 + ci)
+        n = 90
+        labels = [f"c{i}" for i in range(cs["ncls"])]
+        if cs["labels_img"] is not None:
+            labels[cs["labels_img"]] = "image"
+        if cs["labels_formula"] is not None:
+            labels[cs["labels_formula"]] = "formula"
+        cls = rng.integers(0, cs["ncls"], n).astype(np.float32)
+        score = rng.uniform(0.05, 1.0, n).astype(np.float32)
+        x0 = rng.uniform(-20, W_ - 100, n); y0 = rng.uniform(-20, H_ - 60, n)
+        bw = rng.uniform(20, 600, n); bh = rng.uniform(10, 400, n)
+        b = np.stack([cls, score, x0, y0, x0 + bw, y0 + bh], 1).astype(np.float32)
+        # near-duplicates (NMS), nested boxes (containment), a page-sized image box, degenerate / outside boxes
+        for k in range(0, 20, 2):
+            b[k + 1, 2:6] = b[k, 2:6] + rng.uniform(-3, 3, 4).astype(np.float32)
+            if k % 4 == 0:
+                b[k + 1, 0] = b[k, 0]
+        for k in range(20, 36, 2):
+            cx0, cy0, cx1, cy1 = b[k, 2:6]
+            b[k + 1, 2:6] = [cx0 + 0.1 * (cx1 - cx0), cy0 + 0.1 * (cy1 - cy0), cx1 - 0.15 * (cx1 - cx0), cy1 - 0.2 * (cy1 - cy0)]
+        if cs["labels_img"] is not None:
+            b[40] = [cs["labels_img"], 0.97, 2, 3, W_ - 2, H_ - 4]
+            b[41] = [cs["labels_img"], 0.96, 100, 100, 700, 600]
+        b[42, 2:6] = [W_ + 5, 10, W_ + 50, 40]
+        b[43, 2:6] = [300, 500, 300, 520]
+        if cs["ncol"] >= 7:
+            order = rng.permutation(n).astype(np.float32)
+            b = np.concatenate([b, order[:, None]], 1)
+        if cs["ncol"] == 8:
+            b[:, 6] = np.floor(b[:, 6] / 3)          # ties in the primary key
+            b = np.concatenate([b, rng.uniform(0, 1, (n, 1)).astype(np.float32)], 1)
+        pp = refpp.PPPostProcess(labels, cs["thr"], 0.5, layout_merge_bboxes_mode=cs["merge"],
+                                 layout_unclip_ratio=cs["unclip"], scale_size=(800, 800))
+        res = pp(b.copy(), [W_, H_], None, "rect")
+        res = [] if isinstance(res, np.ndarray) else res
+        out = {"case": {k: (v if not isinstance(v, dict) else {str(a): c for a, c in v.items()}) for k, v in cs.items()},
+               "labels": labels, "boxes": b.tolist(), "img_size": [W_, H_],
+               "result": [{"cls_id": r["cls_id"], "label": r["label"], "score": r["score"], "coordinate": r["coordinate"],
+                           "order": r["order"]} for r in res]}
+        (HERE / f"layout_post_seed{ci}.json").write_text(json.dumps(out))
+        print(f"layout post case {ci}: {n} boxes -> {len(res)} kept")
+
+    # ---------------- filter_overlap_boxes (backend/utils/utils.py:109-173), non-polygon inputs ----------------
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+    class _L:  # loguru.logger stand-in
+        def __getattr__(self, k):
+            return lambda *a, **kw: None
+    stub("loguru", logger=_L())
+    for pkg in ("rapid_doc", "rapid_doc.utils", "rapid_doc.model", "rapid_doc.model.layout", "rapid_doc.model.layout.rapid_layout_self",
+                "rapid_doc.model.layout.rapid_layout_self.model_handler", "rapid_doc.model.layout.rapid_layout_self.model_handler.pp_doclayout",
+                "rapid_doc.model.reading_order"):
+        stub(pkg)
+    stub("rapid_doc.utils.table_merge", merge_table=None)
+    stub("rapid_doc.utils.span_pre_proc", txt_in_ori_image=None)
+    sys.modules["rapid_doc.model.layout.rapid_layout_self.model_handler.pp_doclayout.post_process"] = refpp
+    for modname, rel in (("rapid_doc.model.reading_order.utils", "rapid_doc/model/reading_order/utils.py"),
+                         ("rapid_doc.utils.boxbase", "rapid_doc/utils/boxbase.py")):
+        sp = importlib.util.spec_from_file_location(modname, REF / rel)
+        mod = importlib.util.module_from_spec(sp)
+        sys.modules[modname] = mod
+        sp.loader.exec_module(mod)
+    sp = importlib.util.spec_from_file_location("ref_backend_utils", REF / "rapid_doc/backend/utils/utils.py")
+    refbu = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(refbu)
+    label_pool = ["text", "paragraph_title", "image", "table", "seal", "chart", "inline_formula", "display_formula", "reference",
+                  "footer", "number"]
+    for seed in range(4):
+        rng = np.random.default_rng(3000 + seed)
+        dets = []
+        for k in range(60):
+            x0, y0 = float(rng.uniform(0, 1000)), float(rng.uniform(0, 1500))
+            w, h = float(rng.uniform(3, 400)), float(rng.uniform(3, 200))
+            if k % 5 == 1 and dets:   # heavy overlap with the previous box
+                px = dets[-1]["poly"]
+                x0, y0 = px[0] + float(rng.uniform(0, 10)), px[1] + float(rng.uniform(0, 10))
+                w, h = (px[4] - px[0]) * float(rng.uniform(0.5, 1.1)), (px[5] - px[1]) * float(rng.uniform(0.5, 1.1))
+            dets.append({"category_id": int(rng.integers(0, 15)), "original_label": str(rng.choice(label_pool)),
+                         "poly": [x0, y0, x0 + w, y0, x0 + w, y0 + h, x0, y0 + h], "score": round(float(rng.uniform(0.3, 1)), 3),
+                         "uid": k})
+        out = {"dets": dets}
+        for flag in (False, True):
+            kept = refbu.filter_overlap_boxes([dict(d) for d in dets], flag)
+            out[f"kept_custom_ocr_{flag}"] = [d["uid"] for d in kept]
+        (HERE / f"layout_overlap_seed{seed}.json").write_text(json.dumps(out))
+        print(f"filter_overlap_boxes seed {seed}: 60 -> {len(out['kept_custom_ocr_False'])} / {len(out['kept_custom_ocr_True'])}")
+
     (HERE / "summary.json").write_text(json.dumps(summary, indent=1))
     print(summary)
 
