@@ -189,3 +189,34 @@ def crop_geometry(det: dict, paste_x: int = 0, paste_y: int = 0) -> List[int]:
     p = det["poly"]
     x0, y0, x1, y1 = int(p[0]), int(p[1]), int(p[4]), int(p[5])
     return [paste_x, paste_y, x0, y0, x1, y1, x1 - x0 + 2 * paste_x, y1 - y0 + 2 * paste_y]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# label -> CategoryId mapping and the per-box dict schema of RapidLayoutModel.batch_predict
+# (rapid_doc/model/layout/rapid_layout.py:55-108,131-227).  The tables are data captured from the reference
+# (rapiddoc_amd/data/layout_category_maps.json, regenerated by tests/golden/make_golden.py).
+# ------------------------------------------------------------------------------------------------------------------
+import json as _json
+from pathlib import Path as _Path
+
+_TABLES = _json.loads((_Path(__file__).resolve().parent / "data" / "layout_category_maps.json").read_text())
+CATEGORY_ID: Dict[str, int] = _TABLES["category_id"]
+
+
+def category_map(model_family: str, markdown_ignore_labels: Sequence[str] = ()) -> Dict[str, int]:
+    """model_family: 'pp_doclayout' (S/M/L), 'pp_doclayout_plus' (plus-L) or 'pp_doclayoutv2' (V2/V3).  Labels in
+    `markdown_ignore_labels` map to Abandon (rapid_layout.py:162-165)."""
+    base = _TABLES["label_to_category"][model_family]
+    return {k: (CATEGORY_ID["Abandon"] if k in markdown_ignore_labels else v) for k, v in base.items()}
+
+
+def to_layout_dets(post: Sequence[dict], model_family: str, ordered: bool, markdown_ignore_labels: Sequence[str] = ()) -> List[dict]:
+    """LayoutPostProcess output -> the `layout_dets` dicts BatchAnalyze consumes: category_id, original_label,
+    original_order, poly [x0,y0,x1,y0,x1,y1,x0,y1], polygon_points, score rounded to 3 decimals."""
+    cmap = category_map(model_family, markdown_ignore_labels)
+    out = []
+    for i, d in enumerate(post):
+        x0, y0, x1, y1 = d["coordinate"]
+        out.append({"category_id": cmap[d["label"]], "original_label": d["label"], "original_order": i if ordered else -1,
+                    "poly": [x0, y0, x1, y0, x1, y1, x0, y1], "polygon_points": None, "score": round(float(d["score"]), 3)})
+    return out

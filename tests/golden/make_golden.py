@@ -287,6 +287,23 @@ def main():
         (HERE / f"layout_overlap_seed{seed}.json").write_text(json.dumps(out))
         print(f"filter_overlap_boxes seed {seed}: 60 -> {len(out['kept_custom_ocr_False'])} / {len(out['kept_custom_ocr_True'])}")
 
+    # ---------------- label -> CategoryId tables (model/layout/rapid_layout.py:131-227), evaluated from the reference source ----
+    src = (REF / "rapid_doc/model/layout/rapid_layout.py").read_text()
+    tree = ast.parse(src)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "get_cls_dicts")
+    ens = ast.parse((REF / "rapid_doc/utils/enum_class.py").read_text())
+    cat = next(n for n in ens.body if isinstance(n, ast.ClassDef) and n.name == "CategoryId")
+    ns = {}
+    exec(compile(ast.Module([cat, fn], []), "<ref>", "exec"), ns)
+    names = ("pp_doclayout", "pp_doclayout_plus", "pp_doclayoutv2")
+    maps = dict(zip(names, ns["get_cls_dicts"]([])))
+    maps_ign = dict(zip(names, ns["get_cls_dicts"](["header", "footer", "number"])))
+    cat_ids = {k: v for k, v in vars(ns["CategoryId"]).items() if not k.startswith("_")}
+    tables = {"category_id": cat_ids, "label_to_category": maps, "label_to_category_ignoring_header_footer_number": maps_ign}
+    (HERE / "layout_category_maps.json").write_text(json.dumps(tables))
+    (ROOT / "rapiddoc_amd" / "data" / "layout_category_maps.json").write_text(json.dumps({"category_id": cat_ids, "label_to_category": maps}))
+    print("category tables:", {k: len(v) for k, v in maps.items()})
+
     (HERE / "summary.json").write_text(json.dumps(summary, indent=1))
     print(summary)
 

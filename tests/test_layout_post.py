@@ -71,3 +71,15 @@ def test_region_split_and_crop_geometry():
     assert len(ocr) == 1 and len(tables) == 1 and len(formulas) == 2
     assert formulas[0]["bbox"] == [3, 4, 20, 9]
     assert crop_geometry(mk(1, 10.5, 20.5, 110.2, 60.9), 50, 50) == [50, 50, 10, 20, 110, 60, 200, 140]
+
+
+def test_category_tables_match_reference_capture():
+    from rapiddoc_amd.layout_host import CATEGORY_ID, category_map, to_layout_dets
+    g = json.loads((GOLD / "layout_category_maps.json").read_text())
+    assert CATEGORY_ID == g["category_id"]
+    for fam in ("pp_doclayout", "pp_doclayout_plus", "pp_doclayoutv2"):
+        assert category_map(fam) == g["label_to_category"][fam]
+        assert category_map(fam, ["header", "footer", "number"]) == g["label_to_category_ignoring_header_footer_number"][fam]
+    assert len(category_map("pp_doclayoutv2")) == 25
+    dets = to_layout_dets([{"label": "table", "score": 0.87654, "coordinate": [1.5, 2.5, 30.0, 40.0]}], "pp_doclayoutv2", True)
+    assert dets[0]["category_id"] == 5 and dets[0]["poly"] == [1.5, 2.5, 30.0, 2.5, 30.0, 40.0, 1.5, 40.0] and dets[0]["score"] == 0.877
