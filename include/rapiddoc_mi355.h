@@ -40,7 +40,7 @@ typedef struct rd_handle rd_handle;
 #define RD_REC_WANT_LOGITS 4  /* also write raw logits [B,T,C]                                          */
 
 const char* rd_version(void);
-/* model_kind: "ppocrv6_det" | "ppocrv6_rec" | "pphgnetv2_b4".  NULL on failure -> rd_create_error(). */
+/* model_kind: "ppocrv6_det" | "ppocrv6_rec" | "pphgnetv2_b4" | "pphgnetv2_b6_formula".  NULL on failure -> rd_create_error(). */
 rd_handle* rd_create(int device_id, const char* model_kind);
 const char* rd_create_error(void);
 void rd_destroy(rd_handle* h);
@@ -68,6 +68,13 @@ int rd_rec_seq_len(int W);
  * channels 128/512/1024/2048. */
 int rd_backbone_forward(rd_handle* h, const float* x_nchw_dev, int B, int H, int W, float* const feats_dev[4],
                         void* ws_dev, size_t ws_bytes, void* stream);
+
+/* PP-FormulaNet_plus encoder (PPHGNetV2_B6_Formula): x [B,C,H,W], C = 1 (grey, replicated to 3 channels like
+ * rapid_doc/model/formula/rapid_formula_self/networks/backbones/rec_pphgnetv2.py:1626-1628) or 3; H, W multiples of 32.
+ * enc_dev: [B, (H/32)*(W/32), 2048] = `last_hidden_state` of the reference backbone (:1629-1633).
+ * model_kind "pphgnetv2_b6_formula". */
+int rd_formula_encoder_forward(rd_handle* h, const float* x_nchw_dev, int B, int C, int H, int W, float* enc_dev,
+                               void* ws_dev, size_t ws_bytes, void* stream);
 
 /* u8 HWC (3 channels) device image -> resize to OHxOW -> (v*scale - mean[c]) / std[c] -> CHW float32.
  * interp: 1 bilinear, 2 bicubic (a = -0.75, result rounded/saturated to u8 range like an 8-bit resize). */

@@ -317,6 +317,24 @@ def pphgnetv2_features(state, x: Tensor, cfg=HGV2_B4_DET, prefix="") -> List[Ten
     return outs
 
 
+HGV2_B6_FORMULA = [
+    [96, 96, 192, 2, False, False, 3, 6, 2],
+    [192, 192, 512, 3, True, False, 3, 6, 2],
+    [512, 384, 1024, 6, True, True, 5, 6, 2],
+    [1024, 768, 2048, 3, True, True, 5, 6, 2],
+]
+
+
+def formula_encoder_forward(state, x: Tensor, prefix="backbone.pphgnet_b6.") -> Tensor:
+    """PPHGNetV2_B6_Formula.forward (rec_pphgnetv2.py:1616-1642): grey input repeated to 3 channels, last stage
+    output [B,2048,h,w] -> [B, h*w, 2048]."""
+    if x.shape[1] == 1:
+        x = torch.repeat_interleave(x, repeats=3, dim=1)
+    f = pphgnetv2_features(state, x, HGV2_B6_FORMULA, prefix)[-1]
+    b, c, h, w = f.shape
+    return f.reshape(b, c, h * w).permute(0, 2, 1)
+
+
 # --------------------------------------------------------------------------------------------------
 # algorithmic FLOPs (2*MAC, conv + linear) used by bench.py's roofline bookkeeping - SURVEY.md section 8d
 # --------------------------------------------------------------------------------------------------

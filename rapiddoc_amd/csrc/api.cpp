@@ -99,6 +99,15 @@ int rd_backbone_forward(rd_handle* h, const float* x, int B, int H, int W, float
     });
 }
 
+int rd_formula_encoder_forward(rd_handle* h, const float* x, int B, int C, int H, int W, float* enc, void* ws, size_t ws_bytes,
+                               void* stream) {
+    return guarded(h, [&] {
+        RD_CHECK(h->eng->kind() == "pphgnetv2_b6_formula", "handle is not a pphgnetv2_b6_formula model");
+        RD_CHECK(x && enc && B > 0 && (C == 1 || C == 3), "null input/output or channel count not 1/3");
+        h->eng->run(B, H, W, C == 1 ? 1 : 0, {(void*)x, (void*)enc}, ws, ws_bytes, (hipStream_t)stream);
+    });
+}
+
 int rd_preproc_resize_norm(int device_id, const uint8_t* src, int H, int W, int OH, int OW, const float mean[3],
                            const float std[3], float scale, int interp, int swap_rb, float* out, void* stream) {
     if (!src || !out || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || (interp != 1 && interp != 2)) return 1;

@@ -532,7 +532,7 @@ TView Builder::stem3x3s2(const std::string& wname, const std::string& bn, const 
         return y;
     }
     StemParams p{};
-    p.N = xin.n; p.H = xin.h; p.W = xin.w;
+    p.N = xin.n; p.H = xin.h; p.W = xin.w; p.in_ch = xin.c;   // c == 1: grey image replicated to 3 channels
     p.w = pb_->ptr(key + "#w");
     p.bias = pb_->ptr(key + "#b");
     p.yld = plan_->ld(y);
@@ -542,7 +542,7 @@ TView Builder::stem3x3s2(const std::string& wname, const std::string& bn, const 
     r.name = wname;
     r.kind = "stem3x3s2";
     r.flops = 2.0 * xin.n * oh * ow * 27.0 * cout;
-    r.bytes = 4.0 * ((double)xin.n * 3 * xin.h * xin.w + (double)xin.n * oh * ow * cout);
+    r.bytes = 4.0 * ((double)xin.n * xin.c * xin.h * xin.w + (double)xin.n * oh * ow * cout);
     const TView xv = xin, yv = y;
     r.run = [p, xv, yv](const Plan& pl, const RunCtx& c) {
         StemParams q = p;
@@ -811,6 +811,20 @@ void Builder::to_nchw(const TView& x, const TView& out_ext) {
     emit(std::move(r));
 }
 
+void Builder::copy(const TView& x, const TView& out) {
+    RD_CHECK(x.pixels() == out.pixels() && x.c == out.c && x.c % 4 == 0, "copy: shape mismatch");
+    if (!planning()) return;
+    OpRecord r;
+    r.name = "copy";
+    r.kind = "scale";
+    r.bytes = 8.0 * x.pixels() * x.c;
+    const TView xv = x, yv = out;
+    r.run = [xv, yv](const Plan& pl, const RunCtx& c) {
+        launch_upsample(pl.vptr(xv, c), pl.ld(xv), pl.vptr(yv, c), pl.ld(yv), yv.n, yv.h, yv.w, yv.c, 1, 0, c.stream);
+    };
+    emit(std::move(r));
+}
+
 void Builder::ctc_stats(const TView& logits, const TView& idx_ext, const TView& prob_ext) {
     if (!planning()) return;
     OpRecord r;
@@ -889,7 +903,8 @@ extern bool g_disable_fused_mixer;
 Engine::Engine(int device, const std::string& kind) : device_(device), kind_(kind) {
     if (const char* e = getenv("RD_DISABLE_FUSED_MIXER")) g_disable_fused_mixer = e[0] == '1';
     if (const char* e = getenv("RD_PRECISION")) h3_ = std::string(e) == "h3";
-    RD_CHECK(kind == "ppocrv6_det" || kind == "ppocrv6_rec" || kind == "pphgnetv2_b4", "unknown model kind '" + kind + "'");
+    RD_CHECK(kind == "ppocrv6_det" || kind == "ppocrv6_rec" || kind == "pphgnetv2_b4" || kind == "pphgnetv2_b6_formula",
+             "unknown model kind '" + kind + "'");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) throw Error("no HIP device available (MI355X required; there is no CPU fallback)");
@@ -905,6 +920,7 @@ Engine::~Engine() {
 void Engine::build(Builder& b, int B, int H, int W, int flags) {
     if (kind_ == "ppocrv6_det") build_ppocrv6_det(b, B, H, W);
     else if (kind_ == "ppocrv6_rec") build_ppocrv6_rec(b, B, H, W, flags);
+    else if (kind_ == "pphgnetv2_b6_formula") build_pphgnetv2_b6_formula(b, B, H, W, flags);
     else build_pphgnetv2_b4(b, B, H, W);
 }
 

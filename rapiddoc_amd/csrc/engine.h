@@ -168,6 +168,7 @@ class Builder {
     TView attention(const TView& qkv, int B, int T, int heads, int hd);
     TView add(const TView& a, const TView& b);
     void to_nchw(const TView& x, const TView& out_ext);
+    void copy(const TView& x, const TView& out);   // same geometry, possibly different channel strides
     void ctc_stats(const TView& logits, const TView& idx_ext, const TView& prob_ext);
     void softmax_rows(const TView& logits, const TView& out_ext);
     void ctc_head(const std::string& prefix, const TView& x, const TView& idx_ext, const TView& prob_ext);
@@ -235,5 +236,7 @@ void build_ppocrv6_det(Builder& b, int B, int H, int W);
 enum RecFlags : int { REC_UNFUSED_CTC = 1, REC_WANT_SOFTMAX = 2, REC_WANT_LOGITS = 4 };
 void build_ppocrv6_rec(Builder& b, int B, int H, int W, int flags);
 void build_pphgnetv2_b4(Builder& b, int B, int H, int W);
+// PP-FormulaNet_plus encoder; flags bit 0: the caller's image has 1 channel (replicated to 3 like the reference)
+void build_pphgnetv2_b6_formula(Builder& b, int B, int H, int W, int flags);
 
 }  // namespace rd

@@ -299,7 +299,8 @@ __global__ void __launch_bounds__(256) stem_conv3x3s2_kernel(StemParams p) {
         float acc[CO_T];
 #pragma unroll
         for (int c = 0; c < CO_T; ++c) acc[c] = wsm[nw + g * CO_T + c];
-        const float* xb = p.x + (size_t)b * 3 * p.H * p.W;
+        const float* xb = p.x + (size_t)b * p.in_ch * p.H * p.W;
+        const size_t cstride = p.in_ch == 1 ? 0 : (size_t)p.H * p.W;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int ih = oh * 2 - 1 + kh;
@@ -310,7 +311,7 @@ __global__ void __launch_bounds__(256) stem_conv3x3s2_kernel(StemParams p) {
                 if ((unsigned)iw >= (unsigned)p.W) continue;
 #pragma unroll
                 for (int ci = 0; ci < 3; ++ci) {
-                    const float xv = xb[((size_t)ci * p.H + ih) * p.W + iw];
+                    const float xv = xb[ci * cstride + (size_t)ih * p.W + iw];
                     const float* wr = &wsm[((kh * 3 + kw) * 3 + ci) * p.Cout + g * CO_T];
 #pragma unroll
                     for (int c = 0; c < CO_T; ++c) acc[c] = fmaf(xv, wr[c], acc[c]);

@@ -258,13 +258,22 @@ static const HgStageCfg kB4Det[4] = {
     {1024, 384, 2048, 1, true, true, 5, 6},
 };
 
-void build_pphgnetv2_b4(Builder& b, int B, int H, int W) {
-    RD_CHECK(H % 32 == 0 && W % 32 == 0 && H >= 64 && W >= 64, "backbone input H, W must be multiples of 32 (>= 64)");
-    TView x = b.external(0, B, H, W, 3);
-    auto cw = [&](const std::string& p) { return p + ".conv.weight"; };
-    auto bn = [&](const std::string& p) { return p + ".bn"; };
+static const HgStageCfg kB6Formula[4] = {   // rec_pphgnetv2.py:1601-1607
+    {96, 96, 192, 2, false, false, 3, 6},
+    {192, 192, 512, 3, true, false, 3, 6},
+    {512, 384, 1024, 6, true, true, 5, 6},
+    {1024, 768, 2048, 3, true, true, 5, 6},
+};
+
+// Shared PPHGNetV2 body.  `pre` = state-dict prefix ("" or "backbone.pphgnet_b6.").  Every stage output listed in
+// `want` is handed to `emit(stage, view)`.
+template <typename Emit>
+static void build_pphgnetv2(Builder& b, const TView& x, const HgStageCfg (&cfg)[4], const std::string& pre, Emit emit) {
+    const int B = x.n;
+    auto cw = [&](const std::string& p) { return pre + p + ".conv.weight"; };
+    auto bn = [&](const std::string& p) { return pre + p + ".bn"; };
     // stem (StemBlock, rec_pphgnetv2.py:979-1056)
-    TView e = b.stem3x3s2(cw("stem.stem1"), bn("stem.stem1"), x, ACT_RELU);  // 32 @ H/2
+    TView e = b.stem3x3s2(cw("stem.stem1"), bn("stem.stem1"), x, ACT_RELU);
     TView a = b.conv(cw("stem.stem2a"), "", bn("stem.stem2a"), e, geom_same_even(2), ACT_RELU);
     TView cat = b.alloc(B, e.h, e.w, 2 * e.c);
     TView cat_pool = b.slice(cat, 0, e.c), cat_b = b.slice(cat, e.c, e.c);
@@ -276,28 +285,25 @@ void build_pphgnetv2_b4(Builder& b, int B, int H, int W) {
     b.release(cat);
 
     // stage inputs are produced straight into channel slot 0 of the stage's dense-concat buffer
-    TView cur;         // current block input (a slice of `cur_cat`)
-    TView cur_cat;     // its concat buffer
-    auto new_cat = [&](int n, int h, int w, const HgStageCfg& c, int cin) {
-        return b.alloc(n, h, w, cin + c.layers * c.mid);
-    };
+    TView cur, cur_cat;
+    auto new_cat = [&](int n, int h, int w, const HgStageCfg& c, int cin) { return b.alloc(n, h, w, cin + c.layers * c.mid); };
     {
-        const HgStageCfg& c = kB4Det[0];
+        const HgStageCfg& c = cfg[0];
+        RD_CHECK(!c.down, "PPHGNetV2: the first stage does not downsample");
         cur_cat = new_cat(B, s3.h, s3.w, c, c.cin);
         cur = b.slice(cur_cat, 0, c.cin);
         b.conv(cw("stem.stem4"), "", bn("stem.stem4"), s3, geom(1), ACT_RELU, &cur);
         b.release(s3);
     }
     for (int si = 0; si < 4; ++si) {
-        const HgStageCfg& c = kB4Det[si];
+        const HgStageCfg& c = cfg[si];
         const std::string sp = "stages." + std::to_string(si);
-        if (c.down) {
-            // depthwise 3x3 stride 2 + BN, no activation (HGV2_Stage.downsample)
-            G g = geom(3, 2);
+        RD_CHECK(si == 0 || c.down, "PPHGNetV2: stages 2-4 downsample");
+        if (c.down) {  // depthwise 3x3 stride 2 + BN, no activation (HGV2_Stage.downsample)
             const int oh = (cur.h + 2 - 3) / 2 + 1, ow = (cur.w + 2 - 3) / 2 + 1;
             TView ncat = new_cat(B, oh, ow, c, c.cin);
             TView nin = b.slice(ncat, 0, c.cin);
-            b.dwconv(cw(sp + ".downsample"), "", bn(sp + ".downsample"), cur, g, ACT_NONE, &nin);
+            b.dwconv(cw(sp + ".downsample"), "", bn(sp + ".downsample"), cur, geom(3, 2), ACT_NONE, &nin);
             b.release(cur_cat);
             cur_cat = ncat;
             cur = nin;
@@ -320,16 +326,12 @@ void build_pphgnetv2_b4(Builder& b, int B, int H, int W) {
             }
             TView full = b.slice(cur_cat, 0, cin + c.layers * c.mid);
             TView sq = b.conv(cw(bp + ".aggregation_squeeze_conv"), "", bn(bp + ".aggregation_squeeze_conv"), full, geom(1), ACT_RELU);
-            // destination of the block output: slot 0 of the next consumer's concat buffer
+            // destination of the block output: slot 0 of the next block's concat buffer, or a plain buffer at a stage end
             const bool last_block = bi + 1 == c.blocks;
             TView ncat, nout;
             if (!last_block) {
                 ncat = new_cat(B, cur.h, cur.w, c, c.cout);
                 nout = b.slice(ncat, 0, c.cout);
-            } else if (si + 1 < 4 ) {
-                // next stage downsamples from here: a plain buffer is enough
-                ncat = b.alloc(B, cur.h, cur.w, c.cout);
-                nout = ncat;
             } else {
                 ncat = b.alloc(B, cur.h, cur.w, c.cout);
                 nout = ncat;
@@ -342,10 +344,33 @@ void build_pphgnetv2_b4(Builder& b, int B, int H, int W) {
             cur_cat = ncat;
             cur = nout;
         }
-        TView o = b.external(1 + si, B, cur.h, cur.w, c.cout);
-        b.to_nchw(cur, o);
+        emit(si, cur);
     }
     b.release(cur_cat);
+}
+
+void build_pphgnetv2_b4(Builder& b, int B, int H, int W) {
+    RD_CHECK(H % 32 == 0 && W % 32 == 0 && H >= 64 && W >= 64, "backbone input H, W must be multiples of 32 (>= 64)");
+    TView x = b.external(0, B, H, W, 3);
+    build_pphgnetv2(b, x, kB4Det, "", [&](int si, const TView& v) {
+        TView o = b.external(1 + si, B, v.h, v.w, v.c);
+        b.to_nchw(v, o);
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------
+// PP-FormulaNet_plus-M encoder = PPHGNetV2_B6_Formula (rec_pphgnetv2.py:1587-1642): x [B,1|3,H,W] -> [B, H/32*W/32, 2048].
+// NHWC [B,h,w,2048] IS the reference's reshape(b,c,h*w).permute(0,2,1), so the result is written without a transpose.
+// ext[0] = x NCHW; ext[1] = encoder states [B, h*w, 2048]
+// ---------------------------------------------------------------------------------------------------
+void build_pphgnetv2_b6_formula(Builder& b, int B, int H, int W, int flags) {
+    RD_CHECK(H % 32 == 0 && W % 32 == 0 && H >= 64 && W >= 64, "formula encoder input H, W must be multiples of 32 (>= 64)");
+    TView x = b.external(0, B, H, W, (flags & 1) ? 1 : 3);
+    build_pphgnetv2(b, x, kB6Formula, "backbone.pphgnet_b6.", [&](int si, const TView& v) {
+        if (si != 3) return;
+        TView o = b.external(1, B, v.h, v.w, v.c);
+        b.copy(v, o);
+    });
 }
 
 }  // namespace rd

@@ -36,8 +36,8 @@ const char* conv_igemm_config_name(const ConvParams& p);
 
 // First conv of a network: 3x3 stride 2 pad 1, Cin = 3, reads the caller's NCHW (or NHWC u8/f32) image.
 struct StemParams {
-    const float* x;   // NCHW f32 [N,3,H,W]
-    int N, H, W;
+    const float* x;   // NCHW f32 [N,3,H,W]  (or [N,1,H,W] read three times when in_ch == 1: the reference repeats grey formulas)
+    int N, H, W, in_ch;
     const float* w;   // [27][Cout] (kh,kw,ci major; co fastest)
     const float* bias;
     float* y; int yld; int OH, OW, Cout;

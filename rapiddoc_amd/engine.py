@@ -12,7 +12,7 @@ import torch
 from . import _lib, weights as W
 
 REC_UNFUSED_CTC, REC_WANT_SOFTMAX, REC_WANT_LOGITS = 1, 2, 4
-KINDS = ("ppocrv6_det", "ppocrv6_rec", "pphgnetv2_b4")
+KINDS = ("ppocrv6_det", "ppocrv6_rec", "pphgnetv2_b4", "pphgnetv2_b6_formula")
 
 
 class EngineError(RuntimeError):
@@ -115,6 +115,15 @@ class RdEngine:
         self._chk(self._l.rd_backbone_forward(self._h, x.data_ptr(), B, H, W_, arr, None, 0, _stream_ptr()))
         self._log()
         return feats
+
+    def formula_encoder_forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x [B,1|3,H,W] -> encoder states [B, (H/32)*(W/32), 2048] (PPHGNetV2_B6_Formula.last_hidden_state)."""
+        x = self._prep(x)
+        B, Cc, H, W_ = x.shape
+        out = torch.empty((B, (H // 32) * (W_ // 32), 2048), dtype=torch.float32, device=x.device)
+        self._chk(self._l.rd_formula_encoder_forward(self._h, x.data_ptr(), B, Cc, H, W_, out.data_ptr(), None, 0, _stream_ptr()))
+        self._log()
+        return out
 
     # ------------------------------------------------------------------ profiling
     def set_profiling(self, on: bool):

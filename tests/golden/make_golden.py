@@ -137,6 +137,34 @@ def main():
         assert d < 2e-5, d
         np.savez_compressed(HERE / f"b4_seed0_{tag}.npz", x=x, **{f"feat{i}": f.numpy() for i, f in enumerate(feats)})
 
+    # ---------------- PP-FormulaNet_plus-M encoder (PPHGNetV2_B6_Formula) ----------------
+    from networks.backbones.rec_pphgnetv2 import PPHGNetV2_B6_Formula
+
+    class _Wrap(torch.nn.Module):   # gives the state dict the `backbone.` prefix of the full formula model
+        def __init__(self):
+            super().__init__()
+            self.backbone = PPHGNetV2_B6_Formula(in_channels=3, class_num=1024)
+    b6 = _Wrap()
+    full = manifest_of(b6)
+    man = [m for m in full if not m[0].startswith(("backbone.pphgnet_b6.fc.", "backbone.pphgnet_b6.last_conv."))]
+    (HERE / "manifest_pphgnetv2_b6_formula.json").write_text(json.dumps(man))
+    state = W.synth_state_dict([(n, tuple(s_), d) for n, s_, d in full], SEED)
+    b6.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    b6.eval()
+    state = {k: v for k, v in state.items() if k in {m[0] for m in man}}
+    summary["b6_checksum"] = W.checksum(state)
+    tstate = O.as_torch_state(state)
+    for tag, shape in (("b2_c1_64x96", (2, 1, 64, 96)), ("b1_c3_96x64", (1, 3, 96, 64))):
+        x = make_input(shape, 400 + shape[1], "pm1")
+        xt = torch.from_numpy(x)
+        with torch.no_grad():
+            enc = b6.backbone(xt).last_hidden_state
+            mine = O.formula_encoder_forward(tstate, xt)
+        d = maxdiff(enc, mine)
+        print(f"b6 formula encoder {tag}: oracle-vs-reference max|diff| = {d:.3e}; out {tuple(enc.shape)} absmax {float(enc.abs().max()):.3f}")
+        assert d < 2e-5, d
+        np.savez_compressed(HERE / f"b6_seed0_{tag}.npz", x=x, enc=enc.numpy())
+
     # ---------------- host box helpers (pure python in the reference; cv2 stubbed, it is not called by them) ----------
     import importlib.util
     import types

@@ -161,3 +161,15 @@ def test_h3_precision_mode_matches_golden(golden_dir, monkeypatch):
     g = np.load(golden_dir / "b4_seed0_64x96.npz")
     for i, f in enumerate(eng.backbone_forward(torch.from_numpy(g["x"]).cuda())):
         assert np.abs(f.cpu().numpy() - g[f"feat{i}"]).max() < TOL
+
+
+@pytest.mark.parametrize("tag", ["b2_c1_64x96", "b1_c3_96x64"])
+def test_formula_encoder_matches_golden(golden_dir, tag):
+    """PP-FormulaNet_plus-M encoder (PPHGNetV2_B6_Formula) vs vectors minted from the reference backbone."""
+    from rapiddoc_amd.engine import RdEngine
+    st = W.synth_state_dict(W.load_manifest(golden_dir / "manifest_pphgnetv2_b6_formula.json"), 0)
+    eng = RdEngine("pphgnetv2_b6_formula").load_weights(st)
+    g = np.load(golden_dir / f"b6_seed0_{tag}.npz")
+    enc = eng.formula_encoder_forward(torch.from_numpy(g["x"]).cuda()).cpu().numpy()
+    assert enc.shape == g["enc"].shape
+    assert np.abs(enc - g["enc"]).max() < TOL

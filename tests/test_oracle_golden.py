@@ -59,3 +59,11 @@ def test_b4_oracle_matches_reference_golden(golden_dir):
     feats = O.pphgnetv2_features(st, torch.from_numpy(g["x"]))
     for i, f in enumerate(feats):
         assert np.abs(f.numpy() - g[f"feat{i}"]).max() < TOL
+
+
+@pytest.mark.parametrize("tag", ["b2_c1_64x96", "b1_c3_96x64"])
+def test_formula_encoder_oracle_matches_reference_golden(golden_dir, tag):
+    _, st = _state(golden_dir, "pphgnetv2_b6_formula")
+    g = np.load(golden_dir / f"b6_seed0_{tag}.npz")
+    enc = O.formula_encoder_forward(st, torch.from_numpy(g["x"]))
+    assert np.abs(enc.numpy() - g["enc"]).max() < TOL
