@@ -40,7 +40,7 @@ typedef struct rd_handle rd_handle;
 #define RD_REC_WANT_LOGITS 4  /* also write raw logits [B,T,C]                                          */
 
 const char* rd_version(void);
-/* model_kind: "ppocrv6_det" | "ppocrv6_rec" | "pphgnetv2_b4" | "pphgnetv2_b6_formula".  NULL on failure -> rd_create_error(). */
+/* model_kind: "ppocrv6_det" | "ppocrv6_rec" | "pphgnetv2_b4" | "pphgnetv2_b6_formula" | "ppformulanet_head".  NULL on failure -> rd_create_error(). */
 rd_handle* rd_create(int device_id, const char* model_kind);
 const char* rd_create_error(void);
 void rd_destroy(rd_handle* h);
@@ -75,6 +75,16 @@ int rd_backbone_forward(rd_handle* h, const float* x_nchw_dev, int B, int H, int
  * model_kind "pphgnetv2_b6_formula". */
 int rd_formula_encoder_forward(rd_handle* h, const float* x_nchw_dev, int B, int C, int H, int W, float* enc_dev,
                                void* ws_dev, size_t ws_bytes, void* stream);
+
+/* PP-FormulaNet_plus decoder head (model_kind "ppformulanet_head"; load the full model's .safetensors / state dict, only
+ * `head.*` tensors are used): greedy decode with KV cache of all B formulas at once.  Replaces PPFormulaNet_Head.forward ->
+ * generate_export (rapid_doc/model/formula/rapid_formula_self/networks/heads/rec_ppformulanet_head.py:1054-1176,1367-1380).
+ * enc_dev [B,S,2048] = encoder states; ids_dev [B][max_new_tokens+1] int64 (start token 0 first, pad 1 after EOS 2);
+ * *n_cols = number of leading columns the reference would return (it stops when every sequence has produced EOS). */
+int rd_formula_decode(rd_handle* h, const float* enc_dev, int B, int S, int max_new_tokens, int64_t* ids_dev, int32_t* n_cols,
+                      void* stream);
+/* largest max_new_tokens the loaded positional table supports (2560 for the shipped PP-FormulaNet_plus-M) */
+int rd_formula_max_new_tokens(rd_handle* h);
 
 /* u8 HWC (3 channels) device image -> resize to OHxOW -> (v*scale - mean[c]) / std[c] -> CHW float32.
  * interp: 1 bilinear, 2 bicubic (a = -0.75, result rounded/saturated to u8 range like an 8-bit resize). */

@@ -6,8 +6,19 @@
 
 #include "engine.h"
 
+namespace rd {
+class FormulaDecoder;
+FormulaDecoder* formula_decoder_create(int device, const void* blob, size_t nbytes);
+void formula_decoder_destroy(FormulaDecoder* d);
+int formula_decoder_decode(FormulaDecoder* d, const float* enc, int B, int S, int max_new, long long* ids, hipStream_t s);
+int formula_decoder_max_new(FormulaDecoder* d);
+}  // namespace rd
+
 struct rd_handle {
-    rd::Engine* eng = nullptr;
+    rd::Engine* eng = nullptr;           // convolutional networks (plan-based)
+    rd::FormulaDecoder* dec = nullptr;   // "ppformulanet_head": autoregressive decoder
+    int device = 0;
+    std::string kind;
     std::string err;
     std::string prof;
 };
@@ -16,7 +27,7 @@ static thread_local std::string g_create_err;
 
 template <typename F>
 static int guarded(rd_handle* h, F&& f) {
-    if (!h || !h->eng) return 2;
+    if (!h || (!h->eng && h->kind != "ppformulanet_head")) return 2;
     try {
         f();
         h->err.clear();
@@ -35,7 +46,17 @@ rd_handle* rd_create(int device_id, const char* model_kind) {
     try {
         if (!model_kind) throw rd::Error("model_kind is NULL");
         auto* h = new rd_handle();
-        h->eng = new rd::Engine(device_id, model_kind);
+        h->device = device_id;
+        h->kind = model_kind;
+        if (h->kind == "ppformulanet_head") {
+            int count = 0;
+            if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count) {
+                delete h;
+                throw rd::Error("no HIP device available (MI355X required; there is no CPU fallback)");
+            }
+        } else {
+            h->eng = new rd::Engine(device_id, model_kind);
+        }
         g_create_err.clear();
         return h;
     } catch (const std::exception& e) {
@@ -48,17 +69,26 @@ const char* rd_create_error(void) { return g_create_err.c_str(); }
 void rd_destroy(rd_handle* h) {
     if (!h) return;
     delete h->eng;
+    if (h->dec) rd::formula_decoder_destroy(h->dec);
     delete h;
 }
 const char* rd_last_error(rd_handle* h) { return h ? h->err.c_str() : "null handle"; }
 
 int rd_load_weights(rd_handle* h, const void* img, size_t nbytes) {
-    return guarded(h, [&] { h->eng->load_weights(img, nbytes); });
+    return guarded(h, [&] {
+        if (h->kind == "ppformulanet_head") {
+            RD_CHECK(!h->dec, "weights already loaded for this handle");
+            h->dec = rd::formula_decoder_create(h->device, img, nbytes);
+        } else {
+            h->eng->load_weights(img, nbytes);
+        }
+    });
 }
 
 int rd_query_workspace(rd_handle* h, int B, int H, int W, int flags, size_t* ws_bytes) {
     return guarded(h, [&] {
         RD_CHECK(ws_bytes, "ws_bytes is NULL");
+        RD_CHECK(h->eng, "this model kind owns its workspace");
         if (h->eng->kind() == "ppocrv6_rec") H = 48;
         *ws_bytes = h->eng->workspace_bytes(B, H, W, flags);
     });
@@ -66,7 +96,7 @@ int rd_query_workspace(rd_handle* h, int B, int H, int W, int flags, size_t* ws_
 
 int rd_det_forward(rd_handle* h, const float* x, int B, int H, int W, float* prob, void* ws, size_t ws_bytes, void* stream) {
     return guarded(h, [&] {
-        RD_CHECK(h->eng->kind() == "ppocrv6_det", "handle is not a ppocrv6_det model");
+        RD_CHECK(h->eng && h->eng->kind() == "ppocrv6_det", "handle is not a ppocrv6_det model");
         RD_CHECK(x && prob && B > 0, "null input/output");
         h->eng->run(B, H, W, 0, {(void*)x, (void*)prob}, ws, ws_bytes, (hipStream_t)stream);
     });
@@ -75,7 +105,7 @@ int rd_det_forward(rd_handle* h, const float* x, int B, int H, int W, float* pro
 int rd_rec_forward(rd_handle* h, const float* x, int B, int W, int32_t* idx, float* prob, float* full, int flags, void* ws,
                    size_t ws_bytes, void* stream) {
     return guarded(h, [&] {
-        RD_CHECK(h->eng->kind() == "ppocrv6_rec", "handle is not a ppocrv6_rec model");
+        RD_CHECK(h->eng && h->eng->kind() == "ppocrv6_rec", "handle is not a ppocrv6_rec model");
         RD_CHECK(x && idx && prob && B > 0, "null input/output");
         if (flags & (RD_REC_WANT_SOFTMAX | RD_REC_WANT_LOGITS)) RD_CHECK(full, "full_btc_dev is NULL");
         RD_CHECK(!((flags & RD_REC_WANT_SOFTMAX) && (flags & RD_REC_WANT_LOGITS)), "choose softmax OR logits");
@@ -92,7 +122,7 @@ int rd_rec_num_classes(rd_handle* h) { return (h && h->eng) ? h->eng->n_classes(
 int rd_backbone_forward(rd_handle* h, const float* x, int B, int H, int W, float* const feats[4], void* ws, size_t ws_bytes,
                         void* stream) {
     return guarded(h, [&] {
-        RD_CHECK(h->eng->kind() == "pphgnetv2_b4", "handle is not a pphgnetv2_b4 model");
+        RD_CHECK(h->eng && h->eng->kind() == "pphgnetv2_b4", "handle is not a pphgnetv2_b4 model");
         RD_CHECK(x && feats && feats[0] && feats[1] && feats[2] && feats[3], "null input/output");
         h->eng->run(B, H, W, 0, {(void*)x, (void*)feats[0], (void*)feats[1], (void*)feats[2], (void*)feats[3]}, ws, ws_bytes,
                     (hipStream_t)stream);
@@ -102,11 +132,20 @@ int rd_backbone_forward(rd_handle* h, const float* x, int B, int H, int W, float
 int rd_formula_encoder_forward(rd_handle* h, const float* x, int B, int C, int H, int W, float* enc, void* ws, size_t ws_bytes,
                                void* stream) {
     return guarded(h, [&] {
-        RD_CHECK(h->eng->kind() == "pphgnetv2_b6_formula", "handle is not a pphgnetv2_b6_formula model");
+        RD_CHECK(h->eng && h->eng->kind() == "pphgnetv2_b6_formula", "handle is not a pphgnetv2_b6_formula model");
         RD_CHECK(x && enc && B > 0 && (C == 1 || C == 3), "null input/output or channel count not 1/3");
         h->eng->run(B, H, W, C == 1 ? 1 : 0, {(void*)x, (void*)enc}, ws, ws_bytes, (hipStream_t)stream);
     });
 }
+
+int rd_formula_decode(rd_handle* h, const float* enc, int B, int S, int max_new_tokens, int64_t* ids, int32_t* n_cols, void* stream) {
+    return guarded(h, [&] {
+        RD_CHECK(h->kind == "ppformulanet_head" && h->dec, "handle is not a loaded ppformulanet_head model");
+        RD_CHECK(enc && ids && n_cols, "null input/output");
+        *n_cols = rd::formula_decoder_decode(h->dec, enc, B, S, max_new_tokens, reinterpret_cast<long long*>(ids), (hipStream_t)stream);
+    });
+}
+int rd_formula_max_new_tokens(rd_handle* h) { return (h && h->dec) ? rd::formula_decoder_max_new(h->dec) : -1; }
 
 int rd_preproc_resize_norm(int device_id, const uint8_t* src, int H, int W, int OH, int OW, const float mean[3],
                            const float std[3], float scale, int interp, int swap_rb, float* out, void* stream) {
@@ -174,7 +213,7 @@ float rd_debug_time_gemm(int M, int K, int N, int act, int iters, float* x, floa
 }
 
 int rd_set_profiling(rd_handle* h, int on) {
-    return guarded(h, [&] { h->eng->set_profiling(on != 0); });
+    return guarded(h, [&] { if (h->eng) h->eng->set_profiling(on != 0); });
 }
 const char* rd_profile_json(rd_handle* h) {
     if (!h || !h->eng) return "[]";

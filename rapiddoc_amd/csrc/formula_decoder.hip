@@ -1,0 +1,419 @@
+// PP-FormulaNet_plus decoder head on the GPU: enc_to_dec_proj + 6-layer MBart decoder + lm_head, greedy decode with a
+// KV cache, batched over all formulas of a page batch.
+//
+// Reference (rapid_doc/model/formula/rapid_formula_self/networks/heads/):
+//   rec_ppformulanet_head.py:1054-1176 generate_export, :919-962 generate_single_iter, :407-630 CustomMBartDecoder
+//   rec_unimernet_head.py:502-628 MBartAttention, :635-746 MBartDecoderLayer, :440-456 positional offset 2,
+//   :1545-1572 ForcedEOSTokenLogitsProcessor (max_length 1537)
+// Differences in HOW (not WHAT): the reference re-applies enc_to_dec_proj to all encoder tokens and re-derives the
+// cross-attention K/V every step (:934-936); here they are computed once per batch.  q scaling (head_dim^-0.5) and the
+// embedding scale sqrt(d_model) are folded into the weights at load time.  The step index lives in device memory so
+// every launch of a step has constant arguments (hipGraph-ready).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+namespace rd {
+
+static constexpr int D = 512, HEADS = 16, HD = 32, FFN = 2048;
+static constexpr int EOS_ID = 2, PAD_ID = 1, START_ID = 0, FORCED_EOS_LEN = 1537;
+
+struct DecState {  // device-resident scalars
+    int step;          // number of tokens generated so far (position of the token being consumed)
+    int n_unfinished;
+};
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// x[b] = LayerNorm(emb[ids[b][t]] + pos[t + 2])   (emb pre-multiplied by sqrt(d_model)); one wavefront per sequence
+__global__ void __launch_bounds__(64) dec_embed_ln_kernel(const float* emb, const float* pos, const long long* ids, int ids_ld,
+                                                          const DecState* st, const float* g, const float* b, float* x) {
+    const int bi = blockIdx.x, lane = threadIdx.x, t = st->step;
+    const long long tok = ids[(size_t)bi * ids_ld + t];
+    float v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = emb[(size_t)tok * D + c] + pos[(size_t)(t + 2) * D + c];
+        s += v[i];
+    }
+    const float mean = wsum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q += (v[i] - mean) * (v[i] - mean);
+    const float rstd = rsqrtf(wsum(q) / D + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        x[(size_t)bi * D + c] = (v[i] - mean) * rstd * g[c] + b[c];
+    }
+}
+
+// Single-query attention for one (sequence, head): keys/values from a cache [B][T][ld] (+ optionally the current step's
+// k, v which are also appended to the cache), softmax(q.k) v.  q is already scaled.
+struct AttnDecParams {
+    const float* q; int ldq;          // [B][ldq], head h at q + h*HD
+    const float* kc; const float* vc; int ldkv; long long seq_stride;   // cache rows
+    const float* kcur; const float* vcur; int ldcur;                   // current k, v (self-attention) or nullptr
+    float* kw; float* vw;             // where to append (self-attention) or nullptr
+    const DecState* st; int fixed_T;  // T = fixed_T (cross) or st->step (self, then + current)
+    float* out; int ldo;
+};
+__global__ void __launch_bounds__(128) dec_attention_kernel(AttnDecParams p) {
+    extern __shared__ float sm[];  // scores[Tmax] + red[128]
+    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    const int Tc = p.kcur ? p.st->step : p.fixed_T;   // cached keys
+    const int T = Tc + (p.kcur ? 1 : 0);
+    float* sc = sm;
+    float* red = sm + ((T + 3) & ~3);
+    float q[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) q[d] = p.q[(size_t)b * p.ldq + h * HD + d];
+    if (p.kcur && tid < HD) {  // append this step's k, v for head h
+        p.kw[(size_t)b * p.seq_stride + (size_t)Tc * p.ldkv + h * HD + tid] = p.kcur[(size_t)b * p.ldcur + h * HD + tid];
+        p.vw[(size_t)b * p.seq_stride + (size_t)Tc * p.ldkv + h * HD + tid] = p.vcur[(size_t)b * p.ldcur + h * HD + tid];
+    }
+    float mx = -INFINITY;
+    for (int j = tid; j < T; j += 128) {
+        const float* kr = (j < Tc) ? p.kc + (size_t)b * p.seq_stride + (size_t)j * p.ldkv + h * HD : p.kcur + (size_t)b * p.ldcur + h * HD;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) s = fmaf(q[d], kr[d], s);
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    red[tid] = mx;
+    __syncthreads();
+    for (int o = 64; o > 0; o >>= 1) {
+        if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+        __syncthreads();
+    }
+    mx = red[0];
+    __syncthreads();
+    float sum = 0.f;
+    for (int j = tid; j < T; j += 128) {
+        const float e = __expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+    red[tid] = sum;
+    __syncthreads();
+    for (int o = 64; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    const float inv = 1.f / red[0];
+    __syncthreads();
+    // output: thread (g = tid / 32, d = tid % 32) sums its quarter of the keys for dimension d
+    const int d = tid & 31, g = tid >> 5;
+    float acc = 0.f;
+    for (int j = g; j < T; j += 4) {
+        const float* vr = (j < Tc) ? p.vc + (size_t)b * p.seq_stride + (size_t)j * p.ldkv + h * HD : p.vcur + (size_t)b * p.ldcur + h * HD;
+        acc = fmaf(sc[j], vr[d], acc);
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < 32) p.out[(size_t)b * p.ldo + h * HD + tid] = (red[tid] + red[tid + 32] + red[tid + 64] + red[tid + 96]) * inv;
+}
+
+// next token: argmax of the logits row (forced EOS at the length limit), pad for finished sequences, append
+__global__ void __launch_bounds__(256) dec_select_kernel(const float* logits, int V, long long* ids, int ids_ld, int* unfinished,
+                                                         DecState* st) {
+    const int b = blockIdx.x, tid = threadIdx.x, t = st->step;
+    const float* z = logits + (size_t)b * V;
+    float mx = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int c = tid; c < V; c += 256) {
+        const float v = z[c];
+        if (v > mx) { mx = v; mi = c; }
+    }
+    __shared__ float smx[256];
+    __shared__ int smi[256];
+    smx[tid] = mx;
+    smi[tid] = mi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            const float a = smx[tid], c = smx[tid + o];
+            const int ia = smi[tid], ic = smi[tid + o];
+            if (c > a || (c == a && ic < ia)) { smx[tid] = c; smi[tid] = ic; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int tok = smi[0];
+        if (t + 1 == FORCED_EOS_LEN - 1) tok = EOS_ID;          // input length == max_length - 1 -> only EOS survives
+        const int unf = unfinished[b];
+        tok = unf ? tok : PAD_ID;
+        ids[(size_t)b * ids_ld + t + 1] = tok;
+        if (unf && tok == EOS_ID) {
+            unfinished[b] = 0;
+            atomicSub(&st->n_unfinished, 1);
+        }
+    }
+}
+__global__ void dec_advance_kernel(DecState* st) { st->step += 1; }
+__global__ void dec_init_kernel(DecState* st, int* unfinished, long long* ids, int ids_ld, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { st->step = 0; st->n_unfinished = B; }
+    if (i < B) unfinished[i] = 1;
+    for (long long k = i; k < (long long)B * ids_ld; k += (long long)gridDim.x * blockDim.x) ids[k] = (k % ids_ld == 0) ? START_ID : PAD_ID;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+class FormulaDecoder {
+   public:
+    explicit FormulaDecoder(int device) : device_(device) {}
+    ~FormulaDecoder() {
+        (void)hipSetDevice(device_);
+        if (buf_) (void)hipFree(buf_);
+    }
+    void load(const WeightStore& ws);
+    // enc [B,S,2048] (device) -> ids [B][max_new+1] (device, int64); returns the number of columns the reference returns
+    int decode(const float* enc, int B, int S, int max_new, long long* ids_out, hipStream_t s);
+    int max_positions() const { return n_pos_ - 2; }
+
+   private:
+    void gemm(const float* x, int M, int K, const std::string& key, int N, float* y, int act, const float* res, hipStream_t s);
+    void ln(const float* x, const std::string& key, float* y, int M, hipStream_t s) {
+        launch_layernorm(x, D, y, D, params_.ptr(key + ".weight"), params_.ptr(key + ".bias"), M, D, 1e-5f, s);
+    }
+    int device_;
+    int n_layers_ = 0, vocab_ = 0, n_pos_ = 0, enc_dim_ = 0;
+    ParamBlock params_;
+    uint8_t* buf_ = nullptr;
+    size_t buf_bytes_ = 0;
+};
+
+static std::vector<float> vec_of(const HostTensor& t) { return std::vector<float>(t.f32(), t.f32() + t.numel()); }
+
+void FormulaDecoder::load(const WeightStore& ws) {
+    const std::string P = "head.decoder.model.decoder.";
+    const HostTensor& emb = ws.get(P + "embed_tokens.weight");
+    vocab_ = (int)emb.shape[0];
+    RD_CHECK((int)emb.shape[1] == D, "formula decoder: d_model must be 512");
+    {
+        std::vector<float> e = vec_of(emb);
+        const float sc = std::sqrt((float)D);  // scale_embedding=True (rec_ppformulanet_head.py:769)
+        for (auto& v : e) v *= sc;
+        params_.add("emb", e);
+    }
+    const HostTensor& pos = ws.get(P + "embed_positions.weight");
+    n_pos_ = (int)pos.shape[0];
+    params_.add("pos", vec_of(pos));
+    auto add_ln = [&](const std::string& name, const std::string& key) {
+        params_.add(key + ".weight", vec_of(ws.get(name + ".weight")));
+        params_.add(key + ".bias", vec_of(ws.get(name + ".bias")));
+    };
+    add_ln(P + "layernorm_embedding", "ln_emb");
+    add_ln(P + "layer_norm", "ln_out");
+    const float qs = 1.0f / std::sqrt((float)HD);
+    auto lin = [&](const std::string& name, const std::string& key, float scale) {
+        std::vector<float> w = vec_of(ws.get(name + ".weight"));
+        for (auto& v : w) v *= scale;
+        params_.add(key + "#w", w);
+        if (ws.has(name + ".bias")) {
+            std::vector<float> b = vec_of(ws.get(name + ".bias"));
+            for (auto& v : b) v *= scale;
+            params_.add(key + "#b", b);
+        }
+    };
+    n_layers_ = 0;
+    while (ws.has(P + "layers." + std::to_string(n_layers_) + ".fc1.weight")) ++n_layers_;
+    RD_CHECK(n_layers_ > 0, "formula decoder: no layers found");
+    for (int l = 0; l < n_layers_; ++l) {
+        const std::string L = P + "layers." + std::to_string(l) + ".", K = "l" + std::to_string(l) + ".";
+        add_ln(L + "self_attn_layer_norm", K + "ln1");
+        add_ln(L + "encoder_attn_layer_norm", K + "ln2");
+        add_ln(L + "final_layer_norm", K + "ln3");
+        // fused q|k|v projection [1536][512]; q rows carry the head_dim^-0.5 scaling (rec_unimernet_head.py:553)
+        std::vector<float> w, bvec;
+        for (const char* nm : {"q_proj", "k_proj", "v_proj"}) {
+            std::vector<float> a = vec_of(ws.get(L + "self_attn." + nm + ".weight")), bb = vec_of(ws.get(L + "self_attn." + nm + ".bias"));
+            const float sc = std::string(nm) == "q_proj" ? qs : 1.f;
+            for (auto& v : a) v *= sc;
+            for (auto& v : bb) v *= sc;
+            w.insert(w.end(), a.begin(), a.end());
+            bvec.insert(bvec.end(), bb.begin(), bb.end());
+        }
+        params_.add(K + "qkv#w", w);
+        params_.add(K + "qkv#b", bvec);
+        lin(L + "self_attn.out_proj", K + "so", 1.f);
+        lin(L + "encoder_attn.q_proj", K + "cq", qs);
+        w.clear(); bvec.clear();
+        for (const char* nm : {"k_proj", "v_proj"}) {
+            std::vector<float> a = vec_of(ws.get(L + "encoder_attn." + nm + ".weight")), bb = vec_of(ws.get(L + "encoder_attn." + nm + ".bias"));
+            w.insert(w.end(), a.begin(), a.end());
+            bvec.insert(bvec.end(), bb.begin(), bb.end());
+        }
+        params_.add(K + "ckv#w", w);
+        params_.add(K + "ckv#b", bvec);
+        lin(L + "encoder_attn.out_proj", K + "co", 1.f);
+        lin(L + "fc1", K + "fc1", 1.f);
+        lin(L + "fc2", K + "fc2", 1.f);
+    }
+    lin("head.decoder.lm_head", "lm", 1.f);
+    if (ws.has("head.enc_to_dec_proj.weight")) {
+        enc_dim_ = (int)ws.get("head.enc_to_dec_proj.weight").shape[1];
+        lin("head.enc_to_dec_proj", "encp", 1.f);
+    } else {
+        enc_dim_ = D;
+    }
+    params_.upload();
+}
+
+void FormulaDecoder::gemm(const float* x, int M, int K, const std::string& key, int N, float* y, int act, const float* res, hipStream_t s) {
+    ConvParams p{};
+    p.x = x; p.xld = K; p.N = 1; p.H = 1; p.W = M; p.Cin = K;
+    p.w = params_.ptr(key + "#w");
+    p.bias = params_.has(key + "#b") ? params_.ptr(key + "#b") : nullptr;
+    p.y = y; p.yld = N; p.OH = 1; p.OW = M; p.Cout = N;
+    p.KH = p.KW = p.SH = p.SW = 1;
+    p.res = res; p.rld = N;
+    p.act = act; p.out_mode = OUT_NHWC;
+    p.M = M; p.K = K; p.Ng = N;
+    launch_conv_igemm(p, s);
+}
+
+int FormulaDecoder::decode(const float* enc, int B, int S, int max_new, long long* ids_out, hipStream_t s) {
+    RD_HIP(hipSetDevice(device_));
+    RD_CHECK(B > 0 && S > 0 && max_new > 0, "formula decode: empty batch");
+    RD_CHECK(max_new + 2 <= n_pos_, "formula decode: max_new_tokens exceeds the positional table of these weights");
+    const int Tmax = max_new + 1, ids_ld = max_new + 1;
+    auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+    const size_t f = sizeof(float);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+    const size_t o_state = take(sizeof(DecState)), o_unf = take(B * sizeof(int));
+    const size_t o_encp = take((size_t)B * S * D * f);
+    const size_t o_ckv = take((size_t)n_layers_ * B * S * 2 * D * f);
+    const size_t o_kc = take((size_t)n_layers_ * B * Tmax * D * f), o_vc = take((size_t)n_layers_ * B * Tmax * D * f);
+    const size_t o_x = take((size_t)B * D * f), o_x2 = take((size_t)B * D * f), o_h = take((size_t)B * D * f);
+    const size_t o_qkv = take((size_t)B * 3 * D * f), o_a = take((size_t)B * D * f), o_f = take((size_t)B * FFN * f);
+    const size_t o_lg = take((size_t)B * vocab_ * f);
+    if (off > buf_bytes_) {
+        RD_HIP(hipStreamSynchronize(s));
+        if (buf_) RD_HIP(hipFree(buf_));
+        buf_ = nullptr;
+        RD_HIP(hipMalloc((void**)&buf_, off));
+        buf_bytes_ = off;
+    }
+    DecState* st = reinterpret_cast<DecState*>(buf_ + o_state);
+    int* unf = reinterpret_cast<int*>(buf_ + o_unf);
+    float* encp = reinterpret_cast<float*>(buf_ + o_encp);
+    float* ckv = reinterpret_cast<float*>(buf_ + o_ckv);
+    float* kc = reinterpret_cast<float*>(buf_ + o_kc);
+    float* vc = reinterpret_cast<float*>(buf_ + o_vc);
+    float* x = reinterpret_cast<float*>(buf_ + o_x);
+    float* x2 = reinterpret_cast<float*>(buf_ + o_x2);
+    float* h = reinterpret_cast<float*>(buf_ + o_h);
+    float* qkv = reinterpret_cast<float*>(buf_ + o_qkv);
+    float* a = reinterpret_cast<float*>(buf_ + o_a);
+    float* ff = reinterpret_cast<float*>(buf_ + o_f);
+    float* lg = reinterpret_cast<float*>(buf_ + o_lg);
+
+    hipLaunchKernelGGL(dec_init_kernel, dim3(64), dim3(256), 0, s, st, unf, ids_out, ids_ld, B);
+    // once per batch: project the encoder states and derive every layer's cross-attention K | V
+    const float* enc_d = enc;
+    if (params_.has("encp#w")) {
+        gemm(enc, B * S, enc_dim_, "encp", D, encp, ACT_NONE, nullptr, s);
+        enc_d = encp;
+    }
+    for (int l = 0; l < n_layers_; ++l)
+        gemm(enc_d, B * S, D, "l" + std::to_string(l) + ".ckv", 2 * D, ckv + (size_t)l * B * S * 2 * D, ACT_NONE, nullptr, s);
+
+    const size_t attn_sh_self = (size_t)(((Tmax + 3) & ~3) + 128) * f, attn_sh_cross = (size_t)(((S + 3) & ~3) + 128) * f;
+    int host_unf = B, steps = 0;
+    for (int t = 0; t < max_new; ++t) {
+        hipLaunchKernelGGL(dec_embed_ln_kernel, dim3(B), dim3(64), 0, s, params_.ptr("emb"), params_.ptr("pos"), ids_out, ids_ld, st,
+                           params_.ptr("ln_emb.weight"), params_.ptr("ln_emb.bias"), x);
+        float* cur = x;
+        float* nxt = x2;
+        for (int l = 0; l < n_layers_; ++l) {
+            const std::string K = "l" + std::to_string(l) + ".";
+            // self-attention
+            ln(cur, K + "ln1", h, B, s);
+            gemm(h, B, D, K + "qkv", 3 * D, qkv, ACT_NONE, nullptr, s);
+            AttnDecParams ap{};
+            ap.q = qkv; ap.ldq = 3 * D;
+            ap.kc = kc + (size_t)l * B * Tmax * D; ap.vc = vc + (size_t)l * B * Tmax * D; ap.ldkv = D; ap.seq_stride = (long long)Tmax * D;
+            ap.kcur = qkv + D; ap.vcur = qkv + 2 * D; ap.ldcur = 3 * D;
+            ap.kw = kc + (size_t)l * B * Tmax * D; ap.vw = vc + (size_t)l * B * Tmax * D;
+            ap.st = st; ap.fixed_T = 0; ap.out = a; ap.ldo = D;
+            hipLaunchKernelGGL(dec_attention_kernel, dim3(B, HEADS), dim3(128), attn_sh_self, s, ap);
+            gemm(a, B, D, K + "so", D, nxt, ACT_NONE, cur, s);
+            std::swap(cur, nxt);
+            // cross-attention over the (projected) encoder tokens
+            ln(cur, K + "ln2", h, B, s);
+            gemm(h, B, D, K + "cq", D, qkv, ACT_NONE, nullptr, s);
+            AttnDecParams cp{};
+            cp.q = qkv; cp.ldq = D;
+            cp.kc = ckv + (size_t)l * B * S * 2 * D; cp.vc = cp.kc + D; cp.ldkv = 2 * D; cp.seq_stride = (long long)S * 2 * D;
+            cp.st = st; cp.fixed_T = S; cp.out = a; cp.ldo = D;
+            hipLaunchKernelGGL(dec_attention_kernel, dim3(B, HEADS), dim3(128), attn_sh_cross, s, cp);
+            gemm(a, B, D, K + "co", D, nxt, ACT_NONE, cur, s);
+            std::swap(cur, nxt);
+            // feed-forward
+            ln(cur, K + "ln3", h, B, s);
+            gemm(h, B, D, K + "fc1", FFN, ff, ACT_GELU, nullptr, s);
+            gemm(ff, B, FFN, K + "fc2", D, nxt, ACT_NONE, cur, s);
+            std::swap(cur, nxt);
+        }
+        ln(cur, "ln_out", h, B, s);
+        gemm(h, B, D, "lm", vocab_, lg, ACT_NONE, nullptr, s);
+        hipLaunchKernelGGL(dec_select_kernel, dim3(B), dim3(256), 0, s, lg, vocab_, ids_out, ids_ld, unf, st);
+        hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(1), 0, s, st);
+        steps = t + 1;
+        if ((t & 7) == 7 || t + 1 == max_new) {  // all sequences ended? (checked every 8 steps: one small D2H + sync)
+            DecState hs;
+            RD_HIP(hipMemcpyAsync(&hs, st, sizeof(DecState), hipMemcpyDeviceToHost, s));
+            RD_HIP(hipStreamSynchronize(s));
+            host_unf = hs.n_unfinished;
+            if (host_unf == 0) break;
+        }
+    }
+    RD_HIP(hipGetLastError());
+    // the reference stops right after the step in which the last sequence emitted EOS: trim the run-ahead columns
+    if (host_unf == 0) {
+        std::vector<long long> ids((size_t)B * ids_ld);
+        RD_HIP(hipMemcpyAsync(ids.data(), ids_out, ids.size() * sizeof(long long), hipMemcpyDeviceToHost, s));
+        RD_HIP(hipStreamSynchronize(s));
+        int last = 0;
+        for (int b = 0; b < B; ++b)
+            for (int c = 1; c <= steps; ++c)
+                if (ids[(size_t)b * ids_ld + c] == EOS_ID) { last = std::max(last, c); break; }
+        return last + 1;
+    }
+    return steps + 1;
+}
+
+// ---- C++ side of the C-ABI handle (api.cpp) -----------------------------------------------------------------------
+FormulaDecoder* formula_decoder_create(int device, const void* blob, size_t nbytes) {
+    RD_HIP(hipSetDevice(device));
+    WeightStore ws;
+    ws.load_safetensors(blob, nbytes);
+    auto* d = new FormulaDecoder(device);
+    try {
+        d->load(ws);
+    } catch (...) {
+        delete d;
+        throw;
+    }
+    return d;
+}
+void formula_decoder_destroy(FormulaDecoder* d) { delete d; }
+int formula_decoder_decode(FormulaDecoder* d, const float* enc, int B, int S, int max_new, long long* ids, hipStream_t s) {
+    return d->decode(enc, B, S, max_new, ids, s);
+}
+int formula_decoder_max_new(FormulaDecoder* d) { return d->max_positions(); }
+
+}  // namespace rd

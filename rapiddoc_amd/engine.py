@@ -12,7 +12,7 @@ import torch
 from . import _lib, weights as W
 
 REC_UNFUSED_CTC, REC_WANT_SOFTMAX, REC_WANT_LOGITS = 1, 2, 4
-KINDS = ("ppocrv6_det", "ppocrv6_rec", "pphgnetv2_b4", "pphgnetv2_b6_formula")
+KINDS = ("ppocrv6_det", "ppocrv6_rec", "pphgnetv2_b4", "pphgnetv2_b6_formula", "ppformulanet_head")
 
 
 class EngineError(RuntimeError):
@@ -124,6 +124,19 @@ class RdEngine:
         self._chk(self._l.rd_formula_encoder_forward(self._h, x.data_ptr(), B, Cc, H, W_, out.data_ptr(), None, 0, _stream_ptr()))
         self._log()
         return out
+
+    def formula_decode(self, enc: torch.Tensor, max_new_tokens: int) -> torch.Tensor:
+        """enc [B,S,2048] -> token ids [B,L] int64 exactly as PPFormulaNet_Head.forward returns them."""
+        enc = self._prep(enc)
+        B, S, _ = enc.shape
+        ids = torch.empty((B, max_new_tokens + 1), dtype=torch.int64, device=enc.device)
+        n = C.c_int32(0)
+        self._chk(self._l.rd_formula_decode(self._h, enc.data_ptr(), B, S, max_new_tokens, ids.data_ptr(), C.byref(n), _stream_ptr()))
+        return ids[:, : n.value]
+
+    @property
+    def formula_max_new_tokens(self) -> int:
+        return self._l.rd_formula_max_new_tokens(self._h)
 
     # ------------------------------------------------------------------ profiling
     def set_profiling(self, on: bool):

@@ -165,6 +165,60 @@ def main():
         assert d < 2e-5, d
         np.savez_compressed(HERE / f"b6_seed0_{tag}.npz", x=x, enc=enc.numpy())
 
+    # ---------------- PP-FormulaNet_plus-M full model: encoder + MBart decoder, greedy generate ----------------
+    from networks.architectures.base_model import BaseModel as FormulaModel
+    from oracle import formula as OF
+    fcfg = yaml.safe_load(open(REF / "rapid_doc/model/formula/rapid_formula_self/networks/pp_formulanet_arch_config.yaml"))["PP-FormulaNet_plus-M"]
+    for tag, max_new, shape in (("m8", 8, (2, 1, 96, 128)),):
+        cfgc = yaml.safe_load(yaml.safe_dump(fcfg))
+        cfgc["Head"]["max_new_tokens"] = max_new
+        fm = FormulaModel(cfgc)
+        fm.eval()
+        man = manifest_of(fm)
+        used = [m for m in man if not m[0].startswith(("backbone.pphgnet_b6.fc.", "backbone.pphgnet_b6.last_conv."))]
+        (HERE / f"manifest_ppformulanet_plus_m_{tag}.json").write_text(json.dumps(used))
+        state = W.synth_state_dict([(n, tuple(s_), d) for n, s_, d in man], SEED)
+        fm.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+        tstate = O.as_torch_state({k: v for k, v in state.items() if k in {m[0] for m in used}})
+        x = make_input(shape, 500 + max_new, "pm1")
+        xt = torch.from_numpy(x)
+        with torch.no_grad():
+            ids_ref = fm(xt)
+            enc = fm.backbone(xt).last_hidden_state
+            ids_mine, lgs = OF.formula_decode(tstate, enc, max_new, return_logits=True)
+        assert ids_ref.shape == ids_mine.shape and bool((ids_ref == ids_mine).all()), (ids_ref, ids_mine)
+        top2 = torch.stack([torch.topk(l, 2, dim=-1).values for l in lgs], 1)   # [B, steps, 2]
+        print(f"formula {tag}: reference ids == oracle ids {tuple(ids_ref.shape)}; min top-2 gap {float((top2[...,0]-top2[...,1]).min()):.4f}")
+        np.savez_compressed(HERE / f"formula_seed0_{tag}.npz", x=x, enc=enc.numpy(), ids=ids_ref.numpy(),
+                            top2gap=(top2[..., 0] - top2[..., 1]).numpy(), logits_step0=lgs[0][:, ::50].contiguous().numpy())
+        enc_out_type = type(fm.backbone(xt))
+        del fm
+    # decoder alone, driven by random encoder states (synthetic-weight encoders give nearly input-independent states, which
+    # would make every sequence decode identically).  `eos_gain` scales lm_head row 2 so that sequences END at different steps.
+    for tag, max_new, B_, S_, eos_gain in (("dec_a", 16, 4, 10, 6.0), ("dec_b", 24, 3, 7, 1.0)):
+        cfgc = yaml.safe_load(yaml.safe_dump(fcfg))
+        cfgc["Head"]["max_new_tokens"] = max_new
+        fm = FormulaModel(cfgc)
+        fm.eval()
+        man = [m for m in manifest_of(fm) if m[0].startswith("head.")]
+        (HERE / f"manifest_ppformulanet_head_{tag}.json").write_text(json.dumps(man))
+        state = W.synth_state_dict([(n, tuple(s_), d) for n, s_, d in man], SEED)
+        state["head.decoder.lm_head.weight"][2] *= eos_gain
+        fm.head.load_state_dict({k[len("head."):]: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+        tstate = O.as_torch_state(state)
+        enc = torch.from_numpy((np.random.default_rng(600 + max_new).standard_normal((B_, S_, 2048)) * 3.0).astype(np.float32))
+        with torch.no_grad():
+            ids_ref = fm.head(enc_out_type(last_hidden_state=enc, pooler_output=None, hidden_states=None, attentions=False,
+                                           reshaped_hidden_states=None))
+            ids_mine, lgs = OF.formula_decode(tstate, enc, max_new, return_logits=True)
+        assert ids_ref.shape == ids_mine.shape and bool((ids_ref == ids_mine).all()), (ids_ref, ids_mine)
+        top2 = torch.stack([torch.topk(l, 2, dim=-1).values for l in lgs], 1)
+        print(f"formula {tag}: reference ids == oracle ids {tuple(ids_ref.shape)}; EOS at {[(r == 2).nonzero().flatten().tolist() for r in ids_ref]}; "
+              f"min top-2 gap {float((top2[...,0]-top2[...,1]).min()):.4f}")
+        np.savez_compressed(HERE / f"formula_seed0_{tag}.npz", enc=enc.numpy(), ids=ids_ref.numpy(), eos_gain=np.float32(eos_gain),
+                            top2gap=(top2[..., 0] - top2[..., 1]).numpy(), logits_step0=lgs[0][:, ::50].contiguous().numpy())
+        del fm
+
     # ---------------- host box helpers (pure python in the reference; cv2 stubbed, it is not called by them) ----------
     import importlib.util
     import types

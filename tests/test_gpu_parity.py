@@ -173,3 +173,42 @@ def test_formula_encoder_matches_golden(golden_dir, tag):
     enc = eng.formula_encoder_forward(torch.from_numpy(g["x"]).cuda()).cpu().numpy()
     assert enc.shape == g["enc"].shape
     assert np.abs(enc - g["enc"]).max() < TOL
+
+
+def _safe_prefix_equal(ids, ref, gaps, min_gap=1e-2):
+    """Token ids must match up to (not including) the first step whose top-2 logit gap is inside fp32 noise."""
+    for b in range(ref.shape[0]):
+        unsafe = np.nonzero(gaps[b] < min_gap)[0]
+        n = (unsafe[0] if len(unsafe) else gaps.shape[1]) + 1   # +1: the start token column
+        assert (ids[b, :n] == ref[b, :n]).all(), (b, ids[b], ref[b])
+    return True
+
+
+@pytest.mark.parametrize("tag,max_new", [("dec_a", 16), ("dec_b", 24)])
+def test_formula_decoder_matches_reference_golden(golden_dir, tag, max_new):
+    """GPU MBart decoder (KV cache, hoisted cross-attention K/V) vs the reference head's generate_export token ids."""
+    from rapiddoc_amd.engine import RdEngine
+    g = np.load(golden_dir / f"formula_seed0_{tag}.npz")
+    st = W.synth_state_dict(W.load_manifest(golden_dir / f"manifest_ppformulanet_head_{tag}.json"), 0)
+    st["head.decoder.lm_head.weight"][2] *= float(g["eos_gain"])
+    eng = RdEngine("ppformulanet_head").load_weights(st)
+    assert eng.formula_max_new_tokens == max_new
+    ids = eng.formula_decode(torch.from_numpy(g["enc"]).cuda(), max_new).cpu().numpy()
+    assert ids.shape == g["ids"].shape
+    _safe_prefix_equal(ids, g["ids"], g["top2gap"])
+    if (g["top2gap"] >= 1e-2).all():
+        assert (ids == g["ids"]).all()
+
+
+def test_formula_full_model_image_to_ids(golden_dir):
+    """encoder handle + decoder handle composed = the reference BaseModel(image) -> ids."""
+    from rapiddoc_amd.engine import RdEngine
+    g = np.load(golden_dir / "formula_seed0_m8.npz")
+    st = W.synth_state_dict(W.load_manifest(golden_dir / "manifest_ppformulanet_plus_m_m8.json"), 0)
+    enc_eng = RdEngine("pphgnetv2_b6_formula").load_weights({k: v for k, v in st.items() if k.startswith("backbone.")})
+    dec_eng = RdEngine("ppformulanet_head").load_weights({k: v for k, v in st.items() if k.startswith("head.")})
+    enc = enc_eng.formula_encoder_forward(torch.from_numpy(g["x"]).cuda())
+    assert np.abs(enc.cpu().numpy() - g["enc"]).max() < TOL
+    ids = dec_eng.formula_decode(enc, 8).cpu().numpy()
+    assert ids.shape == g["ids"].shape
+    _safe_prefix_equal(ids, g["ids"], g["top2gap"])

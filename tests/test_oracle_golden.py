@@ -67,3 +67,14 @@ def test_formula_encoder_oracle_matches_reference_golden(golden_dir, tag):
     g = np.load(golden_dir / f"b6_seed0_{tag}.npz")
     enc = O.formula_encoder_forward(st, torch.from_numpy(g["x"]))
     assert np.abs(enc.numpy() - g["enc"]).max() < TOL
+
+
+@pytest.mark.parametrize("tag,max_new", [("dec_a", 16), ("dec_b", 24)])
+def test_formula_decoder_oracle_matches_reference_golden(golden_dir, tag, max_new):
+    """oracle/formula.py vs token ids produced by the reference PPFormulaNet_Head (generate_export)."""
+    from oracle import formula as OF
+    g = np.load(golden_dir / f"formula_seed0_{tag}.npz")
+    st = W.synth_state_dict(W.load_manifest(golden_dir / f"manifest_ppformulanet_head_{tag}.json"), 0)
+    st["head.decoder.lm_head.weight"][2] *= float(g["eos_gain"])
+    ids = OF.formula_decode(O.as_torch_state(st), torch.from_numpy(g["enc"]), max_new)
+    assert ids.shape == g["ids"].shape and (ids.numpy() == g["ids"]).all()
