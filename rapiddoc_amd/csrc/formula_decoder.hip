@@ -11,6 +11,7 @@
 // every launch of a step has constant arguments (hipGraph-ready).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -25,6 +26,7 @@ static constexpr int EOS_ID = 2, PAD_ID = 1, START_ID = 0, FORCED_EOS_LEN = 1537
 struct DecState {  // device-resident scalars
     int step;          // number of tokens generated so far (position of the token being consumed)
     int n_unfinished;
+    int arrived;       // select-kernel arrival ticket
 };
 
 __device__ __forceinline__ float wsum(float v) {
@@ -125,23 +127,24 @@ __global__ void __launch_bounds__(128) dec_attention_kernel(AttnDecParams p) {
     if (tid < 32) p.out[(size_t)b * p.ldo + h * HD + tid] = (red[tid] + red[tid + 32] + red[tid + 64] + red[tid + 96]) * inv;
 }
 
-// next token: argmax of the logits row (forced EOS at the length limit), pad for finished sequences, append
-__global__ void __launch_bounds__(256) dec_select_kernel(const float* logits, int V, long long* ids, int ids_ld, int* unfinished,
-                                                         DecState* st) {
+// next token: argmax of the logits row (forced EOS at the length limit), pad for finished sequences, append.  The last
+// block to finish advances the step counter (arrival ticket), so no separate launch is needed.
+__global__ void __launch_bounds__(1024) dec_select_kernel(const float* logits, int V, long long* ids, int ids_ld, int* unfinished,
+                                                          DecState* st, int B) {
     const int b = blockIdx.x, tid = threadIdx.x, t = st->step;
     const float* z = logits + (size_t)b * V;
     float mx = -INFINITY;
     int mi = 0x7fffffff;
-    for (int c = tid; c < V; c += 256) {
+    for (int c = tid; c < V; c += 1024) {
         const float v = z[c];
         if (v > mx) { mx = v; mi = c; }
     }
-    __shared__ float smx[256];
-    __shared__ int smi[256];
+    __shared__ float smx[1024];
+    __shared__ int smi[1024];
     smx[tid] = mx;
     smi[tid] = mi;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if (tid < o) {
             const float a = smx[tid], c = smx[tid + o];
             const int ia = smi[tid], ic = smi[tid + o];
@@ -159,12 +162,17 @@ __global__ void __launch_bounds__(256) dec_select_kernel(const float* logits, in
             unfinished[b] = 0;
             atomicSub(&st->n_unfinished, 1);
         }
+        __threadfence();
+        if (atomicAdd(&st->arrived, 1) == B - 1) {   // every block has read `step` (t) before its ticket: safe to advance
+            st->arrived = 0;
+            st->step = t + 1;
+        }
     }
 }
 __global__ void dec_advance_kernel(DecState* st) { st->step += 1; }
 __global__ void dec_init_kernel(DecState* st, int* unfinished, long long* ids, int ids_ld, int B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { st->step = 0; st->n_unfinished = B; }
+    if (i == 0) { st->step = 0; st->n_unfinished = B; st->arrived = 0; }
     if (i < B) unfinished[i] = 1;
     for (long long k = i; k < (long long)B * ids_ld; k += (long long)gridDim.x * blockDim.x) ids[k] = (k % ids_ld == 0) ? START_ID : PAD_ID;
 }
@@ -183,7 +191,8 @@ class FormulaDecoder {
     int max_positions() const { return n_pos_ - 2; }
 
    private:
-    void gemm(const float* x, int M, int K, const std::string& key, int N, float* y, int act, const float* res, hipStream_t s);
+    void gemm(const float* x, int M, int K, const std::string& key, int N, float* y, int act, const float* res, hipStream_t s,
+              const std::string& ln_key = "", float* ln_tmp = nullptr);
     void ln(const float* x, const std::string& key, float* y, int M, hipStream_t s) {
         launch_layernorm(x, D, y, D, params_.ptr(key + ".weight"), params_.ptr(key + ".bias"), M, D, 1e-5f, s);
     }
@@ -271,8 +280,20 @@ void FormulaDecoder::load(const WeightStore& ws) {
     params_.upload();
 }
 
-void FormulaDecoder::gemm(const float* x, int M, int K, const std::string& key, int N, float* y, int act, const float* res, hipStream_t s) {
+// y = act(LN?(x) . W^T + b) (+ res).  With `ln_key` the pre-LayerNorm is fused into the small-M GEMM when it applies, otherwise
+// it runs as its own kernel through `ln_tmp`.
+void FormulaDecoder::gemm(const float* x, int M, int K, const std::string& key, int N, float* y, int act, const float* res, hipStream_t s,
+                          const std::string& ln_key, float* ln_tmp) {
     ConvParams p{};
+    if (!ln_key.empty()) {
+        if (skinny_gemm_applies(M, K) && N <= 4096) {   // every workgroup re-normalises X: only worth it for few workgroups
+            p.ln_g = params_.ptr(ln_key + ".weight");
+            p.ln_b = params_.ptr(ln_key + ".bias");
+        } else {
+            ln(x, ln_key, ln_tmp, M, s);
+            x = ln_tmp;
+        }
+    }
     p.x = x; p.xld = K; p.N = 1; p.H = 1; p.W = M; p.Cin = K;
     p.w = params_.ptr(key + "#w");
     p.bias = params_.has(key + "#b") ? params_.ptr(key + "#b") : nullptr;
@@ -332,8 +353,9 @@ int FormulaDecoder::decode(const float* enc, int B, int S, int max_new, long lon
         gemm(enc_d, B * S, D, "l" + std::to_string(l) + ".ckv", 2 * D, ckv + (size_t)l * B * S * 2 * D, ACT_NONE, nullptr, s);
 
     const size_t attn_sh_self = (size_t)(((Tmax + 3) & ~3) + 128) * f, attn_sh_cross = (size_t)(((S + 3) & ~3) + 128) * f;
-    int host_unf = B, steps = 0;
-    for (int t = 0; t < max_new; ++t) {
+    // One decode step = ~70 dependent launches whose arguments never change (the step index lives in device memory), so
+    // the step is captured once into a hipGraph and replayed: the host cost per step drops from ~70 launches to one.
+    auto enqueue_step = [&]() {
         hipLaunchKernelGGL(dec_embed_ln_kernel, dim3(B), dim3(64), 0, s, params_.ptr("emb"), params_.ptr("pos"), ids_out, ids_ld, st,
                            params_.ptr("ln_emb.weight"), params_.ptr("ln_emb.bias"), x);
         float* cur = x;
@@ -341,8 +363,7 @@ int FormulaDecoder::decode(const float* enc, int B, int S, int max_new, long lon
         for (int l = 0; l < n_layers_; ++l) {
             const std::string K = "l" + std::to_string(l) + ".";
             // self-attention
-            ln(cur, K + "ln1", h, B, s);
-            gemm(h, B, D, K + "qkv", 3 * D, qkv, ACT_NONE, nullptr, s);
+            gemm(cur, B, D, K + "qkv", 3 * D, qkv, ACT_NONE, nullptr, s, K + "ln1", h);
             AttnDecParams ap{};
             ap.q = qkv; ap.ldq = 3 * D;
             ap.kc = kc + (size_t)l * B * Tmax * D; ap.vc = vc + (size_t)l * B * Tmax * D; ap.ldkv = D; ap.seq_stride = (long long)Tmax * D;
@@ -353,8 +374,7 @@ int FormulaDecoder::decode(const float* enc, int B, int S, int max_new, long lon
             gemm(a, B, D, K + "so", D, nxt, ACT_NONE, cur, s);
             std::swap(cur, nxt);
             // cross-attention over the (projected) encoder tokens
-            ln(cur, K + "ln2", h, B, s);
-            gemm(h, B, D, K + "cq", D, qkv, ACT_NONE, nullptr, s);
+            gemm(cur, B, D, K + "cq", D, qkv, ACT_NONE, nullptr, s, K + "ln2", h);
             AttnDecParams cp{};
             cp.q = qkv; cp.ldq = D;
             cp.kc = ckv + (size_t)l * B * S * 2 * D; cp.vc = cp.kc + D; cp.ldkv = 2 * D; cp.seq_stride = (long long)S * 2 * D;
@@ -363,15 +383,33 @@ int FormulaDecoder::decode(const float* enc, int B, int S, int max_new, long lon
             gemm(a, B, D, K + "co", D, nxt, ACT_NONE, cur, s);
             std::swap(cur, nxt);
             // feed-forward
-            ln(cur, K + "ln3", h, B, s);
-            gemm(h, B, D, K + "fc1", FFN, ff, ACT_GELU, nullptr, s);
+            gemm(cur, B, D, K + "fc1", FFN, ff, ACT_GELU, nullptr, s, K + "ln3", h);
             gemm(ff, B, FFN, K + "fc2", D, nxt, ACT_NONE, cur, s);
             std::swap(cur, nxt);
         }
-        ln(cur, "ln_out", h, B, s);
-        gemm(h, B, D, "lm", vocab_, lg, ACT_NONE, nullptr, s);
-        hipLaunchKernelGGL(dec_select_kernel, dim3(B), dim3(256), 0, s, lg, vocab_, ids_out, ids_ld, unf, st);
-        hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(1), 0, s, st);
+        gemm(cur, B, D, "lm", vocab_, lg, ACT_NONE, nullptr, s, "ln_out", h);
+        hipLaunchKernelGGL(dec_select_kernel, dim3(B), dim3(1024), 0, s, lg, vocab_, ids_out, ids_ld, unf, st, B);
+    };
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    static const bool use_graph = [] { const char* e = getenv("RD_DECODE_GRAPH"); return !(e && e[0] == '0'); }();
+    if (use_graph && max_new > 2) {
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            enqueue_step();
+            if (hipStreamEndCapture(s, &graph) != hipSuccess || hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) != hipSuccess) {
+                if (graph) (void)hipGraphDestroy(graph);
+                graph = nullptr;
+                gexec = nullptr;
+                (void)hipGetLastError();
+            }
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    int host_unf = B, steps = 0;
+    for (int t = 0; t < max_new; ++t) {
+        if (gexec) RD_HIP(hipGraphLaunch(gexec, s));
+        else enqueue_step();
         steps = t + 1;
         if ((t & 7) == 7 || t + 1 == max_new) {  // all sequences ended? (checked every 8 steps: one small D2H + sync)
             DecState hs;
@@ -380,6 +418,11 @@ int FormulaDecoder::decode(const float* enc, int B, int S, int max_new, long lon
             host_unf = hs.n_unfinished;
             if (host_unf == 0) break;
         }
+    }
+    if (gexec) {
+        RD_HIP(hipStreamSynchronize(s));
+        (void)hipGraphExecDestroy(gexec);
+        (void)hipGraphDestroy(graph);
     }
     RD_HIP(hipGetLastError());
     // the reference stops right after the step in which the last sequence emitted EOS: trim the run-ahead columns

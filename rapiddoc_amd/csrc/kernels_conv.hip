@@ -267,8 +267,128 @@ static void launch_cfg(const ConvParams& p, hipStream_t s) {
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false>), grid, block, 0, s, p, ntn);
 }
 
+// --------------------------------------------------------------------------------------------------
+// Skinny GEMM for M <= 32 rows (autoregressive decode steps: M = number of sequences).  A 128-row MFMA tile would
+// spend >= 75 % of its matrix-core time on padding and leave the chip with N/128 workgroups; this kernel is a
+// weight-streaming design instead: a workgroup owns a slice of output columns, X[M][K] is staged through LDS in
+// K chunks of 512 and shared by its 4 wavefronts, each wavefront owns whole columns (lanes split K, 16-byte
+// coalesced weight loads, butterfly reduction), summation order is fixed (deterministic).
+// --------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ void __launch_bounds__(256) skinny_gemm_kernel(ConvParams p, int cols_per_wave) {
+    constexpr int KC = 512;
+    __shared__ __attribute__((aligned(16))) float xs[MT * KC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_base = (blockIdx.x * 4 + wave) * cols_per_wave;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < cols_per_wave; c0 += 2) {
+        // (all waves execute the same number of c0 iterations and K chunks: the barriers below are uniform)
+        const int n0 = n_base + c0, n1 = n0 + 1;
+        const bool v0 = n0 < p.Ng, v1 = n1 < p.Ng && c0 + 1 < cols_per_wave;
+        float acc0[MT], acc1[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc0[m] = acc1[m] = 0.f;
+        for (int k0 = 0; k0 < p.K; k0 += KC) {
+            __syncthreads();
+            for (int i = tid; i < MT * (KC / 4); i += 256) {
+                const int m = i / (KC / 4), q = i - m * (KC / 4);
+                const int k = k0 + 4 * q;
+                *reinterpret_cast<f32x4*>(&xs[m * KC + 4 * q]) =
+                    (m < p.M && k < p.K) ? *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.xld + k) : zero4;
+            }
+            __syncthreads();
+            if (p.ln_g) {  // fused pre-LayerNorm: K <= KC, so the chunk holds whole rows; wave w normalises rows w, w+4, ...
+                for (int m = wave; m < MT; m += 4) {
+                    float v[KC / 64], s1 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < KC / 64; ++i) {
+                        const int k = lane + 64 * i;
+                        v[i] = k < p.K ? xs[m * KC + k] : 0.f;
+                        s1 += v[i];
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+                    const float mean = s1 / p.K;
+                    float s2 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < KC / 64; ++i) {
+                        const int k = lane + 64 * i;
+                        const float d = k < p.K ? v[i] - mean : 0.f;
+                        s2 += d * d;
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+                    const float rstd = rsqrtf(s2 / p.K + 1e-5f);
+#pragma unroll
+                    for (int i = 0; i < KC / 64; ++i) {
+                        const int k = lane + 64 * i;
+                        if (k < p.K) xs[m * KC + k] = (v[i] - mean) * rstd * p.ln_g[k] + p.ln_b[k];
+                    }
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int h = 0; h < KC / 256; ++h) {
+                const int kq = h * 256 + 4 * lane, k = k0 + kq;
+                const bool kv = k < p.K;
+                const f32x4 w0 = (v0 && kv) ? *reinterpret_cast<const f32x4*>(p.w + (size_t)n0 * p.K + k) : zero4;
+                const f32x4 w1 = (v1 && kv) ? *reinterpret_cast<const f32x4*>(p.w + (size_t)n1 * p.K + k) : zero4;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(&xs[m * KC + kq]);
+                    acc0[m] += xv[0] * w0[0] + xv[1] * w0[1] + xv[2] * w0[2] + xv[3] * w0[3];
+                    acc1[m] += xv[0] * w1[0] + xv[1] * w1[1] + xv[2] * w1[2] + xv[3] * w1[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                acc0[m] += __shfl_xor(acc0[m], o, 64);
+                acc1[m] += __shfl_xor(acc1[m], o, 64);
+            }
+        }
+        // lane m writes row m of the two columns
+        float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (lane == m) { r0 = acc0[m]; r1 = acc1[m]; }
+        }
+        if (lane < p.M) {
+            if (v0) {
+                float v = act_apply(r0 + (p.bias ? p.bias[n0] : 0.f), p.act);
+                if (p.res) v += p.res[(size_t)lane * p.rld + n0];
+                p.y[(size_t)lane * p.yld + n0] = v;
+            }
+            if (v1) {
+                float v = act_apply(r1 + (p.bias ? p.bias[n1] : 0.f), p.act);
+                if (p.res) v += p.res[(size_t)lane * p.rld + n1];
+                p.y[(size_t)lane * p.yld + n1] = v;
+            }
+        }
+    }
+}
+
+static void launch_skinny(const ConvParams& p, hipStream_t s) {
+    // columns per wavefront: enough workgroups to fill the chip, not so many that X is re-staged excessively
+    int cpw = 2;
+    while ((p.Ng + 4 * cpw - 1) / (4 * cpw) > 2048 && cpw < 16) cpw *= 2;
+    const int blocks = (p.Ng + 4 * cpw - 1) / (4 * cpw);
+    if (p.M <= 8) hipLaunchKernelGGL(skinny_gemm_kernel<8>, dim3(blocks), dim3(256), 0, s, p, cpw);
+    else if (p.M <= 16) hipLaunchKernelGGL(skinny_gemm_kernel<16>, dim3(blocks), dim3(256), 0, s, p, cpw);
+    else hipLaunchKernelGGL(skinny_gemm_kernel<32>, dim3(blocks), dim3(256), 0, s, p, cpw);
+}
+
+bool skinny_gemm_applies(int M, int K) { return M <= 32 && K % 4 == 0 && K >= 64 && K <= 512; }
+
 void launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     if (p.M <= 0) return;
+    if (p.M <= 32 && p.out_mode == OUT_NHWC && is_1x1(p) && p.K % 4 == 0 && p.K >= 64 && (!p.ln_g || p.K <= 512)) {
+        launch_skinny(p, s);
+        return;
+    }
+    // (ln_g is only honoured by the skinny path; callers check skinny_gemm_applies() before relying on it)
     switch (pick_cfg(p).bn) {
         case 32: launch_cfg<128, 32, 4, 1>(p, s); break;
         case 64: launch_cfg<128, 64, 4, 1>(p, s); break;

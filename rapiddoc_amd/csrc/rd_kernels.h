@@ -25,10 +25,13 @@ struct ConvParams {
     int KH, KW, SH, SW, PT, PL;
     const float* res; int rld;      // added after the activation, same geometry as y
     const float* ascale;            // optional [N][Cin] multiplier applied to X rows on load (1x1 only)
+    const float* ln_g; const float* ln_b;   // skinny path (M <= 32, K <= 512) only: LayerNorm(eps 1e-5) applied to every X row
+                                            // before the product (fuses the pre-LN of a transformer decode step)
     int act, out_mode;
     int M, K, Ng;
 };
 void launch_conv_igemm(const ConvParams& p, hipStream_t s);
+bool skinny_gemm_applies(int M, int K);   // true when launch_conv_igemm will take the small-M path that can fuse ln_g / ln_b
 // fp32-accurate variant on the fp16 matrix cores (3 MFMAs per product, see kernels_conv_h3.hip); needs p.wh / p.wl
 void launch_conv_igemm_h3(const ConvParams& p, hipStream_t s);
 // a short human-readable tag of the tile configuration chosen for p (for the per-op profile)
