@@ -1,0 +1,46 @@
+"""CPU: formula pre-processing geometry and constants (rapiddoc_amd/formula_host.py) - known answers derived from the
+reference's definitions (pp_formulanet_plus/pre_process.py:39-246)."""
+import numpy as np
+
+from rapiddoc_amd import formula_host as F
+
+
+def _img(h, w, box, ink=100):
+    im = np.full((h, w, 3), 255, np.uint8)
+    y0, x0, y1, x1 = box
+    im[y0:y1, x0:x1] = ink
+    im[y0, x0] = 0          # one darker pixel so that the min/max normalisation has a range
+    return im
+
+
+def test_crop_resize_pad_geometry():
+    # a 40x200 black bar inside a 300x500 white canvas: margin cropped to the bar, short side -> 384 would overflow the
+    # width, so thumbnail() shrinks to width 384, height round(40*384/200)=77 (PIL thumbnail rounding), centred
+    out = F.decode_image(_img(300, 500, (100, 150, 140, 350)))
+    assert out.shape == (384, 384, 3)
+    rows = np.nonzero((out[..., 0] > 50).any(axis=1))[0]      # the grey (100) bar; padding is 0 (ImageOps.expand default)
+    cols = np.nonzero((out[..., 0] > 50).any(axis=0))[0]
+    assert cols[0] == 0 and cols[-1] == 383
+    assert 74 <= len(rows) <= 78 and abs((rows[0] + rows[-1]) / 2 - 191.5) <= 1.0
+    assert out[0, 0, 0] == 0 and out[-1, -1, 0] == 0
+
+
+def test_uniform_image_is_not_cropped_and_empty_is_none():
+    out = F.decode_image(np.full((50, 80, 3), 200, np.uint8))
+    assert out.shape == (384, 384, 3)
+
+
+def test_normalisation_and_latex_format():
+    im = np.zeros((40, 50, 3), np.uint8)
+    im[..., 0], im[..., 1], im[..., 2] = 10, 100, 250
+    x = F.to_network_input(im)
+    assert x.shape == (1, 1, 48, 64) and x.dtype == np.float32
+    n = lambda v: (np.float32(v) * np.float32(1 / 255.0) - np.float32(0.7931)) / np.float32(0.1738)
+    exp = np.float32(0.114) * n(10) + np.float32(0.587) * n(100) + np.float32(0.299) * n(250)
+    assert abs(float(x[0, 0, 0, 0]) - float(exp)) < 1e-6
+    assert (x[0, 0, 40:, :] == 1).all() and (x[0, 0, :, 50:] == 1).all()
+
+
+def test_preprocess_batch_shapes():
+    xs = F.preprocess([_img(100, 300, (30, 40, 70, 260)), _img(400, 100, (10, 10, 390, 90))])
+    assert all(x.shape == (1, 1, 384, 384) for x in xs)

@@ -212,3 +212,27 @@ def test_formula_full_model_image_to_ids(golden_dir):
     ids = dec_eng.formula_decode(enc, 8).cpu().numpy()
     assert ids.shape == g["ids"].shape
     _safe_prefix_equal(ids, g["ids"], g["top2gap"])
+
+
+def test_formula_recognizer_batch_predict(golden_dir):
+    """FormulaRecognizer.batch_predict (CustomBaseModel-shaped driver): crops -> ids, equal to the oracle on the same tensors."""
+    from oracle import formula as OF
+    from rapiddoc_amd import formula_host as FH
+    st = W.synth_state_dict(W.load_manifest(golden_dir / "manifest_ppformulanet_plus_m_m8.json"), 0)
+    rec = FH.FormulaRecognizer(st, max_new_tokens=6)
+    rng = np.random.default_rng(0)
+    imgs = [np.full((60, 200, 3), 255, np.uint8), np.full((90, 90, 3), 255, np.uint8), np.full((50, 50, 3), 128, np.uint8)]
+    imgs[0][20:40, 30:170] = rng.integers(0, 120, (20, 140, 3))
+    imgs[1][10:80, 10:80] = rng.integers(0, 120, (70, 70, 3))
+    out = rec.batch_predict(imgs, batch_size=2)
+    assert len(out) == 3 and all(isinstance(o, list) for o in out)
+    xs = FH.preprocess(imgs)
+    tst = O.as_torch_state(st)
+    for i, x in enumerate(xs):
+        enc = O.formula_encoder_forward(tst, torch.from_numpy(x))
+        ids, lgs = OF.formula_decode(tst, enc, 6, return_logits=True)
+        gaps = torch.stack([torch.topk(l, 2, dim=-1).values for l in lgs], 1)
+        gaps = (gaps[..., 0] - gaps[..., 1]).numpy()
+        ref = ids[0, 1:].tolist()
+        n = int(np.nonzero(gaps[0] < 1e-2)[0][0]) if (gaps[0] < 1e-2).any() else len(ref)
+        assert out[i][:n] == ref[:n]
