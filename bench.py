@@ -80,12 +80,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; RD_BENCH_BACKEND=gloo (+ fewer GPUs than ranks) exists only to exercise the multi-process code
+    # path on a single-GPU box
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    backend = os.environ.get("RD_BENCH_BACKEND", "nccl")
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist_mod.init_process_group(backend)
         dist = dist_mod
 
     from rapiddoc_amd import build as rd_build
@@ -99,7 +106,7 @@ def main():
     from rapiddoc_amd.dist import gather_page_results
 
     states = load_states()
-    pipe = PagePipeline(states, device=local_rank, rec_batch_num=args.rec_batch)
+    pipe = PagePipeline(states, device=dev_index, rec_batch_num=args.rec_batch)
     P = args.pages
     pages_np, boxes = synth_batch(rank * P, P)
     pages = torch.from_numpy(pages_np).cuda()
@@ -129,7 +136,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_lines = sum(len(l) for _, l in out)
