@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-profile", type=str, default="")
     ap.add_argument("--rec-batch", type=int, default=128)
+    ap.add_argument("--rec-streams", type=int, default=8)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,7 +107,7 @@ def main():
     from rapiddoc_amd.dist import gather_page_results
 
     states = load_states()
-    pipe = PagePipeline(states, device=dev_index, rec_batch_num=args.rec_batch)
+    pipe = PagePipeline(states, device=dev_index, rec_batch_num=args.rec_batch, n_rec_streams=args.rec_streams)
     P = args.pages
     pages_np, boxes = synth_batch(rank * P, P)
     pages = torch.from_numpy(pages_np).cuda()
@@ -145,14 +146,15 @@ def main():
     # ---- roofline of the dominant kernel: per-op HIP events (recorded by the library on the launch stream)
     roof = None
     if rank == 0:
-        for e in (pipe.det, pipe.rec, pipe.layout):
+        engines = [pipe.det, pipe.layout] + list(pipe.rec_engines)
+        for e in engines:
             e.set_profiling(True)
             e.profile_log = []
         pipe.run_batch(pages, quads, det_maps_override=text_maps)
         torch.cuda.synchronize()
         agg = defaultdict(lambda: [0.0, 0.0, 0.0, 0])
         tot_ms = 0.0
-        for e in (pipe.det, pipe.rec, pipe.layout):
+        for e in engines:
             for op in e.profile_log:
                 name = op["kind"]
                 if op["kind"].startswith(("conv", "deconv")):  # name = the HIP kernel instantiation rocprofv3 reports
@@ -181,7 +183,8 @@ def main():
                 "step_kernel_ms": round(tot_ms, 2)}
         if args.dump_profile:
             with open(args.dump_profile + ".ops.json", "w") as f:
-                json.dump({"det": pipe.det.profile_log, "rec": pipe.rec.profile_log, "layout": pipe.layout.profile_log}, f)
+                json.dump({"det": pipe.det.profile_log, "rec": sum((e.profile_log for e in pipe.rec_engines), []),
+                           "layout": pipe.layout.profile_log}, f)
             table = sorted(((k, v[3], v[2], v[0] / 1e9, v[1] / 1e6) for k, v in agg.items()), key=lambda r: -r[2])
             with open(args.dump_profile, "w") as f:
                 f.write("kernel,launches,total_ms,gflop,algorithmic_MB,TFLOPs,GBs\n")

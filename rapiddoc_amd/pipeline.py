@@ -86,13 +86,18 @@ class PageResult:
 
 class PagePipeline:
     def __init__(self, states: Dict[str, object], device: int = 0, characters: Optional[Sequence[str]] = None,
-                 rec_batch_num: int = 64, rec_width_multiple: int = 32, keep_feats: bool = False):
+                 rec_batch_num: int = 64, rec_width_multiple: int = 32, keep_feats: bool = False, n_rec_streams: int = 4):
         """`states`: {'ppocrv6_det': ..., 'ppocrv6_rec': ..., 'pphgnetv2_b4': ...}, each a .safetensors path,
         bytes, or name->ndarray dict."""
         self.device = device
         self.tdev = torch.device("cuda", device)
         self.det = RdEngine("ppocrv6_det", device).load_weights(states["ppocrv6_det"])
-        self.rec = RdEngine("ppocrv6_rec", device).load_weights(states["ppocrv6_rec"])
+        # rec batches are independent: they alternate between `n_rec_streams` HIP streams (one engine handle = one
+        # workspace per stream) so that the launch gaps / tails of one batch are filled by kernels of the other
+        self.rec_engines = [RdEngine("ppocrv6_rec", device).load_weights(states["ppocrv6_rec"]) for _ in range(max(1, n_rec_streams))]
+        self.rec = self.rec_engines[0]
+        self.rec_streams = [torch.cuda.Stream(device=self.tdev) for _ in self.rec_engines]
+        self.layout_stream = torch.cuda.Stream(device=self.tdev)
         self.layout = RdEngine("pphgnetv2_b4", device).load_weights(states["pphgnetv2_b4"]) if "pphgnetv2_b4" in states else None
         ncls = self.rec.num_classes
         self.characters = list(characters) if characters is not None else ["blank"] + [chr(0x4E00 + i) for i in range(ncls - 2)] + [" "]
@@ -152,25 +157,35 @@ class PagePipeline:
         descs_dev = torch.from_numpy(descs.view(np.uint8)).to(pages.device, non_blocking=True)
         mean = (C.c_float * 3)(0.5, 0.5, 0.5)
         std = (C.c_float * 3)(0.5, 0.5, 0.5)
-        stream = torch.cuda.current_stream().cuda_stream
         outs = []
         pos = 0
-        for chunk, wpad in batches:
+        main = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for bi, (chunk, wpad) in enumerate(batches):
             nb = len(chunk)
-            x = torch.empty((nb, 3, ocr_host.REC_IMG_H, wpad), dtype=torch.float32, device=pages.device)
-            rc = self._lib.rd_crop_resize_norm_batch(
-                self.device, pages.data_ptr(), P, H, W, descs_dev.data_ptr() + pos * CROP_DTYPE.itemsize, nb,
-                ocr_host.REC_IMG_H, wpad, mean, std, 1.0 / 255.0, 1, x.data_ptr(), stream)
-            if rc != 0:
-                raise RuntimeError("rd_crop_resize_norm_batch failed")
-            idx, prob, _ = self.rec.rec_forward(x)
-            outs.append((idx, prob))
+            k = bi % len(self.rec_engines)
+            st = self.rec_streams[k]
+            if bi < len(self.rec_engines):
+                st.wait_event(ready)          # descriptors (and the pages) are ready
+            with torch.cuda.stream(st):
+                x = torch.empty((nb, 3, ocr_host.REC_IMG_H, wpad), dtype=torch.float32, device=pages.device)
+                rc = self._lib.rd_crop_resize_norm_batch(
+                    self.device, pages.data_ptr(), P, H, W, descs_dev.data_ptr() + pos * CROP_DTYPE.itemsize, nb,
+                    ocr_host.REC_IMG_H, wpad, mean, std, 1.0 / 255.0, 1, x.data_ptr(), st.cuda_stream)
+                if rc != 0:
+                    raise RuntimeError("rd_crop_resize_norm_batch failed")
+                idx, prob, _ = self.rec_engines[k].rec_forward(x)
+                done = torch.cuda.Event()
+                done.record(st)
+            outs.append((idx, prob, done, x))
             pos += nb
         self.stats["t_rec_enqueue_ms"] = (time.perf_counter() - t0) * 1e3 - self.stats["t_descs_ms"]
         # D2H per batch result (small) as soon as that batch is done, host CTC decode (rapidocr CTCLabelDecode)
         # overlaps the GPU work of the batches still in flight
         t_dec = 0.0
-        for (chunk, wpad), (idx, prob) in zip(batches, outs):
+        for (chunk, wpad), (idx, prob, done, _x) in zip(batches, outs):
+            done.synchronize()
             idx_h, prob_h = idx.cpu().numpy(), prob.cpu().numpy()
             t1 = time.perf_counter()
             dec = ocr_host.ctc_decode(idx_h, prob_h, self.characters)
@@ -179,6 +194,8 @@ class PagePipeline:
                 texts[i] = (t, ocr_host.format_score(s))
             t_dec += time.perf_counter() - t1
         self.stats["t_decode_ms"] = t_dec * 1e3
+        for st in self.rec_streams:
+            main.wait_stream(st)
         per_page: List[List[Tuple[str, float]]] = [[] for _ in range(P)]
         for i, pi in enumerate(page_of.tolist()):
             per_page[pi].append(texts[i])
@@ -229,8 +246,11 @@ class PagePipeline:
                 copy_done = torch.cuda.Event()
                 copy_done.record()
         # the layout backbone keeps the GPU busy while the host turns the det maps into boxes
+        # ... on its own stream, so it also overlaps the recognition batches that follow
         if self.layout is not None:
-            feats = self.layout_forward(pages)
+            self.layout_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.layout_stream):
+                feats = self.layout_forward(pages)
             if self.keep_feats:
                 for i in range(P):
                     results[i].layout_feats = [f[i] for f in feats]
@@ -242,6 +262,8 @@ class PagePipeline:
             self.stats["t_wait_maps_ms"] = (t1 - t0) * 1e3
             self.stats["t_db_post_ms"] = (time.perf_counter() - t1) * 1e3
         texts = self.rec_forward_lines(pages, quads_per_page)
+        if self.layout is not None:
+            torch.cuda.current_stream().wait_stream(self.layout_stream)
         for i in range(P):
             qs = np.asarray(quads_per_page[i], dtype=np.float32).reshape(-1, 4, 2)
             results[i].lines = [(qs[j], t, s) for j, (t, s) in enumerate(texts[i])]
