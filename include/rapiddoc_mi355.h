@@ -137,6 +137,18 @@ typedef struct rd_layout_post_cfg {
 int rd_layout_postprocess(const float* boxes, int n, int ncol, int img_w, int img_h, const rd_layout_post_cfg* cfg,
                           float* out, int32_t* out_order, int32_t* n_out);
 
+/* Arithmetic of the dense layers of a network handle; every mode returns fp32 tensors with fp32-level error
+ * (the reference runs the same layers through onnxruntime / torch fp32: rapid_doc/model/ocr/.../torch.py:58-76).
+ *   "auto" (default)  fp32 MFMA, except the fused PPLCNetV4 channel mixers: fp16 matrix cores with (hi, lo) operand
+ *                     splitting, 3 MFMAs per product, fp32 accumulate (measured error vs fp64 below the fp32 MFMA path's).
+ *   "fp32"            native fp32 MFMA only.
+ *   "h3"              every dense layer split (experimental; needs RD_PRECISION=h3 in the environment at rd_load_weights).
+ * Split operands must stay inside the fp16 range (|v| < 65504).  The kernels never return a silently wrong answer:
+ * they raise a flag instead, which rd_range_status() returns (1) and clears after synchronising `stream`; the caller
+ * then switches the handle to "fp32" and repeats the forward call.  rd_range_status returns -1 on error. */
+int rd_set_precision(rd_handle* h, const char* mode);
+int rd_range_status(rd_handle* h, void* stream);
+
 /* per-op HIP-event timing of the NEXT forward calls; rd_profile_json returns the last call's table as a JSON
  * array [{"name","kind","cfg","flops","bytes","ms"}, ...] owned by the handle. */
 int rd_set_profiling(rd_handle* h, int on);

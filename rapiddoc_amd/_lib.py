@@ -29,6 +29,8 @@ SYMBOLS = {
     "rd_crop_resize_norm_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "rd_db_postprocess": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "rd_layout_postprocess": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rd_set_precision": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "rd_range_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rd_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "rd_profile_json": (C.c_char_p, [C.c_void_p]),
 }

@@ -182,14 +182,31 @@ float rd_debug_time_mixer(int C, int M, int variant, int iters, float* x, float*
     p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    rd::launch_mixer_debug(p, variant, nullptr);
+    void* hbuf[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (variant >= 100) {  // fp16x3 mixer (+ ablation bits)
+        p.dbg = variant - 100;
+        std::vector<float> hw1((size_t)2 * C * C), hw2((size_t)2 * C * C);
+        (void)hipMemcpy(hw1.data(), w1, hw1.size() * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hw2.data(), w2, hw2.size() * 4, hipMemcpyDeviceToHost);
+        std::vector<uint16_t> v[4];
+        rd::prepare_mixer_weights_h3(hw1.data(), hw2.data(), C, v[0], v[1], v[2], v[3]);
+        for (int i = 0; i < 4; ++i) {
+            (void)hipMalloc(&hbuf[i], v[i].size() * 2);
+            (void)hipMemcpy(hbuf[i], v[i].data(), v[i].size() * 2, hipMemcpyHostToDevice);
+        }
+        p.w1h = (const uint16_t*)hbuf[0]; p.w1l = (const uint16_t*)hbuf[1];
+        p.w2h = (const uint16_t*)hbuf[2]; p.w2l = (const uint16_t*)hbuf[3];
+    }
+    auto go = [&] { if (variant >= 100) rd::launch_mixer_fused_h3(p, nullptr); else rd::launch_mixer_debug(p, variant, nullptr); };
+    go();
     (void)hipEventRecord(e0, nullptr);
-    for (int i = 0; i < iters; ++i) rd::launch_mixer_debug(p, variant, nullptr);
+    for (int i = 0; i < iters; ++i) go();
     (void)hipEventRecord(e1, nullptr);
     (void)hipEventSynchronize(e1);
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    for (void* b : hbuf) if (b) (void)hipFree(b);
     return ms / iters;
 }
 float rd_debug_time_gemm(int M, int K, int N, int act, int iters, float* x, float* w, float* b, float* y, void* wh, void* wl) {
@@ -210,6 +227,20 @@ float rd_debug_time_gemm(int M, int K, int N, int act, int iters, float* x, floa
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return ms / iters;
+}
+
+int rd_set_precision(rd_handle* h, const char* mode) {
+    return guarded(h, [&] {
+        RD_CHECK(h->eng, "precision modes apply to the network engines");
+        const std::string m = mode ? mode : "";
+        RD_CHECK(m == "auto" || m == "fp32" || m == "h3", "precision must be auto, fp32 or h3");
+        h->eng->set_precision(m == "h3" ? rd::Engine::PREC_H3 : m == "fp32" ? rd::Engine::PREC_FP32 : rd::Engine::PREC_AUTO);
+    });
+}
+int rd_range_status(rd_handle* h, void* stream) {
+    int out = 0;
+    const int rc = guarded(h, [&] { if (h->eng) out = h->eng->take_range_flag((hipStream_t)stream); });
+    return rc != 0 ? -1 : out;
 }
 
 int rd_set_profiling(rd_handle* h, int on) {

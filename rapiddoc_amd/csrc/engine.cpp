@@ -178,6 +178,12 @@ const float* ParamBlock::ptr(const std::string& key) const {
     return dev_ + it->second;
 }
 
+const float* ParamBlock::host_ptr(const std::string& key) const {
+    auto it = off_.find(key);
+    if (it == off_.end()) throw Error("params: missing folded tensor '" + key + "'");
+    return host_.data() + it->second;
+}
+
 // =================================================================================================
 // Builder: memory
 // =================================================================================================
@@ -289,7 +295,16 @@ std::vector<float> Builder::bn_scale_shift(const std::string& bn, int c, std::ve
     return scale;
 }
 
+// weights beyond the fp16 range cannot be split: such a layer stays on the fp32 MFMA kernel in every precision mode
+static bool fits_fp16_range(const std::vector<float>& w) {
+    for (float v : w)
+        if (!(std::fabs(v) < 65504.f)) return false;
+    return true;
+}
 static inline int out_dim(int in, int k, int s, int p0, int p1) { return (in + p0 + p1 - k) / s + 1; }
+// "auto" precision: pointwise convolutions with a long reduction also run on the split-fp16 matrix-core path (the
+// activation split is amortised over K; measured 1.2-1.5x the fp32 MFMA kernel from K = 512 up, no gain below)
+static inline bool auto_split_conv(int kh, int kw, int K, int cout) { return kh == 1 && kw == 1 && K >= 512 && cout >= 128; }
 
 // =================================================================================================
 // Builder: layers
@@ -335,11 +350,13 @@ TView Builder::conv(const std::string& wname, const std::string& bname, const st
     const TView xv = x, yv = y;
     const bool has_res = res != nullptr, has_as = ascale != nullptr;
     const TView rv = res ? *res : TView{}, av = ascale ? *ascale : TView{};
-    const bool h3 = h3_;
+    const bool h3 = (h3_ || (mixer_h3_ && !ascale && g.sh == 1 && g.sw == 1 && p.M >= 2048 && auto_split_conv(kh, kw, K, cout))) &&
+                    pb_->has(key + "#wh");
     if (h3) {
         p.wh = reinterpret_cast<const uint16_t*>(pb_->ptr(key + "#wh"));
         p.wl = reinterpret_cast<const uint16_t*>(pb_->ptr(key + "#wl"));
-        r.cfg += "/h3";
+        p.range_flag = range_flag_;
+        r.cfg = std::string(K <= 256 || cout <= 32 ? "128x32" : "128x64") + "/h3";
     }
     r.run = [p, xv, yv, rv, av, has_res, has_as, h3](const Plan& pl, const RunCtx& c) mutable {
         ConvParams q = p;
@@ -380,7 +397,7 @@ void Builder::fold_conv(const std::string& wname, const std::string& bname, cons
     for (int co = 0; co < cout; ++co) bias[co] += shift[co];
     pb_->add(key + "#w", wf);
     if (any_bias) pb_->add(key + "#b", bias);
-    if (h3_) {
+    if ((h3_ || (mixer_h3_ && auto_split_conv(kh, kw, K, cout))) && fits_fp16_range(wf)) {
         std::vector<uint16_t> hi, lo;
         split_weights_h3(wf.data(), cout, K, hi, lo);
         pb_->add_u16(key + "#wh", hi);
@@ -397,12 +414,28 @@ TView Builder::mixer_fused(const std::string& prefix, const TView& x, const TVie
     RD_CHECK(weight_dim(w1, 0) == 2 * C && weight_dim(w1, 1) == C && weight_dim(w2, 0) == C && weight_dim(w2, 1) == 2 * C,
              "mixer_fused: weight shapes: " + prefix);
     TView y = alloc(x.n, x.h, x.w, C);
+    const std::string hkey = prefix + ".mixer#h3";
     if (!planning()) {
         fold_conv(w1, "", bn1);
         fold_conv(w2, "", bn2);
+        const float* f1 = pb_->host_ptr(w1 + "|" + bn1 + "#w");
+        const float* f2 = pb_->host_ptr(w2 + "|" + bn2 + "#w");
+        const bool fits = fits_fp16_range(std::vector<float>(f1, f1 + (size_t)2 * C * C)) && fits_fp16_range(std::vector<float>(f2, f2 + (size_t)2 * C * C));
+        if (!pb_->has(hkey + ".w1h") && fits) {   // split-fp16 copies for the default (auto) precision
+            std::vector<uint16_t> v[4];
+            prepare_mixer_weights_h3(f1, f2, C, v[0], v[1], v[2], v[3]);
+            pb_->add_u16(hkey + ".w1h", v[0]); pb_->add_u16(hkey + ".w1l", v[1]);
+            pb_->add_u16(hkey + ".w2h", v[2]); pb_->add_u16(hkey + ".w2l", v[3]);
+        }
         return y;
     }
+    const bool split = (h3_ || mixer_h3_) && pb_->has(hkey + ".w1h");
     MixerParams p{};
+    if (split) {
+        p.w1h = reinterpret_cast<const uint16_t*>(pb_->ptr(hkey + ".w1h")); p.w1l = reinterpret_cast<const uint16_t*>(pb_->ptr(hkey + ".w1l"));
+        p.w2h = reinterpret_cast<const uint16_t*>(pb_->ptr(hkey + ".w2h")); p.w2l = reinterpret_cast<const uint16_t*>(pb_->ptr(hkey + ".w2l"));
+        p.range_flag = range_flag_;
+    }
     p.xld = plan_->ld(x);
     p.yld = plan_->ld(y);
     p.M = (int)x.pixels(); p.HW = x.h * x.w; p.C = C;
@@ -410,7 +443,7 @@ TView Builder::mixer_fused(const std::string& prefix, const TView& x, const TVie
     p.w2 = pb_->ptr(w2 + "|" + bn2 + "#w"); p.b2 = pb_->ptr(w2 + "|" + bn2 + "#b");
     OpRecord r;
     r.name = prefix + ".mixer";
-    r.kind = "mixer_fused";
+    r.kind = split ? "mixer_fused_h3" : "mixer_fused";
     r.cfg = "C" + std::to_string(C);
     r.shape = "M" + std::to_string(p.M) + "_C" + std::to_string(C);
     r.flops = 8.0 * p.M * (double)C * C;
@@ -418,12 +451,13 @@ TView Builder::mixer_fused(const std::string& prefix, const TView& x, const TVie
     const TView xv = x, yv = y;
     const bool has_gate = gate != nullptr;
     const TView gv = gate ? *gate : TView{};
-    r.run = [p, xv, yv, gv, has_gate](const Plan& pl, const RunCtx& c) {
+    r.run = [p, xv, yv, gv, has_gate, split](const Plan& pl, const RunCtx& c) {
         MixerParams q = p;
         q.x = pl.vptr(xv, c);
         q.y = pl.vptr(yv, c);
         q.gate = has_gate ? pl.vptr(gv, c) : nullptr;
-        launch_mixer_fused(q, c.stream);
+        if (split) launch_mixer_fused_h3(q, c.stream);
+        else launch_mixer_fused(q, c.stream);
     };
     emit(std::move(r));
     return y;
@@ -463,7 +497,7 @@ TView Builder::deconv2x2(const std::string& wname, const std::string& bname, con
             for (int co = 0; co < cout; ++co) bias[co] += shift[co];
             pb_->add(key + "#w", wf);
             pb_->add(key + "#b", bias);
-            if (h3_) {
+            if (h3_ && fits_fp16_range(wf)) {
                 std::vector<uint16_t> hi, lo;
                 split_weights_h3(wf.data(), 4 * cout, cin, hi, lo);
                 pb_->add_u16(key + "#wh", hi);
@@ -477,9 +511,10 @@ TView Builder::deconv2x2(const std::string& wname, const std::string& bname, con
     p.N = x.n; p.H = x.h; p.W = x.w; p.Cin = cin;
     p.w = pb_->ptr(key + "#w");
     p.bias = pb_->ptr(key + "#b");
-    if (h3_) {
+    if (h3_ && pb_->has(key + "#wh")) {
         p.wh = reinterpret_cast<const uint16_t*>(pb_->ptr(key + "#wh"));
         p.wl = reinterpret_cast<const uint16_t*>(pb_->ptr(key + "#wl"));
+        p.range_flag = range_flag_;
     }
     p.yld = plan_->ld(y);
     p.OH = x.h; p.OW = x.w; p.Cout = cout;
@@ -494,7 +529,7 @@ TView Builder::deconv2x2(const std::string& wname, const std::string& bname, con
     r.flops = 2.0 * p.M * (double)cin * 4 * cout;
     r.bytes = 4.0 * ((double)p.M * cin + (double)p.M * 4 * cout);
     const TView xv = x, yv = y;
-    const bool h3 = h3_;
+    const bool h3 = h3_ && p.wh != nullptr;
     r.run = [p, xv, yv, h3](const Plan& pl, const RunCtx& c) {
         ConvParams q = p;
         q.x = pl.vptr(xv, c);
@@ -902,7 +937,11 @@ void Builder::ctc_head(const std::string& prefix, const TView& x, const TView& i
 extern bool g_disable_fused_mixer;
 Engine::Engine(int device, const std::string& kind) : device_(device), kind_(kind) {
     if (const char* e = getenv("RD_DISABLE_FUSED_MIXER")) g_disable_fused_mixer = e[0] == '1';
-    if (const char* e = getenv("RD_PRECISION")) h3_ = std::string(e) == "h3";
+    if (const char* e = getenv("RD_PRECISION")) {
+        const std::string v(e);
+        RD_CHECK(v == "auto" || v == "fp32" || v == "h3", "RD_PRECISION must be auto, fp32 or h3");
+        precision_ = v == "h3" ? PREC_H3 : v == "fp32" ? PREC_FP32 : PREC_AUTO;
+    }
     RD_CHECK(kind == "ppocrv6_det" || kind == "ppocrv6_rec" || kind == "pphgnetv2_b4" || kind == "pphgnetv2_b6_formula",
              "unknown model kind '" + kind + "'");
     int count = 0;
@@ -915,6 +954,7 @@ Engine::~Engine() {
     (void)hipSetDevice(device_);
     for (auto ev : events_) (void)hipEventDestroy(ev);
     if (arena_) (void)hipFree(arena_);
+    if (range_flag_) (void)hipFree(range_flag_);
 }
 
 void Engine::build(Builder& b, int B, int H, int W, int flags) {
@@ -930,7 +970,10 @@ void Engine::load_weights(const void* blob, size_t nbytes) {
     store_.load_safetensors(blob, nbytes);
     if (kind_ == "ppocrv6_rec") n_classes_ = (int)store_.get("head.head.weight").shape[0];  // torch.py:112-116
     Plan dummy;
-    Builder b(Mode::PREPARE, &store_, &params_, &dummy, h3_);
+    h3_prepared_ = precision_ == PREC_H3;
+    RD_HIP(hipMalloc((void**)&range_flag_, sizeof(unsigned)));
+    RD_HIP(hipMemset(range_flag_, 0, sizeof(unsigned)));
+    Builder b(Mode::PREPARE, &store_, &params_, &dummy, h3_prepared_, true);
     // smallest legal geometry; only weight names/shapes matter in PREPARE mode
     if (kind_ == "ppocrv6_rec") build(b, 1, 48, 64, 0), build(b, 1, 48, 64, REC_UNFUSED_CTC);
     else build(b, 1, 64, 64, 0);
@@ -938,14 +981,33 @@ void Engine::load_weights(const void* blob, size_t nbytes) {
     loaded_ = true;
 }
 
+void Engine::set_precision(int p) {
+    RD_CHECK(p == PREC_AUTO || p == PREC_FP32 || p == PREC_H3, "unknown precision mode");
+    RD_CHECK(p != PREC_H3 || h3_prepared_ || !loaded_, "precision h3 needs RD_PRECISION=h3 when the weights are loaded");
+    precision_ = p;
+}
+
+int Engine::take_range_flag(hipStream_t s) {
+    if (!range_flag_) return 0;
+    RD_HIP(hipSetDevice(device_));
+    unsigned v = 0;
+    RD_HIP(hipMemcpyAsync(&v, range_flag_, sizeof(v), hipMemcpyDeviceToHost, s));
+    RD_HIP(hipStreamSynchronize(s));
+    if (v) {
+        RD_HIP(hipMemsetAsync(range_flag_, 0, sizeof(unsigned), s));
+        RD_HIP(hipStreamSynchronize(s));
+    }
+    return v ? 1 : 0;
+}
+
 const Plan& Engine::plan_for(int B, int H, int W, int flags) {
     RD_CHECK(loaded_, "weights not loaded");
-    auto key = std::make_tuple(B, H, W, flags);
+    auto key = std::make_tuple(B, H, W, flags | (precision_ << 24));
     auto it = plans_.find(key);
     if (it != plans_.end()) return *it->second;
     if (plans_.size() >= 256) plans_.clear();
     auto plan = std::make_unique<Plan>();
-    Builder b(Mode::PLAN, &store_, &params_, plan.get(), h3_);
+    Builder b(Mode::PLAN, &store_, &params_, plan.get(), precision_ == PREC_H3, precision_ == PREC_AUTO, range_flag_);
     build(b, B, H, W, flags);
     plan->arena_bytes = (plan->arena_bytes + 255) / 256 * 256;
     auto& ref = *plan;

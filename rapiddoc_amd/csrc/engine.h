@@ -66,6 +66,7 @@ class ParamBlock {
     bool has(const std::string& key) const { return off_.count(key) != 0; }
     void upload();
     const float* ptr(const std::string& key) const;
+    const float* host_ptr(const std::string& key) const;   // before upload(): the folded host copy
     size_t bytes() const { return host_.size() * sizeof(float); }
 
    private:
@@ -124,8 +125,9 @@ enum class Mode { PREPARE, PLAN };
 // parameter block; in PLAN mode it allocates buffers and records kernel launches for one input shape.
 class Builder {
    public:
-    Builder(Mode m, const WeightStore* ws, ParamBlock* pb, Plan* plan, bool h3 = false)
-        : mode_(m), ws_(ws), pb_(pb), plan_(plan), h3_(h3) {}
+    Builder(Mode m, const WeightStore* ws, ParamBlock* pb, Plan* plan, bool h3 = false, bool mixer_h3 = false,
+            unsigned* range_flag = nullptr)
+        : mode_(m), h3_(h3), mixer_h3_(mixer_h3), range_flag_(range_flag), ws_(ws), pb_(pb), plan_(plan) {}
     bool h3() const { return h3_; }
     Mode mode() const { return mode_; }
     bool planning() const { return mode_ == Mode::PLAN; }
@@ -181,7 +183,9 @@ class Builder {
     void emit(OpRecord&& r) { plan_->ops.push_back(std::move(r)); }
     std::vector<float> bn_scale_shift(const std::string& bn, int c, std::vector<float>& shift) const;
     Mode mode_;
-    bool h3_ = false;   // dense layers on the fp16 matrix cores with hi/lo operand splitting (fp32-accurate)
+    bool h3_ = false;        // every dense layer on the fp16 matrix cores with hi/lo operand splitting (fp32-accurate)
+    bool mixer_h3_ = false;  // only the fused channel mixers (the default "auto" precision)
+    unsigned* range_flag_ = nullptr;   // device word the split kernels raise when an operand leaves the fp16 range
     const WeightStore* ws_;
     ParamBlock* pb_;
     Plan* plan_;
@@ -209,8 +213,19 @@ class Engine {
     const std::vector<ProfileEntry>& last_profile() const { return profile_; }
     std::string profile_json() const;
     int n_classes() const { return n_classes_; }
-    bool h3() const { return h3_; }
+    bool h3() const { return precision_ == PREC_H3; }
     int device() const { return device_; }
+    // Arithmetic of the dense layers.  Every mode returns fp32 results with fp32-level error:
+    //   PREC_AUTO  fp32 MFMA everywhere except the fused PPLCNetV4 channel mixers, which run on the fp16 matrix cores with
+    //              (hi, lo) operand splitting (3 MFMAs per product, fp32 accumulate; measured error vs fp64 is BELOW the
+    //              fp32 MFMA path's).  Split operands must stay inside the fp16 range (|v| < 65504): the kernels raise
+    //              the range flag otherwise and the caller re-runs in PREC_FP32 (take_range_flag()).
+    //   PREC_FP32  native fp32 MFMA only.      PREC_H3  every dense layer split (experimental; needs RD_PRECISION=h3 at load)
+    enum Precision : int { PREC_AUTO = 0, PREC_FP32 = 1, PREC_H3 = 2 };
+    void set_precision(int p);
+    int precision() const { return precision_; }
+    // 1 if a split kernel saw an out-of-range operand since the last call (synchronises the stream); clears the flag
+    int take_range_flag(hipStream_t s);
 
     std::string last_error;
 
@@ -220,7 +235,9 @@ class Engine {
     std::string kind_;
     bool loaded_ = false;
     bool profiling_ = false;
-    bool h3_ = false;
+    int precision_ = PREC_AUTO;
+    bool h3_prepared_ = false;
+    unsigned* range_flag_ = nullptr;
     int n_classes_ = 0;
     ParamBlock params_;
     WeightStore store_;

@@ -29,6 +29,7 @@ struct ConvParams {
                                             // before the product (fuses the pre-LN of a transformer decode step)
     int act, out_mode;
     int M, K, Ng;
+    unsigned* range_flag = nullptr;   // split-fp16 kernels: raised when an activation leaves the fp16 range
 };
 void launch_conv_igemm(const ConvParams& p, hipStream_t s);
 bool skinny_gemm_applies(int M, int K);   // true when launch_conv_igemm will take the small-M path that can fuse ln_g / ln_b
@@ -160,8 +161,15 @@ struct MixerParams {
     int M, HW, C;
     const float* gate;   // [N][C] or nullptr
     const float* w1; const float* b1; const float* w2; const float* b2;
+    // RD_PRECISION=h3 only: fp16 (hi, lo) splits of w1 [2C][C] and of w2 [C][2C] (hidden columns permuted per 32-chunk)
+    const uint16_t* w1h = nullptr; const uint16_t* w1l = nullptr; const uint16_t* w2h = nullptr; const uint16_t* w2l = nullptr;
+    unsigned* range_flag = nullptr;   // raised when a split operand leaves the fp16 range (|v| >= 65504)
+    int dbg = 0;   // microbenchmark ablation bits (h3 kernel): 1 no GELU, 2 no weight streaming, 4 skip GEMM1, 8 skip GEMM2
 };
 bool mixer_fused_supported(int C);
+void launch_mixer_fused_h3(const MixerParams& p, hipStream_t s);
+void prepare_mixer_weights_h3(const float* w1, const float* w2, int C, std::vector<uint16_t>& w1h, std::vector<uint16_t>& w1l,
+                              std::vector<uint16_t>& w2h, std::vector<uint16_t>& w2l);
 void launch_mixer_fused(const MixerParams& p, hipStream_t s);
 void launch_mixer_debug(const MixerParams& p, int variant, hipStream_t s);
 }  // namespace rd

@@ -38,6 +38,7 @@ class RdEngine:
             raise EngineError(self._l.rd_create_error().decode())
         self._tdev = torch.device("cuda", device)
         self._profiling = False
+        self.precision = "auto"
         self.profile_log: List[dict] = []
 
     def close(self):
@@ -137,6 +138,21 @@ class RdEngine:
     @property
     def formula_max_new_tokens(self) -> int:
         return self._l.rd_formula_max_new_tokens(self._h)
+
+    # ------------------------------------------------------------------ precision (include/rapiddoc_mi355.h)
+    def set_precision(self, mode: str):
+        """'auto' (default: split-fp16 channel mixers, fp32 MFMA elsewhere), 'fp32' (native fp32 MFMA only) or 'h3'."""
+        self._chk(self._l.rd_set_precision(self._h, mode.encode()))
+        self.precision = mode
+        return self
+
+    def range_overflow(self) -> bool:
+        """True when a split-fp16 kernel met an operand outside the fp16 range since the last call (synchronises the
+        current stream, clears the flag).  The results of those calls are invalid: switch to 'fp32' and repeat them."""
+        rc = self._l.rd_range_status(self._h, _stream_ptr())
+        if rc < 0:
+            raise EngineError(self._l.rd_last_error(self._h).decode())
+        return rc == 1
 
     # ------------------------------------------------------------------ profiling
     def set_profiling(self, on: bool):

@@ -223,6 +223,20 @@ class PagePipeline:
     # ---------------------------------------------------------------- whole batch
     def run_batch(self, pages: torch.Tensor, quads_per_page: Optional[Sequence[np.ndarray]] = None,
                   det_maps_override: Optional[torch.Tensor] = None) -> List[PageResult]:
+        """`_run_batch_once` plus the range guard of the split-fp16 kernels (include/rapiddoc_mi355.h, rd_range_status):
+        an engine that met an operand outside the fp16 range is switched to native fp32 for good and the batch is
+        repeated, so a result is never silently wrong."""
+        results = self._run_batch_once(pages, quads_per_page, det_maps_override)
+        tripped = [e for e in [self.det, *self.rec_engines] if e.precision != "fp32" and e.range_overflow()]
+        if tripped:
+            for e in tripped:
+                e.set_precision("fp32")
+            self.stats["range_fallbacks"] = self.stats.get("range_fallbacks", 0) + 1
+            results = self._run_batch_once(pages, quads_per_page, det_maps_override)
+        return results
+
+    def _run_batch_once(self, pages: torch.Tensor, quads_per_page: Optional[Sequence[np.ndarray]] = None,
+                        det_maps_override: Optional[torch.Tensor] = None) -> List[PageResult]:
         """pages: [P,H,W,3] uint8 RGB on the GPU.  Text-line quads come from the DB post-process of the det maps
         unless `quads_per_page` is given.  `det_maps_override` (benchmark / tests with random weights, whose maps carry
         no text): device maps [P,1,h,w] that replace the network's output as the post-process input - the det forward

@@ -50,12 +50,22 @@ class _BaseSession:
         return []
 
 
+def _guarded(engine, fn):
+    """Run `fn`; if a split-fp16 kernel flagged an out-of-range operand, switch the engine to fp32 and run it again."""
+    out = fn()
+    if engine.precision != "fp32" and engine.range_overflow():
+        engine.set_precision("fp32")
+        out = fn()
+    return out
+
+
 class Mi355DetSession(_BaseSession):
     """PP-OCRv6 det: [B,3,H,W] -> DB probability map [B,1,H,W] (`maps`, ocr/torch.py:183-184)."""
     kind = "ppocrv6_det"
 
     def __call__(self, img: np.ndarray) -> np.ndarray:
-        return self.engine.det_forward(self._to_dev(img)).cpu().numpy()
+        x = self._to_dev(img)
+        return _guarded(self.engine, lambda: self.engine.det_forward(x).cpu().numpy())
 
 
 class Mi355RecSession(_BaseSession):
@@ -63,13 +73,15 @@ class Mi355RecSession(_BaseSession):
     kind = "ppocrv6_rec"
 
     def __call__(self, img: np.ndarray) -> np.ndarray:
-        _, _, full = self.engine.rec_forward(self._to_dev(img), REC_WANT_SOFTMAX)
-        return full.cpu().numpy()
+        x = self._to_dev(img)
+        return _guarded(self.engine, lambda: self.engine.rec_forward(x, REC_WANT_SOFTMAX)[2].cpu().numpy())
 
     def infer_indices(self, img: Union[np.ndarray, torch.Tensor]) -> Tuple[np.ndarray, np.ndarray]:
         x = img if isinstance(img, torch.Tensor) else self._to_dev(img)
-        idx, prob, _ = self.engine.rec_forward(x)
-        return idx.cpu().numpy(), prob.cpu().numpy()
+        def go():
+            idx, prob, _ = self.engine.rec_forward(x)
+            return idx.cpu().numpy(), prob.cpu().numpy()
+        return _guarded(self.engine, go)
 
 
 class Mi355LayoutBackboneSession(_BaseSession):

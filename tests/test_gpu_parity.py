@@ -163,6 +163,57 @@ def test_h3_precision_mode_matches_golden(golden_dir, monkeypatch):
         assert np.abs(f.cpu().numpy() - g[f"feat{i}"]).max() < TOL
 
 
+def test_native_fp32_precision_mode_matches_golden(golden_dir):
+    """precision 'fp32' (native fp32 MFMA only, no split-fp16 mixer) meets the same bar, and the default 'auto' mode
+    (split-fp16 channel mixers) agrees with it to fp32 noise."""
+    from rapiddoc_amd.engine import REC_WANT_LOGITS, RdEngine
+    st = W.synth_state_dict(W.load_manifest(golden_dir / "manifest_ppocrv6_rec.json"), 0)
+    eng = RdEngine("ppocrv6_rec").load_weights(st)
+    g = np.load(golden_dir / "rec_seed0_b3_w640.npz")
+    x = torch.from_numpy(g["x"]).cuda()
+    auto = eng.rec_forward(x, REC_WANT_LOGITS)[2].cpu().numpy()
+    kinds_auto = {r["kind"] for r in _profile(eng, lambda: eng.rec_forward(x))}
+    eng.set_precision("fp32")
+    nat = eng.rec_forward(x, REC_WANT_LOGITS)[2].cpu().numpy()
+    kinds_nat = {r["kind"] for r in _profile(eng, lambda: eng.rec_forward(x))}
+    assert "mixer_fused_h3" in kinds_auto and "mixer_fused_h3" not in kinds_nat and "mixer_fused" in kinds_nat
+    assert not eng.range_overflow()
+    assert np.abs(nat[:, 0, :] - g["logits_t0"]).max() < TOL
+    assert np.abs(auto - nat).max() < 2e-4
+    idx, prob, _ = eng.rec_forward(x)
+    safe = g["top2gap"] > 1e-2
+    assert (idx.cpu().numpy() == g["idx"])[safe].all()
+
+
+def _profile(eng, fn):
+    eng.set_profiling(True)
+    eng.profile_log.clear()
+    fn()
+    eng.set_profiling(False)
+    return list(eng.profile_log)
+
+
+def test_range_guard_falls_back_to_fp32(golden_dir):
+    """Split-fp16 operands must stay below 65504.  Activations beyond that raise the range flag (never a silently wrong
+    answer) and the session repeats the call in native fp32; the result equals a pure-fp32 engine's bit for bit."""
+    from rapiddoc_amd.engine import RdEngine
+    from rapiddoc_amd.session import Mi355DetSession
+    st = W.synth_state_dict(W.load_manifest(golden_dir / "manifest_ppocrv6_det.json"), 0)
+    big = dict(st)
+    stem = [k for k in big if k.endswith("weight") and big[k].ndim == 4 and big[k].shape[1] == 3][0]
+    big[stem] = big[stem] * 3.0e5          # blow the stem up: every later activation is ~1e5 x larger
+    x = np.load(golden_dir / "det_seed0_64x96.npz")["x"]
+    ref_eng = RdEngine("ppocrv6_det").load_weights(big).set_precision("fp32")
+    ref = ref_eng.det_forward(torch.from_numpy(x).cuda()).cpu().numpy()
+    eng = RdEngine("ppocrv6_det").load_weights(big)
+    eng.det_forward(torch.from_numpy(x).cuda())
+    assert eng.range_overflow() and not eng.range_overflow()      # raised once, cleared by the read
+    sess = Mi355DetSession(big)
+    got = sess(x)
+    assert sess.engine.precision == "fp32"
+    assert np.array_equal(got, ref)
+
+
 @pytest.mark.parametrize("tag", ["b2_c1_64x96", "b1_c3_96x64"])
 def test_formula_encoder_matches_golden(golden_dir, tag):
     """PP-FormulaNet_plus-M encoder (PPHGNetV2_B6_Formula) vs vectors minted from the reference backbone."""

@@ -16,7 +16,7 @@ lib.rd_debug_time_gemm.restype = C.c_float
 lib.rd_debug_time_gemm.argtypes = [C.c_int] * 5 + [C.c_void_p] * 6
 
 
-def mixer(C_, M, variant, iters=20):
+def mixer(C_, M, variant, iters=20, check=False):
     g = torch.Generator(device="cuda").manual_seed(0)
     x = torch.rand((M, C_), device="cuda", generator=g) - 0.5
     y = torch.empty_like(x)
@@ -24,8 +24,26 @@ def mixer(C_, M, variant, iters=20):
     w2 = (torch.rand((C_, 2 * C_), device="cuda", generator=g) - 0.5) * 0.1
     b1 = torch.zeros(2 * C_, device="cuda")
     b2 = torch.zeros(C_, device="cuda")
+    b1 += 0.05
+    b2 -= 0.02
     ms = lib.rd_debug_time_mixer(C_, M, variant, iters, x.data_ptr(), y.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr())
+    if check:
+        xs = x[:2048].double()
+        ref = xs + torch.nn.functional.gelu(xs @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+        return ms, 8.0 * M * C_ * C_ / ms / 1e9, float((y[:2048].double() - ref).abs().max())
     return ms, 8.0 * M * C_ * C_ / ms / 1e9
+
+
+if __name__ == "__main__" and "--mixer-h3" in sys.argv:
+    for C_ in (48, 96, 192):
+        for M in (32768 + 77, 131072 * 192 // C_):
+            for v in (0, 100):
+                ms, tf, err = mixer(C_, M, v, check=True)
+                print(f"mixer C={C_} M={M} {'h3  ' if v else 'fp32'}: {ms*1e3:8.1f} us {tf:7.1f} TF/s(nominal) max abs err vs fp64 {err:.2e}")
+    for v in (100, 101, 102, 104, 108, 110, 111, 115):
+        ms, tf = mixer(192, 131072, v)
+        print(f"mixer-h3 C=192 ablation bits {v-100:2d}: {ms*1e3:8.1f} us")
+    sys.exit(0)
 
 
 def gemm(M, K, N, act=0, iters=20, h3=False, check=False):
@@ -49,6 +67,12 @@ def gemm(M, K, N, act=0, iters=20, h3=False, check=False):
         err = float((y[:4096].double() - ref).abs().max() / ref.abs().max())
     return ms, 2.0 * M * K * N / ms / 1e9, err
 
+
+if __name__ == "__main__" and "--h3only" in sys.argv:
+    for (M, K, N) in ((131072, 192, 384), (131072, 384, 768), (131072, 768, 384), (81920, 2176, 512), (32768, 4096, 4096)):
+        ms, tf, err = gemm(M, K, N, 0, h3=True, check=True)
+        print(f"h3 gemm M={M} K={K} N={N}: {ms*1e3:8.1f} us  {tf:7.1f} TF/s  err {err:.1e}")
+    sys.exit(0)
 
 if __name__ == "__main__":
     names = {0: "full", 1: "no GELU", 2: "no weight stream/barriers", 3: "no GELU, no stream", 4: "GEMM2 only", 8: "GEMM1 only"}
