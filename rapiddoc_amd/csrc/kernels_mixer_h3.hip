@@ -40,7 +40,7 @@ __device__ __forceinline__ void hx_split(float v, _Float16& hi, _Float16& lo) {
 }
 
 template <int C>
-__global__ void __launch_bounds__(256) lc_mixer_h3_kernel(MixerParams p) {
+__global__ void __launch_bounds__(256, C <= 96 ? 2 : 1) lc_mixer_h3_kernel(MixerParams p) {
     constexpr int XS = C + 8;              // LDS row stride (halfs) of X and the W1 chunk: conflict-free b128 reads
     constexpr int WS = HX_HC + 8;          // W2 chunk row stride (halfs)
     constexpr int NTT = (C + 31) / 32;
@@ -55,7 +55,6 @@ __global__ void __launch_bounds__(256) lc_mixer_h3_kernel(MixerParams p) {
     _Float16* W1l = W1h + HX_HC * XS;
     _Float16* W2h = W1l + HX_HC * XS;          // [W2ROWS][WS]
     _Float16* W2l = W2h + W2ROWS * WS;
-    float* B1s = reinterpret_cast<float*>(W2l + W2ROWS * WS);  // [32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -73,7 +72,7 @@ __global__ void __launch_bounds__(256) lc_mixer_h3_kernel(MixerParams p) {
         //  hold a copy of the last row and are never stored)
         constexpr int QPR = C / 4;
         constexpr int XIT = HX_BM * QPR / 256;
-#pragma unroll 6
+#pragma unroll 12
         for (int it = 0; it < XIT; ++it) {
             const int i = tid + 256 * it;
             const int r = i / QPR, q = i - r * QPR;
@@ -97,7 +96,6 @@ __global__ void __launch_bounds__(256) lc_mixer_h3_kernel(MixerParams p) {
     }
     // weight chunk j: W1 rows [32j, 32j+32) x C  and  W2 rows [0, C) x (permuted) hidden [32j, 32j+32)
     u32x4 wreg[WL];
-    f32x4 b1reg = zero4;
     auto piece = [&](int t, int j, const _Float16*& src, _Float16*& dst) {
         // t in [0, 4*WQ): 0..WQ W1 hi, WQ..2WQ W1 lo, then W2 hi, W2 lo
         const int comp = t / WQ, i = t - comp * WQ;
@@ -122,7 +120,6 @@ __global__ void __launch_bounds__(256) lc_mixer_h3_kernel(MixerParams p) {
                 wreg[u] = *reinterpret_cast<const u32x4*>(src);
             }
         }
-        if (tid < 8) b1reg = *reinterpret_cast<const f32x4*>(p.b1 + j * HX_HC + 4 * tid);
     };
     auto store_w = [&](int j) {
 #pragma unroll
@@ -135,7 +132,6 @@ __global__ void __launch_bounds__(256) lc_mixer_h3_kernel(MixerParams p) {
                 *reinterpret_cast<u32x4*>(dst) = wreg[u];
             }
         }
-        if (tid < 8) *reinterpret_cast<f32x4*>(&B1s[4 * tid]) = b1reg;
     };
     load_w(0);
     store_w(0);
@@ -154,6 +150,9 @@ __global__ void __launch_bounds__(256) lc_mixer_h3_kernel(MixerParams p) {
     for (int j = 0; j < NCHUNK; ++j) {
         const bool more = (p.dbg & 2) ? false : j + 1 < NCHUNK;
         if (more) load_w(j + 1);
+        f32x4 b1v[4];   // this chunk's hidden biases (issued early: the loads complete under GEMM1)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b1v[g] = *reinterpret_cast<const f32x4*>(p.b1 + j * HX_HC + g * 8 + 4 * lhi);
         // GEMM1 (transposed): Ht = W1c . X^T
         f32x16 h1, h2;
 #pragma unroll
@@ -195,7 +194,7 @@ __global__ void __launch_bounds__(256) lc_mixer_h3_kernel(MixerParams p) {
         f16x8 hh[2], hl[2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(&B1s[g * 8 + 4 * lhi]);
+            const f32x4 bv = b1v[g];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = g * 4 + e;
@@ -243,8 +242,9 @@ __global__ void __launch_bounds__(256) lc_mixer_h3_kernel(MixerParams p) {
         }
     }
     if (!(amax < 65504.f) && p.range_flag) atomicOr(p.range_flag, 1u);   // also catches NaN
-    // ---- epilogue: + b2 + residual (re-read from global, so it stays exact fp32; unconditional clamped loads), strided store
-    // (rebuilding the residual from the (hi, lo) tile in LDS measured 10 % slower: 2-byte LDS reads)
+    // ---- epilogue: + b2 + residual (re-read from global, so it stays exact fp32; unconditional clamped loads), strided store.
+    // Two alternatives measured slower: rebuilding the residual from the (hi, lo) tile in LDS (2-byte LDS reads, +10 %)
+    // and parking the result rows in LDS to stream them out as float4 rows (+8 %).
 #pragma unroll
     for (int n = 0; n < NTT; ++n) {
         const int co = n * 32 + l31;
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(256) lc_mixer_h3_kernel(MixerParams p) {
 
 template <int C>
 static void launch_mixer_h3_c(const MixerParams& p, hipStream_t s) {
-    const size_t sh = (size_t)(2 * (HX_BM + HX_HC) * (C + 8) + 2 * ((C + 31) / 32 * 32) * (HX_HC + 8)) * sizeof(_Float16) + 32 * sizeof(float);
+    const size_t sh = (size_t)(2 * (HX_BM + HX_HC) * (C + 8) + 2 * ((C + 31) / 32 * 32) * (HX_HC + 8)) * sizeof(_Float16);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)lc_mixer_h3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
