@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--dump-profile", type=str, default="")
     ap.add_argument("--rec-batch", type=int, default=128)
     ap.add_argument("--rec-streams", type=int, default=8)
+    ap.add_argument("--workers", type=int, default=1, help="page-batch shards in flight per GPU (host stages of one overlap GPU stages of the other)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -104,11 +105,13 @@ def main():
         if dist:
             dist.barrier()
     from rapiddoc_amd.pages import synth_batch
-    from rapiddoc_amd.pipeline import PagePipeline, boxes_to_quads, render_text_maps
+    from rapiddoc_amd.pipeline import PagePipelinePool, boxes_to_quads, render_text_maps
     from rapiddoc_amd.dist import gather_page_results
 
     states = load_states()
-    pipe = PagePipeline(states, device=dev_index, rec_batch_num=args.rec_batch, n_rec_streams=args.rec_streams)
+    pool = PagePipelinePool(states, device=dev_index, workers=args.workers, rec_batch_num=args.rec_batch,
+                            n_rec_streams=max(1, args.rec_streams // max(1, args.workers)))
+    pipe = pool.pipes[0]
     P = args.pages
     pages_np, boxes = synth_batch(rank * P, P)
     pages = torch.from_numpy(pages_np).cuda()
@@ -119,7 +122,7 @@ def main():
     quads = None
 
     def step():
-        res = pipe.run_batch(pages, quads, det_maps_override=text_maps)
+        res = pool.run_batch(pages, quads, det_maps_override=text_maps)
         payload = [(rank * P + i, [(t, s) for _, t, s in r.lines]) for i, r in enumerate(res)]
         return gather_page_results(payload, dist)
 
@@ -142,16 +145,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_lines = sum(len(l) for _, l in out)
-    host_stats = {k: round(v, 2) for k, v in pipe.stats.items()}
+    host_stats = {k: round(v, 2) for k, v in pool.stats.items()}
 
     # ---- roofline of the dominant kernel: per-op HIP events (recorded by the library on the launch stream)
     roof = None
     if rank == 0:
-        engines = [pipe.det, pipe.layout] + list(pipe.rec_engines)
+        engines = pool.engines
         for e in engines:
             e.set_profiling(True)
             e.profile_log = []
-        pipe.run_batch(pages, quads, det_maps_override=text_maps)
+        pool.run_batch(pages, quads, det_maps_override=text_maps)
         torch.cuda.synchronize()
         agg = defaultdict(lambda: [0.0, 0.0, 0.0, 0])
         tot_ms = 0.0
@@ -190,8 +193,9 @@ def main():
                 "step_kernel_ms": round(tot_ms, 2)}
         if args.dump_profile:
             with open(args.dump_profile + ".ops.json", "w") as f:
-                json.dump({"det": pipe.det.profile_log, "rec": sum((e.profile_log for e in pipe.rec_engines), []),
-                           "layout": pipe.layout.profile_log}, f)
+                json.dump({"det": sum((q.det.profile_log for q in pool.pipes), []),
+                           "rec": sum((e.profile_log for q in pool.pipes for e in q.rec_engines), []),
+                           "layout": sum((q.layout.profile_log for q in pool.pipes), [])}, f)
             table = sorted(((k, v[3], v[2], v[0] / 1e9, v[1] / 1e6) for k, v in agg.items()), key=lambda r: -r[2])
             with open(args.dump_profile, "w") as f:
                 f.write("kernel,launches,total_ms,gflop,algorithmic_MB,TFLOPs,GBs\n")
@@ -209,7 +213,7 @@ def main():
                        "precision": "fp32 results; dense layers on fp32 MFMA, PPLCNetV4 channel mixers on split-fp16 MFMA "
                                     "(3 MFMAs/product, fp32 accumulate, error vs fp64 <= fp32 MFMA's)" if pipe.det.precision == "auto"
                                     else pipe.det.precision,
-                       "pages_per_gpu": P, "lines_per_step": n_lines, "host_stage_ms": host_stats, "parallelism": "page-sharded dp%d" % world,
+                       "pages_per_gpu": P, "lines_per_step": n_lines, "host_stage_ms": host_stats, "parallelism": "page-sharded dp%d; %d page shards in flight per GPU" % (world, len(pool.pipes)),
                        "layout_head": "absent (ONNX-only in the reference; backbone only)",
                        "det_postprocess": "DB post-process (host C++) runs on maps rendered from the generator's line boxes "
                                           "(random-weight det output has no text); its boxes drive crop+rec"},

@@ -302,9 +302,9 @@ static bool fits_fp16_range(const std::vector<float>& w) {
     return true;
 }
 static inline int out_dim(int in, int k, int s, int p0, int p1) { return (in + p0 + p1 - k) / s + 1; }
-// "auto" precision: pointwise convolutions with a long reduction also run on the split-fp16 matrix-core path (the
-// activation split is amortised over K; measured 1.2-1.5x the fp32 MFMA kernel from K = 512 up, no gain below)
-static inline bool auto_split_conv(int kh, int kw, int K, int cout) { return kh == 1 && kw == 1 && K >= 512 && cout >= 128; }
+// "auto" precision: wide pointwise convolutions also run on the split-fp16 matrix-core path (256x128 tile; measured
+// 1.2x the fp32 MFMA kernel at K = 192, 2x at K >= 768 - table in kernels_conv_h3.hip)
+static inline bool auto_split_conv(int kh, int kw, int K, int cout) { return kh == 1 && kw == 1 && K >= 192 && cout >= 128; }
 
 // =================================================================================================
 // Builder: layers
@@ -356,7 +356,7 @@ TView Builder::conv(const std::string& wname, const std::string& bname, const st
         p.wh = reinterpret_cast<const uint16_t*>(pb_->ptr(key + "#wh"));
         p.wl = reinterpret_cast<const uint16_t*>(pb_->ptr(key + "#wl"));
         p.range_flag = range_flag_;
-        r.cfg = std::string(K <= 256 || cout <= 32 ? "128x32" : "128x64") + "/h3";
+        r.cfg = std::string(cout > 96 ? "256x128" : K <= 256 || cout <= 32 ? "128x32" : "128x64") + "/h3";
     }
     r.run = [p, xv, yv, rv, av, has_res, has_as, h3](const Plan& pl, const RunCtx& c) mutable {
         ConvParams q = p;

@@ -66,13 +66,14 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_h3_kernel(ConvParams p
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int AL = BM * 8 / NT, BL = BN * 8 / NT;
-    static_assert(AL >= 1 && BL >= 1 && NT == 256, "tile/loader mismatch");
+    static_assert(AL >= 1 && BL >= 1 && (NT == 256 || NT == 512), "tile/loader mismatch");
 
-    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * (BM + BN) * HLD];
-    _Float16* Ah = smem;
-    _Float16* Al = Ah + BM * HLD;
-    _Float16* Bh = Al + BM * HLD;
-    _Float16* Bl = Bh + BN * HLD;
+    // 8-wavefront tiles keep two LDS stages (one barrier per K tile instead of two); the 4-wavefront tiles stay
+    // single-staged so that several workgroups fit a CU
+    constexpr bool DB = NT == 512;
+    constexpr int STAGE = 2 * (BM + BN) * HLD;
+    __shared__ __attribute__((aligned(16))) _Float16 smem[(DB ? 2 : 1) * STAGE];
+    constexpr int AH0 = 0, AL0 = BM * HLD, BH0 = 2 * BM * HLD, BL0 = 2 * BM * HLD + BN * HLD;
 
     int tile_m, tile_n;
     {
@@ -92,7 +93,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_h3_kernel(ConvParams p
     int a_ih0[AL], a_iw0[AL];
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
-        const int m = m0 + lrow + 32 * i;
+        const int m = m0 + lrow + (NT / 8) * i;
         avalid[i] = m < p.M;
         const int mm = avalid[i] ? m : 0;
         if (IS1X1) {
@@ -113,14 +114,14 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_h3_kernel(ConvParams p
     int b_lds[BL], b_col[BL];
 #pragma unroll
     for (int i = 0; i < BL; ++i) {
-        const int t = tid + 256 * i;
+        const int t = tid + NT * i;
         const int which = t / (BN * 4), rem = t - which * (BN * 4);
         const int r = rem >> 2, c = rem & 3;
         const int n = n0 + r;
         bvalid[i] = n < p.Ng;
         bsrc[i] = reinterpret_cast<const _Float16*>(which ? p.wl : p.wh) + (size_t)(bvalid[i] ? n : 0) * Kp;
         b_col[i] = c * 8;
-        b_lds[i] = (which ? (int)(Bl - smem) : (int)(Bh - smem)) + r * HLD + c * 8;
+        b_lds[i] = (which ? BL0 : BH0) + r * HLD + c * 8;
     }
 
     f32x4 areg[AL];
@@ -160,18 +161,19 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_h3_kernel(ConvParams p
             bmask |= (unsigned)ok << i;
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int buf) {
+        _Float16* st = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < AL; ++i) {
             f16x4 hi, lo;
             const f32x4 av = ((amask >> i) & 1u) ? areg[i] : zero4;
             split4(av, hi, lo);
-            const int o = (lrow + 32 * i) * HLD + 4 * lkq;
-            *reinterpret_cast<f16x4*>(&Ah[o]) = hi;
-            *reinterpret_cast<f16x4*>(&Al[o]) = lo;
+            const int o = (lrow + (NT / 8) * i) * HLD + 4 * lkq;
+            *reinterpret_cast<f16x4*>(&st[AH0 + o]) = hi;
+            *reinterpret_cast<f16x4*>(&st[AL0 + o]) = lo;
         }
 #pragma unroll
-        for (int i = 0; i < BL; ++i) *reinterpret_cast<u32x4*>(&smem[b_lds[i]]) = ((bmask >> i) & 1u) ? breg[i] : zero4u;
+        for (int i = 0; i < BL; ++i) *reinterpret_cast<u32x4*>(&st[b_lds[i]]) = ((bmask >> i) & 1u) ? breg[i] : zero4u;
     };
 
     const int lane = tid & 63, wave = tid >> 6;
@@ -188,13 +190,18 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_h3_kernel(ConvParams p
 
     const int KT = (K + HBK - 1) / HBK;
     load_tiles(0);
-    store_tiles();
+    store_tiles(0);
     __syncthreads();
     const int aoff = ((wm * TM) * 32 + l31) * HLD + 8 * lhi;
     const int boff = ((wn * TN) * 32 + l31) * HLD + 8 * lhi;
     for (int kt = 0; kt < KT; ++kt) {
         const bool more = kt + 1 < KT;
         if (more) load_tiles((kt + 1) * HBK);
+        const int cur = DB ? (kt & 1) : 0;
+        const _Float16* Ah = smem + cur * STAGE + AH0;
+        const _Float16* Al = smem + cur * STAGE + AL0;
+        const _Float16* Bh = smem + cur * STAGE + BH0;
+        const _Float16* Bl = smem + cur * STAGE + BL0;
         const int kleft = K - kt * HBK;
         const int nks = kleft > 16 ? 2 : 1;
         for (int ks = 0; ks < nks; ++ks) {
@@ -218,10 +225,15 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_h3_kernel(ConvParams p
                     acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc2[i][j], 0, 0, 0);
                 }
         }
-        __syncthreads();
-        if (more) {
-            store_tiles();
+        if (DB) {
+            if (more) store_tiles(cur ^ 1);
             __syncthreads();
+        } else {
+            __syncthreads();
+            if (more) {
+                store_tiles(0);
+                __syncthreads();
+            }
         }
     }
 
@@ -271,9 +283,15 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_h3_kernel(ConvParams p
 static inline int h3_pick_bn(const ConvParams& p) {
     static const int forced = [] { const char* e = getenv("RD_H3_BN"); return e ? atoi(e) : 0; }();
     if (forced) return forced;
-    // narrow tiles: 2 (BN 64) or 3 (BN 32) wavefronts per SIMD hide the split/staging latency that a 128-wide tile
-    // (220 VGPR + 128 AGPR, one wavefront per SIMD) exposes - measured 1.2-1.4x faster on every shape tried
+    // Measured on MI355X (TF/s of fp32-equivalent work, M = 131072; fp32 MFMA kernel in brackets):
+    //   K192/N384  K384/N768  K768/N384  K2176/N512  4096^2
+    //     102        150        204        253        288     256x128 tile, 8 wavefronts (4x2), two LDS stages
+    //      77        113        143        170        182     128x64 tile, 4 wavefronts
+    //     [87]      [110]      [116]      [126]      [130]
+    // The A tile is split once per K step whatever the tile width, so wide tiles amortise the split; narrow tiles are
+    // for narrow layers only.
     const int n = p.Ng;
+    if (n > 96) return 258;
     if (n <= 32 || p.K <= 256) return 32;
     return 64;
 }
@@ -296,6 +314,7 @@ void launch_conv_igemm_h3(const ConvParams& p, hipStream_t s) {
         case 32: h3_launch_cfg<128, 32, 4, 1>(p, s); break;
         case 64: h3_launch_cfg<128, 64, 4, 1>(p, s); break;
         case 96: h3_launch_cfg<128, 96, 4, 1>(p, s); break;
+        case 258: h3_launch_cfg<256, 128, 4, 2>(p, s); break;
         default: h3_launch_cfg<128, 128, 2, 2>(p, s); break;
     }
 }

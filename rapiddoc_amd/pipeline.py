@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import time
 import ctypes as C
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -301,3 +302,56 @@ def render_text_maps(boxes_per_page: Sequence[np.ndarray], page_hw: Tuple[int, i
             if xb > xa and yb > ya:
                 maps[i, 0, ya:yb, xa:xb] = 0.9
     return maps.to(device)
+
+
+class PagePipelinePool:
+    """`workers` PagePipelines on one GPU, each fed a contiguous shard of the page batch from its own host thread and HIP
+    streams.  A page batch has host stages between its GPU stages (det maps -> DB post-process -> crop descriptors;
+    rec indices -> CTC decode): with two shards in flight the GPU runs one shard's networks while the host works on the
+    other's.  Results come back in page order, identical to a single pipeline's (pages are independent)."""
+
+    def __init__(self, states: Dict[str, object], device: int = 0, workers: int = 2, **kw):
+        self.device = device
+        self.pipes = [PagePipeline(states, device, **kw) for _ in range(max(1, workers))]
+        self.streams = [torch.cuda.Stream(device=self.pipes[0].tdev) for _ in self.pipes]
+        self.pool = ThreadPoolExecutor(max_workers=len(self.pipes))
+        self.stats: Dict[str, float] = {}
+
+    @property
+    def engines(self) -> List[RdEngine]:
+        out = []
+        for p in self.pipes:
+            out += [p.det, *([p.layout] if p.layout is not None else []), *p.rec_engines]
+        return out
+
+    def run_batch(self, pages: torch.Tensor, quads_per_page: Optional[Sequence[np.ndarray]] = None,
+                  det_maps_override: Optional[torch.Tensor] = None) -> List[PageResult]:
+        P = pages.shape[0]
+        n = min(len(self.pipes), max(1, P))
+        bounds = [P * k // n for k in range(n + 1)]
+        ready = torch.cuda.Event()
+        ready.record()
+
+        def work(k: int):
+            lo, hi = bounds[k], bounds[k + 1]
+            torch.cuda.set_device(self.device)
+            st = self.streams[k]
+            with torch.cuda.stream(st):
+                st.wait_event(ready)
+                res = self.pipes[k].run_batch(pages[lo:hi], None if quads_per_page is None else quads_per_page[lo:hi],
+                                              None if det_maps_override is None else det_maps_override[lo:hi])
+                done = torch.cuda.Event()
+                done.record(st)
+            return res, done
+
+        outs = list(self.pool.map(work, range(n)))
+        results: List[PageResult] = []
+        for res, done in outs:
+            torch.cuda.current_stream().wait_event(done)
+            results += res
+        self.stats = {}
+        for k, p in enumerate(self.pipes[:n]):
+            for key, v in p.stats.items():
+                self.stats[key] = self.stats.get(key, 0.0) + v
+        return results
+
