@@ -304,7 +304,9 @@ static bool fits_fp16_range(const std::vector<float>& w) {
 static inline int out_dim(int in, int k, int s, int p0, int p1) { return (in + p0 + p1 - k) / s + 1; }
 // "auto" precision: wide pointwise convolutions also run on the split-fp16 matrix-core path (256x128 tile; measured
 // 1.2x the fp32 MFMA kernel at K = 192, 2x at K >= 768 - table in kernels_conv_h3.hip)
-static inline bool auto_split_conv(int kh, int kw, int K, int cout) { return kh == 1 && kw == 1 && K >= 192 && cout >= 128; }
+static inline bool auto_split_conv(int kh, int kw, int K, int cout) {
+    return (kh == 1 && kw == 1) ? (K >= 192 && cout >= 128) : (K >= 288 && cout >= 48);
+}
 
 // =================================================================================================
 // Builder: layers
@@ -350,13 +352,14 @@ TView Builder::conv(const std::string& wname, const std::string& bname, const st
     const TView xv = x, yv = y;
     const bool has_res = res != nullptr, has_as = ascale != nullptr;
     const TView rv = res ? *res : TView{}, av = ascale ? *ascale : TView{};
-    const bool h3 = (h3_ || (mixer_h3_ && !ascale && g.sh == 1 && g.sw == 1 && p.M >= 2048 && auto_split_conv(kh, kw, K, cout))) &&
+    const bool h3 = (h3_ || (mixer_h3_ && !ascale && p.M >= 2048 && auto_split_conv(kh, kw, K, cout))) &&
                     pb_->has(key + "#wh");
     if (h3) {
         p.wh = reinterpret_cast<const uint16_t*>(pb_->ptr(key + "#wh"));
         p.wl = reinterpret_cast<const uint16_t*>(pb_->ptr(key + "#wl"));
         p.range_flag = range_flag_;
-        r.cfg = std::string(cout > 96 ? "256x128" : K <= 256 || cout <= 32 ? "128x32" : "128x64") + "/h3";
+        r.cfg = std::string(cout > 96 ? "256x128" : cout > 64 ? "128x96" : (cout > 32 && p.M >= 65536) ? "256x64"
+                                          : K <= 256 || cout <= 32 ? "128x32" : "128x64") + "/h3";
     }
     r.run = [p, xv, yv, rv, av, has_res, has_as, h3](const Plan& pl, const RunCtx& c) mutable {
         ConvParams q = p;

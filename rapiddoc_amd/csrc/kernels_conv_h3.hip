@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_h3_kernel(ConvParams p
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int AL = BM * 8 / NT, BL = BN * 8 / NT;
-    static_assert(AL >= 1 && BL >= 1 && (NT == 256 || NT == 512), "tile/loader mismatch");
+    static_assert(AL >= 1 && BL >= 1 && (BM * 8) % NT == 0 && (BN * 8) % NT == 0 && (NT == 256 || NT == 512), "tile/loader mismatch");
 
     // 8-wavefront tiles keep two LDS stages (one barrier per K tile instead of two); the 4-wavefront tiles stay
     // single-staged so that several workgroups fit a CU
@@ -292,6 +292,8 @@ static inline int h3_pick_bn(const ConvParams& p) {
     // for narrow layers only.
     const int n = p.Ng;
     if (n > 96) return 258;
+    if (n > 32 && n <= 64 && p.M >= 65536) return 260;
+    if (n > 64) return 96;
     if (n <= 32 || p.K <= 256) return 32;
     return 64;
 }
@@ -315,6 +317,7 @@ void launch_conv_igemm_h3(const ConvParams& p, hipStream_t s) {
         case 64: h3_launch_cfg<128, 64, 4, 1>(p, s); break;
         case 96: h3_launch_cfg<128, 96, 4, 1>(p, s); break;
         case 258: h3_launch_cfg<256, 128, 4, 2>(p, s); break;
+        case 260: h3_launch_cfg<256, 64, 4, 2>(p, s); break;
         default: h3_launch_cfg<128, 128, 2, 2>(p, s); break;
     }
 }
