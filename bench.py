@@ -168,13 +168,15 @@ def main():
                     name = "lc_mixer_kernel<%s>" % op["cfg"][1:]
                 elif op["kind"] == "mixer_fused_h3":
                     name = "lc_mixer_h3_kernel<%s>" % op["cfg"][1:]
+                elif op["kind"] == "ctc_head_fused_h3":
+                    name = "ctc_head_h3_kernel"
                 elif op["kind"] == "ctc_head_fused":
                     name = "ctc_head_kernel"
                 a = agg[name]
                 a[0] += op["flops"]; a[1] += op["bytes"]; a[2] += op["ms"]; a[3] += 1
                 tot_ms += op["ms"]
             e.set_profiling(False)
-        mfma = {k: v for k, v in agg.items() if k.startswith(("conv_igemm", "lc_mixer")) or k == "ctc_head_kernel"}
+        mfma = {k: v for k, v in agg.items() if k.startswith(("conv_igemm", "lc_mixer", "ctc_head"))}
         dom = max(mfma, key=lambda k: mfma[k][2])
         fl, by, ms, n = mfma[dom]
         ach = fl / (ms * 1e-3) / 1e12

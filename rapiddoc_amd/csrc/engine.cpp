@@ -907,6 +907,12 @@ void Builder::ctc_head(const std::string& prefix, const TView& x, const TView& i
                 wp[(size_t)c * 128 + K] = bs[c];
             }
             pb_->add(prefix + "|ctc#w", wp);
+            if (fits_fp16_range(wp)) {   // split-fp16 copy (K is already padded to 128)
+                std::vector<uint16_t> hi, lo;
+                split_weights_h3(wp.data(), C, 128, hi, lo);
+                pb_->add_u16(prefix + "|ctc#wh", hi);
+                pb_->add_u16(prefix + "|ctc#wl", lo);
+            }
         }
         release(part);
         return;
@@ -916,9 +922,15 @@ void Builder::ctc_head(const std::string& prefix, const TView& x, const TView& i
     p.w = pb_->ptr(prefix + "|ctc#w");
     p.bias = nullptr;
     p.M = M; p.K = K; p.C = C; p.nsplit = nsplit;
+    const bool split = (h3_ || mixer_h3_) && pb_->has(prefix + "|ctc#wh");
+    if (split) {
+        p.wh = reinterpret_cast<const uint16_t*>(pb_->ptr(prefix + "|ctc#wh"));
+        p.wl = reinterpret_cast<const uint16_t*>(pb_->ptr(prefix + "|ctc#wl"));
+        p.range_flag = range_flag_;
+    }
     OpRecord r;
     r.name = prefix;
-    r.kind = "ctc_head_fused";
+    r.kind = split ? "ctc_head_fused_h3" : "ctc_head_fused";
     r.flops = 2.0 * M * (double)K * C;
     r.bytes = 4.0 * ((double)M * K + (double)C * K);
     const TView xv = x, pv = part, iv = idx_ext, prv = prob_ext;

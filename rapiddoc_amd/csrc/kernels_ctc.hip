@@ -134,6 +134,150 @@ __global__ void __launch_bounds__(256) ctc_head_kernel(CtcParams p, int cls_per_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Split-fp16 variant (precision "auto" / "h3"): same tiling, split and statistics, but the products run on the fp16 matrix
+// cores with (hi, lo) operands - 3 x v_mfma_f32_32x32x16_f16 per 16-wide k-step instead of 8 fp32 MFMAs, fp32 accumulate
+// (arithmetic as in kernels_conv_h3.hip).  The token tile is split once per block, the weights once at load time.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+static constexpr int CH_LD = CT_K + 8;   // LDS row stride in halfs (272 B): conflict-free ds_read_b128
+
+__global__ void __launch_bounds__(256) ctc_head_h3_kernel(CtcParams p, int cls_per_split) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* Xh = reinterpret_cast<_Float16*>(smem);
+    _Float16* Xl = Xh + CT_TOK * CH_LD;
+    _Float16* Wh = Xl + CT_TOK * CH_LD;
+    _Float16* Wl = Wh + CT_CLS * CH_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int split = blockIdx.x % p.nsplit, ttile = blockIdx.x / p.nsplit;
+    const int tok0 = ttile * CT_TOK;
+    const int c_begin = split * cls_per_split;
+    const int c_end = min(p.C, c_begin + cls_per_split);
+    const int nit = (c_end - c_begin + CT_CLS - 1) / CT_CLS;
+    const _Float16* wh_g = reinterpret_cast<const _Float16*>(p.wh);
+    const _Float16* wl_g = reinterpret_cast<const _Float16*>(p.wl);
+
+    // ---- X tile (tokens): bias column appended, split once
+    float amax = 0.f;
+    {
+        const int lrow = tid >> 5, lkq = tid & 31;
+#pragma unroll 4
+        for (int r = lrow; r < CT_TOK; r += 8) {
+            const int tok = min(tok0 + r, p.M - 1), k = 4 * lkq;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < p.K) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)tok * p.xld + k);
+            else if (k == p.K) v[0] = 1.f;
+            f16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const _Float16 h = (_Float16)v[e];
+                hi[e] = h;
+                lo[e] = (_Float16)((v[e] - (float)h) * 2048.f);
+                amax = fmaxf(amax, fabsf(v[e]));
+            }
+            *reinterpret_cast<f16x4*>(&Xh[r * CH_LD + k]) = hi;
+            *reinterpret_cast<f16x4*>(&Xl[r * CH_LD + k]) = lo;
+        }
+    }
+    // W tile: 128 classes x 128 halfs, hi and lo: 2 x 2048 16-byte pieces, 16 per thread
+    const int wrow = tid >> 4, wc8 = tid & 15;   // 16 rows x 16 pieces per pass
+    const u32x4 zero4u = {0u, 0u, 0u, 0u};
+    u32x4 wreg[16];
+    auto load_w = [&](int it) {
+        const int cb = c_begin + it * CT_CLS;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = cb + wrow + 16 * i;
+            const bool ok = c < c_end;
+            const size_t off = (size_t)(ok ? c : c_begin) * CT_K + 8 * wc8;
+            const u32x4 a = *reinterpret_cast<const u32x4*>(wh_g + off), b = *reinterpret_cast<const u32x4*>(wl_g + off);
+            wreg[i] = ok ? a : zero4u;
+            wreg[8 + i] = ok ? b : zero4u;
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            *reinterpret_cast<u32x4*>(&Wh[(wrow + 16 * i) * CH_LD + 8 * wc8]) = wreg[i];
+            *reinterpret_cast<u32x4*>(&Wl[(wrow + 16 * i) * CH_LD + 8 * wc8]) = wreg[8 + i];
+        }
+    };
+    load_w(0);
+    store_w();
+    __syncthreads();
+
+    float m_run = -INFINITY, s_run = 0.f;
+    int i_run = 0;
+    const int xo = (wave * 32 + l31) * CH_LD + 8 * lhi;
+    const int wo = l31 * CH_LD + 8 * lhi;
+    for (int it = 0; it < nit; ++it) {
+        const bool more = it + 1 < nit;
+        if (more) load_w(it + 1);
+        f32x16 acc1[4], acc2[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[ct][r] = acc2[ct][r] = 0.f;
+#pragma unroll 2
+        for (int ks = 0; ks < CT_K / 16; ++ks) {
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(&Xh[xo + ks * 16]);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(&Xl[xo + ks * 16]);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(&Wh[wo + ct * 32 * CH_LD + ks * 16]);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(&Wl[wo + ct * 32 * CH_LD + ks * 16]);
+                acc1[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[ct], 0, 0, 0);
+                acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[ct], 0, 0, 0);
+                acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[ct], 0, 0, 0);
+            }
+        }
+        const int cb = c_begin + it * CT_CLS + 4 * lhi;
+        float lm = -INFINITY;
+        int li = 0;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = cb + ct * 32 + (r & 3) + 8 * (r >> 2);
+                const float v = (c < c_end) ? fmaf(acc2[ct][r], 1.f / 2048.f, acc1[ct][r]) : -INFINITY;
+                acc1[ct][r] = v;
+                if (v > lm) { lm = v; li = c; }
+            }
+        const float m_new = fmaxf(m_run, lm);
+        if (m_new > -INFINITY) {
+            float s = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += __expf(acc1[ct][r] - m_new);
+            s_run = s_run * __expf(m_run - m_new) + s;
+            if (lm > m_run) i_run = li;
+            m_run = m_new;
+        }
+        __syncthreads();
+        if (more) {
+            store_w();
+            __syncthreads();
+        }
+    }
+    if (!(amax < 65504.f) && p.range_flag) atomicOr(p.range_flag, 1u);
+    const float om = __shfl_xor(m_run, 32, 64), os = __shfl_xor(s_run, 32, 64);
+    const int oi = __shfl_xor(i_run, 32, 64);
+    const float mm = fmaxf(m_run, om);
+    const float ss = s_run * __expf(m_run - mm) + os * __expf(om - mm);
+    const int ii = (om > m_run || (om == m_run && oi < i_run)) ? oi : i_run;
+    const int tok = tok0 + wave * 32 + l31;
+    if (lhi == 0 && tok < p.M) {
+        float* o = p.part + ((size_t)tok * p.nsplit + split) * 4;
+        o[0] = mm;
+        o[1] = ss;
+        o[2] = __int_as_float(ii);
+    }
+}
+
 __global__ void __launch_bounds__(256) ctc_merge_kernel(const float* part, int M, int nsplit, int32_t* idx, float* prob) {
     const int tok = blockIdx.x * 256 + threadIdx.x;
     if (tok >= M) return;
@@ -163,12 +307,15 @@ void launch_ctc_head(const CtcParams& p, hipStream_t s) {
     int cps = (p.C + p.nsplit - 1) / p.nsplit;
     cps = (cps + 3) / 4 * 4;
     const size_t sh = (size_t)(CT_TOK + CT_CLS) * CT_LD * sizeof(float);
+    const size_t sh3 = (size_t)2 * (CT_TOK + CT_CLS) * CH_LD * sizeof(_Float16);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)ctc_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute((const void*)ctc_head_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh3);
         attr_set = true;
     }
-    hipLaunchKernelGGL(ctc_head_kernel, dim3(tiles * p.nsplit), dim3(256), sh, s, p, cps);
+    if (p.wh) hipLaunchKernelGGL(ctc_head_h3_kernel, dim3(tiles * p.nsplit), dim3(256), sh3, s, p, cps);
+    else hipLaunchKernelGGL(ctc_head_kernel, dim3(tiles * p.nsplit), dim3(256), sh, s, p, cps);
     hipLaunchKernelGGL(ctc_merge_kernel, dim3((p.M + 255) / 256), dim3(256), 0, s, p.part, p.M, p.nsplit, p.idx, p.prob);
 }
 

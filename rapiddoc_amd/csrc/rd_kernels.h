@@ -109,8 +109,11 @@ struct CtcParams {
     float* part;               // workspace [M][nsplit][4] (max, sumexp, idx, pad)
     int nsplit;
     int32_t* idx; float* prob;
+    // split-fp16 variant: W' [C][128] as (hi, lo) fp16; range_flag as in ConvParams
+    const uint16_t* wh = nullptr; const uint16_t* wl = nullptr;
+    unsigned* range_flag = nullptr;
 };
-void launch_ctc_head(const CtcParams& p, hipStream_t s);
+void launch_ctc_head(const CtcParams& p, hipStream_t s);   // dispatches on p.wh
 int ctc_head_nsplit(int M, int C);
 
 // layout conversion at the C-ABI boundary
