@@ -189,12 +189,7 @@ float rd_debug_time_mixer(int C, int M, int variant, int iters, float* x, float*
         (void)hipMemcpy(hw1.data(), w1, hw1.size() * 4, hipMemcpyDeviceToHost);
         (void)hipMemcpy(hw2.data(), w2, hw2.size() * 4, hipMemcpyDeviceToHost);
         std::vector<uint16_t> v[4];
-        if (C == 384 || (p.dbg & 16)) {
-            rd::prepare_mixer_weights_h3_wide(hw1.data(), hw2.data(), C, v[0], v[1], v[2]);
-            v[3].assign(8, 0);
-        } else {
-            rd::prepare_mixer_weights_h3(hw1.data(), hw2.data(), C, v[0], v[1], v[2], v[3]);
-        }
+        rd::prepare_mixer_weights_h3(hw1.data(), hw2.data(), C, v[0], v[1], v[2], v[3]);
         for (int i = 0; i < 4; ++i) {
             (void)hipMalloc(&hbuf[i], v[i].size() * 2);
             (void)hipMemcpy(hbuf[i], v[i].data(), v[i].size() * 2, hipMemcpyHostToDevice);

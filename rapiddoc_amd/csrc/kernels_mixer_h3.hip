@@ -8,6 +8,9 @@
 //     hold hidden index 8*(r>>2) + 4*(lane>>5) + (r&3); W2's columns are therefore PERMUTED inside every 32-wide hidden
 //     chunk at weight-preparation time (position 16*(a>>1) + 8*b + 4*(a&1) + c for hidden 8a + 4b + c) so that one
 //     ds_read_b128 still yields the B fragment that matches registers 8s .. 8s+7.
+// Tried and dropped: a "wide" variant for C = 384 / 192 (64-pixel tile, hidden chunks of 16, the four wavefronts as 2 pixel
+// groups x 2 output-channel halves so that two workgroups fit a CU).  GEMM1 and the GELU are then computed twice; it
+// measured 107 TF/s at C = 384 (the unfused pair of split-fp16 GEMMs reaches ~170) and 104 at C = 192 (this kernel: 160).
 #include <cstdlib>
 #include <vector>
 
@@ -266,221 +269,6 @@ __global__ void __launch_bounds__(256, C <= 96 ? 2 : 1) lc_mixer_h3_kernel(Mixer
 }
 
 
-// ------------------------------------------------------------------------------------------------------------------
-// "Wide" variant for C = 384 (and an alternative for C = 192): the (hi, lo) X tile only fits LDS for 64 pixels, so the
-// four wavefronts are arranged 2 (pixel groups of 32) x 2 (output-channel halves) and the hidden dimension is streamed in
-// chunks of 16.  Both wavefronts of a pixel group compute the same 16 x 32 hidden tile (GEMM1 and the GELU are done
-// twice, and the 32x32x16 MFMA runs with half of its rows duplicated): MFMA issue slots are not what bounds this kernel,
-// LDS capacity is.  Registers 0..7 of the GEMM1 accumulator are exactly the k-step-0 A fragment of GEMM2.
-// W2 arrives pre-packed per row and chunk as 32 halfs: 16 hi | 16 lo, hidden order permuted (prepare_mixer_weights_h3_wide).
-static constexpr int HW_BM = 64;
-static constexpr int HW_HC = 16;
-
-template <int C>
-__global__ void __launch_bounds__(256, C <= 192 ? 2 : 1) lc_mixer_h3_wide_kernel(MixerParams p) {
-    constexpr int XS = C + 8;
-    constexpr int WS = 40;                 // 16 hi | 16 lo | 8 pad
-    constexpr int NH = C / 2;              // output channels per wavefront
-    constexpr int NTT = NH / 32;
-    constexpr int KS1 = C / 16;
-    constexpr int NCHUNK = 2 * C / HW_HC;
-    constexpr int WL = 8 * C / 256;        // 16-byte pieces per thread and chunk: 4C of W1 (hi, lo), 4C of W2
-    static_assert(NH % 32 == 0 && (8 * C) % 256 == 0, "unsupported width");
-    extern __shared__ __attribute__((aligned(16))) _Float16 smemh[];
-    _Float16* Xh = smemh;                      // [64][XS]
-    _Float16* Xl = Xh + HW_BM * XS;
-    _Float16* W1h = Xl + HW_BM * XS;           // [16][XS]
-    _Float16* W1l = W1h + HW_HC * XS;
-    _Float16* W2s = W1l + HW_HC * XS;          // [C][WS]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lhi = lane >> 5;
-    const int pg = wave & 1, nh = wave >> 1;
-    const int m0 = blockIdx.x * HW_BM;
-    const _Float16* w1h_g = reinterpret_cast<const _Float16*>(p.w1h);
-    const _Float16* w1l_g = reinterpret_cast<const _Float16*>(p.w1l);
-    const _Float16* w2_g = reinterpret_cast<const _Float16*>(p.w2h);
-
-    float amax = 0.f;
-    {
-        constexpr int QPR = C / 4;
-        constexpr int XIT = HW_BM * QPR / 256;
-#pragma unroll 12
-        for (int it = 0; it < XIT; ++it) {
-            const int i = tid + 256 * it;
-            const int r = i / QPR, q = i - r * QPR;
-            const int m = min(m0 + r, p.M - 1);
-            f32x4 v = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.xld + 4 * q);
-            if (p.gate) v *= *reinterpret_cast<const f32x4*>(p.gate + (size_t)(m / p.HW) * C + 4 * q);
-            f16x4 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                _Float16 a, b;
-                hx_split(v[e], a, b);
-                hi[e] = a;
-                lo[e] = b;
-                amax = fmaxf(amax, fabsf(v[e]));
-            }
-            *reinterpret_cast<f16x4*>(&Xh[r * XS + 4 * q]) = hi;
-            *reinterpret_cast<f16x4*>(&Xl[r * XS + 4 * q]) = lo;
-        }
-    }
-    u32x4 wreg[WL];
-    auto piece = [&](int t, int j, const _Float16*& src, _Float16*& dst) {
-        if (t < 4 * C) {
-            const int comp = t / (2 * C), i = t - comp * (2 * C);
-            const int r = i / (C / 8), c8 = i - r * (C / 8);
-            src = (comp ? w1l_g : w1h_g) + (size_t)(j * HW_HC + r) * C + 8 * c8;
-            dst = (comp ? W1l : W1h) + r * XS + 8 * c8;
-        } else {
-            const int u = t - 4 * C;
-            const int r = u >> 2, c4 = u & 3;
-            src = w2_g + ((size_t)r * NCHUNK + j) * 32 + 8 * c4;
-            dst = W2s + r * WS + 8 * c4;
-        }
-    };
-    auto load_w = [&](int j) {
-#pragma unroll
-        for (int u = 0; u < WL; ++u) {
-            const _Float16* src;
-            _Float16* dst;
-            piece(tid + 256 * u, j, src, dst);
-            wreg[u] = *reinterpret_cast<const u32x4*>(src);
-        }
-    };
-    auto store_w = [&](int j) {
-#pragma unroll
-        for (int u = 0; u < WL; ++u) {
-            const _Float16* src;
-            _Float16* dst;
-            piece(tid + 256 * u, j, src, dst);
-            *reinterpret_cast<u32x4*>(dst) = wreg[u];
-        }
-    };
-    load_w(0);
-    store_w(0);
-    __syncthreads();
-
-    f32x16 y1[NTT], y2[NTT];
-#pragma unroll
-    for (int n = 0; n < NTT; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) y1[n][r] = y2[n][r] = 0.f;
-
-    const int xo = (pg * 32 + l31) * XS + 8 * lhi;
-    const int w1o = (l31 & 15) * XS + 8 * lhi;          // rows 16..31 of the MFMA tile repeat rows 0..15 (ignored)
-    const int w2o = (nh * NH + l31) * WS + 8 * lhi;
-    for (int j = 0; j < NCHUNK; ++j) {
-        const bool more = j + 1 < NCHUNK;
-        if (more) load_w(j + 1);
-        f32x4 b1v[2];
-#pragma unroll
-        for (int g = 0; g < 2; ++g) b1v[g] = *reinterpret_cast<const f32x4*>(p.b1 + j * HW_HC + g * 8 + 4 * lhi);
-        f32x16 h1, h2;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h1[r] = h2[r] = 0.f;
-        {
-            f16x8 ah[3], al[3], bh[3], bl[3];
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                ah[g] = *reinterpret_cast<const f16x8*>(&W1h[w1o + g * 16]);
-                bh[g] = *reinterpret_cast<const f16x8*>(&Xh[xo + g * 16]);
-                bl[g] = *reinterpret_cast<const f16x8*>(&Xl[xo + g * 16]);
-                al[g] = *reinterpret_cast<const f16x8*>(&W1l[w1o + g * 16]);
-            }
-#pragma unroll 6
-            for (int g = 0; g < KS1; ++g) {
-                const int c = g % 3, nx = (g + 2) % 3;
-                const int gn = min(g + 2, KS1 - 1);      // the last two iterations re-read the final fragments (ignored)
-                ah[nx] = *reinterpret_cast<const f16x8*>(&W1h[w1o + gn * 16]);
-                bh[nx] = *reinterpret_cast<const f16x8*>(&Xh[xo + gn * 16]);
-                bl[nx] = *reinterpret_cast<const f16x8*>(&Xl[xo + gn * 16]);
-                al[nx] = *reinterpret_cast<const f16x8*>(&W1l[w1o + gn * 16]);
-                h1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c], bh[c], h1, 0, 0, 0);
-                h2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c], bl[c], h2, 0, 0, 0);
-                h2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[c], bh[c], h2, 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            }
-        }
-        // registers 0..7: hidden 16j + 8*(r>>2) + 4*lhi + (r&3)
-        f16x8 hh, hl;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const float pre = fmaf(h2[r], 1.f / 2048.f, h1[r]) + b1v[r >> 2][r & 3];
-            const float v = hx_gelu(pre);
-            _Float16 a, b;
-            hx_split(v, a, b);
-            amax = fmaxf(amax, fabsf(v));
-            hh[r] = a;
-            hl[r] = b;
-        }
-        {
-            f16x8 bh[3], bl[3];
-#pragma unroll
-            for (int i = 0; i < 2 && i < NTT; ++i) {
-                bh[i] = *reinterpret_cast<const f16x8*>(&W2s[w2o + i * 32 * WS]);
-                bl[i] = *reinterpret_cast<const f16x8*>(&W2s[w2o + i * 32 * WS + 16]);
-            }
-#pragma unroll
-            for (int n = 0; n < NTT; ++n) {
-                const int c = n % 3, nx = (n + 2) % 3;
-                if (n + 2 < NTT) {
-                    bh[nx] = *reinterpret_cast<const f16x8*>(&W2s[w2o + (n + 2) * 32 * WS]);
-                    bl[nx] = *reinterpret_cast<const f16x8*>(&W2s[w2o + (n + 2) * 32 * WS + 16]);
-                }
-                y1[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hh, bh[c], y1[n], 0, 0, 0);
-                y2[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hh, bl[c], y2[n], 0, 0, 0);
-                y2[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hl, bh[c], y2[n], 0, 0, 0);
-                if (n + 2 < NTT) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                }
-            }
-        }
-        __syncthreads();
-        if (more) {
-            store_w(j + 1);
-            __syncthreads();
-        }
-    }
-    if (!(amax < 65504.f) && p.range_flag) atomicOr(p.range_flag, 1u);
-#pragma unroll
-    for (int n = 0; n < NTT; ++n) {
-        const int co = nh * NH + n * 32 + l31;
-        const float bv = p.b2[co];
-        float res[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = min(m0 + pg * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi, p.M - 1);
-            res[r] = p.x[(size_t)m * p.xld + co];
-            if (p.gate) res[r] *= p.gate[(size_t)(m / p.HW) * C + co];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + pg * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            if (m < p.M) p.y[(size_t)m * p.yld + co] = fmaf(y2[n][r], 1.f / 2048.f, y1[n][r]) + bv + res[r];
-        }
-    }
-}
-
-template <int C>
-static void launch_mixer_h3_wide_c(const MixerParams& p, hipStream_t s) {
-    const size_t sh = (size_t)(2 * (HW_BM + HW_HC) * (C + 8) + C * 40) * sizeof(_Float16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)lc_mixer_h3_wide_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((lc_mixer_h3_wide_kernel<C>), dim3((p.M + HW_BM - 1) / HW_BM), dim3(256), sh, s, p);
-}
-
 template <int C>
 static void launch_mixer_h3_c(const MixerParams& p, hipStream_t s) {
     const size_t sh = (size_t)(2 * (HX_BM + HX_HC) * (C + 8) + 2 * ((C + 31) / 32 * 32) * (HX_HC + 8)) * sizeof(_Float16);
@@ -497,11 +285,7 @@ void launch_mixer_fused_h3(const MixerParams& p, hipStream_t s) {
     switch (p.C) {
         case 48: launch_mixer_h3_c<48>(p, s); break;
         case 96: launch_mixer_h3_c<96>(p, s); break;
-        case 192:
-            if (p.dbg & 16) launch_mixer_h3_wide_c<192>(p, s);   // microbenchmark A/B only (needs the wide W2 packing)
-            else launch_mixer_h3_c<192>(p, s);
-            break;
-        case 384: launch_mixer_h3_wide_c<384>(p, s); break;
+        case 192: launch_mixer_h3_c<192>(p, s); break;
         default: break;
     }
 }
@@ -525,32 +309,6 @@ void prepare_mixer_weights_h3(const float* w1, const float* w2, int C, std::vect
             const int a = q >> 3, b = (q >> 2) & 1, c = q & 3;
             const int pos = 16 * (a >> 1) + 8 * b + 4 * (a & 1) + c;
             put(w2[(size_t)n * H2 + hid], w2h[(size_t)n * H2 + chunk * 32 + pos], w2l[(size_t)n * H2 + chunk * 32 + pos]);
-        }
-}
-
-bool mixer_h3_wide(int C) { return C == 384; }
-
-// wide kernel: w1 split as above; w2 [C][2C] -> [C][2C/16][32]: per row and hidden chunk of 16, 16 hi then 16 lo halfs,
-// hidden 8a + 4b + c stored at position 8b + 4a + c (registers 0..7 of the transposed GEMM1 tile)
-void prepare_mixer_weights_h3_wide(const float* w1, const float* w2, int C, std::vector<uint16_t>& w1h, std::vector<uint16_t>& w1l,
-                                   std::vector<uint16_t>& w2p) {
-    auto put = [](float v, uint16_t& hb, uint16_t& lb) {
-        const _Float16 h = (_Float16)v;
-        const _Float16 l = (_Float16)((v - (float)h) * 2048.f);
-        __builtin_memcpy(&hb, &h, 2);
-        __builtin_memcpy(&lb, &l, 2);
-    };
-    const int H2 = 2 * C, NCH = H2 / 16;
-    w1h.assign((size_t)H2 * C, 0); w1l.assign((size_t)H2 * C, 0);
-    w2p.assign((size_t)C * NCH * 32, 0);
-    for (size_t i = 0; i < (size_t)H2 * C; ++i) put(w1[i], w1h[i], w1l[i]);
-    for (int n = 0; n < C; ++n)
-        for (int hid = 0; hid < H2; ++hid) {
-            const int chunk = hid / 16, q = hid % 16;
-            const int a = q >> 3, b = (q >> 2) & 1, c = q & 3;
-            const int pos = 8 * b + 4 * a + c;
-            uint16_t* row = &w2p[((size_t)n * NCH + chunk) * 32];
-            put(w2[(size_t)n * H2 + hid], row[pos], row[16 + pos]);
         }
 }
 

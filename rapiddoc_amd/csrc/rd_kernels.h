@@ -171,9 +171,6 @@ struct MixerParams {
 };
 bool mixer_fused_supported(int C);
 void launch_mixer_fused_h3(const MixerParams& p, hipStream_t s);
-bool mixer_h3_wide(int C);   // widths served by the 64-pixel "wide" split kernel only (no fp32 fused counterpart)
-void prepare_mixer_weights_h3_wide(const float* w1, const float* w2, int C, std::vector<uint16_t>& w1h, std::vector<uint16_t>& w1l,
-                                   std::vector<uint16_t>& w2p);
 void prepare_mixer_weights_h3(const float* w1, const float* w2, int C, std::vector<uint16_t>& w1h, std::vector<uint16_t>& w1l,
                               std::vector<uint16_t>& w2h, std::vector<uint16_t>& w2l);
 void launch_mixer_fused(const MixerParams& p, hipStream_t s);
