@@ -57,12 +57,14 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
     for (int i = 0; i < 4; ++i) {
         const _Float16 h = (_Float16)v[i];
         hi[i] = h;
-        lo[i] = (_Float16)((v[i] - (float)h) * 2048.f);
+        // (v - hi) * 2048 as ONE fused op on the f16 source: exact (the difference is representable, the scale is a power
+        // of two), compiles to v_fma_mix{lo,hi}_f16 - 2 VALU ops per element instead of 4
+        lo[i] = (_Float16)__builtin_fmaf((float)h, -2048.f, v[i] * 2048.f);
     }
 }
 
 template <int BM, int BN, int WM, int WN, bool IS1X1>
-__global__ void __launch_bounds__(WM* WN * 64) conv_igemm_h3_kernel(ConvParams p, int ntn) {
+__global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 && BM * BN >= 128 * 128) ? 2 : 1) conv_igemm_h3_kernel(ConvParams p, int ntn, int ntiles) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int AL = BM * 8 / NT, BL = BN * 8 / NT;
@@ -75,15 +77,19 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_h3_kernel(ConvParams p
     __shared__ __attribute__((aligned(16))) _Float16 smem[(DB ? 2 : 1) * STAGE];
     constexpr int AH0 = 0, AL0 = BM * HLD, BH0 = 2 * BM * HLD, BL0 = 2 * BM * HLD + BN * HLD;
 
-    int tile_m, tile_n;
-    {
-        const int nwg = gridDim.x, id = blockIdx.x;
-        const int xcd = id & 7, j = id >> 3, q = nwg >> 3, r = nwg & 7;
+    // Output tiles are numbered so that XCD x (workgroup id % 8) owns one contiguous run of them: consecutive tiles share
+    // their A rows, which then stay in that XCD's L2.  The 8-wavefront configurations run PERSISTENT workgroups (one
+    // per CU, tiles v = id, id + grid, ...): the first K tile of the next output tile is requested before the epilogue
+    // of the current one, so its latency and the store drain no longer sit between two workgroups on a CU whose LDS
+    // only fits one of them.
+    int m0 = 0, n0 = 0;
+    auto map_tile = [&](int v) {
+        const int xcd = v & 7, j = v >> 3, q = ntiles >> 3, r = ntiles & 7;
         const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-        tile_m = w / ntn;
-        tile_n = w - tile_m * ntn;
-    }
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+        const int tile_m = w / ntn;
+        m0 = tile_m * BM;
+        n0 = (w - tile_m * ntn) * BN;
+    };
     const int tid = threadIdx.x;
     const int lrow = tid >> 3, lkq = tid & 7;
     const int K = p.K, Kp = (p.K + 7) & ~7;
@@ -91,6 +97,11 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_h3_kernel(ConvParams p
     const float* arow[AL];
     bool avalid[AL];
     int a_ih0[AL], a_iw0[AL];
+    const _Float16* bsrc[BL];
+    bool bvalid[BL];
+    int b_lds[BL], b_col[BL];
+    auto setup_tile = [&](int v) {
+    map_tile(v);
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
         const int m = m0 + lrow + (NT / 8) * i;
@@ -109,9 +120,6 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_h3_kernel(ConvParams p
         }
     }
     // B loader: BN*8 16-byte pieces (hi then lo), piece t -> (which, row, 8-half column)
-    const _Float16* bsrc[BL];
-    bool bvalid[BL];
-    int b_lds[BL], b_col[BL];
 #pragma unroll
     for (int i = 0; i < BL; ++i) {
         const int t = tid + NT * i;
@@ -123,23 +131,31 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_h3_kernel(ConvParams p
         b_col[i] = c * 8;
         b_lds[i] = (which ? BL0 : BH0) + r * HLD + c * 8;
     }
+    };
+    int v = blockIdx.x;
+    setup_tile(v);
 
-    f32x4 areg[AL];
-    u32x4 breg[BL];
-    unsigned amask = 0, bmask = 0;
+    // staging registers of one K tile.  The 8-wavefront (persistent) configurations keep TWO tiles in flight: with one,
+    // the K loop runs at one memory round trip (~1.8 us measured, 48 KB per CU in flight = 27 GB/s per CU) per K tile.
+    struct Stage {
+        f32x4 a[AL];
+        u32x4 b[BL];
+        unsigned am, bm;
+    };
+    Stage s0, s1;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const u32x4 zero4u = {0u, 0u, 0u, 0u};
 
-    auto load_tiles = [&](int k0) {
+    auto load_tiles = [&](int k0, Stage& st) {
         const int k = k0 + 4 * lkq;
         const bool kvalid = k < K;
         const int kk = kvalid ? k : 0;
-        amask = bmask = 0;
+        st.am = st.bm = 0;
         if (IS1X1) {
 #pragma unroll
             for (int i = 0; i < AL; ++i) {
-                areg[i] = *reinterpret_cast<const f32x4*>(arow[i] + kk);
-                amask |= (unsigned)(kvalid && avalid[i]) << i;
+                st.a[i] = *reinterpret_cast<const f32x4*>(arow[i] + kk);
+                st.am |= (unsigned)(kvalid && avalid[i]) << i;
             }
         } else {
             const int tap = kk / p.Cin, ci = kk - tap * p.Cin;
@@ -149,37 +165,44 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_h3_kernel(ConvParams p
                 const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
                 const bool ok = kvalid && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
                 const size_t off = ok ? ((size_t)ih * p.W + iw) * p.xld + ci : 0;
-                areg[i] = *reinterpret_cast<const f32x4*>(arow[i] + off);
-                amask |= (unsigned)ok << i;
+                st.a[i] = *reinterpret_cast<const f32x4*>(arow[i] + off);
+                st.am |= (unsigned)ok << i;
             }
         }
 #pragma unroll
         for (int i = 0; i < BL; ++i) {
             const int kb = k0 + b_col[i];
             const bool ok = kb < Kp && bvalid[i];
-            breg[i] = *reinterpret_cast<const u32x4*>(bsrc[i] + (ok ? kb : 0));
-            bmask |= (unsigned)ok << i;
+            st.b[i] = *reinterpret_cast<const u32x4*>(bsrc[i] + (ok ? kb : 0));
+            st.bm |= (unsigned)ok << i;
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, const Stage& sg) {
         _Float16* st = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < AL; ++i) {
             f16x4 hi, lo;
-            const f32x4 av = ((amask >> i) & 1u) ? areg[i] : zero4;
+            const f32x4 av = ((sg.am >> i) & 1u) ? sg.a[i] : zero4;
             split4(av, hi, lo);
             const int o = (lrow + (NT / 8) * i) * HLD + 4 * lkq;
             *reinterpret_cast<f16x4*>(&st[AH0 + o]) = hi;
             *reinterpret_cast<f16x4*>(&st[AL0 + o]) = lo;
         }
 #pragma unroll
-        for (int i = 0; i < BL; ++i) *reinterpret_cast<u32x4*>(&st[b_lds[i]]) = ((bmask >> i) & 1u) ? breg[i] : zero4u;
+        for (int i = 0; i < BL; ++i) *reinterpret_cast<u32x4*>(&st[b_lds[i]]) = ((sg.bm >> i) & 1u) ? sg.b[i] : zero4u;
     };
 
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
 
+    const int KT = (K + HBK - 1) / HBK;
+    const int aoff = ((wm * TM) * 32 + l31) * HLD + 8 * lhi;
+    const int boff = ((wn * TN) * 32 + l31) * HLD + 8 * lhi;
+    unsigned emax = 0;
+    load_tiles(0, s0);
+    if (DB && KT > 1) load_tiles(HBK, s1);
+    for (;;) {   // output tiles of this (persistent) workgroup
     f32x16 acc1[TM][TN], acc2[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -187,21 +210,11 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_h3_kernel(ConvParams p
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[i][j][r] = acc2[i][j][r] = 0.f;
-
-    const int KT = (K + HBK - 1) / HBK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    const int aoff = ((wm * TM) * 32 + l31) * HLD + 8 * lhi;
-    const int boff = ((wn * TN) * 32 + l31) * HLD + 8 * lhi;
-    for (int kt = 0; kt < KT; ++kt) {
-        const bool more = kt + 1 < KT;
-        if (more) load_tiles((kt + 1) * HBK);
-        const int cur = DB ? (kt & 1) : 0;
-        const _Float16* Ah = smem + cur * STAGE + AH0;
-        const _Float16* Al = smem + cur * STAGE + AL0;
-        const _Float16* Bh = smem + cur * STAGE + BH0;
-        const _Float16* Bl = smem + cur * STAGE + BL0;
+    auto compute = [&](int buf, int kt) {
+        const _Float16* Ah = smem + buf * STAGE + AH0;
+        const _Float16* Al = smem + buf * STAGE + AL0;
+        const _Float16* Bh = smem + buf * STAGE + BH0;
+        const _Float16* Bl = smem + buf * STAGE + BL0;
         const int kleft = K - kt * HBK;
         const int nks = kleft > 16 ? 2 : 1;
         for (int ks = 0; ks < nks; ++ks) {
@@ -225,27 +238,53 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_h3_kernel(ConvParams p
                     acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc2[i][j], 0, 0, 0);
                 }
         }
-        if (DB) {
-            if (more) store_tiles(cur ^ 1);
+    };
+    store_tiles(0, s0);
+    __syncthreads();
+    if (DB) {
+        // two LDS stages, two register stages: tile kt is multiplied from LDS while kt+1 is split into the other stage
+        // and kt+2 is on its way from memory
+        for (int kt = 0; kt < KT; kt += 2) {
+            if (kt + 2 < KT) load_tiles((kt + 2) * HBK, s0);
+            compute(0, kt);
+            if (kt + 1 < KT) store_tiles(1, s1);
             __syncthreads();
-        } else {
+            if (kt + 1 >= KT) break;
+            if (kt + 3 < KT) load_tiles((kt + 3) * HBK, s1);
+            compute(1, kt + 1);
+            if (kt + 2 < KT) store_tiles(0, s0);
+            __syncthreads();
+        }
+    } else {
+        for (int kt = 0; kt < KT; ++kt) {
+            const bool more = kt + 1 < KT;
+            if (more) load_tiles((kt + 1) * HBK, s0);
+            compute(0, kt);
             __syncthreads();
             if (more) {
-                store_tiles(0);
+                store_tiles(0, s0);
                 __syncthreads();
             }
         }
     }
 
+    // the next output tile's first K tile is requested now and lands while the epilogue below drains
+    const int em0 = m0, en0 = n0;
+    const int vnext = v + (int)gridDim.x;
+    const bool has_next = vnext < ntiles;
+    if (has_next) {
+        setup_tile(vnext);
+        load_tiles(0, s0);
+        if (DB && KT > 1) load_tiles(HBK, s1);
+    }
     // Range guard.  An activation beyond the fp16 range splits into hi = +-inf, which makes every output of its row
     // inf / NaN before the activation function - so the check sits here, on 32 outputs per thread, instead of in the
     // K loop (tracking max |a| there cost 35 % of the kernel's throughput).  Non-finite results that fp32 would also
     // produce only cost the caller a redundant fp32 re-run.
-    unsigned emax = 0;
     const int ohw = p.OH * p.OW;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + l31;
+        const int n = en0 + (wn * TN + j) * 32 + l31;
         if (n >= p.Ng) continue;
         int co = n, dy = 0, dx = 0;
         if (p.out_mode == OUT_DECONV2X2) {
@@ -257,7 +296,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_h3_kernel(ConvParams p
         const float bv = p.bias ? p.bias[co] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + (wm * TM + i) * 32 + 4 * lhi;
+            const int mb = em0 + (wm * TM + i) * 32 + 4 * lhi;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mb + (r & 3) + 8 * (r >> 2);
@@ -276,6 +315,9 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_h3_kernel(ConvParams p
                 }
             }
         }
+    }
+    if (!has_next) break;
+    v = vnext;
     }
     if (emax >= 0x7f800000u && p.range_flag) atomicOr(p.range_flag, 1u);
 }
@@ -302,12 +344,20 @@ static inline bool h3_is_1x1(const ConvParams& p) {
 }
 template <int BM, int BN, int WM, int WN>
 static void h3_launch_cfg(const ConvParams& p, hipStream_t s) {
-    const int ntm = (p.M + BM - 1) / BM, ntn = (p.Ng + BN - 1) / BN;
-    dim3 grid(ntm * ntn), block(WM * WN * 64);
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.Ng + BN - 1) / BN, ntiles = ntm * ntn;
+    // 8-wavefront tiles: persistent workgroups, one per CU (their two LDS stages leave room for one only)
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    const bool persistent = WM * WN == 8;
+    dim3 grid(persistent ? (ntiles < n_cu ? ntiles : n_cu) : ntiles), block(WM * WN * 64);
     if (h3_is_1x1(p))
-        hipLaunchKernelGGL((conv_igemm_h3_kernel<BM, BN, WM, WN, true>), grid, block, 0, s, p, ntn);
+        hipLaunchKernelGGL((conv_igemm_h3_kernel<BM, BN, WM, WN, true>), grid, block, 0, s, p, ntn, ntiles);
     else
-        hipLaunchKernelGGL((conv_igemm_h3_kernel<BM, BN, WM, WN, false>), grid, block, 0, s, p, ntn);
+        hipLaunchKernelGGL((conv_igemm_h3_kernel<BM, BN, WM, WN, false>), grid, block, 0, s, p, ntn, ntiles);
 }
 
 void launch_conv_igemm_h3(const ConvParams& p, hipStream_t s) {

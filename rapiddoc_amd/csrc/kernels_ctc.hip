@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(256) ctc_head_h3_kernel(CtcParams p, int cls_p
             for (int e = 0; e < 4; ++e) {
                 const _Float16 h = (_Float16)v[e];
                 hi[e] = h;
-                lo[e] = (_Float16)((v[e] - (float)h) * 2048.f);
+                lo[e] = (_Float16)__builtin_fmaf((float)h, -2048.f, v[e] * 2048.f);
                 amax = fmaxf(amax, fabsf(v[e]));
             }
             *reinterpret_cast<f16x4*>(&Xh[r * CH_LD + k]) = hi;

@@ -39,7 +39,7 @@ __device__ __forceinline__ float hx_gelu(float v) {
 }
 __device__ __forceinline__ void hx_split(float v, _Float16& hi, _Float16& lo) {
     hi = (_Float16)v;
-    lo = (_Float16)((v - (float)hi) * 2048.f);
+    lo = (_Float16)__builtin_fmaf((float)hi, -2048.f, v * 2048.f);   // exact; one v_fma_mix*_f16 (see kernels_conv_h3.hip)
 }
 
 template <int C>
