@@ -98,11 +98,13 @@ __global__ void __launch_bounds__(256) dwconv_tiled_kernel(DwParams p, int c4n, 
             if ((unsigned)ih >= (unsigned)p.H) continue;
             const float* xr = xb + (size_t)ih * p.W * p.xld;
             f32x4 row[NCOL];
+            // column loads are unconditional from a clamped address and masked afterwards (a predicated load costs one
+            // s_waitcnt per load); whole out-of-range ROWS are still skipped - with the short feature maps of the
+            // recogniser a third of the rows are padding, and loading them measured slower
 #pragma unroll
-            for (int j = 0; j < NCOL; ++j) {
-                const int iw = iw0 + j;
-                row[j] = ((unsigned)iw < (unsigned)p.W) ? *reinterpret_cast<const f32x4*>(xr + (size_t)iw * p.xld) : zero4;
-            }
+            for (int j = 0; j < NCOL; ++j) row[j] = *reinterpret_cast<const f32x4*>(xr + (size_t)min(max(iw0 + j, 0), p.W - 1) * p.xld);
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) row[j] = ((unsigned)(iw0 + j) < (unsigned)p.W) ? row[j] : zero4;
 #pragma unroll
             for (int kw = 0; kw < KW; ++kw) {
                 const f32x4 wv = *reinterpret_cast<const f32x4*>(p.w + (size_t)(kh * KW + kw) * p.C + c);

@@ -23,10 +23,13 @@ def canon(name):
     m = re.match(r"conv_igemm_kernel<128,(\d+),\d,\d,(true|false)>", name)
     if m:
         return "conv_igemm_kernel<128x%s,%s>" % (m.group(1), "1x1" if m.group(2) == "true" else "kxk")
+    m = re.match(r"conv_igemm_h3_kernel<(\d+),(\d+),\d,\d,(true|false)>", name)
+    if m:
+        return "conv_igemm_h3_kernel<%sx%s,%s>" % (m.group(1), m.group(2), "1x1" if m.group(3) == "true" else "kxk")
     m = re.match(r"lc_mixer_kernel<(\d+),0>", name)
     if m:
         return "lc_mixer_kernel<%s>" % m.group(1)
-    return name
+    return name   # lc_mixer_h3_kernel<C>, ctc_head_h3_kernel, ... already match bench.py's names
 
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
