@@ -212,9 +212,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "PP-DocLayout backbone (PPHGNetV2-B4 @800x800) + PP-OCRv6-small det (960x704) + rec "
                                    "(45 lines/page, fused CTC) on %d synthetic 1684x1191 pages per GPU" % P,
-                       "precision": "fp32 results; dense layers on fp32 MFMA, PPLCNetV4 channel mixers on split-fp16 MFMA "
-                                    "(3 MFMAs/product, fp32 accumulate, error vs fp64 <= fp32 MFMA's)" if pipe.det.precision == "auto"
-                                    else pipe.det.precision,
+                       "precision": "auto: fp32 in / fp32 accumulate / fp32 out; products of the channel mixers, the CTC head and the "
+                                    "wide convs on split-fp16 MFMA (x = hi + lo*2^-11, 3 MFMAs per product, error vs fp64 <= the fp32 "
+                                    "MFMA kernels'), fp32 MFMA for the rest; range-guarded with fp32 fallback (DESIGN.md s3)"
+                                    if pipe.det.precision == "auto" else pipe.det.precision,
                        "pages_per_gpu": P, "lines_per_step": n_lines, "host_stage_ms": host_stats, "parallelism": "page-sharded dp%d; %d page shards in flight per GPU" % (world, len(pool.pipes)),
                        "layout_head": "absent (ONNX-only in the reference; backbone only)",
                        "det_postprocess": "DB post-process (host C++) runs on maps rendered from the generator's line boxes "
