@@ -39,6 +39,36 @@ def det_resize_shape(h: int, w: int, limit_side_len: int = 960, limit_type: str 
     return rh, rw
 
 
+def det_buckets(region_hw: Sequence[Tuple[int, int]], langs: Sequence[str], det_batch_num: int = 1, stride: int = 64):
+    """Grouping of the text-region crops for batched detection (`_run_ocr_det_batch`,
+    rapid_doc/backend/pipeline/analyze_utils.py:150-189): first by language in order of first appearance, then by the
+    crop size rounded UP to multiples of 64 (first-appearance order again, insertion order inside a group); every group is
+    padded with 255 to its (H64, W64) and handed to `det_batch_predict` with batch = min(len(group), Det.rec_batch_num).
+    Returns [(lang, (H64, W64), [region indices], batch_size)].  The engine takes a whole group as one batch tensor
+    (`PagePipeline.det_forward` does this for full pages); `batch_size` is what the reference would have used."""
+    by_lang = {}
+    for i, lang in enumerate(langs):
+        by_lang.setdefault(lang, []).append(i)
+    out = []
+    for lang, idxs in by_lang.items():
+        groups = {}
+        for i in idxs:
+            h, w = int(region_hw[i][0]), int(region_hw[i][1])
+            key = (-(-h // stride) * stride, -(-w // stride) * stride)
+            groups.setdefault(key, []).append(i)
+        for key, members in groups.items():
+            out.append((lang, key, members, min(len(members), int(det_batch_num))))
+    return out
+
+
+def pad_to_bucket(img: np.ndarray, bucket_hw: Tuple[int, int]) -> np.ndarray:
+    """White (255) bottom/right padding of one crop to its bucket (analyze_utils.py:180-184)."""
+    h, w = img.shape[:2]
+    out = np.full((bucket_hw[0], bucket_hw[1], 3), 255, dtype=np.uint8)
+    out[:h, :w] = img
+    return out
+
+
 def build_characters(dict_lines: Sequence[str], use_space_char: bool = True) -> List[str]:
     """['blank'] + dictionary + [' ']  (class 0 is the CTC blank; reference SURVEY appendix A.2)."""
     chars = [ln.rstrip("\r\n") for ln in dict_lines]

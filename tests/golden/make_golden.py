@@ -390,5 +390,63 @@ def main():
     print(summary)
 
 
+
+def table_decode_golden():
+    """TableLabelDecode (table_structure/pp_structure/post_process.py:12-131) called on seeded random SLANet_plus-shaped
+    outputs.  The module is loaded by path inside stub packages (its package __init__ pulls cv2 / omegaconf)."""
+    import importlib.util
+    import types
+    base = REF / "rapid_doc/model/table/rapid_table_self"
+    for name in ("rt", "rt.utils", "rt.table_structure", "rt.table_structure.pp_structure"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    import enum
+    ty = types.ModuleType("rt.utils.typings")
+    src = (base / "utils/typings.py").read_text()
+    import ast
+    tree = ast.parse(src)
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "ModelType"][0]
+    ns = {"Enum": enum.Enum}
+    exec(compile(ast.Module(body=[cls], type_ignores=[]), "typings_ModelType", "exec"), ns)
+    ty.ModelType = ns["ModelType"]
+    sys.modules["rt.utils.typings"] = ty
+    for modname, rel in (("rt.table_structure.utils", "table_structure/utils.py"),
+                         ("rt.table_structure.pp_structure.post_process", "table_structure/pp_structure/post_process.py")):
+        sp = importlib.util.spec_from_file_location(modname, base / rel)
+        mod = importlib.util.module_from_spec(sp)
+        sys.modules[modname] = mod
+        sp.loader.exec_module(mod)
+    ref = sys.modules["rt.table_structure.pp_structure.post_process"]
+    vocab = ["<thead>", "</thead>", "<tbody>", "</tbody>", "<tr>", "</tr>", "<td>", "<td", ">", "</td>",
+             ' colspan="2"', ' colspan="3"', ' rowspan="2"', ' rowspan="3"']
+    for seed in range(4):
+        rng = np.random.default_rng(7000 + seed)
+        plus = seed != 3
+        dec = ref.TableLabelDecode(list(vocab), {"model_type": ty.ModelType.SLANETPLUS if plus else ty.ModelType.SLANET1M})
+        V = len(dec.character)
+        B, L = 3, 40
+        probs = rng.random((B, L, V)).astype(np.float32)
+        probs[:, :, dec.char_to_index["eos"]] *= 0.55 + 0.2 * seed      # controls where sequences stop
+        probs[0, 0, dec.char_to_index["eos"]] = 5.0                      # an eos at step 0 must not stop the sequence
+        probs[1, 3, dec.char_to_index["sos"]] = 5.0                      # ignored token mid-sequence
+        probs[:, 1, dec.char_to_index["<td></td>"]] = 6.0                # >= 1 cell per table: with none the reference
+        #                                                                  raises (np.all(axis=1) on an empty 1-D array)
+        bbox = rng.random((B, L, 8)).astype(np.float32)
+        bbox[2, rng.integers(0, L, 6)] = 0.0                             # placeholder boxes
+        shapes = np.array([[488, 488, 1.0, 1.0]] * B, dtype=np.float32)
+        oris = [np.zeros((int(rng.integers(200, 900)), int(rng.integers(200, 900)), 3), np.uint8) for _ in range(B)]
+        structs, boxes = dec.decode(bbox.copy(), probs.copy(), shapes, oris)
+        out = {"vocab": vocab, "slanet_plus": plus, "probs": probs.tolist(), "bbox": bbox.tolist(), "shapes": shapes.tolist(),
+               "ori_shapes": [list(o.shape[:2]) for o in oris],
+               "structs": [[t, s] for t, s in structs], "boxes": [np.asarray(b, dtype=np.float64).reshape(-1, 8).tolist() for b in boxes]}
+        (HERE / f"table_decode_seed{seed}.json").write_text(json.dumps(out))
+        print(f"table decode case {seed}: tokens per table {[len(t) for t, _ in structs]}, boxes {[len(b) for b in boxes]}")
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["table"]:       # only the table-decode vectors
+        table_decode_golden()
+    else:
+        main()
+        table_decode_golden()

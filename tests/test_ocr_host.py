@@ -81,3 +81,24 @@ def test_box_helpers_match_reference_golden(seed):
     assert got == g["merged"]
     got = [np.asarray(b).tolist() for b in H.update_det_boxes([q.copy() for q in quads], g["formulas"])]
     assert got == g["updated"]
+
+
+def test_det_buckets_follow_reference_grouping():
+    """analyze_utils.py:150-189: language groups in first-appearance order, then (ceil64 h, ceil64 w) buckets in
+    first-appearance order, members in input order, batch = min(len, Det.rec_batch_num)."""
+    hw = [(100, 200), (64, 64), (65, 129), (128, 256), (120, 250), (64, 60), (1, 1), (300, 10)]
+    langs = ["ch", "en", "ch", "ch", "ch", "en", "en", "ch"]
+    got = H.det_buckets(hw, langs, det_batch_num=2)
+    assert got == [
+        ("ch", (128, 256), [0, 3, 4], 2),
+        ("ch", (128, 192), [2], 1),
+        ("ch", (320, 64), [7], 1),
+        ("en", (64, 64), [1, 5, 6], 2),
+    ]
+    assert H.det_buckets([], [], 4) == []
+    # default Det.rec_batch_num is 1 in the reference (analyze_utils.py:113)
+    assert [b for *_, b in H.det_buckets(hw, langs)] == [1, 1, 1, 1]
+    img = np.arange(2 * 3 * 3, dtype=np.uint8).reshape(2, 3, 3)
+    pad = H.pad_to_bucket(img, (64, 64))
+    assert pad.shape == (64, 64, 3) and (pad[:2, :3] == img).all() and pad[2:].min() == 255 and pad[:, 3:].min() == 255
+
