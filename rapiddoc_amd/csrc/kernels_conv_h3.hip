@@ -362,6 +362,10 @@ static void h3_launch_cfg(const ConvParams& p, hipStream_t s) {
 
 void launch_conv_igemm_h3(const ConvParams& p, hipStream_t s) {
     if (p.M <= 0) return;
+    if (gemm_h3_dma_applies(p)) {   // pointwise, K % 32 == 0, wide: the LDS-DMA pipeline (kernels_gemm_h3_dma.hip)
+        launch_gemm_h3_dma(p, s);
+        return;
+    }
     switch (h3_pick_bn(p)) {
         case 32: h3_launch_cfg<128, 32, 4, 1>(p, s); break;
         case 64: h3_launch_cfg<128, 64, 4, 1>(p, s); break;

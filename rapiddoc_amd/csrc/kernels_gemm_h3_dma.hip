@@ -1,0 +1,258 @@
+// Split-fp16 GEMM for pointwise convolutions as an LDS-DMA pipeline (precision "auto" / "h3", K % 32 == 0).
+//
+// Same arithmetic as kernels_conv_h3.hip (x = hi + lo*2^-11, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulate),
+// different data path.  The register-staged kernel there runs at 14-37 % of the fp16 MFMA pipe: every K tile is a chain
+// load -> split in VALU -> ds_write -> barrier -> ds_read -> MFMA in which the phases of the wavefronts sharing a SIMD do
+// not overlap, and it cannot keep two K tiles in flight without spilling.  Here
+//   * both operands travel global -> LDS by `global_load_lds_dwordx4` (no staging VGPRs, no ds_write, no VALU):
+//     the activations as RAW fp32 rows, the weights already split at load time;
+//   * three LDS stages of 48 KB, counted `s_waitcnt vmcnt(6)` + a raw `s_barrier` per K tile: one tile is always in
+//     flight behind the one being multiplied (6 = DMA instructions per wavefront and tile);
+//   * the activation split moves to fragment-read time: a lane reads its 8 fp32 values of a k-step with two
+//     ds_read_b128 and splits them in registers (v_cvt_pk_f16_f32 + v_fma_mix*_f16);
+//   * a DMA writes wave-uniform base + lane*16, so the LDS images are unpadded; bank conflicts are avoided by XOR-swizzling
+//     the 16-byte chunk index with the row on the SOURCE address (A: chunk ^ ((row >> 1) & 7) in 128-byte rows, B:
+//     chunk ^ ((row >> 2) & 3) in 64-byte rows - both conflict-free for the ds_read_b128 lane groups of gfx950).
+// 256x128 output tile, 8 wavefronts (4 x 2, 64x64 each), persistent workgroups, XCD-contiguous tile order, epilogue and
+// range guard as in kernels_conv_h3.hip.
+#include <cstdlib>
+
+#include "rd_kernels.h"
+
+namespace rd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+static constexpr int DM = 256, DN = 128, DK = 32;
+static constexpr int D_A_BYTES = DM * DK * 4;             // 32 KB raw fp32 activations per stage
+static constexpr int D_B_BYTES = DN * DK * 2;             // 8 KB per weight plane (hi, lo)
+static constexpr int D_STAGE = D_A_BYTES + 2 * D_B_BYTES; // 48 KB
+static constexpr int D_NSTAGE = 3;
+
+__device__ __forceinline__ float dma_act(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return fmaxf(v, 0.f);
+        case ACT_GELU: {
+            const float z = fabsf(v) * 0.70710678118654752440f;
+            const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+            float poly = fmaf(1.061405429f, t, -1.453152027f);
+            poly = fmaf(poly, t, 1.421413741f);
+            poly = fmaf(poly, t, -0.284496736f);
+            poly = fmaf(poly, t, 0.254829592f);
+            const float erfz = 1.f - poly * t * __expf(-z * z);
+            return 0.5f * v * (1.f + copysignf(erfz, v));
+        }
+        case ACT_SILU: return v / (1.f + __expf(-v));
+        case ACT_SIGMOID: {
+            const float r = 1.f / (1.f + __expf(-v));
+            return (r != r) ? 0.f : r;
+        }
+        case ACT_HSIG: return fminf(fmaxf(v * (1.f / 6.f) + 0.5f, 0.f), 1.f);
+        case ACT_HSIG_PADDLE: return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f);
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ void dma16(const void* src, unsigned lds_byte_offset, unsigned char* smem) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(smem + lds_byte_offset), 16, 0, 0);
+}
+
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 h0 = (_Float16)a[e], h1 = (_Float16)b[e];
+        hi[e] = h0;
+        hi[4 + e] = h1;
+        lo[e] = (_Float16)__builtin_fmaf((float)h0, -2048.f, a[e] * 2048.f);
+        lo[4 + e] = (_Float16)__builtin_fmaf((float)h1, -2048.f, b[e] * 2048.f);
+    }
+}
+
+__global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int K = p.K, KT = K / DK;
+    const _Float16* wh = reinterpret_cast<const _Float16*>(p.wh);
+    const _Float16* wl = reinterpret_cast<const _Float16*>(p.wl);
+
+    // ---- DMA source addressing of this lane.  A: 4 instructions per wavefront and K tile, instruction j fills tile rows
+    // 32*wave + 8*j .. +7 (lane -> row + lane/8, chunk position lane%8).  B: one instruction per plane, rows 16*wave + lane/4.
+    int m0 = 0, n0 = 0;
+    const float* asrc[4];
+    const _Float16* bsrc_h;
+    const _Float16* bsrc_l;
+    auto setup_tile = [&](int v) {
+        const int xcd = v & 7, j = v >> 3, q = ntiles >> 3, r = ntiles & 7;
+        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        const int tile_m = w / ntn;
+        m0 = tile_m * DM;
+        n0 = (w - tile_m * ntn) * DN;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int row = 32 * wave + 8 * jj + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            const int m = min(m0 + row, p.M - 1);               // rows past M re-read the last row; never stored
+            asrc[jj] = p.x + (size_t)m * p.xld + 4 * c;
+        }
+        const int brow = 16 * wave + (lane >> 2);
+        const int bc = (lane & 3) ^ ((brow >> 2) & 3);
+        const size_t boff = (size_t)min(n0 + brow, p.Ng - 1) * K + 8 * bc;
+        bsrc_h = wh + boff;
+        bsrc_l = wl + boff;
+    };
+    auto issue_tile = [&](int kt, int stage) {
+        const unsigned base = (unsigned)stage * D_STAGE;
+        const int k0 = kt * DK;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) dma16(asrc[jj] + k0, base + (unsigned)(4 * wave + jj) * 1024u, smem);
+        dma16(bsrc_h + k0, base + D_A_BYTES + (unsigned)wave * 1024u, smem);
+        dma16(bsrc_l + k0, base + D_A_BYTES + D_B_BYTES + (unsigned)wave * 1024u, smem);
+    };
+
+    // ---- fragment addressing (byte offsets inside a stage)
+    int a_off[2][2], b_off[2][2];   // [tile][ks]: first of the two chunks (A) / the chunk (B)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int R = (wm * 2 + i) * 32 + l31, f = (R >> 1) & 7;
+        const int Rn = (wn * 2 + i) * 32 + l31, g = (Rn >> 2) & 3;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            a_off[i][ks] = R * 128 + (((2 * (lhi + 2 * ks)) ^ f) << 4);   // the partner chunk is this address ^ 16
+            b_off[i][ks] = D_A_BYTES + Rn * 64 + (((lhi + 2 * ks) ^ g) << 4);
+        }
+    }
+
+    unsigned emax = 0;
+    bool fresh = true;
+    int v = blockIdx.x;
+    setup_tile(v);
+    issue_tile(0, 0);
+    if (KT > 1) issue_tile(1, 1);
+    for (;;) {
+        f32x16 acc1[2][2], acc2[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[i][j][r] = acc2[i][j][r] = 0.f;
+
+        int stage = 0;
+        for (int kt = 0; kt < KT; ++kt) {
+            // tile kt has landed (this wavefront's own DMAs: all but the newest 6), then everybody's; the barrier also says
+            // every wavefront is done reading stage (kt + 2) % 3, which the next DMAs overwrite
+            // (the first K tile after an epilogue waits for everything: the epilogue's stores share the counter and are
+            //  not ordered against the DMA loads)
+            if (kt + 1 < KT && (kt > 0 || fresh)) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt + 2 < KT) issue_tile(kt + 2, stage >= 1 ? stage - 1 : 2);
+            const unsigned char* st = smem + stage * D_STAGE;
+            // One wavefront pair per SIMD cannot hide a ds_read -> split -> MFMA chain per k-step: all 16 fragment reads
+            // of the K tile are issued up front and the split of k-step 1 is scheduled between the MFMAs of k-step 0.
+            f32x4 xa[2][2][2];
+            f16x8 bh[2][2], bl[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    xa[ks][i][0] = *reinterpret_cast<const f32x4*>(st + a_off[i][ks]);
+                    xa[ks][i][1] = *reinterpret_cast<const f32x4*>(st + (a_off[i][ks] ^ 16));
+                    bh[ks][i] = *reinterpret_cast<const f16x8*>(st + b_off[i][ks]);
+                    bl[ks][i] = *reinterpret_cast<const f16x8*>(st + b_off[i][ks] + D_B_BYTES);
+                }
+            f16x8 ah0[2], al0[2], ah1[2], al1[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) split8(xa[0][i][0], xa[0][i][1], ah0[i], al0[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) split8(xa[1][i][0], xa[1][i][1], ah1[i], al1[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[i], bh[0][j], acc1[i][j], 0, 0, 0);
+                    acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[i], bl[0][j], acc2[i][j], 0, 0, 0);
+                    acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0[i], bh[0][j], acc2[i][j], 0, 0, 0);
+                }
+#pragma unroll
+            for (int g = 0; g < 12; ++g) {   // split of k-step 1 (~56 VALU ops) under the 12 MFMAs of k-step 0
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[i], bh[1][j], acc1[i][j], 0, 0, 0);
+                    acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[i], bl[1][j], acc2[i][j], 0, 0, 0);
+                    acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1[i], bh[1][j], acc2[i][j], 0, 0, 0);
+                }
+            stage = stage == 2 ? 0 : stage + 1;
+        }
+        // every wavefront must be past its last LDS read before the next output tile's DMAs land in stages 0 / 1
+        asm volatile("s_barrier" ::: "memory");
+        const int em0 = m0, en0 = n0;
+        const int vnext = v + (int)gridDim.x;
+        const bool has_next = vnext < ntiles;
+        if (has_next) {
+            setup_tile(vnext);
+            issue_tile(0, 0);
+            if (KT > 1) issue_tile(1, 1);
+        }
+        // ---- epilogue (bias, activation, residual, range guard on the pre-activation value: kernels_conv_h3.hip)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = en0 + (wn * 2 + j) * 32 + l31;
+            if (n >= p.Ng) continue;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int mb = em0 + (wm * 2 + i) * 32 + 4 * lhi;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (m >= p.M) continue;
+                    const float pre = fmaf(acc2[i][j][r], 1.f / 2048.f, acc1[i][j][r]) + bv;
+                    emax = max(emax, __float_as_uint(pre) & 0x7fffffffu);
+                    float o = dma_act(pre, p.act);
+                    if (p.res) o += p.res[(size_t)m * p.rld + n];
+                    p.y[(size_t)m * p.yld + n] = o;
+                }
+            }
+        }
+        if (!has_next) break;
+        v = vnext;
+        fresh = false;
+    }
+    if (emax >= 0x7f800000u && p.range_flag) atomicOr(p.range_flag, 1u);
+}
+
+bool gemm_h3_dma_applies(const ConvParams& p) {
+    static const bool off = [] { const char* e = getenv("RD_H3_DMA"); return e && e[0] == '0'; }();
+    return !off && p.wh && p.KH == 1 && p.KW == 1 && p.SH == 1 && p.SW == 1 && p.PT == 0 && p.PL == 0 && p.OH == p.H && p.OW == p.W &&
+           p.out_mode == OUT_NHWC && !p.ascale && p.K % DK == 0 && p.K >= 2 * DK && p.Ng > 96 && p.M >= 2048 && (p.xld % 4) == 0;
+}
+
+void launch_gemm_h3_dma(const ConvParams& p, hipStream_t s) {
+    const int ntm = (p.M + DM - 1) / DM, ntn = (p.Ng + DN - 1) / DN, ntiles = ntm * ntn;
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    const size_t sh = (size_t)D_NSTAGE * D_STAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_h3_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_h3_dma_kernel, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), sh, s, p, ntn, ntiles);
+}
+
+}  // namespace rd

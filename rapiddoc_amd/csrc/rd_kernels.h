@@ -34,6 +34,8 @@ struct ConvParams {
 void launch_conv_igemm(const ConvParams& p, hipStream_t s);
 bool skinny_gemm_applies(int M, int K);   // true when launch_conv_igemm will take the small-M path that can fuse ln_g / ln_b
 // fp32-accurate variant on the fp16 matrix cores (3 MFMAs per product, see kernels_conv_h3.hip); needs p.wh / p.wl
+bool gemm_h3_dma_applies(const ConvParams& p);
+void launch_gemm_h3_dma(const ConvParams& p, hipStream_t s);
 void launch_conv_igemm_h3(const ConvParams& p, hipStream_t s);
 // a short human-readable tag of the tile configuration chosen for p (for the per-op profile)
 const char* conv_igemm_config_name(const ConvParams& p);
