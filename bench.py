@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--pages", type=int, default=PAGES_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-profile", type=str, default="")
-    ap.add_argument("--rec-batch", type=int, default=128)
+    ap.add_argument("--rec-batch", type=int, default=64)
     ap.add_argument("--rec-streams", type=int, default=8)
     ap.add_argument("--workers", type=int, default=1, help="page-batch shards in flight per GPU (host stages of one overlap GPU stages of the other)")
     args = ap.parse_args()
@@ -164,6 +164,8 @@ def main():
                 if op["kind"].startswith(("conv", "deconv")):  # name = the HIP kernel instantiation rocprofv3 reports
                     split = op["cfg"].endswith("/h3")
                     name = "conv_igemm%s_kernel<%s,%s>" % ("_h3" if split else "", op["cfg"].replace("/h3", ""), "1x1" if op["kind"] == "conv1x1" else "kxk")
+                    if op["cfg"].startswith("dma"):
+                        name = "gemm_h3_dma_kernel"
                 elif op["kind"] == "mixer_fused":
                     name = "lc_mixer_kernel<%s>" % op["cfg"][1:]
                 elif op["kind"] == "mixer_fused_h3":
@@ -176,7 +178,7 @@ def main():
                 a[0] += op["flops"]; a[1] += op["bytes"]; a[2] += op["ms"]; a[3] += 1
                 tot_ms += op["ms"]
             e.set_profiling(False)
-        mfma = {k: v for k, v in agg.items() if k.startswith(("conv_igemm", "lc_mixer", "ctc_head"))}
+        mfma = {k: v for k, v in agg.items() if k.startswith(("conv_igemm", "gemm_h3", "lc_mixer", "ctc_head"))}
         dom = max(mfma, key=lambda k: mfma[k][2])
         fl, by, ms, n = mfma[dom]
         ach = fl / (ms * 1e-3) / 1e12
@@ -186,7 +188,7 @@ def main():
             traffic = json.loads(tf.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
         # a split-fp16 kernel issues 3 fp16 MFMAs per fp32 product: its ceiling in algorithmic (fp32) FLOPs is the dense
         # fp16 MFMA peak / 3
-        peak = F16_MFMA_PEAK_TFLOPS / 3.0 if "_h3_" in dom else FP32_MFMA_PEAK_TFLOPS
+        peak = F16_MFMA_PEAK_TFLOPS / 3.0 if "_h3_" in dom else FP32_MFMA_PEAK_TFLOPS   # gemm_h3_dma_kernel, *_h3_kernel
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": round(by / n), "launches_per_step": n,
