@@ -287,3 +287,57 @@ def test_formula_recognizer_batch_predict(golden_dir):
         ref = ids[0, 1:].tolist()
         n = int(np.nonzero(gaps[0] < 1e-2)[0][0]) if (gaps[0] < 1e-2).any() else len(ref)
         assert out[i][:n] == ref[:n]
+
+
+@pytest.mark.parametrize("M,K,N", [(2048, 64, 128), (2049, 96, 130), (5000, 192, 384), (4097, 160, 97), (2560, 736, 200),
+                                   (3000, 120, 360), (2300, 384, 120), (70000, 48, 96)])
+def test_split_gemm_tails_match_fp64(M, K, N):
+    """The split-fp16 GEMM kernels (LDS-DMA pipeline for K % 32 == 0 and N > 96, register-staged tiles otherwise) on
+    ragged shapes: partial M / N tiles, K of 2..23 K tiles and K not a multiple of 32, against an fp64 product."""
+    import ctypes as C
+    from rapiddoc_amd import _lib
+    lib = _lib.load()
+    lib.rd_debug_time_gemm.restype = C.c_float
+    lib.rd_debug_time_gemm.argtypes = [C.c_int] * 5 + [C.c_void_p] * 6
+    g = torch.Generator(device="cuda").manual_seed(M + K + N)
+    x = torch.rand((M, K), device="cuda", generator=g) - 0.5
+    w = (torch.rand((N, K), device="cuda", generator=g) - 0.5) * 0.2
+    b = torch.rand(N, device="cuda", generator=g) - 0.5
+    Kp = (K + 7) // 8 * 8
+    hi = w.half()
+    lo = ((w - hi.float()) * 2048.0).half()
+    wh = torch.zeros((N, Kp), dtype=torch.float16, device="cuda"); wh[:, :K] = hi
+    wl = torch.zeros((N, Kp), dtype=torch.float16, device="cuda"); wl[:, :K] = lo
+    y = torch.full((M + 8, N), 777.0, device="cuda")          # guard rows: nothing may be written past M
+    lib.rd_debug_time_gemm(M, K, N, 1, 1, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), wh.data_ptr(), wl.data_ptr())
+    torch.cuda.synchronize()
+    ref = torch.relu(x.double() @ w.double().t() + b.double())
+    assert float((y[:M].double() - ref).abs().max()) < 2e-6
+    assert float((y[M:] - 777.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("C_,M", [(48, 1000), (96, 4097), (192, 333), (192, 12800 + 5)])
+@pytest.mark.parametrize("variant", [0, 100])
+def test_fused_mixer_kernels_match_fp64(C_, M, variant):
+    """Fused channel mixer x + W2 gelu(W1 x + b1) + b2 (rec_lcnetv4.py:226-236): fp32-MFMA kernel (variant 0, C = 192
+    only in the debug entry) and split-fp16 kernel (variant 100) on a ragged pixel count, against fp64."""
+    import ctypes as C
+    from rapiddoc_amd import _lib
+    if variant == 0 and C_ != 192:
+        pytest.skip("the fp32 debug entry is instantiated for C = 192")
+    lib = _lib.load()
+    lib.rd_debug_time_mixer.restype = C.c_float
+    lib.rd_debug_time_mixer.argtypes = [C.c_int] * 4 + [C.c_void_p] * 6
+    g = torch.Generator(device="cuda").manual_seed(C_ + M)
+    x = torch.rand((M, C_), device="cuda", generator=g) - 0.5
+    w1 = (torch.rand((2 * C_, C_), device="cuda", generator=g) - 0.5) * 0.2
+    w2 = (torch.rand((C_, 2 * C_), device="cuda", generator=g) - 0.5) * 0.2
+    b1 = torch.rand(2 * C_, device="cuda", generator=g) - 0.5
+    b2 = torch.rand(C_, device="cuda", generator=g) - 0.5
+    y = torch.full((M + 4, C_), 555.0, device="cuda")
+    lib.rd_debug_time_mixer(C_, M, variant, 1, x.data_ptr(), y.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr())
+    torch.cuda.synchronize()
+    xd = x.double()
+    ref = xd + torch.nn.functional.gelu(xd @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+    assert float((y[:M].double() - ref).abs().max()) < (2e-6 if variant == 0 else 1e-6)
+    assert float((y[M:] - 555.0).abs().max()) == 0.0
