@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--dump-profile", type=str, default="")
     ap.add_argument("--rec-batch", type=int, default=64)
     ap.add_argument("--rec-streams", type=int, default=8)
+    ap.add_argument("--rec-width-multiple", type=int, default=32, help="padded rec batch width is rounded up to this (plan-cache granularity)")
     ap.add_argument("--workers", type=int, default=1, help="page-batch shards in flight per GPU (host stages of one overlap GPU stages of the other)")
     args = ap.parse_args()
 
@@ -109,7 +110,7 @@ def main():
     from rapiddoc_amd.dist import gather_page_results
 
     states = load_states()
-    pool = PagePipelinePool(states, device=dev_index, workers=args.workers, rec_batch_num=args.rec_batch,
+    pool = PagePipelinePool(states, device=dev_index, workers=args.workers, rec_batch_num=args.rec_batch, rec_width_multiple=args.rec_width_multiple,
                             n_rec_streams=max(1, args.rec_streams // max(1, args.workers)))
     pipe = pool.pipes[0]
     P = args.pages
