@@ -31,7 +31,8 @@ static constexpr int BKP = 36;
 // libm erff's ~60 instructions.  GELU(x) = x/2 * (1 + erf(x/sqrt2)) as nn.GELU() (approximate='none').
 __device__ __forceinline__ float gelu_fast(float v) {
     const float z = fabsf(v) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+    // v_rcp_f32 (1 ulp) - `__frcp_rn` compiles to the 10-instruction IEEE division sequence (v_div_scale/fmas/fixup)
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
     float poly = fmaf(1.061405429f, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);
     poly = fmaf(poly, t, -0.284496736f);

@@ -29,7 +29,7 @@ static constexpr int HLD = 40;    // LDS row stride in halfs (64 B data + 16 B p
 
 __device__ __forceinline__ float h3_gelu(float v) {  // erf by A&S 7.1.26, see kernels_conv.hip
     const float z = fabsf(v) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
     float poly = fmaf(1.061405429f, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);
     poly = fmaf(poly, t, -0.284496736f);

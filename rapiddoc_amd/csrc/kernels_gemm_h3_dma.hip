@@ -36,7 +36,7 @@ __device__ __forceinline__ float dma_act(float v, int act) {
         case ACT_RELU: return fmaxf(v, 0.f);
         case ACT_GELU: {
             const float z = fabsf(v) * 0.70710678118654752440f;
-            const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+            const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
             float poly = fmaf(1.061405429f, t, -1.453152027f);
             poly = fmaf(poly, t, 1.421413741f);
             poly = fmaf(poly, t, -0.284496736f);

@@ -25,7 +25,7 @@ static constexpr int MX_HC = 32;
 // erf by Abramowitz-Stegun 7.1.26 (abs err <= 1.5e-7) - see kernels_conv.hip
 __device__ __forceinline__ float gelu_erf(float v) {
     const float z = fabsf(v) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
     float poly = fmaf(1.061405429f, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);
     poly = fmaf(poly, t, -0.284496736f);
