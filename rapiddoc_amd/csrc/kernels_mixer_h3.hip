@@ -42,22 +42,32 @@ __device__ __forceinline__ void hx_split(float v, _Float16& hi, _Float16& lo) {
     lo = (_Float16)__builtin_fmaf((float)hi, -2048.f, v * 2048.f);   // exact; one v_fma_mix*_f16 (see kernels_conv_h3.hip)
 }
 
-template <int C>
+// DBG: compile-time ablation bits for tools/microbench.py (1 no GELU, 2 no weight streaming, 4 skip GEMM1, 8 skip GEMM2);
+// run-time switches here would cut the chunk body into basic blocks the scheduler cannot move instructions across
+template <int C, int DBG>
 __global__ void __launch_bounds__(256, C <= 96 ? 2 : 1) lc_mixer_h3_kernel(MixerParams p) {
-    constexpr int XS = C + 8;              // LDS row stride (halfs) of X and the W1 chunk: conflict-free b128 reads
-    constexpr int WS = HX_HC + 8;          // W2 chunk row stride (halfs)
+    constexpr int XS = C + 8;              // LDS row stride (halfs) of the X tile: conflict-free b128 reads
     constexpr int NTT = (C + 31) / 32;
     constexpr int W2ROWS = NTT * 32;
     constexpr int KS1 = C / 16;            // k-steps of GEMM1
-    constexpr int WQ = C * 4;              // 16-byte pieces per weight chunk component (W1 hi: 32 x C halfs = C*4 pieces)
-    constexpr int WL = (4 * WQ + 255) / 256;   // pieces per thread: W1 hi, W1 lo, W2 hi, W2 lo
+    // Weight chunks arrive by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write, no address VALU in the
+    // loop).  A DMA writes wave-uniform base + lane*16, so the chunk images are UNPADDED and bank conflicts are avoided by
+    // XOR-swizzling the 16-byte chunk index with the row on the SOURCE side (W1: below; W2, rows of 32 halfs:
+    // chunk ^ ((row >> 2) & 3)) - conflict-free for the ds_read_b128 lane groups.
+    // W1 rows are 2C bytes: consecutive rows start 32 / 16 / 8 dwords... apart modulo the 64 banks, which fixes how many
+    // low chunk bits may be XORed (the swizzled chunk must stay inside its row: 24 / 12 / 6 chunks) and which row bits
+    // must drive them: C = 192: ^((row >> 1) & 7), C = 96: ^((row >> 2) & 3), C = 48: ^((row >> 3) & 1).
+    constexpr int SW1_SHIFT = C == 192 ? 1 : C == 96 ? 2 : 3, SW1_MASK = C == 192 ? 7 : C == 96 ? 3 : 1;
+    constexpr int NI = C / 8;              // DMA instructions per chunk and matrix: (2 planes x 32 x C halfs) / 1 KB
+    constexpr int NIW = (NI + 3) / 4;      // ... per wavefront
     extern __shared__ __attribute__((aligned(16))) _Float16 smemh[];
     _Float16* Xh = smemh;                      // [128][XS]
     _Float16* Xl = Xh + HX_BM * XS;
-    _Float16* W1h = Xl + HX_BM * XS;           // [32][XS]
-    _Float16* W1l = W1h + HX_HC * XS;
-    _Float16* W2h = W1l + HX_HC * XS;          // [W2ROWS][WS]
-    _Float16* W2l = W2h + W2ROWS * WS;
+    _Float16* W1h = Xl + HX_BM * XS;           // [32][C]   (lo plane follows)
+    _Float16* W1l = W1h + HX_HC * C;
+    _Float16* W2h = W1l + HX_HC * C;           // [W2ROWS][32]: only rows < C are ever written by the DMA
+    _Float16* W2l = W2h + W2ROWS * HX_HC;
+    float* B1s = reinterpret_cast<float*>(W2l + W2ROWS * HX_HC);       // [2C] hidden biases
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -94,51 +104,54 @@ __global__ void __launch_bounds__(256, C <= 96 ? 2 : 1) lc_mixer_h3_kernel(Mixer
             *reinterpret_cast<f16x4*>(&Xh[r * XS + 4 * q]) = hi;
             *reinterpret_cast<f16x4*>(&Xl[r * XS + 4 * q]) = lo;
         }
-        if (C % 32 != 0)
-            for (int i = tid; i < (W2ROWS - C) * WS; i += 256) W2h[C * WS + i] = W2l[C * WS + i] = (_Float16)0.f;
     }
-    // weight chunk j: W1 rows [32j, 32j+32) x C  and  W2 rows [0, C) x (permuted) hidden [32j, 32j+32)
-    u32x4 wreg[WL];
-    auto piece = [&](int t, int j, const _Float16*& src, _Float16*& dst) {
-        // t in [0, 4*WQ): 0..WQ W1 hi, WQ..2WQ W1 lo, then W2 hi, W2 lo
-        const int comp = t / WQ, i = t - comp * WQ;
-        if (comp < 2) {
-            const int r = i / (C / 8), c8 = i - r * (C / 8);
-            src = (comp == 0 ? w1h_g : w1l_g) + (size_t)(j * HX_HC + r) * C + 8 * c8;
-            dst = (comp == 0 ? W1h : W1l) + r * XS + 8 * c8;
-        } else {
-            const int r = i >> 2, c8 = i & 3;
-            src = (comp == 2 ? w2h_g : w2l_g) + (size_t)r * (2 * C) + j * HX_HC + 8 * c8;
-            dst = (comp == 2 ? W2h : W2l) + r * WS + 8 * c8;
-        }
-    };
-    auto load_w = [&](int j) {
+    // rows [C, W2ROWS) of both W2 planes (C = 48 only) are read by the last n-tile and never written by the DMA
+    if (C % 32 != 0)
+        for (int i = tid; i < (W2ROWS - C) * HX_HC; i += 256) W2h[C * HX_HC + i] = W2l[C * HX_HC + i] = (_Float16)0.f;
+    for (int i = tid; i < 2 * C / 4; i += 256) *reinterpret_cast<f32x4*>(&B1s[4 * i]) = *reinterpret_cast<const f32x4*>(p.b1 + 4 * i);
+
+    // ---- DMA source addressing (per lane, chunk-independent part).  Instruction q of a matrix covers LDS bytes
+    // [q*1024, +1024) of its [hi plane | lo plane] image; wavefront w issues q = w, w + 4, ...
+    unsigned char* lds_bytes = reinterpret_cast<unsigned char*>(smemh);
+    const unsigned w1_base = (unsigned)((W1h - smemh) * 2), w2h_base = (unsigned)((W2h - smemh) * 2), w2l_base = (unsigned)((W2l - smemh) * 2);
+    const _Float16* src1[NIW];
+    const _Float16* src2[NIW];
+    unsigned dst1[NIW], dst2[NIW];
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
-        for (int u = 0; u < WL; ++u) {
-            const int t = tid + 256 * u;
-            if (t < 4 * WQ) {
-                const _Float16* src;
-                _Float16* dst;
-                piece(t, j, src, dst);
-                wreg[u] = *reinterpret_cast<const u32x4*>(src);
-            }
+    for (int u = 0; u < NIW; ++u) {
+        const int q = wv + 4 * u;
+        const int plane = q / (NI / 2), o = (q % (NI / 2)) * 1024 + lane * 16;
+        {   // W1 chunk image: 32 rows x 2C bytes per plane
+            const int row = o / (2 * C), cp = (o % (2 * C)) >> 4;
+            const int c = cp ^ ((row >> SW1_SHIFT) & SW1_MASK);
+            src1[u] = (plane ? w1l_g : w1h_g) + (size_t)row * C + 8 * c;
+            dst1[u] = w1_base + (unsigned)plane * (HX_HC * C * 2) + (unsigned)(q % (NI / 2)) * 1024u;
         }
+        {   // W2 chunk image: C rows x 64 bytes per plane
+            const int row = o >> 6, cp = (o & 63) >> 4;
+            const int c = cp ^ ((row >> 2) & 3);
+            src2[u] = (plane ? w2l_g : w2h_g) + (size_t)row * (2 * C) + 8 * c;
+            dst2[u] = (plane ? w2l_base : w2h_base) + (unsigned)(q % (NI / 2)) * 1024u;
+        }
+    }
+    auto dma = [&](const _Float16* src, unsigned dst) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds_bytes + dst), 16, 0, 0);
     };
-    auto store_w = [&](int j) {
+    auto issue_w1 = [&](int j) {
 #pragma unroll
-        for (int u = 0; u < WL; ++u) {
-            const int t = tid + 256 * u;
-            if (t < 4 * WQ) {
-                const _Float16* src;
-                _Float16* dst;
-                piece(t, j, src, dst);
-                *reinterpret_cast<u32x4*>(dst) = wreg[u];
-            }
-        }
+        for (int u = 0; u < NIW; ++u)
+            if (wv + 4 * u < NI) dma(src1[u] + (size_t)j * HX_HC * C, dst1[u]);
     };
-    load_w(0);
-    store_w(0);
-    __syncthreads();
+    auto issue_w2 = [&](int j) {
+#pragma unroll
+        for (int u = 0; u < NIW; ++u)
+            if (wv + 4 * u < NI) dma(src2[u] + j * HX_HC, dst2[u]);
+    };
+    issue_w1(0);
+    issue_w2(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // X tile, biases, chunk 0 of both matrices
 
     f32x16 y1[NTT], y2[NTT];
 #pragma unroll
@@ -147,38 +160,40 @@ __global__ void __launch_bounds__(256, C <= 96 ? 2 : 1) lc_mixer_h3_kernel(Mixer
         for (int r = 0; r < 16; ++r) y1[n][r] = y2[n][r] = 0.f;
 
     const int xo = (wave * 32 + l31) * XS + 8 * lhi;   // this lane's pixel row (B operand of GEMM1)
-    const int w1o = l31 * XS + 8 * lhi;                 // hidden row (A operand of GEMM1)
-    const int w2o = l31 * WS + 8 * lhi;                 // output-channel row (B operand of GEMM2)
+    const int f1 = (l31 >> SW1_SHIFT) & SW1_MASK, f2 = (l31 >> 2) & 3;   // swizzle keys of this lane's weight rows
+    const int w1row = l31 * C;                            // hidden row (A operand of GEMM1), halfs
+    const int w2row = l31 * HX_HC;                        // output-channel row (B operand of GEMM2), halfs
+    auto w1_at = [&](int ks) { return w1row + (((2 * ks + lhi) ^ f1) << 3); };
+    auto w2_at = [&](int n, int s2) { return n * 32 * HX_HC + w2row + (((2 * s2 + lhi) ^ f2) << 3); };
     constexpr int NCHUNK = 2 * C / HX_HC;
     for (int j = 0; j < NCHUNK; ++j) {
-        const bool more = (p.dbg & 2) ? false : j + 1 < NCHUNK;
-        if (more) load_w(j + 1);
-        f32x4 b1v[4];   // this chunk's hidden biases (issued early: the loads complete under GEMM1)
+        const bool more = (DBG & 2) ? false : j + 1 < NCHUNK;
+        f32x4 b1v[4];   // this chunk's hidden biases
 #pragma unroll
-        for (int g = 0; g < 4; ++g) b1v[g] = *reinterpret_cast<const f32x4*>(p.b1 + j * HX_HC + g * 8 + 4 * lhi);
+        for (int g = 0; g < 4; ++g) b1v[g] = *reinterpret_cast<const f32x4*>(&B1s[j * HX_HC + g * 8 + 4 * lhi]);
         // GEMM1 (transposed): Ht = W1c . X^T
         f32x16 h1, h2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) h1[r] = h2[r] = 0.f;
         // one wavefront per SIMD (LDS-limited): nothing hides a ds_read latency, so the fragments run through a
         // 3-deep register ring and the scheduler is told to interleave the reads of step g+2 with the MFMAs of step g
-        if (!(p.dbg & 4)) {
+        if (!(DBG & 4)) {
             f16x8 ah[3], al[3], bh[3], bl[3];
 #pragma unroll
             for (int g = 0; g < 2 && g < KS1; ++g) {
-                ah[g] = *reinterpret_cast<const f16x8*>(&W1h[w1o + g * 16]);
+                ah[g] = *reinterpret_cast<const f16x8*>(&W1h[w1_at(g)]);
                 bh[g] = *reinterpret_cast<const f16x8*>(&Xh[xo + g * 16]);
                 bl[g] = *reinterpret_cast<const f16x8*>(&Xl[xo + g * 16]);
-                al[g] = *reinterpret_cast<const f16x8*>(&W1l[w1o + g * 16]);
+                al[g] = *reinterpret_cast<const f16x8*>(&W1l[w1_at(g)]);
             }
 #pragma unroll
             for (int g = 0; g < KS1; ++g) {
                 const int c = g % 3, nx = (g + 2) % 3;
                 if (g + 2 < KS1) {
-                    ah[nx] = *reinterpret_cast<const f16x8*>(&W1h[w1o + (g + 2) * 16]);
+                    ah[nx] = *reinterpret_cast<const f16x8*>(&W1h[w1_at(g + 2)]);
                     bh[nx] = *reinterpret_cast<const f16x8*>(&Xh[xo + (g + 2) * 16]);
                     bl[nx] = *reinterpret_cast<const f16x8*>(&Xl[xo + (g + 2) * 16]);
-                    al[nx] = *reinterpret_cast<const f16x8*>(&W1l[w1o + (g + 2) * 16]);
+                    al[nx] = *reinterpret_cast<const f16x8*>(&W1l[w1_at(g + 2)]);
                 }
                 h1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c], bh[c], h1, 0, 0, 0);
                 h2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c], bl[c], h2, 0, 0, 0);
@@ -192,6 +207,10 @@ __global__ void __launch_bounds__(256, C <= 96 ? 2 : 1) lc_mixer_h3_kernel(Mixer
                 }
             }
         }
+        // every wavefront is done with W1 chunk j (and W2 chunk j, requested one barrier ago, has landed): request W1
+        // chunk j+1 - it lands under the GELU and GEMM2
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (more) issue_w1(j + 1);
         // bias + GELU in fp32, then split the 16 hidden values of this lane into the A fragments of GEMM2:
         // register r (hidden 8*(r>>2) + 4*lhi + (r&3)) is element r&7 of k-step r>>3
         f16x8 hh[2], hl[2];
@@ -202,7 +221,7 @@ __global__ void __launch_bounds__(256, C <= 96 ? 2 : 1) lc_mixer_h3_kernel(Mixer
             for (int e = 0; e < 4; ++e) {
                 const int r = g * 4 + e;
                 const float pre = fmaf(h2[r], 1.f / 2048.f, h1[r]) + bv[e];
-                const float v = (p.dbg & 1) ? pre : hx_gelu(pre);
+                const float v = (DBG & 1) ? pre : hx_gelu(pre);
                 _Float16 a, b;
                 hx_split(v, a, b);
                 amax = fmaxf(amax, fabsf(v));
@@ -211,20 +230,20 @@ __global__ void __launch_bounds__(256, C <= 96 ? 2 : 1) lc_mixer_h3_kernel(Mixer
             }
         }
         // GEMM2: Y += H . W2c^T (K = 32, two k-steps); W2's hidden columns were permuted at load time to match
-        if (!(p.dbg & 8)) {
+        if (!(DBG & 8)) {
             constexpr int NP = 2 * NTT;   // (k-step, n-tile) pairs, same 3-deep fragment ring
             f16x8 bh[3], bl[3];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                bh[i] = *reinterpret_cast<const f16x8*>(&W2h[w2o + (i % NTT) * 32 * WS + (i / NTT) * 16]);
-                bl[i] = *reinterpret_cast<const f16x8*>(&W2l[w2o + (i % NTT) * 32 * WS + (i / NTT) * 16]);
+                bh[i] = *reinterpret_cast<const f16x8*>(&W2h[w2_at(i % NTT, i / NTT)]);
+                bl[i] = *reinterpret_cast<const f16x8*>(&W2l[w2_at(i % NTT, i / NTT)]);
             }
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const int c = i % 3, nx = (i + 2) % 3, s = i / NTT, n = i % NTT;
                 if (i + 2 < NP) {
-                    bh[nx] = *reinterpret_cast<const f16x8*>(&W2h[w2o + ((i + 2) % NTT) * 32 * WS + ((i + 2) / NTT) * 16]);
-                    bl[nx] = *reinterpret_cast<const f16x8*>(&W2l[w2o + ((i + 2) % NTT) * 32 * WS + ((i + 2) / NTT) * 16]);
+                    bh[nx] = *reinterpret_cast<const f16x8*>(&W2h[w2_at((i + 2) % NTT, (i + 2) / NTT)]);
+                    bl[nx] = *reinterpret_cast<const f16x8*>(&W2l[w2_at((i + 2) % NTT, (i + 2) / NTT)]);
                 }
                 y1[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hh[s], bh[c], y1[n], 0, 0, 0);
                 y2[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hh[s], bl[c], y2[n], 0, 0, 0);
@@ -238,11 +257,9 @@ __global__ void __launch_bounds__(256, C <= 96 ? 2 : 1) lc_mixer_h3_kernel(Mixer
                 }
             }
         }
-        if (!(p.dbg & 2)) __syncthreads();
-        if (more) {
-            store_w(j + 1);
-            __syncthreads();
-        }
+        // every wavefront is done with W2 chunk j, and W1 chunk j+1 has landed: request W2 chunk j+1 (lands under GEMM1)
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (more) issue_w2(j + 1);
     }
     if (!(amax < 65504.f) && p.range_flag) atomicOr(p.range_flag, 1u);   // also catches NaN
     // ---- epilogue: + b2 + residual (re-read from global, so it stays exact fp32; unconditional clamped loads), strided store.
@@ -270,23 +287,34 @@ __global__ void __launch_bounds__(256, C <= 96 ? 2 : 1) lc_mixer_h3_kernel(Mixer
 }
 
 
-template <int C>
+template <int C, int DBG>
 static void launch_mixer_h3_c(const MixerParams& p, hipStream_t s) {
-    const size_t sh = (size_t)(2 * (HX_BM + HX_HC) * (C + 8) + 2 * ((C + 31) / 32 * 32) * (HX_HC + 8)) * sizeof(_Float16);
+    const size_t sh = (size_t)(2 * HX_BM * (C + 8) + 2 * HX_HC * C + 2 * ((C + 31) / 32 * 32) * HX_HC) * sizeof(_Float16) + 2 * C * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)lc_mixer_h3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute((const void*)lc_mixer_h3_kernel<C, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         attr_set = true;
     }
-    hipLaunchKernelGGL((lc_mixer_h3_kernel<C>), dim3((p.M + HX_BM - 1) / HX_BM), dim3(256), sh, s, p);
+    hipLaunchKernelGGL((lc_mixer_h3_kernel<C, DBG>), dim3((p.M + HX_BM - 1) / HX_BM), dim3(256), sh, s, p);
 }
 
 void launch_mixer_fused_h3(const MixerParams& p, hipStream_t s) {
     if (p.M <= 0) return;
     switch (p.C) {
-        case 48: launch_mixer_h3_c<48>(p, s); break;
-        case 96: launch_mixer_h3_c<96>(p, s); break;
-        case 192: launch_mixer_h3_c<192>(p, s); break;
+        case 48: launch_mixer_h3_c<48, 0>(p, s); break;
+        case 96: launch_mixer_h3_c<96, 0>(p, s); break;
+        case 192:
+            switch (p.dbg) {   // ablation variants: microbenchmark only
+                case 0: launch_mixer_h3_c<192, 0>(p, s); break;
+                case 1: launch_mixer_h3_c<192, 1>(p, s); break;
+                case 2: launch_mixer_h3_c<192, 2>(p, s); break;
+                case 4: launch_mixer_h3_c<192, 4>(p, s); break;
+                case 8: launch_mixer_h3_c<192, 8>(p, s); break;
+                case 10: launch_mixer_h3_c<192, 10>(p, s); break;
+                case 11: launch_mixer_h3_c<192, 11>(p, s); break;
+                default: launch_mixer_h3_c<192, 15>(p, s); break;
+            }
+            break;
         default: break;
     }
 }
