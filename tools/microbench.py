@@ -68,6 +68,14 @@ def gemm(M, K, N, act=0, iters=20, h3=False, check=False):
     return ms, 2.0 * M * K * N / ms / 1e9, err
 
 
+if __name__ == "__main__" and "--small" in sys.argv:
+    # the short / narrow layers of the recogniser's neck (LightSVTR): launch- and latency-bound
+    for (M, K, N) in ((4352, 120, 120), (4352, 120, 360), (4352, 240, 120), (4352, 384, 120), (10240, 120, 240), (10240, 384, 120)):
+        for h3 in (False, True):
+            ms, tf, err = gemm(M, K, N, 0, iters=50, h3=h3, check=True)
+            print(f"small gemm M={M} K={K} N={N} {'h3  ' if h3 else 'fp32'}: {ms*1e3:7.1f} us  {tf:6.1f} TF/s  err {err:.1e}")
+    sys.exit(0)
+
 if __name__ == "__main__" and "--h3only" in sys.argv:
     for (M, K, N) in ((131072, 192, 384), (131072, 384, 768), (131072, 768, 384), (81920, 2176, 512), (32768, 4096, 4096)):
         ms, tf, err = gemm(M, K, N, 0, h3=True, check=True)
