@@ -8,6 +8,9 @@
 //     hold hidden index 8*(r>>2) + 4*(lane>>5) + (r&3); W2's columns are therefore PERMUTED inside every 32-wide hidden
 //     chunk at weight-preparation time (position 16*(a>>1) + 8*b + 4*(a&1) + c for hidden 8a + 4b + c) so that one
 //     ds_read_b128 still yields the B fragment that matches registers 8s .. 8s+7.
+// Tried and dropped: a chunk-level software pipeline (GELU + split of chunk j in one scheduling region with the MFMAs of
+// GEMM1 for chunk j+1): it needs a second 32-register hidden accumulator, which at C = 192 (192 + 32 output / hidden
+// accumulators) spills 49-65 VGPRs (351 us instead of 194) and at C = 96 costs the second workgroup per CU (143 vs 118 us).
 // Tried and dropped: a "wide" variant for C = 384 / 192 (64-pixel tile, hidden chunks of 16, the four wavefronts as 2 pixel
 // groups x 2 output-channel halves so that two workgroups fit a CU).  GEMM1 and the GELU are then computed twice; it
 // measured 107 TF/s at C = 384 (the unfused pair of split-fp16 GEMMs reaches ~170) and 104 at C = 192 (this kernel: 160).
