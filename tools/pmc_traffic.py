@@ -26,6 +26,9 @@ def canon(name):
     m = re.match(r"conv_igemm_h3_kernel<(\d+),(\d+),\d,\d,(true|false)>", name)
     if m:
         return "conv_igemm_h3_kernel<%sx%s,%s>" % (m.group(1), m.group(2), "1x1" if m.group(3) == "true" else "kxk")
+    m = re.match(r"lc_mixer_h3_kernel<(\d+),0>", name)
+    if m:
+        return "lc_mixer_h3_kernel<%s>" % m.group(1)
     m = re.match(r"lc_mixer_kernel<(\d+),0>", name)
     if m:
         return "lc_mixer_kernel<%s>" % m.group(1)
