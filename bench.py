@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--rec-batch", type=int, default=64)
     ap.add_argument("--rec-streams", type=int, default=8)
     ap.add_argument("--rec-width-multiple", type=int, default=32, help="padded rec batch width is rounded up to this (plan-cache granularity)")
+    ap.add_argument("--inflight", type=int, default=1, help="page batches (steps) in flight per GPU: each runs a whole batch on its own "
+                    "pipeline / host thread, so the GPU has the next batch's det + layout while this one decodes")
     ap.add_argument("--workers", type=int, default=1, help="page-batch shards in flight per GPU (host stages of one overlap GPU stages of the other)")
     args = ap.parse_args()
 
@@ -113,6 +115,10 @@ def main():
     pool = PagePipelinePool(states, device=dev_index, workers=args.workers, rec_batch_num=args.rec_batch, rec_width_multiple=args.rec_width_multiple,
                             n_rec_streams=max(1, args.rec_streams // max(1, args.workers)))
     pipe = pool.pipes[0]
+    extra_pools = [PagePipelinePool(states, device=dev_index, workers=args.workers, rec_batch_num=args.rec_batch,
+                                    rec_width_multiple=args.rec_width_multiple,
+                                    n_rec_streams=max(1, args.rec_streams // max(1, args.workers))) for _ in range(max(1, args.inflight) - 1)]
+    pools = [pool] + extra_pools
     P = args.pages
     pages_np, boxes = synth_batch(rank * P, P)
     pages = torch.from_numpy(pages_np).cuda()
@@ -122,10 +128,46 @@ def main():
     text_maps = render_text_maps(boxes, pages_np.shape[1:3], det_hw, pages.device)
     quads = None
 
+    def compute(k=0):
+        res = pools[k].run_batch(pages, quads, det_maps_override=text_maps)
+        return [(rank * P + i, [(t, s) for _, t, s in r.lines]) for i, r in enumerate(res)]
+
     def step():
-        res = pool.run_batch(pages, quads, det_maps_override=text_maps)
-        payload = [(rank * P + i, [(t, s) for _, t, s in r.lines]) for i, r in enumerate(res)]
-        return gather_page_results(payload, dist)
+        return gather_page_results(compute(0), dist)
+
+    def run_steps(n):
+        """n steps; with --inflight > 1 they are dealt round-robin to `inflight` host threads (one pipeline each) and the
+        result collectives are issued from this thread in step order."""
+        if len(pools) == 1:
+            out = None
+            for _ in range(n):
+                out = step()
+            return out
+        from concurrent.futures import ThreadPoolExecutor
+        streams = [torch.cuda.Stream() for _ in pools]
+
+        def work(i):
+            torch.cuda.set_device(dev_index)
+            with torch.cuda.stream(streams[i % len(pools)]):
+                r = compute(i % len(pools))
+                torch.cuda.current_stream().synchronize()
+            return r
+        # one thread per pipeline: a pipeline is never used by two steps at once
+        with ThreadPoolExecutor(max_workers=len(pools)) as ex:
+            lanes = [[] for _ in pools]
+            futs = {}
+            for i in range(n):
+                lanes[i % len(pools)].append(i)
+            def lane_run(k):
+                return [(i, work(i)) for i in lanes[k]]
+            done = {}
+            for fut in [ex.submit(lane_run, k) for k in range(len(pools))]:
+                for i, r in fut.result():
+                    done[i] = r
+        out = None
+        for i in range(n):
+            out = gather_page_results(done[i], dist)
+        return out
 
     def fence():
         torch.cuda.synchronize()
@@ -134,11 +176,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        for k in range(len(pools)):
+            gather_page_results(compute(k), dist)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    out = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
     if dist:
@@ -219,7 +261,7 @@ def main():
                                     "wide convs on split-fp16 MFMA (x = hi + lo*2^-11, 3 MFMAs per product, error vs fp64 <= the fp32 "
                                     "MFMA kernels'), fp32 MFMA for the rest; range-guarded with fp32 fallback (DESIGN.md s3)"
                                     if pipe.det.precision == "auto" else pipe.det.precision,
-                       "pages_per_gpu": P, "lines_per_step": n_lines, "host_stage_ms": host_stats, "parallelism": "page-sharded dp%d; %d page shards in flight per GPU" % (world, len(pool.pipes)),
+                       "pages_per_gpu": P, "lines_per_step": n_lines, "host_stage_ms": host_stats, "parallelism": "page-sharded dp%d; %d page batch(es) in flight per GPU" % (world, len(pools)),
                        "layout_head": "absent (ONNX-only in the reference; backbone only)",
                        "det_postprocess": "DB post-process (host C++) runs on maps rendered from the generator's line boxes "
                                           "(random-weight det output has no text); its boxes drive crop+rec"},
