@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import ctypes as C
 import json
+import os
 from typing import Dict, List, Optional, Tuple, Union
 
 import numpy as np
@@ -38,7 +39,7 @@ class RdEngine:
             raise EngineError(self._l.rd_create_error().decode())
         self._tdev = torch.device("cuda", device)
         self._profiling = False
-        self.precision = "auto"
+        self.precision = os.environ.get("RD_PRECISION", "auto")   # the library reads the same variable in rd_create
         self.profile_log: List[dict] = []
 
     def close(self):
