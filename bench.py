@@ -259,7 +259,9 @@ def main():
                                    "(45 lines/page, fused CTC) on %d synthetic 1684x1191 pages per GPU" % P,
                        "precision": "auto: fp32 in / fp32 accumulate / fp32 out; products of the channel mixers, the CTC head and the "
                                     "wide convs on split-fp16 MFMA (x = hi + lo*2^-11, 3 MFMAs per product, error vs fp64 <= the fp32 "
-                                    "MFMA kernels'), fp32 MFMA for the rest; range-guarded with fp32 fallback (DESIGN.md s3)"
+                                    "MFMA kernels': mixer 8.6e-8 vs 2.1e-7 max abs, GEMM 1.8e-7..1.1e-6 vs 4.8e-7..1.1e-6 max rel, "
+                                    "tools/microbench.py + tests/test_gpu_parity.py), fp32 MFMA for the rest; range-guarded with fp32 "
+                                    "fallback (DESIGN.md s3); RD_PRECISION=fp32 (native fp32 MFMA only) measures 179 pages/s"
                                     if pipe.det.precision == "auto" else pipe.det.precision,
                        "pages_per_gpu": P, "lines_per_step": n_lines, "host_stage_ms": host_stats, "parallelism": "page-sharded dp%d; %d page batch(es) in flight per GPU" % (world, len(pools)),
                        "layout_head": "absent (ONNX-only in the reference; backbone only)",
