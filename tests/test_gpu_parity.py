@@ -163,10 +163,11 @@ def test_h3_precision_mode_matches_golden(golden_dir, monkeypatch):
         assert np.abs(f.cpu().numpy() - g[f"feat{i}"]).max() < TOL
 
 
-def test_native_fp32_precision_mode_matches_golden(golden_dir):
+def test_native_fp32_precision_mode_matches_golden(golden_dir, monkeypatch):
     """precision 'fp32' (native fp32 MFMA only, no split-fp16 mixer) meets the same bar, and the default 'auto' mode
     (split-fp16 channel mixers) agrees with it to fp32 noise."""
     from rapiddoc_amd.engine import REC_WANT_LOGITS, RdEngine
+    monkeypatch.setenv("RD_PRECISION", "auto")      # the suite may be run under RD_PRECISION=fp32 / h3
     st = W.synth_state_dict(W.load_manifest(golden_dir / "manifest_ppocrv6_rec.json"), 0)
     eng = RdEngine("ppocrv6_rec").load_weights(st)
     g = np.load(golden_dir / "rec_seed0_b3_w640.npz")
@@ -193,11 +194,12 @@ def _profile(eng, fn):
     return list(eng.profile_log)
 
 
-def test_range_guard_falls_back_to_fp32(golden_dir):
+def test_range_guard_falls_back_to_fp32(golden_dir, monkeypatch):
     """Split-fp16 operands must stay below 65504.  Activations beyond that raise the range flag (never a silently wrong
     answer) and the session repeats the call in native fp32; the result equals a pure-fp32 engine's bit for bit."""
     from rapiddoc_amd.engine import RdEngine
     from rapiddoc_amd.session import Mi355DetSession
+    monkeypatch.setenv("RD_PRECISION", "auto")
     st = W.synth_state_dict(W.load_manifest(golden_dir / "manifest_ppocrv6_det.json"), 0)
     big = dict(st)
     stem = [k for k in big if k.endswith("weight") and big[k].ndim == 4 and big[k].shape[1] == 3][0]
