@@ -148,9 +148,10 @@ __global__ void __launch_bounds__(256) ctc_head_h3_kernel(CtcParams p, int cls_p
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* Xh = reinterpret_cast<_Float16*>(smem);
     _Float16* Xl = Xh + CT_TOK * CH_LD;
-    _Float16* Wh = Xl + CT_TOK * CH_LD;
-    _Float16* Wl = Wh + CT_CLS * CH_LD;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    _Float16* Wh = Xl + CT_TOK * CH_LD;         // [128 classes][128] UNPADDED: filled by LDS-DMA, 16-byte chunk c of row r
+    _Float16* Wl = Wh + CT_CLS * CT_K;          // sits at chunk c ^ (r & 15) (rows are 256 B = a whole bank sweep apart)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
     const int split = blockIdx.x % p.nsplit, ttile = blockIdx.x / p.nsplit;
     const int tok0 = ttile * CT_TOK;
@@ -182,40 +183,40 @@ __global__ void __launch_bounds__(256) ctc_head_h3_kernel(CtcParams p, int cls_p
             *reinterpret_cast<f16x4*>(&Xl[r * CH_LD + k]) = lo;
         }
     }
-    // W tile: 128 classes x 128 halfs, hi and lo: 2 x 2048 16-byte pieces, 16 per thread
-    const int wrow = tid >> 4, wc8 = tid & 15;   // 16 rows x 16 pieces per pass
-    const u32x4 zero4u = {0u, 0u, 0u, 0u};
-    u32x4 wreg[16];
-    auto load_w = [&](int it) {
+    // W tile by LDS-DMA: 64 KB = 64 instructions of 1 KB per iteration, 16 per wavefront (no staging registers, no
+    // ds_write).  Instruction q covers bytes [q*1024, +1024) of [hi plane | lo plane]; lane -> (row, chunk position).
+    unsigned char* lds_bytes = reinterpret_cast<unsigned char*>(smem);
+    const unsigned w_base = (unsigned)((Wh - Xh) * 2);
+    int woff[16];            // element offset of this lane's source chunk inside a 128-class block of W
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int q = wave + 4 * u;                       // 0..63
+        const int o = (q & 31) * 1024 + lane * 16;        // byte offset inside the plane
+        const int row = o >> 8, cp = (o & 255) >> 4;
+        woff[u] = row * CT_K + 8 * (cp ^ (row & 15));
+    }
+    auto issue_w = [&](int it) {
         const int cb = c_begin + it * CT_CLS;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = cb + wrow + 16 * i;
-            const bool ok = c < c_end;
-            const size_t off = (size_t)(ok ? c : c_begin) * CT_K + 8 * wc8;
-            const u32x4 a = *reinterpret_cast<const u32x4*>(wh_g + off), b = *reinterpret_cast<const u32x4*>(wl_g + off);
-            wreg[i] = ok ? a : zero4u;
-            wreg[8 + i] = ok ? b : zero4u;
+        for (int u = 0; u < 16; ++u) {
+            const int q = wave + 4 * u;
+            const int row = woff[u] / CT_K;
+            // classes past the end of this split re-read its last class; their logits are masked to -inf below
+            const int cls = min(cb + row, c_end - 1);
+            const _Float16* src = ((q >> 5) ? wl_g : wh_g) + (size_t)cls * CT_K + (woff[u] - row * CT_K);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds_bytes + w_base + (unsigned)q * 1024u), 16, 0, 0);
         }
     };
-    auto store_w = [&]() {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            *reinterpret_cast<u32x4*>(&Wh[(wrow + 16 * i) * CH_LD + 8 * wc8]) = wreg[i];
-            *reinterpret_cast<u32x4*>(&Wl[(wrow + 16 * i) * CH_LD + 8 * wc8]) = wreg[8 + i];
-        }
-    };
-    load_w(0);
-    store_w();
-    __syncthreads();
+    issue_w(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     float m_run = -INFINITY, s_run = 0.f;
     int i_run = 0;
     const int xo = (wave * 32 + l31) * CH_LD + 8 * lhi;
-    const int wo = l31 * CH_LD + 8 * lhi;
+    const int wrow = l31 * CT_K, wkey = l31 & 15;
     for (int it = 0; it < nit; ++it) {
         const bool more = it + 1 < nit;
-        if (more) load_w(it + 1);
         f32x16 acc1[4], acc2[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
@@ -227,13 +228,17 @@ __global__ void __launch_bounds__(256) ctc_head_h3_kernel(CtcParams p, int cls_p
             const f16x8 bl = *reinterpret_cast<const f16x8*>(&Xl[xo + ks * 16]);
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
-                const f16x8 ah = *reinterpret_cast<const f16x8*>(&Wh[wo + ct * 32 * CH_LD + ks * 16]);
-                const f16x8 al = *reinterpret_cast<const f16x8*>(&Wl[wo + ct * 32 * CH_LD + ks * 16]);
+                const int wa = ct * 32 * CT_K + wrow + (((2 * ks + lhi) ^ wkey) << 3);
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(&Wh[wa]);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(&Wl[wa]);
                 acc1[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[ct], 0, 0, 0);
                 acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[ct], 0, 0, 0);
                 acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[ct], 0, 0, 0);
             }
         }
+        // every wavefront is done with this W tile: request the next one, it lands under the statistics below
+        asm volatile("s_barrier" ::: "memory");
+        if (more) issue_w(it + 1);
         const int cb = c_begin + it * CT_CLS + 4 * lhi;
         float lm = -INFINITY;
         int li = 0;
@@ -257,11 +262,7 @@ __global__ void __launch_bounds__(256) ctc_head_h3_kernel(CtcParams p, int cls_p
             if (lm > m_run) i_run = li;
             m_run = m_new;
         }
-        __syncthreads();
-        if (more) {
-            store_w();
-            __syncthreads();
-        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
     if (!(amax < 65504.f) && p.range_flag) atomicOr(p.range_flag, 1u);
     const float om = __shfl_xor(m_run, 32, 64), os = __shfl_xor(s_run, 32, 64);
@@ -307,7 +308,7 @@ void launch_ctc_head(const CtcParams& p, hipStream_t s) {
     int cps = (p.C + p.nsplit - 1) / p.nsplit;
     cps = (cps + 3) / 4 * 4;
     const size_t sh = (size_t)(CT_TOK + CT_CLS) * CT_LD * sizeof(float);
-    const size_t sh3 = (size_t)2 * (CT_TOK + CT_CLS) * CH_LD * sizeof(_Float16);
+    const size_t sh3 = (size_t)(2 * CT_TOK * CH_LD + 2 * CT_CLS * CT_K) * sizeof(_Float16);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)ctc_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
