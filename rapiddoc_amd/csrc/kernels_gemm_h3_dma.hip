@@ -15,6 +15,10 @@
 //     chunk ^ ((row >> 2) & 3) in 64-byte rows - both conflict-free for the ds_read_b128 lane groups of gfx950).
 // 256x128 output tile, 8 wavefronts (4 x 2, 64x64 each), persistent workgroups, XCD-contiguous tile order, epilogue and
 // range guard as in kernels_conv_h3.hip.
+// Tried and dropped: the same pipeline as an implicit GEMM for k x k convolutions (every lane's 16-byte chunk gathered by
+// the DMA from its tap, padding taps from a zero page, BN = 32 / 64 / 128): no faster than the register-staged kernel on
+// the stem and 3x3 layers (81 vs 92 TFLOP/s at N = 48..64) - with 3..27 K tiles per output tile those layers are bound by
+// the per-tile fixed costs, not by the staging path.
 #include <cstdlib>
 
 #include "rd_kernels.h"
