@@ -236,6 +236,133 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
     if (emax >= 0x7f800000u && p.range_flag) atomicOr(p.range_flag, 1u);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 16-wavefront variant of the same pipeline: 256x128 tile, wavefronts as 4 x 4 with 64x32 each (64 accumulator registers
+// instead of 128), so FOUR wavefronts share a SIMD instead of two.  The 8-wavefront kernel spends its time in phases that
+// do not overlap inside one wavefront (fragment read -> split -> MFMA); with twice the wavefronts the SIMD has another
+// wavefront's MFMAs to issue while one splits.  Costs: every A row tile is read and split by 4 wavefronts instead of 2.
+__global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int ntn, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..15
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int K = p.K, KT = K / DK;
+    const _Float16* wh = reinterpret_cast<const _Float16*>(p.wh);
+    const _Float16* wl = reinterpret_cast<const _Float16*>(p.wl);
+
+    // DMA per wavefront and K tile: A instructions 2*wave, 2*wave+1 (rows 16*wave .. +15), B instruction `wave` of
+    // [hi plane (8) | lo plane (8)]
+    int m0 = 0, n0 = 0;
+    const float* asrc[2];
+    const _Float16* bsrc;
+    auto setup_tile = [&](int v) {
+        const int xcd = v & 7, j = v >> 3, q = ntiles >> 3, r = ntiles & 7;
+        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        const int tile_m = w / ntn;
+        m0 = tile_m * DM;
+        n0 = (w - tile_m * ntn) * DN;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int row = 16 * wave + 8 * jj + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            asrc[jj] = p.x + (size_t)min(m0 + row, p.M - 1) * p.xld + 4 * c;
+        }
+        const int brow = 16 * (wave & 7) + (lane >> 2);
+        const int bc = (lane & 3) ^ ((brow >> 2) & 3);
+        bsrc = ((wave >> 3) ? wl : wh) + (size_t)min(n0 + brow, p.Ng - 1) * K + 8 * bc;
+    };
+    auto issue_tile = [&](int kt, int stage) {
+        const unsigned base = (unsigned)stage * D_STAGE;
+        const int k0 = kt * DK;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) dma16(asrc[jj] + k0, base + (unsigned)(2 * wave + jj) * 1024u, smem);
+        dma16(bsrc + k0, base + D_A_BYTES + (unsigned)(wave >> 3) * D_B_BYTES + (unsigned)(wave & 7) * 1024u, smem);
+    };
+    int a_off[2][2], b_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int R = (wm * 2 + i) * 32 + l31;
+            a_off[i][ks] = R * 128 + (((2 * (lhi + 2 * ks)) ^ ((R >> 1) & 7)) << 4);
+        }
+        const int Rn = wn * 32 + l31;
+        b_off[ks] = D_A_BYTES + Rn * 64 + (((lhi + 2 * ks) ^ ((Rn >> 2) & 3)) << 4);
+    }
+
+    unsigned emax = 0;
+    bool fresh = true;
+    int v = blockIdx.x;
+    setup_tile(v);
+    issue_tile(0, 0);
+    if (KT > 1) issue_tile(1, 1);
+    for (;;) {
+        f32x16 acc1[2], acc2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[i][r] = acc2[i][r] = 0.f;
+        int stage = 0;
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt + 1 < KT && (kt > 0 || fresh)) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt + 2 < KT) issue_tile(kt + 2, stage >= 1 ? stage - 1 : 2);
+            const unsigned char* st = smem + stage * D_STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 ah[2], al[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(st + a_off[i][ks]);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(st + (a_off[i][ks] ^ 16));
+                    split8(x0, x1, ah[i], al[i]);
+                }
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(st + b_off[ks]);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(st + b_off[ks] + D_B_BYTES);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc1[i], 0, 0, 0);
+                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc2[i], 0, 0, 0);
+                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc2[i], 0, 0, 0);
+                }
+            }
+            stage = stage == 2 ? 0 : stage + 1;
+        }
+        asm volatile("s_barrier" ::: "memory");
+        const int em0 = m0, en0 = n0;
+        const int vnext = v + (int)gridDim.x;
+        const bool has_next = vnext < ntiles;
+        if (has_next) {
+            setup_tile(vnext);
+            issue_tile(0, 0);
+            if (KT > 1) issue_tile(1, 1);
+        }
+        const int n = en0 + wn * 32 + l31;
+        if (n < p.Ng) {
+            const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int mb = em0 + (wm * 2 + i) * 32 + 4 * lhi;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (m >= p.M) continue;
+                    const float pre = fmaf(acc2[i][r], 1.f / 2048.f, acc1[i][r]) + bv;
+                    emax = max(emax, __float_as_uint(pre) & 0x7fffffffu);
+                    float o = dma_act(pre, p.act);
+                    if (p.res) o += p.res[(size_t)m * p.rld + n];
+                    p.y[(size_t)m * p.yld + n] = o;
+                }
+            }
+        }
+        if (!has_next) break;
+        v = vnext;
+        fresh = false;
+    }
+    if (emax >= 0x7f800000u && p.range_flag) atomicOr(p.range_flag, 1u);
+}
+
 bool gemm_h3_dma_applies(const ConvParams& p) {
     static const bool off = [] { const char* e = getenv("RD_H3_DMA"); return e && e[0] == '0'; }();
     return !off && p.wh && p.KH == 1 && p.KW == 1 && p.SH == 1 && p.SW == 1 && p.PT == 0 && p.PL == 0 && p.OH == p.H && p.OW == p.W &&
@@ -255,6 +382,20 @@ void launch_gemm_h3_dma(const ConvParams& p, hipStream_t s) {
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_h3_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         attr_set = true;
+    }
+    // measured (TFLOP/s, 8 vs 16 wavefronts): K192 117 / 127, K384 162 / 172, K768 214 / 215, K2176 263 / 252, K4096 288 / 274:
+    // the K loop itself runs at the same ~1.8 us per K tile with two or four wavefronts per SIMD (it is not latency hiding
+    // inside a SIMD that is missing); the 16-wavefront tile only drains its prologue / epilogue faster, which shows for short K
+    static const int force16 = [] { const char* e = getenv("RD_H3_DMA16"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    const bool use16 = force16 >= 0 ? force16 == 1 : p.K <= 384;
+    if (use16) {
+        static bool attr16 = false;
+        if (!attr16) {
+            (void)hipFuncSetAttribute((const void*)gemm_h3_dma16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+            attr16 = true;
+        }
+        hipLaunchKernelGGL(gemm_h3_dma16_kernel, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(1024), sh, s, p, ntn, ntiles);
+        return;
     }
     hipLaunchKernelGGL(gemm_h3_dma_kernel, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), sh, s, p, ntn, ntiles);
 }
