@@ -207,8 +207,8 @@ def main():
                 if op["kind"].startswith(("conv", "deconv")):  # name = the HIP kernel instantiation rocprofv3 reports
                     split = op["cfg"].endswith("/h3")
                     name = "conv_igemm%s_kernel<%s,%s>" % ("_h3" if split else "", op["cfg"].replace("/h3", ""), "1x1" if op["kind"] == "conv1x1" else "kxk")
-                    if op["cfg"].startswith("dma"):
-                        name = "gemm_h3_dma_kernel"
+                    if op["cfg"].startswith("dma"):   # LDS-DMA GEMM: 8-wavefront kernel, 16-wavefront one for K <= 384
+                        name = "gemm_h3_dma16_kernel" if op["cfg"].startswith("dma16w") else "gemm_h3_dma_kernel"
                 elif op["kind"] == "mixer_fused":
                     name = "lc_mixer_kernel<%s>" % op["cfg"][1:]
                 elif op["kind"] == "mixer_fused_h3":
