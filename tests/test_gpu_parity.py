@@ -343,3 +343,16 @@ def test_fused_mixer_kernels_match_fp64(C_, M, variant):
     ref = xd + torch.nn.functional.gelu(xd @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
     assert float((y[:M].double() - ref).abs().max()) < (2e-6 if variant == 0 else 1e-6)
     assert float((y[M:] - 555.0).abs().max()) == 0.0
+
+
+def test_forward_is_deterministic(engines, golden_dir):
+    """Same input, same handle, twice: bit-identical outputs (no atomics or run-to-run scheduling in the arithmetic; the SE
+    pooling is a fixed two-stage reduction, the split-fp16 kernels only use an atomic for the range flag)."""
+    eng, _ = engines["ppocrv6_rec"]
+    x = torch.from_numpy(np.load(golden_dir / "rec_seed0_b3_w640.npz")["x"]).cuda()
+    a = [t.clone() for t in eng.rec_forward(x)[:2]]
+    b = eng.rec_forward(x)[:2]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    eng, _ = engines["ppocrv6_det"]
+    x = torch.from_numpy(np.load(golden_dir / "det_seed0_b2_96x160.npz")["x"]).cuda()
+    assert torch.equal(eng.det_forward(x).clone(), eng.det_forward(x))
