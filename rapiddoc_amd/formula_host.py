@@ -76,10 +76,14 @@ class FormulaRecognizer:
 
     Returns one entry per input image: the decoded string when `token_decoder` (ids -> str, e.g. the reference's
     UniMERNetDecode.token2str with its downloaded tokenizer) is given, otherwise the list of generated token ids with the
-    start token, everything from EOS on, and padding removed."""
+    start token, everything from EOS on, and padding removed.  Alternatively pass `bpe_decode` (ids -> raw string: only the
+    tokenizer, whose JSON the reference downloads) and, optionally, `fix_text` (ftfy's): the LaTeX fix-ups in between are
+    this package's own (`rapiddoc_amd.latex_post`, pinned to the reference's)."""
 
     def __init__(self, weights, device: int = 0, max_new_tokens: Optional[int] = None,
-                 token_decoder: Optional[Callable[[List[int]], str]] = None):
+                 token_decoder: Optional[Callable[[List[int]], str]] = None,
+                 bpe_decode: Optional[Callable[[List[int]], str]] = None,
+                 fix_text: Optional[Callable[[str], str]] = None):
         import torch  # noqa: F401  (device memory + stream only)
         from . import weights as W
         from .engine import RdEngine
@@ -91,6 +95,12 @@ class FormulaRecognizer:
         self.encoder = RdEngine("pphgnetv2_b6_formula", device).load_weights({k: v for k, v in state.items() if k.startswith("backbone.")})
         self.decoder = RdEngine("ppformulanet_head", device).load_weights({k: v for k, v in state.items() if k.startswith("head.")})
         self.max_new_tokens = max_new_tokens or self.decoder.formula_max_new_tokens
+        if token_decoder is None and bpe_decode is not None:
+            from .latex_post import latex_postprocess
+
+            def token_decoder(ids, _bpe=bpe_decode, _fix=fix_text):   # UniMERNetDecode.token2str after the EOS cut
+                text = latex_postprocess(_bpe(ids))
+                return _fix(text) if _fix else text
         self.token_decoder = token_decoder
 
     def batch_predict(self, image_list: Sequence[np.ndarray], batch_size: int = 16, **kwargs) -> list:

@@ -444,9 +444,71 @@ def table_decode_golden():
         print(f"table decode case {seed}: tokens per table {[len(t) for t, _ in structs]}, boxes {[len(b) for b in boxes]}")
 
 
+
+def latex_post_golden():
+    """The string fix-ups of the formula path (pp_formulanet_plus/utils.py + UniMERNetDecode.remove_chinese_text_wrapping)
+    called on seeded LaTeX token soups.  utils.py imports only `re`; the method is lifted out of post_process.py with ast
+    (that module imports tokenizers / ftfy lazily but its package __init__ pulls cv2)."""
+    import ast
+    import importlib.util
+    import re as _re
+    base = REF / "rapid_doc/model/formula/rapid_formula_self/model_handler/pp_formulanet_plus"
+    sp = importlib.util.spec_from_file_location("ref_latex_utils", base / "utils.py")
+    U = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(U)
+    tree = ast.parse((base / "post_process.py").read_text())
+    fn = [n for c in tree.body if isinstance(c, ast.ClassDef) and c.name == "UniMERNetDecode"
+          for n in c.body if isinstance(n, ast.FunctionDef) and n.name == "remove_chinese_text_wrapping"][0]
+    ns = {"re": _re}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "unwrap", "exec"), ns)
+    unwrap = lambda t: ns["remove_chinese_text_wrapping"](None, t)
+
+    def ref_post(t):     # UniMERNetDecode.post_process minus ftfy (post_process.py:350-381)
+        t = unwrap(t)
+        t = U.fix_latex_left_right(t, fix_delimiter=False)
+        t = U.fix_latex_environments(t)
+        t = U.remove_up_commands(t)
+        return U.remove_unsupported_commands(t)
+
+    vocab = ["\\left", "\\right", "(", ")", "[", "]", "\\{", "\\}", "{", "}", ".", "|", "\\lceil", "\\rceil", "x", "y", "1",
+             "+", "=", "^", "_", "\\frac", "\\begin{array}", "\\end{array}", "{c}", "{l l}", "\\begin{matrix}", "\\end{matrix}",
+             "\\begin{align*}", "\\end{align*}", "\\begin{align}", "\\end{align}", "\\begin{cases}", "\\end{cases}",
+             "\\begin{alig}", "\\upalpha", "\\uparrow", "\\uplus", "\\upsilon", "\\updownarrow", "\\upmu", "\\emph",
+             "\\protect", "\\lefteqn", "\\leftarrow", "\\rightarrow", "\\Leftarrow", "\\\\", "\\\\\\", "\\text{\u4e2d\u6587abc}",
+             "\\text { \u516c\u5f0f }", "\\text{abc}", '"', " ", " ", "\\null", "\\textsl", "&", "\\left.", "\\right.", "\\right)",
+             "\\left(", "\\left[", "\\right]", "\\left\\{", "\\right\\}"]
+    for seed in range(3):
+        rng = np.random.default_rng(9000 + seed)
+        ins, outs = [], []
+        for _ in range(250):
+            n = int(rng.integers(1, 28))
+            toks = [vocab[int(i)] for i in rng.integers(0, len(vocab), n)]
+            t = (" " if rng.random() < 0.5 else "").join(toks)
+            ins.append(t)
+            outs.append(ref_post(t))
+        # second family: \\left / \\right counts balanced by construction, braces opened and closed around them, so that the
+        # "\\right sits in another brace group than its \\left" relocation (utils.py:51-131) is exercised
+        vb = ["\\left(", "\\right)", "\\left[", "\\right.", "{", "}", "{", "}", "x", "\\{", "\\}", "\\\\", " ", "^", "\\frac"]
+        for _ in range(150):
+            n = int(rng.integers(2, 22))
+            toks = [vb[int(i)] for i in rng.integers(0, len(vb), n)]
+            nl = sum(t.startswith("\\left") for t in toks)
+            nr = sum(t.startswith("\\right") for t in toks)
+            toks = ["\\left("] * max(0, nr - nl) + toks + ["\\right)"] * max(0, nl - nr)
+            t = (" " if rng.random() < 0.5 else "").join(toks)
+            ins.append(t)
+            outs.append(ref_post(t))
+        changed = sum(a != b for a, b in zip(ins, outs))
+        (HERE / f"latex_post_seed{seed}.json").write_text(json.dumps({"inputs": ins, "outputs": outs}, ensure_ascii=False))
+        print(f"latex post case {seed}: {len(ins)} strings, {changed} changed by the reference")
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["table"]:       # only the table-decode vectors
         table_decode_golden()
+    elif sys.argv[1:] == ["latex"]:
+        latex_post_golden()
     else:
         main()
         table_decode_golden()
+        latex_post_golden()
