@@ -1,0 +1,167 @@
+"""OCR branch of the reference's page-batch driver, for GIVEN layout detections.
+
+`BatchAnalyze.__call__` (rapid_doc/backend/pipeline/batch_analyze.py:78-164) runs layout first; its network's neck /
+decoder exist only inside an ONNX file that is not available, so this module starts one step later: it takes
+the per-page layout detections (the dict schema of `RapidLayoutModel.batch_predict`: `layout_host.to_layout_dets`) and
+reproduces what follows for the text regions, keeping every image on the GPU:
+
+  `_run_ocr_det_batch` (analyze_utils.py:105-212)
+     crop each OCR region with a 50-px white margin, white out the formula boxes inside it, group the crops by language and
+     by size rounded up to 64, pad each group with 255, detect, DB post-process, sort / merge the boxes, cut them around the
+     formulas, map them back to page coordinates (`get_ocr_result_list`, utils/ocr_utils.py:361-431) -> OcrText spans
+  `_run_ocr_rec_postprocess` (analyze_utils.py:216-292)
+     recognise every span's line crop, write text / score, demote low-confidence spans
+
+Deviations (both documented in DESIGN.md s4): the recogniser batches the lines of one size group at a time (the reference
+sorts all lines of a language globally before chunking), and `rec_batch_num` is GPU sized.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import layout_host, ocr_host
+from .engine import preproc_resize_norm
+
+OCR_TEXT, LOW_SCORE_TEXT = 15, 16                 # utils/enum_class.py:103-104
+MIN_CONFIDENCE, MIN_WIDTH = 0.5, 3                # utils/ocr_utils.py:9-11
+PASTE = 50                                        # analyze_utils.py:131
+_SPECIAL = ("（204号", "（20", "（2", "（2号", "（20号", "号", "（204")   # analyze_utils.py:288
+
+
+def _formula_boxes_in_crop(formulas: Sequence[dict], useful: Sequence[int]) -> List[List[float]]:
+    """get_adjusted_mfdetrec_res (utils/ocr_utils.py:320-342): formula boxes in crop coordinates, those outside dropped."""
+    px, py, xmin, ymin, _xmax, _ymax, nw, nh = useful
+    out = []
+    for f in formulas:
+        x0, y0, x1, y1 = f["bbox"]
+        x0, y0, x1, y1 = x0 - xmin + px, y0 - ymin + py, x1 - xmin + px, y1 - ymin + py
+        if x1 < 0 or y1 < 0 or x0 > nw or y0 > nh:
+            continue
+        out.append([x0, y0, x1, y1])
+    return out
+
+
+def _int_box(b, h: int, w: int) -> Optional[List[int]]:
+    """normalize_to_int_bbox (utils/bbox_utils.py:6-55): floor / ceil, clip to the image, None if empty."""
+    x0, y0 = int(np.floor(b[0])), int(np.floor(b[1]))
+    x1, y1 = int(np.ceil(b[2])), int(np.ceil(b[3]))
+    x0, y0, x1, y1 = max(0, x0), max(0, y0), min(w, x1), min(h, y1)
+    return [x0, y0, x1, y1] if x1 > x0 and y1 > y0 else None
+
+
+class RegionOcr:
+    def __init__(self, pipeline, box_thresh: float = 0.3, unclip_ratio: float = 1.8, lang: str = "ch"):
+        """`pipeline`: a `rapiddoc_amd.pipeline.PagePipeline` (its det / rec engines and streams are reused).  box_thresh 0.3 /
+        unclip 1.8 are the page-OCR settings of backend/pipeline/model_init.py:73."""
+        self.pipe = pipeline
+        self.box_thresh, self.unclip_ratio, self.lang = box_thresh, unclip_ratio, lang
+
+    # ------------------------------------------------------------------ det on one size group
+    def _detect_group(self, canvases: torch.Tensor, maps_override: Optional[torch.Tensor] = None) -> List[np.ndarray]:
+        """canvases [b, H64, W64, 3] u8 RGB on the GPU -> per image the reading-order sorted, merged boxes [n,4,2] (group
+        image coordinates).  `maps_override` [b,1,dh,dw] replaces the network output as the post-process input (tests and
+        benchmarks with random weights, whose maps carry no text); the det forward still runs."""
+        b, H, W, _ = canvases.shape
+        dh, dw = ocr_host.det_resize_shape(H, W, 960, "max")
+        x = torch.empty((b, 3, dh, dw), dtype=torch.float32, device=canvases.device)
+        for i in range(b):   # DetPreProcess: BGR, (x/255 - 0.5)/0.5 (rapid_ocr.py:474-536)
+            preproc_resize_norm(canvases[i], (dh, dw), mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), interp=1, swap_rb=True, out=x[i])
+        maps = self.pipe.det.det_forward(x)
+        if self.pipe.det.precision != "fp32" and self.pipe.det.range_overflow():
+            self.pipe.det.set_precision("fp32")
+            maps = self.pipe.det.det_forward(x)
+        if maps_override is not None:
+            assert tuple(maps_override.shape) == tuple(maps.shape)
+            maps = maps_override
+        res = ocr_host.db_postprocess(maps.cpu().numpy(), [(H, W)] * b, thresh=0.3, box_thresh=self.box_thresh,
+                                      unclip_ratio=self.unclip_ratio)
+        out = []
+        for boxes, _scores in res:
+            if len(boxes) == 0:
+                out.append(np.zeros((0, 4, 2), np.float32))
+                continue
+            q = ocr_host.merge_det_boxes(ocr_host.sorted_boxes(boxes.astype(np.float32)))
+            out.append(np.asarray(q, dtype=np.float32).reshape(-1, 4, 2))
+        return out
+
+    # ------------------------------------------------------------------ whole batch
+    def __call__(self, pages: torch.Tensor, layout_dets_per_page: Sequence[Sequence[dict]], det_maps_fn=None) -> List[List[dict]]:
+        """pages [P,H,W,3] u8 RGB (GPU); returns, per page, the layout detections followed by their OcrText spans
+        (`layout_res` of the reference after both OCR stages).  `det_maps_fn(regions, (gh, gw), (dh, dw))` may supply the
+        det maps of a size group (see `_detect_group`); regions = [(page, region dict, useful_list)]."""
+        assert pages.is_cuda and pages.dtype == torch.uint8
+        P, H, W, _ = pages.shape
+        out: List[List[dict]] = [list(d) for d in layout_dets_per_page]
+        regions = []                                   # (page, region dict, useful_list, formula boxes in crop coords)
+        for p, dets in enumerate(layout_dets_per_page):
+            ocr_regions, _tables, formulas = layout_host.split_regions(dets)
+            for r in ocr_regions:
+                useful = layout_host.crop_geometry(r, PASTE, PASTE)
+                if useful[6] <= 2 * PASTE or useful[7] <= 2 * PASTE:
+                    continue
+                regions.append((p, r, useful, _formula_boxes_in_crop(formulas, useful)))
+        if not regions:
+            return out
+        groups = ocr_host.det_buckets([(u[7], u[6]) for _, _, u, _ in regions], [self.lang] * len(regions),
+                                      det_batch_num=len(regions))
+        for _lang, (gh, gw), members, _bs in groups:
+            canv = torch.full((len(members), gh, gw, 3), 255, dtype=torch.uint8, device=pages.device)
+            for k, ridx in enumerate(members):
+                p, _r, (px, py, x0, y0, x1, y1, _nw, _nh), fboxes = regions[ridx]
+                x0c, y0c, x1c, y1c = max(0, x0), max(0, y0), min(W, x1), min(H, y1)      # numpy slicing clips the same way
+                if x1c > x0c and y1c > y0c:
+                    canv[k, py + (y0c - y0): py + (y0c - y0) + (y1c - y0c), px + (x0c - x0): px + (x0c - x0) + (x1c - x0c)] = \
+                        pages[p, y0c:y1c, x0c:x1c]
+                nh, nw = regions[ridx][2][7], regions[ridx][2][6]
+                for fb in fboxes:                       # _apply_mask_boxes_to_image (analyze_utils.py:82-103)
+                    ib = _int_box(fb, nh, nw)
+                    if ib:
+                        canv[k, ib[1]:ib[3], ib[0]:ib[2]] = 255
+            override = None
+            if det_maps_fn is not None:
+                override = det_maps_fn([regions[i][:3] for i in members], (gh, gw), ocr_host.det_resize_shape(gh, gw, 960, "max"))
+            boxes_per_img = self._detect_group(canv, override)
+            spans_per_img: List[List[dict]] = []
+            quads_per_img: List[np.ndarray] = []
+            for k, ridx in enumerate(members):
+                p, r, useful, fboxes = regions[ridx]
+                boxes = list(boxes_per_img[k])
+                if boxes and fboxes:
+                    boxes = ocr_host.update_det_boxes(boxes, [{"bbox": fb} for fb in fboxes])
+                px, py, x0, y0 = useful[0], useful[1], useful[2], useful[3]
+                spans, quads = [], []
+                for q in boxes:
+                    q = np.asarray(q, dtype=np.float32).reshape(4, 2)
+                    p1, p2, p3, p4 = [list(map(float, pt)) for pt in q]
+                    if p3[0] - p1[0] < MIN_WIDTH:
+                        continue
+                    if ocr_host.quad_is_tilted([p1, p2, p3, p4]):      # utils/ocr_utils.py:392-404
+                        xc, yc = sum(pt[0] for pt in (p1, p2, p3, p4)) / 4, sum(pt[1] for pt in (p1, p2, p3, p4)) / 4
+                        nh_, nw_ = ((p4[1] - p1[1]) + (p3[1] - p2[1])) / 2, p3[0] - p1[0]
+                        p1, p2 = [xc - nw_ / 2, yc - nh_ / 2], [xc + nw_ / 2, yc - nh_ / 2]
+                        p3, p4 = [xc + nw_ / 2, yc + nh_ / 2], [xc - nw_ / 2, yc + nh_ / 2]
+                    poly = []
+                    for pt in (p1, p2, p3, p4):
+                        poly += [float(pt[0] - px + x0), float(pt[1] - py + y0)]
+                    spans.append({"category_id": OCR_TEXT, "original_label": r.get("original_label"),
+                                  "original_order": r.get("original_order", -1), "poly": poly, "score": 1, "text": ""})
+                    quads.append(q)                    # the line crop is taken from the UNcorrected box (:381-383)
+                spans_per_img.append(spans)
+                quads_per_img.append(np.asarray(quads, dtype=np.float32).reshape(-1, 4, 2))
+            texts = self.pipe.rec_forward_lines(canv, quads_per_img)
+            for k, ridx in enumerate(members):
+                p = regions[ridx][0]
+                for span, (text, score) in zip(spans_per_img[k], texts[k]):
+                    span["text"] = text
+                    span["score"] = float(f"{score:.3f}")
+                    if score < MIN_CONFIDENCE:
+                        span["category_id"] = LOW_SCORE_TEXT
+                    else:
+                        w_, h_ = span["poly"][4] - span["poly"][0], span["poly"][5] - span["poly"][1]
+                        if text in _SPECIAL and score < 0.8 and w_ < h_:
+                            span["category_id"] = LOW_SCORE_TEXT
+                    out[p].append(span)
+        return out

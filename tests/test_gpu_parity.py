@@ -356,3 +356,66 @@ def test_forward_is_deterministic(engines, golden_dir):
     eng, _ = engines["ppocrv6_det"]
     x = torch.from_numpy(np.load(golden_dir / "det_seed0_b2_96x160.npz")["x"]).cuda()
     assert torch.equal(eng.det_forward(x).clone(), eng.det_forward(x))
+
+
+def test_region_ocr_flow_on_given_layout(golden_dir):
+    """The OCR branch of BatchAnalyze for given layout detections (rapiddoc_amd/analyze.py): crops with a 50-px white
+    margin, 64-px size groups, det + DB post-process, box sort / merge / formula cut, page-coordinate spans, rec.  Random
+    weights give meaningless det maps, so the maps are rendered from the generator's line boxes; checked: one span per text
+    line, polys back in page coordinates, formula boxes cut out, schema and score conventions of the reference."""
+    from rapiddoc_amd.analyze import LOW_SCORE_TEXT, OCR_TEXT, RegionOcr
+    from rapiddoc_amd.pages import synth_batch
+    from rapiddoc_amd.pipeline import PagePipeline
+    states = {k: W.synth_state_dict(W.load_manifest(golden_dir / f"manifest_{k}.json"), 0) for k in ("ppocrv6_det", "ppocrv6_rec")}
+    pipe = PagePipeline(states, rec_batch_num=32)
+    pages_np, boxes = synth_batch(0, 2)
+    pages = torch.from_numpy(pages_np).cuda()
+    dets_per_page, expect = [], []
+    for p in range(2):
+        b = np.asarray(boxes[p], dtype=np.float64).reshape(-1, 4)
+        thirds = np.array_split(np.arange(len(b)), 3)
+        dets, n_lines = [], 0
+        for t, idx in enumerate(thirds):                      # three text regions, each the hull of its lines
+            x0, y0, x1, y1 = b[idx, 0].min() - 6, b[idx, 1].min() - 6, b[idx, 2].max() + 6, b[idx, 3].max() + 6
+            dets.append({"category_id": 1, "original_label": "text", "original_order": t, "score": 0.9,
+                         "poly": [x0, y0, x1, y0, x1, y1, x0, y1]})
+            n_lines += len(idx)
+        l0 = b[thirds[0][0]]                                  # an inline formula in the middle of the first line
+        fx0, fx1 = l0[0] + 0.4 * (l0[2] - l0[0]), l0[0] + 0.6 * (l0[2] - l0[0])
+        dets.append({"category_id": 13, "original_label": "inline_formula", "original_order": 9, "score": 0.9,
+                     "poly": [fx0, l0[1] - 1, fx1, l0[1] - 1, fx1, l0[3] + 1, fx0, l0[3] + 1]})
+        dets_per_page.append(dets)
+        expect.append(n_lines + 1)                            # the cut line becomes two spans
+
+    def maps_fn(regions, ghw, dhw):
+        (gh, gw), (dh, dw) = ghw, dhw
+        m = torch.zeros((len(regions), 1, dh, dw), dtype=torch.float32)
+        for k, (p, r, useful) in enumerate(regions):
+            px, py, x0, y0 = useful[:4]
+            for lb in np.asarray(boxes[p], dtype=np.float64).reshape(-1, 4):
+                if lb[0] >= r["poly"][0] and lb[2] <= r["poly"][4] and lb[1] >= r["poly"][1] and lb[3] <= r["poly"][5]:
+                    cx0, cy0, cx1, cy1 = lb[0] - x0 + px, lb[1] - y0 + py, lb[2] - x0 + px, lb[3] - y0 + py
+                    sy, sx = dh / gh, dw / gw
+                    # the DB map marks the SHRUNK text kernel (pipeline.render_text_maps: 0.32 x height per side)
+                    d = 0.32 * min(cx1 - cx0, cy1 - cy0)
+                    m[k, 0, int(round((cy0 + d) * sy)):int(round((cy1 - d) * sy)), int(round((cx0 + d) * sx)):int(round((cx1 - d) * sx))] = 0.95
+        return m.cuda()
+
+    out = RegionOcr(pipe)(pages, dets_per_page, det_maps_fn=maps_fn)
+    for p in range(2):
+        spans = [d for d in out[p] if d["category_id"] in (OCR_TEXT, LOW_SCORE_TEXT)]
+        assert out[p][: len(dets_per_page[p])] == dets_per_page[p]        # layout detections are passed through
+        assert len(spans) == expect[p], (len(spans), expect[p])
+        lines = np.asarray(boxes[p], dtype=np.float64).reshape(-1, 4)
+        for s in spans:
+            assert set(s) == {"category_id", "original_label", "original_order", "poly", "score", "text"}
+            assert isinstance(s["text"], str) and 0.0 <= s["score"] <= 1.0 and s["score"] == float(f"{s['score']:.3f}")
+            assert (s["category_id"] == LOW_SCORE_TEXT) == (s["score"] < 0.5)
+            x0, y0, x1, y1 = s["poly"][0], s["poly"][1], s["poly"][4], s["poly"][5]
+            # every span sits on a generator line (page coordinates), within the DB unclip slack
+            hit = (np.abs(lines[:, 1] - y0) < 8) & (np.abs(lines[:, 3] - y1) < 8) & (lines[:, 0] - 8 <= x0) & (x1 <= lines[:, 2] + 8)
+            assert hit.any(), s["poly"]
+        # the formula's x-range is not covered by any span of its line
+        f = dets_per_page[p][3]["poly"]
+        on_line = [s for s in spans if abs(s["poly"][1] - (f[1] + 1)) < 8]
+        assert len(on_line) == 2 and all(s["poly"][4] <= f[0] + 1 or s["poly"][0] >= f[4] - 1 for s in on_line)
