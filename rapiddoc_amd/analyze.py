@@ -3,7 +3,8 @@
 `BatchAnalyze.__call__` (rapid_doc/backend/pipeline/batch_analyze.py:78-164) runs layout first; its network's neck /
 decoder exist only inside an ONNX file that is not available, so this module starts one step later: it takes
 the per-page layout detections (the dict schema of `RapidLayoutModel.batch_predict`: `layout_host.to_layout_dets`) and
-reproduces what follows for the text regions, keeping every image on the GPU:
+reproduces what follows for the text regions (and, `recognise_formulas`, for the formula regions), keeping every image on
+the GPU:
 
   `_run_ocr_det_batch` (analyze_utils.py:105-212)
      crop each OCR region with a 50-px white margin, white out the formula boxes inside it, group the crops by language and
@@ -50,6 +51,32 @@ def _int_box(b, h: int, w: int) -> Optional[List[int]]:
     x1, y1 = int(np.ceil(b[2])), int(np.ceil(b[3]))
     x0, y0, x1, y1 = max(0, x0), max(0, y0), min(w, x1), min(h, y1)
     return [x0, y0, x1, y1] if x1 > x0 and y1 > y0 else None
+
+
+def recognise_formulas(pages: torch.Tensor, layout_dets_per_page: Sequence[Sequence[dict]], formula_model,
+                       expand_px: int = 2, batch_size: int = 16) -> int:
+    """Formula branch of BatchAnalyze (batch_analyze.py:258-283): every formula region (category 8 / 13 / 14) is cropped
+    - grown by `bbox_expand_px` where no neighbouring layout box is in the way - and handed to
+    `formula_model.batch_predict(images, batch_size=...)` (a `formula_host.FormulaRecognizer` or any CustomBaseModel-shaped
+    object); a non-empty result is written to the detection's `latex` field IN PLACE.  Returns the number of formulas."""
+    P, H, W, _ = pages.shape
+    targets, crops = [], []
+    for p, dets in enumerate(layout_dets_per_page):
+        for d in dets:
+            if int(d["category_id"]) not in layout_host.FORMULA_CATEGORY_IDS:
+                continue
+            c = layout_host.expand_formula_crop(d, dets, (H, W), expand_px)
+            x0, y0, x1, y1 = int(c["poly"][0]), int(c["poly"][1]), int(c["poly"][4]), int(c["poly"][5])
+            x0, y0, x1, y1 = max(0, x0), max(0, y0), min(W, x1), min(H, y1)
+            if x1 <= x0 or y1 <= y0:
+                continue
+            targets.append(d)
+            crops.append(pages[p, y0:y1, x0:x1].cpu().numpy())          # RGB crop, no margin (crop_img with paste 0)
+    if crops:
+        for d, res in zip(targets, formula_model.batch_predict(crops, batch_size=batch_size)):
+            if res:
+                d["latex"] = res
+    return len(crops)
 
 
 class RegionOcr:

@@ -191,6 +191,55 @@ def crop_geometry(det: dict, paste_x: int = 0, paste_y: int = 0) -> List[int]:
     return [paste_x, paste_y, x0, y0, x1, y1, x1 - x0 + 2 * paste_x, y1 - y0 + 2 * paste_y]
 
 
+def _int_rect(det: dict):
+    """Rounded bounding rectangle of a detection's poly (backend/utils/utils.py:175-182), None without a poly."""
+    poly = det.get("poly")
+    if not poly or len(poly) < 6:
+        return None
+    xs = [int(round(float(v))) for v in poly[0::2]]
+    ys = [int(round(float(v))) for v in poly[1::2]]
+    return min(xs), min(ys), max(xs), max(ys)
+
+
+def expand_formula_crop(formula: dict, layout_dets: Sequence[dict], image_hw: Tuple[int, int], expand_px: int = 2) -> dict:
+    """`_expand_formula_crop_res` (backend/utils/utils.py:189-243): the crop of a formula grows by `expand_px` on every side,
+    clipped to the page and stopped at any other layout box that lies beside / above / below it and overlaps the grown
+    extent in the other axis.  Returns the detection itself when nothing changes is possible, else a copy with the new
+    `poly` / `bbox` and without `polygon_points`."""
+    rect = _int_rect(formula) if expand_px > 0 else None
+    if rect is None:
+        return formula
+    H, W = image_hw[:2]
+    x0, y0, x1, y1 = rect
+    ex0, ey0, ex1, ey1 = max(0, x0 - expand_px), max(0, y0 - expand_px), min(W, x1 + expand_px), min(H, y1 + expand_px)
+
+    def overlap(a0, a1, b0, b1):
+        return max(a0, b0) < min(a1, b1)
+
+    for other in layout_dets:
+        if other is formula:
+            continue
+        r = _int_rect(other)
+        if r is None:
+            continue
+        ox0, oy0, ox1, oy1 = r
+        if ox1 <= x0 and overlap(ey0, ey1, oy0, oy1):
+            ex0 = max(ex0, ox1)
+        if ox0 >= x1 and overlap(ey0, ey1, oy0, oy1):
+            ex1 = min(ex1, ox0)
+        if oy1 <= y0 and overlap(ex0, ex1, ox0, ox1):
+            ey0 = max(ey0, oy1)
+        if oy0 >= y1 and overlap(ex0, ex1, ox0, ox1):
+            ey1 = min(ey1, oy0)
+    if ex0 >= ex1 or ey0 >= ey1:
+        return formula
+    out = dict(formula)
+    out["poly"] = [ex0, ey0, ex1, ey0, ex1, ey1, ex0, ey1]
+    out["bbox"] = [ex0, ey0, ex1, ey1]
+    out.pop("polygon_points", None)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # label -> CategoryId mapping and the per-box dict schema of RapidLayoutModel.batch_predict
 # (rapid_doc/model/layout/rapid_layout.py:55-108,131-227).  The tables are data captured from the reference

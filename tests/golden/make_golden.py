@@ -503,12 +503,55 @@ def latex_post_golden():
         print(f"latex post case {seed}: {len(ins)} strings, {changed} changed by the reference")
 
 
+
+def formula_expand_golden():
+    """_expand_formula_crop_res (backend/utils/utils.py:189-243): the formula crop grows by bbox_expand_px but not into a
+    neighbouring layout box.  Only that function (and its two helpers) is lifted out of the module with ast: the module
+    itself imports loguru / cv2-dependent packages."""
+    import ast
+    src = (REF / "rapid_doc/backend/utils/utils.py").read_text()
+    tree = ast.parse(src)
+    want = {"_rect_from_poly", "_ranges_overlap", "_expand_formula_crop_res"}
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    from typing import Dict, List, Optional, Tuple
+    ns = {"Dict": Dict, "List": List, "Optional": Optional, "Tuple": Tuple}
+    exec(compile(ast.Module(body=body, type_ignores=[]), "expand", "exec"), ns)
+    fn = ns["_expand_formula_crop_res"]
+    cases = []
+    for seed in range(40):
+        rng = np.random.default_rng(11000 + seed)
+        H_, W_ = int(rng.integers(300, 1700)), int(rng.integers(300, 1200))
+        dets = []
+        for k in range(int(rng.integers(2, 9))):
+            x0, y0 = float(rng.uniform(0, W_ - 40)), float(rng.uniform(0, H_ - 40))
+            w, h = float(rng.uniform(8, 300)), float(rng.uniform(8, 120))
+            dets.append({"category_id": 1, "poly": [x0, y0, x0 + w, y0, x0 + w, y0 + h, x0, y0 + h], "polygon_points": [1, 2]})
+        f = dets[0]
+        f["category_id"] = 14
+        if seed % 3 == 0 and len(dets) > 1:      # a neighbour that touches the formula on one side
+            p = f["poly"]
+            side = seed % 4
+            if side == 0: dets[1]["poly"] = [p[2] + 1, p[1], p[2] + 60, p[1], p[2] + 60, p[5], p[2] + 1, p[5]]
+            if side == 1: dets[1]["poly"] = [max(0.0, p[0] - 60), p[1], p[0] - 1, p[1], p[0] - 1, p[5], max(0.0, p[0] - 60), p[5]]
+            if side == 2: dets[1]["poly"] = [p[0], p[5] + 1, p[2], p[5] + 1, p[2], p[5] + 30, p[0], p[5] + 30]
+            if side == 3: dets[1]["poly"] = [p[0], max(0.0, p[1] - 30), p[2], max(0.0, p[1] - 30), p[2], p[1] - 1, p[0], p[1] - 1]
+        px = int(rng.integers(0, 6))
+        res = fn(f, dets, (H_, W_, 3), px)
+        cases.append({"dets": [{k: v for k, v in d.items()} for d in dets], "image_hw": [H_, W_], "expand_px": px,
+                      "poly": [float(v) for v in res["poly"]], "has_polygon_points": "polygon_points" in res})
+    (HERE / "formula_expand.json").write_text(json.dumps(cases))
+    print("formula expand: %d cases, %d changed" % (len(cases), sum(c["poly"] != [float(v) for v in c["dets"][0]["poly"]] for c in cases)))
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["table"]:       # only the table-decode vectors
         table_decode_golden()
     elif sys.argv[1:] == ["latex"]:
         latex_post_golden()
+    elif sys.argv[1:] == ["formula_expand"]:
+        formula_expand_golden()
     else:
         main()
         table_decode_golden()
         latex_post_golden()
+        formula_expand_golden()

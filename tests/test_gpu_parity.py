@@ -419,3 +419,31 @@ def test_region_ocr_flow_on_given_layout(golden_dir):
         f = dets_per_page[p][3]["poly"]
         on_line = [s for s in spans if abs(s["poly"][1] - (f[1] + 1)) < 8]
         assert len(on_line) == 2 and all(s["poly"][4] <= f[0] + 1 or s["poly"][0] >= f[4] - 1 for s in on_line)
+
+
+def test_formula_branch_on_given_layout(golden_dir):
+    """batch_analyze.py:258-283: formula regions are cropped (grown by 2 px unless a neighbour is in the way), recognised and
+    get a `latex` field; other detections are untouched.  Token ids stand in for the string (the tokenizer is download-only)."""
+    from rapiddoc_amd.analyze import recognise_formulas
+    from rapiddoc_amd.formula_host import FormulaRecognizer
+    man = W.load_manifest(golden_dir / "manifest_ppformulanet_plus_m_m8.json")
+    rec = FormulaRecognizer(W.synth_state_dict(man, 0), max_new_tokens=6)
+    rng = np.random.default_rng(5)
+    pages = torch.from_numpy(rng.integers(0, 255, (2, 400, 600, 3), dtype=np.uint8)).cuda()
+    pages[:, 100:160, 200:420] = 255
+    pages[:, 120:140, 230:390] = 30                                        # a dark "formula" on white
+    mk = lambda cid, x0, y0, x1, y1: {"category_id": cid, "poly": [x0, y0, x1, y0, x1, y1, x0, y1], "score": 0.9}
+    dets = [[mk(14, 200, 100, 420, 160), mk(1, 20, 20, 580, 90), mk(13, 230, 300, 300, 330)], [mk(8, 200, 100, 420, 160)]]
+    before = [[dict(d) for d in page] for page in dets]
+    n = recognise_formulas(pages, dets, rec)
+    assert n == 3
+    for page, page0 in zip(dets, before):
+        for d, d0 in zip(page, page0):
+            if d["category_id"] in (8, 13, 14):
+                assert {k: v for k, v in d.items() if k != "latex"} == d0
+                if "latex" in d:
+                    assert isinstance(d["latex"], list) and len(d["latex"]) <= 6 and all(isinstance(t, int) for t in d["latex"])
+            else:
+                assert d == d0 and "latex" not in d
+    assert "latex" in dets[0][0] and "latex" in dets[1][0]                # same crop content on both pages
+    assert dets[0][0]["latex"] == dets[1][0]["latex"]

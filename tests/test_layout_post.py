@@ -83,3 +83,16 @@ def test_category_tables_match_reference_capture():
     assert len(category_map("pp_doclayoutv2")) == 25
     dets = to_layout_dets([{"label": "table", "score": 0.87654, "coordinate": [1.5, 2.5, 30.0, 40.0]}], "pp_doclayoutv2", True)
     assert dets[0]["category_id"] == 5 and dets[0]["poly"] == [1.5, 2.5, 30.0, 2.5, 30.0, 40.0, 1.5, 40.0] and dets[0]["score"] == 0.877
+
+
+def test_expand_formula_crop_matches_reference(golden_dir):
+    """backend/utils/utils.py:189-243 on 40 seeded layouts (page clipping, neighbours on each side, expand_px 0..5)."""
+    from rapiddoc_amd.layout_host import expand_formula_crop
+    cases = json.loads((golden_dir / "formula_expand.json").read_text())
+    assert len(cases) == 40
+    for c in cases:
+        dets = c["dets"]
+        res = expand_formula_crop(dets[0], dets, tuple(c["image_hw"]), c["expand_px"])
+        assert [float(v) for v in res["poly"]] == c["poly"]
+        assert ("polygon_points" in res) == c["has_polygon_points"]
+
