@@ -15,46 +15,15 @@
 //   * epilogue fused: + bias (BN folded), activation, + residual, strided (channel-slice) store,
 //     or the 2x2/stride-2 transposed-conv scatter
 //   * 1-D grid with a bijective XCD swizzle so that the n-tiles sharing an A panel run on one XCD (L2)
-#include "rd_kernels.h"
+#include "rd_device.h"
 
 #include <cstdlib>
 
 namespace rd {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int BK = 32;
 static constexpr int BKP = 36;
-
-// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 round-off class): 1 exp + 1 rcp + 7 FMAs instead of
-// libm erff's ~60 instructions.  GELU(x) = x/2 * (1 + erf(x/sqrt2)) as nn.GELU() (approximate='none').
-__device__ __forceinline__ float gelu_fast(float v) {
-    const float z = fabsf(v) * 0.70710678118654752440f;
-    // v_rcp_f32 (1 ulp) - `__frcp_rn` compiles to the 10-instruction IEEE division sequence (v_div_scale/fmas/fixup)
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float erfz = 1.f - poly * t * __expf(-z * z);
-    return 0.5f * v * (1.f + copysignf(erfz, v));
-}
-
-__device__ __forceinline__ float act_apply(float v, int act) {
-    switch (act) {
-        case ACT_RELU: return fmaxf(v, 0.f);
-        case ACT_GELU: return gelu_fast(v);
-        case ACT_SILU: return v / (1.f + __expf(-v));
-        case ACT_SIGMOID: {
-            float r = 1.f / (1.f + __expf(-v));
-            return (r != r) ? 0.f : r;  // nan_to_num (det_db_head.py:143-144)
-        }
-        case ACT_HSIG: return fminf(fmaxf(v * (1.f / 6.f) + 0.5f, 0.f), 1.f);
-        case ACT_HSIG_PADDLE: return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f);
-        default: return v;
-    }
-}
 
 template <int BM, int BN, int WM, int WN, bool IS1X1>
 __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(ConvParams p, int ntn) {
@@ -224,7 +193,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_igemm_kernel(ConvParams p, i
             for (int r = 0; r < 16; ++r) {
                 const int m = mb + (r & 3) + 8 * (r >> 2);
                 if (m >= p.M) continue;
-                float v = act_apply(acc[i][j][r] + bv, p.act);
+                float v = rd_act(acc[i][j][r] + bv, p.act);
                 if (p.out_mode == OUT_NHWC) {
                     if (p.res) v += p.res[(size_t)m * p.rld + co];
                     p.y[(size_t)m * p.yld + co] = v;
@@ -358,12 +327,12 @@ __global__ void __launch_bounds__(256) skinny_gemm_kernel(ConvParams p, int cols
         }
         if (lane < p.M) {
             if (v0) {
-                float v = act_apply(r0 + (p.bias ? p.bias[n0] : 0.f), p.act);
+                float v = rd_act(r0 + (p.bias ? p.bias[n0] : 0.f), p.act);
                 if (p.res) v += p.res[(size_t)lane * p.rld + n0];
                 p.y[(size_t)lane * p.yld + n0] = v;
             }
             if (v1) {
-                float v = act_apply(r1 + (p.bias ? p.bias[n1] : 0.f), p.act);
+                float v = rd_act(r1 + (p.bias ? p.bias[n1] : 0.f), p.act);
                 if (p.res) v += p.res[(size_t)lane * p.rld + n1];
                 p.y[(size_t)lane * p.yld + n1] = v;
             }
@@ -442,8 +411,8 @@ __global__ void __launch_bounds__(256) stem_conv3x3s2_kernel(StemParams p) {
         float* yo = p.y + (((size_t)b * p.OH + oh) * p.OW + ow) * p.yld + g * CO_T;
 #pragma unroll
         for (int c = 0; c < CO_T; c += 4) {
-            f32x4 v = {act_apply(acc[c], p.act), act_apply(acc[c + 1], p.act), act_apply(acc[c + 2], p.act),
-                       act_apply(acc[c + 3], p.act)};
+            f32x4 v = {rd_act(acc[c], p.act), rd_act(acc[c + 1], p.act), rd_act(acc[c + 2], p.act),
+                       rd_act(acc[c + 3], p.act)};
             *reinterpret_cast<f32x4*>(yo + c) = v;
         }
     }

@@ -14,52 +14,21 @@
 #include <cstdlib>
 #include <vector>
 
-#include "rd_kernels.h"
+#include "rd_device.h"
 
 namespace rd {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int HBK = 32;    // K tile (fp32 elements)
 static constexpr int HLD = 40;    // LDS row stride in halfs (64 B data + 16 B pad: conflict-free ds_read_b128)
 
-__device__ __forceinline__ float h3_gelu(float v) {  // erf by A&S 7.1.26, see kernels_conv.hip
-    const float z = fabsf(v) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float erfz = 1.f - poly * t * __expf(-z * z);
-    return 0.5f * v * (1.f + copysignf(erfz, v));
-}
-__device__ __forceinline__ float h3_act(float v, int act) {
-    switch (act) {
-        case ACT_RELU: return fmaxf(v, 0.f);
-        case ACT_GELU: return h3_gelu(v);
-        case ACT_SILU: return v / (1.f + __expf(-v));
-        case ACT_SIGMOID: {
-            float r = 1.f / (1.f + __expf(-v));
-            return (r != r) ? 0.f : r;
-        }
-        case ACT_HSIG: return fminf(fmaxf(v * (1.f / 6.f) + 0.5f, 0.f), 1.f);
-        case ACT_HSIG_PADDLE: return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f);
-        default: return v;
-    }
-}
-
 __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const _Float16 h = (_Float16)v[i];
+        _Float16 h, l;
+        rd_split(v[i], h, l);
         hi[i] = h;
-        // (v - hi) * 2048 as ONE fused op on the f16 source: exact (the difference is representable, the scale is a power
-        // of two), compiles to v_fma_mix{lo,hi}_f16 - 2 VALU ops per element instead of 4
-        lo[i] = (_Float16)__builtin_fmaf((float)h, -2048.f, v[i] * 2048.f);
+        lo[i] = l;
     }
 }
 
@@ -303,7 +272,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 && BM * BN >= 128 *
                 if (m >= p.M) continue;
                 const float pre = fmaf(acc2[i][j][r], 1.f / 2048.f, acc1[i][j][r]) + bv;
                 emax = max(emax, __float_as_uint(pre) & 0x7fffffffu);
-                float v = h3_act(pre, p.act);
+                float v = rd_act(pre, p.act);
                 if (p.out_mode == OUT_NHWC) {
                     if (p.res) v += p.res[(size_t)m * p.rld + co];
                     p.y[(size_t)m * p.yld + co] = v;

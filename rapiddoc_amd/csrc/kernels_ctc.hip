@@ -11,12 +11,10 @@
 //   * the bias rides in the padded K column (K=120 -> 128: X[:,120] = 1, W'[:,120] = bias)
 //   * class ranges are split across blocks so that split s runs on XCD s%8: each XCD keeps its ~1.2 MB slice
 //     of W' resident in its private L2 while the token tiles stream past
-#include "rd_kernels.h"
+#include "rd_device.h"
 
 namespace rd {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int CT_TOK = 128;   // tokens per block (4 waves x 32)
 static constexpr int CT_CLS = 128;   // classes per iteration (4 MFMA tiles)
@@ -139,9 +137,6 @@ __global__ void __launch_bounds__(256) ctc_head_kernel(CtcParams p, int cls_per_
 // Split-fp16 variant (precision "auto" / "h3"): same tiling, split and statistics, but the products run on the fp16 matrix
 // cores with (hi, lo) operands - 3 x v_mfma_f32_32x32x16_f16 per 16-wide k-step instead of 8 fp32 MFMAs, fp32 accumulate
 // (arithmetic as in kernels_conv_h3.hip).  The token tile is split once per block, the weights once at load time.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 static constexpr int CH_LD = CT_K + 8;   // LDS row stride in halfs (272 B): conflict-free ds_read_b128
 
 __global__ void __launch_bounds__(256) ctc_head_h3_kernel(CtcParams p, int cls_per_split) {
@@ -174,9 +169,10 @@ __global__ void __launch_bounds__(256) ctc_head_h3_kernel(CtcParams p, int cls_p
             f16x4 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const _Float16 h = (_Float16)v[e];
+                _Float16 h, l;
+                rd_split(v[e], h, l);
                 hi[e] = h;
-                lo[e] = (_Float16)__builtin_fmaf((float)h, -2048.f, v[e] * 2048.f);
+                lo[e] = l;
                 amax = fmaxf(amax, fabsf(v[e]));
             }
             *reinterpret_cast<f16x4*>(&Xh[r * CH_LD + k]) = hi;

@@ -21,43 +21,16 @@
 // the per-tile fixed costs, not by the staging path.
 #include <cstdlib>
 
-#include "rd_kernels.h"
+#include "rd_device.h"
 
 namespace rd {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 static constexpr int DM = 256, DN = 128, DK = 32;
 static constexpr int D_A_BYTES = DM * DK * 4;             // 32 KB raw fp32 activations per stage
 static constexpr int D_B_BYTES = DN * DK * 2;             // 8 KB per weight plane (hi, lo)
 static constexpr int D_STAGE = D_A_BYTES + 2 * D_B_BYTES; // 48 KB
 static constexpr int D_NSTAGE = 3;
-
-__device__ __forceinline__ float dma_act(float v, int act) {
-    switch (act) {
-        case ACT_RELU: return fmaxf(v, 0.f);
-        case ACT_GELU: {
-            const float z = fabsf(v) * 0.70710678118654752440f;
-            const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
-            float poly = fmaf(1.061405429f, t, -1.453152027f);
-            poly = fmaf(poly, t, 1.421413741f);
-            poly = fmaf(poly, t, -0.284496736f);
-            poly = fmaf(poly, t, 0.254829592f);
-            const float erfz = 1.f - poly * t * __expf(-z * z);
-            return 0.5f * v * (1.f + copysignf(erfz, v));
-        }
-        case ACT_SILU: return v / (1.f + __expf(-v));
-        case ACT_SIGMOID: {
-            const float r = 1.f / (1.f + __expf(-v));
-            return (r != r) ? 0.f : r;
-        }
-        case ACT_HSIG: return fminf(fmaxf(v * (1.f / 6.f) + 0.5f, 0.f), 1.f);
-        case ACT_HSIG_PADDLE: return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f);
-        default: return v;
-    }
-}
 
 __device__ __forceinline__ void dma16(const void* src, unsigned lds_byte_offset, unsigned char* smem) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -67,11 +40,13 @@ __device__ __forceinline__ void dma16(const void* src, unsigned lds_byte_offset,
 __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const _Float16 h0 = (_Float16)a[e], h1 = (_Float16)b[e];
+        _Float16 h0, l0, h1, l1;
+        rd_split(a[e], h0, l0);
+        rd_split(b[e], h1, l1);
         hi[e] = h0;
         hi[4 + e] = h1;
-        lo[e] = (_Float16)__builtin_fmaf((float)h0, -2048.f, a[e] * 2048.f);
-        lo[4 + e] = (_Float16)__builtin_fmaf((float)h1, -2048.f, b[e] * 2048.f);
+        lo[e] = l0;
+        lo[4 + e] = l1;
     }
 }
 
@@ -223,7 +198,7 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
                     if (m >= p.M) continue;
                     const float pre = fmaf(acc2[i][j][r], 1.f / 2048.f, acc1[i][j][r]) + bv;
                     emax = max(emax, __float_as_uint(pre) & 0x7fffffffu);
-                    float o = dma_act(pre, p.act);
+                    float o = rd_act(pre, p.act);
                     if (p.res) o += p.res[(size_t)m * p.rld + n];
                     p.y[(size_t)m * p.yld + n] = o;
                 }
@@ -350,7 +325,7 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
                     if (m >= p.M) continue;
                     const float pre = fmaf(acc2[i][r], 1.f / 2048.f, acc1[i][r]) + bv;
                     emax = max(emax, __float_as_uint(pre) & 0x7fffffffu);
-                    float o = dma_act(pre, p.act);
+                    float o = rd_act(pre, p.act);
                     if (p.res) o += p.res[(size_t)m * p.rld + n];
                     p.y[(size_t)m * p.yld + n] = o;
                 }

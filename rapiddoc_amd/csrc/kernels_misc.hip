@@ -2,25 +2,13 @@
 // nearest upsample (FPN), LayerNorm, the small LightSVTR attention, CTC row statistics, layout
 // conversion at the C-ABI boundary and the image resize+normalise pre-processing.
 // Everything is NHWC fp32 with the channel dimension innermost => 16-byte coalesced accesses.
-#include "rd_kernels.h"
+#include "rd_device.h"
 
 namespace rd {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float act1(float v, int act) {
-    switch (act) {
-        case ACT_RELU: return fmaxf(v, 0.f);
-        case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-        case ACT_SILU: return v / (1.f + __expf(-v));
-        case ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
-        case ACT_HSIG: return fminf(fmaxf(v * (1.f / 6.f) + 0.5f, 0.f), 1.f);
-        case ACT_HSIG_PADDLE: return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f);
-        default: return v;
-    }
-}
 __device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
-    f32x4 r = {act1(v[0], act), act1(v[1], act), act1(v[2], act), act1(v[3], act)};
+    f32x4 r = {rd_act(v[0], act), rd_act(v[1], act), rd_act(v[2], act), rd_act(v[3], act)};
     return r;
 }
 
@@ -294,7 +282,7 @@ __global__ void __launch_bounds__(256) se_fc_kernel(SeFcParams p) {
         float s = p.b2[c];
         const float* w = p.w2 + (size_t)c * p.Cr;
         for (int r = 0; r < p.Cr; ++r) s = fmaf(w[r], hid[r], s);
-        p.scale[(size_t)n * p.C + c] = act1(s, p.gate);
+        p.scale[(size_t)n * p.C + c] = rd_act(s, p.gate);
     }
 }
 void launch_se_fc(const SeFcParams& p, hipStream_t s) {

@@ -12,27 +12,13 @@
 //                                                            4*(lane>>5) + (r&3)) is exactly the k order the
 //                                                            B fragment (ds_read_b128 at 8*g + 4*(lane>>5)) uses.
 // No LDS round trip, shuffle or barrier between the two GEMMs.
-#include "rd_kernels.h"
+#include "rd_device.h"
 
 namespace rd {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int MX_BM = 128;
 static constexpr int MX_HC = 32;
-
-// erf by Abramowitz-Stegun 7.1.26 (abs err <= 1.5e-7) - see kernels_conv.hip
-__device__ __forceinline__ float gelu_erf(float v) {
-    const float z = fabsf(v) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float erfz = 1.f - poly * t * __expf(-z * z);
-    return 0.5f * v * (1.f + copysignf(erfz, v));
-}
 
 template <int C, int DBG>
 __global__ void __launch_bounds__(256) lc_mixer_kernel(MixerParams p) {
@@ -148,7 +134,7 @@ __global__ void __launch_bounds__(256) lc_mixer_kernel(MixerParams p) {
         for (int g = 0; g < 4; ++g) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(&B1s[g * 8 + 4 * lhi]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) h[g * 4 + e] = (DBG & 1) ? h[g * 4 + e] + bv[e] : gelu_erf(h[g * 4 + e] + bv[e]);
+            for (int e = 0; e < 4; ++e) h[g * 4 + e] = (DBG & 1) ? h[g * 4 + e] + bv[e] : rd_gelu(h[g * 4 + e] + bv[e]);
         }
         // GEMM2: Y += H . W2c^T  (K = 32): A = h registers, B = W2s rows (double-buffered like GEMM1)
         if (!(DBG & 8)) {   // DBG 8: skip GEMM2

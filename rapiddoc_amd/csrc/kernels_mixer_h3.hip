@@ -17,33 +17,13 @@
 #include <cstdlib>
 #include <vector>
 
-#include "rd_kernels.h"
+#include "rd_device.h"
 
 namespace rd {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int HX_BM = 128;
 static constexpr int HX_HC = 32;
-
-__device__ __forceinline__ float hx_gelu(float v) {
-    const float z = fabsf(v) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float erfz = 1.f - poly * t * __expf(-z * z);
-    return 0.5f * v * (1.f + copysignf(erfz, v));
-}
-__device__ __forceinline__ void hx_split(float v, _Float16& hi, _Float16& lo) {
-    hi = (_Float16)v;
-    lo = (_Float16)__builtin_fmaf((float)hi, -2048.f, v * 2048.f);   // exact; one v_fma_mix*_f16 (see kernels_conv_h3.hip)
-}
 
 // DBG: compile-time ablation bits for tools/microbench.py (1 no GELU, 2 no weight streaming, 4 skip GEMM1, 8 skip GEMM2);
 // run-time switches here would cut the chunk body into basic blocks the scheduler cannot move instructions across
@@ -99,7 +79,7 @@ __global__ void __launch_bounds__(256, C <= 96 ? 2 : 1) lc_mixer_h3_kernel(Mixer
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 _Float16 a, b;
-                hx_split(v[e], a, b);
+                rd_split(v[e], a, b);
                 hi[e] = a;
                 lo[e] = b;
                 amax = fmaxf(amax, fabsf(v[e]));
@@ -224,9 +204,9 @@ __global__ void __launch_bounds__(256, C <= 96 ? 2 : 1) lc_mixer_h3_kernel(Mixer
             for (int e = 0; e < 4; ++e) {
                 const int r = g * 4 + e;
                 const float pre = fmaf(h2[r], 1.f / 2048.f, h1[r]) + bv[e];
-                const float v = (DBG & 1) ? pre : hx_gelu(pre);
+                const float v = (DBG & 1) ? pre : rd_gelu(pre);
                 _Float16 a, b;
-                hx_split(v, a, b);
+                rd_split(v, a, b);
                 amax = fmaxf(amax, fabsf(v));
                 hh[r >> 3][r & 7] = a;
                 hl[r >> 3][r & 7] = b;

@@ -1,0 +1,53 @@
+// Device-side helpers shared by the HIP translation units: vector types, the GELU / activation epilogue, the (hi, lo)
+// fp16 split of the split-MFMA kernels.  Everything is __forceinline__: no cross-TU device linking.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rd_kernels.h"
+
+namespace rd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// GELU(x) = x/2 * (1 + erf(x/sqrt2)) as nn.GELU() (approximate='none'), erf by Abramowitz-Stegun 7.1.26
+// (|abs err| <= 1.5e-7, i.e. fp32 round-off class): 1 exp + 1 rcp + 7 FMAs instead of libm erff's ~60 instructions.
+// v_rcp_f32 (1 ulp) on purpose: `__frcp_rn` compiles to the 10-instruction IEEE division sequence.
+__device__ __forceinline__ float rd_gelu(float v) {
+    const float z = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float erfz = 1.f - poly * t * __expf(-z * z);
+    return 0.5f * v * (1.f + copysignf(erfz, v));
+}
+
+__device__ __forceinline__ float rd_act(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return fmaxf(v, 0.f);
+        case ACT_GELU: return rd_gelu(v);
+        case ACT_SILU: return v / (1.f + __expf(-v));
+        case ACT_SIGMOID: {
+            const float r = 1.f / (1.f + __expf(-v));
+            return (r != r) ? 0.f : r;  // nan_to_num (det_db_head.py:143-144)
+        }
+        case ACT_HSIG: return fminf(fmaxf(v * (1.f / 6.f) + 0.5f, 0.f), 1.f);
+        case ACT_HSIG_PADDLE: return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f);
+        default: return v;
+    }
+}
+
+// x = hi + lo * 2^-11 with hi = fp16(x), lo = fp16((x - hi) * 2^11).  The second line is ONE fused op on the f16 source
+// (exact: the difference is representable and the scale is a power of two); it compiles to v_fma_mix{lo,hi}_f16, so the
+// split costs 2 VALU ops per element (v_cvt_pk_f16_f32 + v_fma_mix) instead of 4.
+__device__ __forceinline__ void rd_split(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)__builtin_fmaf((float)hi, -2048.f, v * 2048.f);
+}
+
+}  // namespace rd
