@@ -192,3 +192,35 @@ class RegionOcr:
                             span["category_id"] = LOW_SCORE_TEXT
                     out[p].append(span)
         return out
+
+
+class RegionTextModel:
+    """The OCR seam S1 of the reference: an `ocr_config['custom_model']` object
+    (`rapid_doc.model.custom.CustomBaseModel.batch_predict(image_list, **kwargs) -> list[str]`, model/custom/__init__.py:4-20),
+    called by `BatchAnalyze._run_custom_ocr` (batch_analyze.py:286-331) with the BGR crop of every text REGION and expected
+    to return that region's text, lines separated by newlines; the reference wraps each string into one OcrText item.
+    Here a region is read the conventional way - det, box sort / merge, rec - on the GPU, and its lines with a
+    confidence >= 0.5 are joined in reading order."""
+
+    def __init__(self, pipeline, box_thresh: float = 0.3, unclip_ratio: float = 1.8):
+        self._ocr = RegionOcr(pipeline, box_thresh, unclip_ratio)
+
+    def batch_predict(self, image_list: Sequence[np.ndarray], det_maps_fn=None, **kwargs) -> List[str]:
+        pipe = self._ocr.pipe
+        texts = [""] * len(image_list)
+        shapes = [(int(im.shape[0]), int(im.shape[1])) for im in image_list]
+        keep = [i for i, (h, w) in enumerate(shapes) if h > 0 and w > 0]
+        groups = ocr_host.det_buckets([shapes[i] for i in keep], ["_"] * len(keep), det_batch_num=max(1, len(keep)))
+        for _lang, (gh, gw), members, _bs in groups:
+            ids = [keep[m] for m in members]
+            canv = torch.full((len(ids), gh, gw, 3), 255, dtype=torch.uint8, device=pipe.tdev)
+            for k, i in enumerate(ids):
+                rgb = np.ascontiguousarray(np.asarray(image_list[i], dtype=np.uint8)[:, :, ::-1])     # BGR -> RGB
+                canv[k, : shapes[i][0], : shapes[i][1]] = torch.from_numpy(rgb).to(pipe.tdev)
+            override = det_maps_fn(ids, (gh, gw), ocr_host.det_resize_shape(gh, gw, 960, "max")) if det_maps_fn else None
+            boxes = self._ocr._detect_group(canv, override)
+            quads = [np.asarray([q for q in b if q[2][0] - q[0][0] >= MIN_WIDTH], dtype=np.float32).reshape(-1, 4, 2) for b in boxes]
+            lines = pipe.rec_forward_lines(canv, quads)
+            for k, i in enumerate(ids):
+                texts[i] = "\n".join(t for t, s in lines[k] if s >= MIN_CONFIDENCE and t)
+        return texts

@@ -447,3 +447,42 @@ def test_formula_branch_on_given_layout(golden_dir):
                 assert d == d0 and "latex" not in d
     assert "latex" in dets[0][0] and "latex" in dets[1][0]                # same crop content on both pages
     assert dets[0][0]["latex"] == dets[1][0]["latex"]
+
+
+def test_region_text_model_is_a_custom_ocr_model(golden_dir):
+    """Seam S1: `batch_predict(list of BGR region crops) -> list[str]`, one (multi-line) string per region, order kept,
+    ragged sizes grouped by 64-px buckets; empty regions give an empty string."""
+    from rapiddoc_amd.analyze import RegionTextModel
+    from rapiddoc_amd.pages import synth_batch
+    from rapiddoc_amd.pipeline import PagePipeline
+    states = {k: W.synth_state_dict(W.load_manifest(golden_dir / f"manifest_{k}.json"), 0) for k in ("ppocrv6_det", "ppocrv6_rec")}
+    model = RegionTextModel(PagePipeline(states, rec_batch_num=32))
+    pages_np, boxes = synth_batch(0, 1)
+    b = np.asarray(boxes[0], dtype=np.float64).reshape(-1, 4)
+    crops, want = [], []
+    for lo, hi in ((0, 5), (5, 6), (6, 20)):                       # three regions of 5, 1 and 14 lines
+        x0, y0, x1, y1 = int(b[lo:hi, 0].min()) - 8, int(b[lo:hi, 1].min()) - 8, int(b[lo:hi, 2].max()) + 8, int(b[lo:hi, 3].max()) + 8
+        crops.append(np.ascontiguousarray(pages_np[0, y0:y1, x0:x1, ::-1]))       # BGR like cv2.cvtColor(.., RGB2BGR)
+        want.append((hi - lo, (x0, y0)))
+    crops.append(np.full((40, 300, 3), 255, np.uint8))             # a blank region
+
+    def maps_fn(ids, ghw, dhw):
+        (gh, gw), (dh, dw) = ghw, dhw
+        m = torch.zeros((len(ids), 1, dh, dw), dtype=torch.float32)
+        for k, i in enumerate(ids):
+            if i >= len(want):
+                continue
+            n, (ox, oy) = want[i]
+            lo = (0, 5, 6)[i]
+            for lb in b[lo:lo + n]:
+                cx0, cy0, cx1, cy1 = lb[0] - ox, lb[1] - oy, lb[2] - ox, lb[3] - oy
+                d = 0.32 * min(cx1 - cx0, cy1 - cy0)
+                m[k, 0, int(round((cy0 + d) * dh / gh)):int(round((cy1 - d) * dh / gh)),
+                  int(round((cx0 + d) * dw / gw)):int(round((cx1 - d) * dw / gw))] = 0.95
+        return m.cuda()
+
+    out = model.batch_predict(crops, det_maps_fn=maps_fn, batch_size=4)
+    assert isinstance(out, list) and len(out) == 4 and all(isinstance(t, str) for t in out)
+    assert out[3] == ""
+    for (n, _), text in zip(want, out[:3]):
+        assert len(text.split("\n")) <= n                           # never more lines than text lines in the region
