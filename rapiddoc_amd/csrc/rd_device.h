@@ -31,9 +31,9 @@ __device__ __forceinline__ float rd_act(float v, int act) {
     switch (act) {
         case ACT_RELU: return fmaxf(v, 0.f);
         case ACT_GELU: return rd_gelu(v);
-        case ACT_SILU: return v / (1.f + __expf(-v));
+        case ACT_SILU: return v * __builtin_amdgcn_rcpf(1.f + __expf(-v));   // v_rcp_f32: 1 ulp, vs the IEEE division sequence
         case ACT_SIGMOID: {
-            const float r = 1.f / (1.f + __expf(-v));
+            const float r = __builtin_amdgcn_rcpf(1.f + __expf(-v));
             return (r != r) ? 0.f : r;  // nan_to_num (det_db_head.py:143-144)
         }
         case ACT_HSIG: return fminf(fmaxf(v * (1.f / 6.f) + 0.5f, 0.f), 1.f);
