@@ -305,12 +305,9 @@ void launch_ctc_head(const CtcParams& p, hipStream_t s) {
     cps = (cps + 3) / 4 * 4;
     const size_t sh = (size_t)(CT_TOK + CT_CLS) * CT_LD * sizeof(float);
     const size_t sh3 = (size_t)(2 * CT_TOK * CH_LD + 2 * CT_CLS * CT_K) * sizeof(_Float16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)ctc_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        (void)hipFuncSetAttribute((const void*)ctc_head_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh3);
-        attr_set = true;
-    }
+    static unsigned long long lds_ok = 0, lds_ok3 = 0;
+    rd_allow_dynamic_lds((const void*)ctc_head_kernel, sh, lds_ok);
+    rd_allow_dynamic_lds((const void*)ctc_head_h3_kernel, sh3, lds_ok3);
     if (p.wh) hipLaunchKernelGGL(ctc_head_h3_kernel, dim3(tiles * p.nsplit), dim3(256), sh3, s, p, cps);
     else hipLaunchKernelGGL(ctc_head_kernel, dim3(tiles * p.nsplit), dim3(256), sh, s, p, cps);
     hipLaunchKernelGGL(ctc_merge_kernel, dim3((p.M + 255) / 256), dim3(256), 0, s, p.part, p.M, p.nsplit, p.idx, p.prob);

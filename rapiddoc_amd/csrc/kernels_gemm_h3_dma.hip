@@ -353,22 +353,15 @@ void launch_gemm_h3_dma(const ConvParams& p, hipStream_t s) {
         return n > 0 ? n : 256;
     }();
     const size_t sh = (size_t)D_NSTAGE * D_STAGE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_h3_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        attr_set = true;
-    }
+    static unsigned long long lds_ok = 0, lds_ok16 = 0;
+    rd_allow_dynamic_lds((const void*)gemm_h3_dma_kernel, sh, lds_ok);
     // measured (TFLOP/s, 8 vs 16 wavefronts): K192 117 / 127, K384 162 / 172, K768 214 / 215, K2176 263 / 252, K4096 288 / 274:
     // the K loop itself runs at the same ~1.8 us per K tile with two or four wavefronts per SIMD (it is not latency hiding
     // inside a SIMD that is missing); the 16-wavefront tile only drains its prologue / epilogue faster, which shows for short K
     static const int force16 = [] { const char* e = getenv("RD_H3_DMA16"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     const bool use16 = force16 >= 0 ? force16 == 1 : p.K <= 384;
     if (use16) {
-        static bool attr16 = false;
-        if (!attr16) {
-            (void)hipFuncSetAttribute((const void*)gemm_h3_dma16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-            attr16 = true;
-        }
+        rd_allow_dynamic_lds((const void*)gemm_h3_dma16_kernel, sh, lds_ok16);
         hipLaunchKernelGGL(gemm_h3_dma16_kernel, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(1024), sh, s, p, ntn, ntiles);
         return;
     }

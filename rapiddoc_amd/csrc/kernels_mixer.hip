@@ -196,11 +196,8 @@ bool mixer_fused_supported(int C) { return C == 48 || C == 96 || C == 192; }
 template <int C, int DBG>
 static void launch_mixer_c(const MixerParams& p, hipStream_t s) {
     const size_t sh = mixer_lds_bytes<C>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)lc_mixer_kernel<C, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        attr_set = true;
-    }
+    static unsigned long long lds_ok = 0;
+    rd_allow_dynamic_lds((const void*)lc_mixer_kernel<C, DBG>, sh, lds_ok);
     hipLaunchKernelGGL((lc_mixer_kernel<C, DBG>), dim3((p.M + MX_BM - 1) / MX_BM), dim3(256), sh, s, p);
 }
 

@@ -273,11 +273,8 @@ __global__ void __launch_bounds__(256, C <= 96 ? 2 : 1) lc_mixer_h3_kernel(Mixer
 template <int C, int DBG>
 static void launch_mixer_h3_c(const MixerParams& p, hipStream_t s) {
     const size_t sh = (size_t)(2 * HX_BM * (C + 8) + 2 * HX_HC * C + 2 * ((C + 31) / 32 * 32) * HX_HC) * sizeof(_Float16) + 2 * C * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)lc_mixer_h3_kernel<C, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        attr_set = true;
-    }
+    static unsigned long long lds_ok = 0;
+    rd_allow_dynamic_lds((const void*)lc_mixer_h3_kernel<C, DBG>, sh, lds_ok);
     hipLaunchKernelGGL((lc_mixer_h3_kernel<C, DBG>), dim3((p.M + HX_BM - 1) / HX_BM), dim3(256), sh, s, p);
 }
 

@@ -8,6 +8,18 @@
 
 namespace rd {
 
+// Kernels that need more than 64 KB of dynamic LDS opt in once per (kernel, device): the attribute belongs to the device
+// the call is made on, and one process may drive several GPUs.  `mask` is a static of the launcher, one bit per device.
+inline void rd_allow_dynamic_lds(const void* kernel, size_t bytes, unsigned long long& mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(mask & bit)) {
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        mask |= bit;
+    }
+}
+
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_SIGMOID = 4, ACT_HSIG = 5, ACT_HSIG_PADDLE = 6 };
 enum OutMode : int { OUT_NHWC = 0, OUT_DECONV2X2 = 1 };
 
