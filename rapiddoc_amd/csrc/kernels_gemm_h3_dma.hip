@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
                     emax = max(emax, __float_as_uint(pre) & 0x7fffffffu);
                     float o = rd_act(pre, p.act);
                     if (p.res) o += p.res[(size_t)m * p.rld + n];
-                    p.y[(size_t)m * p.yld + n] = o;
+                    __builtin_nontemporal_store(o, &p.y[(size_t)m * p.yld + n]);
                 }
             }
         }
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
                     emax = max(emax, __float_as_uint(pre) & 0x7fffffffu);
                     float o = rd_act(pre, p.act);
                     if (p.res) o += p.res[(size_t)m * p.rld + n];
-                    p.y[(size_t)m * p.yld + n] = o;
+                    __builtin_nontemporal_store(o, &p.y[(size_t)m * p.yld + n]);
                 }
             }
         }

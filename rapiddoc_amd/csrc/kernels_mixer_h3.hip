@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(256, C <= 96 ? 2 : 1) lc_mixer_h3_kernel(Mixer
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            if (m < p.M) p.y[(size_t)m * p.yld + co] = fmaf(y2[n][r], 1.f / 2048.f, y1[n][r]) + bv + res[r];
+            if (m < p.M) __builtin_nontemporal_store(fmaf(y2[n][r], 1.f / 2048.f, y1[n][r]) + bv + res[r], &p.y[(size_t)m * p.yld + co]);
         }
     }
 }
