@@ -305,7 +305,7 @@ static inline int out_dim(int in, int k, int s, int p0, int p1) { return (in + p
 // "auto" precision: wide pointwise convolutions also run on the split-fp16 matrix-core path (256x128 tile; measured
 // 1.2x the fp32 MFMA kernel at K = 192, 2x at K >= 768 - table in kernels_conv_h3.hip)
 static inline bool auto_split_conv(int kh, int kw, int K, int cout) {
-    return (kh == 1 && kw == 1) ? (K >= 192 && cout >= 96) : (K >= 288 && cout >= 48);
+    return (kh == 1 && kw == 1) ? (K >= 96 && cout >= 96) : (K >= 288 && cout >= 48);
 }
 
 // =================================================================================================

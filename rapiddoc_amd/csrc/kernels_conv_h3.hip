@@ -10,7 +10,7 @@
 // Operand range: |x| must stay below 65504 (fp16 max); tiny values degrade gracefully (absolute error < 2e-11).
 //
 // Activations are split on the fly while a K tile is staged into LDS (5 VALU ops per element, hidden under the
-// MFMAs); weights are split once at load time (rd_load_weights) and stored as two fp16 matrices [Ng][Kp].
+// MFMAs); weights are split once at load time (rd_load_weights) and stored as two fp16 matrices [Ng][Kp], Kp = K rounded up to 32.
 #include <cstdlib>
 #include <vector>
 
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 && BM * BN >= 128 *
     };
     const int tid = threadIdx.x;
     const int lrow = tid >> 3, lkq = tid & 7;
-    const int K = p.K, Kp = (p.K + 7) & ~7;
+    const int K = p.K, Kp = (p.K + 31) & ~31;
 
     const float* arow[AL];
     bool avalid[AL];
@@ -345,9 +345,10 @@ void launch_conv_igemm_h3(const ConvParams& p, hipStream_t s) {
     }
 }
 
-// host helper: split a weight matrix [rows][K] fp32 into hi/lo fp16 matrices [rows][Kp] (Kp = K rounded up to 8)
+// host helper: split a weight matrix [rows][K] fp32 into hi/lo fp16 matrices [rows][Kp] (Kp = K rounded up to 32, zero filled:
+// the LDS-DMA GEMM reads whole 32-wide K tiles of the weights and relies on the zeros past K)
 void split_weights_h3(const float* w, int rows, int K, std::vector<uint16_t>& hi, std::vector<uint16_t>& lo) {
-    const int Kp = (K + 7) & ~7;
+    const int Kp = (K + 31) & ~31;
     hi.assign((size_t)rows * Kp, 0);
     lo.assign((size_t)rows * Kp, 0);
     for (int r = 0; r < rows; ++r)

@@ -1,4 +1,4 @@
-// Split-fp16 GEMM for pointwise convolutions as an LDS-DMA pipeline (precision "auto" / "h3", K % 32 == 0).
+// Split-fp16 GEMM for pointwise convolutions as an LDS-DMA pipeline (precision "auto" / "h3").
 //
 // Same arithmetic as kernels_conv_h3.hip (x = hi + lo*2^-11, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulate),
 // different data path.  The register-staged kernel there runs at 14-37 % of the fp16 MFMA pipe: every K tile is a chain
@@ -56,14 +56,15 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int K = p.K, KT = K / DK;
+    const int K = p.K, KT = (K + DK - 1) / DK, Kp = KT * DK;   // weight rows are zero padded to Kp (split_weights_h3)
     const _Float16* wh = reinterpret_cast<const _Float16*>(p.wh);
     const _Float16* wl = reinterpret_cast<const _Float16*>(p.wl);
 
     // ---- DMA source addressing of this lane.  A: 4 instructions per wavefront and K tile, instruction j fills tile rows
     // 32*wave + 8*j .. +7 (lane -> row + lane/8, chunk position lane%8).  B: one instruction per plane, rows 16*wave + lane/4.
     int m0 = 0, n0 = 0;
-    const float* asrc[4];
+    const float* asrc[4];   // row base; the chunk's channel offset is kc[] (clamped per K tile, see issue_tile)
+    int kc[4];
     const _Float16* bsrc_h;
     const _Float16* bsrc_l;
     auto setup_tile = [&](int v) {
@@ -77,11 +78,12 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
             const int row = 32 * wave + 8 * jj + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
             const int m = min(m0 + row, p.M - 1);               // rows past M re-read the last row; never stored
-            asrc[jj] = p.x + (size_t)m * p.xld + 4 * c;
+            asrc[jj] = p.x + (size_t)m * p.xld;
+            kc[jj] = 4 * c;
         }
         const int brow = 16 * wave + (lane >> 2);
         const int bc = (lane & 3) ^ ((brow >> 2) & 3);
-        const size_t boff = (size_t)min(n0 + brow, p.Ng - 1) * K + 8 * bc;
+        const size_t boff = (size_t)min(n0 + brow, p.Ng - 1) * Kp + 8 * bc;
         bsrc_h = wh + boff;
         bsrc_l = wl + boff;
     };
@@ -89,7 +91,8 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
         const unsigned base = (unsigned)stage * D_STAGE;
         const int k0 = kt * DK;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) dma16(asrc[jj] + k0, base + (unsigned)(4 * wave + jj) * 1024u, smem);
+        // K need not be a multiple of 32: chunks past K re-read the row's last chunk (finite data) and meet zero weights
+        for (int jj = 0; jj < 4; ++jj) dma16(asrc[jj] + min(k0 + kc[jj], K - 4), base + (unsigned)(4 * wave + jj) * 1024u, smem);
         dma16(bsrc_h + k0, base + D_A_BYTES + (unsigned)wave * 1024u, smem);
         dma16(bsrc_l + k0, base + D_A_BYTES + D_B_BYTES + (unsigned)wave * 1024u, smem);
     };
@@ -222,7 +225,7 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..15
     const int wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int K = p.K, KT = K / DK;
+    const int K = p.K, KT = (K + DK - 1) / DK, Kp = KT * DK;
     const _Float16* wh = reinterpret_cast<const _Float16*>(p.wh);
     const _Float16* wl = reinterpret_cast<const _Float16*>(p.wl);
 
@@ -230,6 +233,7 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
     // [hi plane (8) | lo plane (8)]
     int m0 = 0, n0 = 0;
     const float* asrc[2];
+    int kc[2];
     const _Float16* bsrc;
     auto setup_tile = [&](int v) {
         const int xcd = v & 7, j = v >> 3, q = ntiles >> 3, r = ntiles & 7;
@@ -241,17 +245,18 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
         for (int jj = 0; jj < 2; ++jj) {
             const int row = 16 * wave + 8 * jj + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
-            asrc[jj] = p.x + (size_t)min(m0 + row, p.M - 1) * p.xld + 4 * c;
+            asrc[jj] = p.x + (size_t)min(m0 + row, p.M - 1) * p.xld;
+            kc[jj] = 4 * c;
         }
         const int brow = 16 * (wave & 7) + (lane >> 2);
         const int bc = (lane & 3) ^ ((brow >> 2) & 3);
-        bsrc = ((wave >> 3) ? wl : wh) + (size_t)min(n0 + brow, p.Ng - 1) * K + 8 * bc;
+        bsrc = ((wave >> 3) ? wl : wh) + (size_t)min(n0 + brow, p.Ng - 1) * Kp + 8 * bc;
     };
     auto issue_tile = [&](int kt, int stage) {
         const unsigned base = (unsigned)stage * D_STAGE;
         const int k0 = kt * DK;
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) dma16(asrc[jj] + k0, base + (unsigned)(2 * wave + jj) * 1024u, smem);
+        for (int jj = 0; jj < 2; ++jj) dma16(asrc[jj] + min(k0 + kc[jj], K - 4), base + (unsigned)(2 * wave + jj) * 1024u, smem);
         dma16(bsrc + k0, base + D_A_BYTES + (unsigned)(wave >> 3) * D_B_BYTES + (unsigned)(wave & 7) * 1024u, smem);
     };
     int a_off[2][2], b_off[2];
@@ -341,7 +346,7 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
 bool gemm_h3_dma_applies(const ConvParams& p) {
     static const bool off = [] { const char* e = getenv("RD_H3_DMA"); return e && e[0] == '0'; }();
     return !off && p.wh && p.KH == 1 && p.KW == 1 && p.SH == 1 && p.SW == 1 && p.PT == 0 && p.PL == 0 && p.OH == p.H && p.OW == p.W &&
-           p.out_mode == OUT_NHWC && !p.ascale && p.K % DK == 0 && p.K >= 2 * DK && p.Ng > 96 && p.M >= 2048 && (p.xld % 4) == 0;
+           p.out_mode == OUT_NHWC && !p.ascale && p.K % 4 == 0 && p.K >= 2 * DK && p.Ng >= 96 && p.M >= 2048 && (p.xld % 4) == 0;
 }
 
 void launch_gemm_h3_dma(const ConvParams& p, hipStream_t s) {

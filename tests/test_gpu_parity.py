@@ -305,7 +305,7 @@ def test_split_gemm_tails_match_fp64(M, K, N):
     x = torch.rand((M, K), device="cuda", generator=g) - 0.5
     w = (torch.rand((N, K), device="cuda", generator=g) - 0.5) * 0.2
     b = torch.rand(N, device="cuda", generator=g) - 0.5
-    Kp = (K + 7) // 8 * 8
+    Kp = (K + 31) // 32 * 32
     hi = w.half()
     lo = ((w - hi.float()) * 2048.0).half()
     wh = torch.zeros((N, Kp), dtype=torch.float16, device="cuda"); wh[:, :K] = hi

@@ -54,7 +54,7 @@ def gemm(M, K, N, act=0, iters=20, h3=False, check=False):
     y = torch.empty((M, N), device="cuda")
     wh = wl = None
     if h3:
-        Kp = (K + 7) // 8 * 8
+        Kp = (K + 31) // 32 * 32
         hi = w.half()
         lo = ((w - hi.float()) * 2048.0).half()
         wh = torch.zeros((N, Kp), dtype=torch.float16, device="cuda"); wh[:, :K] = hi
