@@ -96,3 +96,22 @@ def test_expand_formula_crop_matches_reference(golden_dir):
         assert [float(v) for v in res["poly"]] == c["poly"]
         assert ("polygon_points" in res) == c["has_polygon_points"]
 
+
+
+def test_analyze_crop_helpers():
+    """Pure-host pieces of rapiddoc_amd.analyze: formula boxes moved into a region crop (get_adjusted_mfdetrec_res,
+    utils/ocr_utils.py:320-342) and the integer box used for the white-out (normalize_to_int_bbox, utils/bbox_utils.py)."""
+    from rapiddoc_amd.analyze import _formula_boxes_in_crop, _int_box
+    from rapiddoc_amd.layout_host import crop_geometry
+    region = {"poly": [100, 200, 400, 200, 400, 260, 100, 260]}
+    useful = crop_geometry(region, 50, 50)
+    assert useful == [50, 50, 100, 200, 400, 260, 400, 160]
+    formulas = [{"bbox": [150, 210, 200, 240]},      # inside
+                {"bbox": [0, 0, 40, 40]},            # left of / above the crop: x1 = -10 < 0 -> dropped
+                {"bbox": [380, 250, 520, 300]},      # sticks out on the right: kept, clipped later by _int_box
+                {"bbox": [460, 210, 500, 240]}]      # x0 = 410 > new_width 400 -> dropped
+    got = _formula_boxes_in_crop(formulas, useful)
+    assert got == [[100, 60, 150, 90], [330, 100, 470, 150]]
+    assert _int_box(got[1], 160, 400) == [330, 100, 400, 150]
+    assert _int_box([10.2, 5.7, 10.9, 5.9], 100, 100) == [10, 5, 11, 6]
+    assert _int_box([120, 5, 130, 9], 100, 100) is None
