@@ -15,6 +15,7 @@
 // groups x 2 output-channel halves so that two workgroups fit a CU).  GEMM1 and the GELU are then computed twice; it
 // measured 107 TF/s at C = 384 (the unfused pair of split-fp16 GEMMs reaches ~170) and 104 at C = 192 (this kernel: 160).
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "rd_device.h"
@@ -68,24 +69,54 @@ __global__ void __launch_bounds__(256, C <= 96 ? 2 : 1) lc_mixer_h3_kernel(Mixer
         //  hold a copy of the last row and are never stored)
         constexpr int QPR = C / 4;
         constexpr int XIT = HX_BM * QPR / 256;
+        // two copies of the loop: a run-time `if (gate)` inside it is a branch per iteration, which keeps the compiler from
+        // batching the tile loads of different iterations (seen in the ISA: one s_cbranch per load)
+        auto load_tile = [&](auto gated) {
 #pragma unroll 12
-        for (int it = 0; it < XIT; ++it) {
-            const int i = tid + 256 * it;
-            const int r = i / QPR, q = i - r * QPR;
-            const int m = min(m0 + r, p.M - 1);
-            f32x4 v = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.xld + 4 * q);
-            if (p.gate) v *= *reinterpret_cast<const f32x4*>(p.gate + (size_t)(m / p.HW) * C + 4 * q);
-            f16x4 hi, lo;
+            for (int it = 0; it < XIT; ++it) {
+                const int i = tid + 256 * it;
+                const int r = i / QPR, q = i - r * QPR;
+                const int m = min(m0 + r, p.M - 1);
+                f32x4 v = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.xld + 4 * q);
+                if (decltype(gated)::value) v *= *reinterpret_cast<const f32x4*>(p.gate + (size_t)(m / p.HW) * C + 4 * q);
+                f16x4 hi, lo;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                _Float16 a, b;
-                rd_split(v[e], a, b);
-                hi[e] = a;
-                lo[e] = b;
-                amax = fmaxf(amax, fabsf(v[e]));
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 a, b;
+                    rd_split(v[e], a, b);
+                    hi[e] = a;
+                    lo[e] = b;
+                    amax = fmaxf(amax, fabsf(v[e]));
+                }
+                *reinterpret_cast<f16x4*>(&Xh[r * XS + 4 * q]) = hi;
+                *reinterpret_cast<f16x4*>(&Xl[r * XS + 4 * q]) = lo;
             }
-            *reinterpret_cast<f16x4*>(&Xh[r * XS + 4 * q]) = hi;
-            *reinterpret_cast<f16x4*>(&Xl[r * XS + 4 * q]) = lo;
+        };
+        // (at C = 192 the kernel sits at its register ceiling and the batched loads cost more than the branches: 207 vs 192 us)
+        if (C == 192) {
+#pragma unroll 12
+            for (int it = 0; it < XIT; ++it) {
+                const int i = tid + 256 * it;
+                const int r = i / QPR, q = i - r * QPR;
+                const int m = min(m0 + r, p.M - 1);
+                f32x4 v = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.xld + 4 * q);
+                if (p.gate) v *= *reinterpret_cast<const f32x4*>(p.gate + (size_t)(m / p.HW) * C + 4 * q);
+                f16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 a, b;
+                    rd_split(v[e], a, b);
+                    hi[e] = a;
+                    lo[e] = b;
+                    amax = fmaxf(amax, fabsf(v[e]));
+                }
+                *reinterpret_cast<f16x4*>(&Xh[r * XS + 4 * q]) = hi;
+                *reinterpret_cast<f16x4*>(&Xl[r * XS + 4 * q]) = lo;
+            }
+        } else if (p.gate) {
+            load_tile(std::true_type{});
+        } else {
+            load_tile(std::false_type{});
         }
     }
     // rows [C, W2ROWS) of both W2 planes (C = 48 only) are read by the last n-tile and never written by the DMA
