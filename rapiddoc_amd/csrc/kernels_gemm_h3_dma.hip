@@ -50,6 +50,52 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, f16x8& hi, 
     }
 }
 
+// Epilogue of one 32x32 accumulator tile (16 rows of one output column per lane): combine the two accumulators, bias,
+// range guard, activation, residual, store.  The activation switch and the residual test sit OUTSIDE the 16-element loops
+// and the residual loads are unconditional (clamped row): per-element branches would serialise the loads and stores.
+template <bool LEAN>
+__device__ __forceinline__ void dma_finish_tile(const ConvParams& p, const f32x16& a1, const f32x16& a2, int mb, int n, float bv,
+                                                unsigned& emax) {
+    float o[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        o[r] = fmaf(a2[r], 1.f / 2048.f, a1[r]) + bv;
+        emax = max(emax, __float_as_uint(o[r]) & 0x7fffffffu);
+    }
+    switch (p.act) {
+        case ACT_NONE: break;
+        case ACT_RELU:
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = fmaxf(o[r], 0.f);
+            break;
+        case ACT_GELU:
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = rd_gelu(o[r]);
+            break;
+        default:
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = rd_act(o[r], p.act);
+            break;
+    }
+    if (p.res) {
+        if (LEAN) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] += p.res[(size_t)min(mb + (r & 3) + 8 * (r >> 2), p.M - 1) * p.rld + n];
+        } else {
+            float res[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) res[r] = p.res[(size_t)min(mb + (r & 3) + 8 * (r >> 2), p.M - 1) * p.rld + n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] += res[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        if (m < p.M) __builtin_nontemporal_store(o[r], &p.y[(size_t)m * p.yld + n]);
+    }
+}
+
 __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -193,19 +239,7 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
             if (n >= p.Ng) continue;
             const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int mb = em0 + (wm * 2 + i) * 32 + 4 * lhi;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mb + (r & 3) + 8 * (r >> 2);
-                    if (m >= p.M) continue;
-                    const float pre = fmaf(acc2[i][j][r], 1.f / 2048.f, acc1[i][j][r]) + bv;
-                    emax = max(emax, __float_as_uint(pre) & 0x7fffffffu);
-                    float o = rd_act(pre, p.act);
-                    if (p.res) o += p.res[(size_t)m * p.rld + n];
-                    __builtin_nontemporal_store(o, &p.y[(size_t)m * p.yld + n]);
-                }
-            }
+            for (int i = 0; i < 2; ++i) dma_finish_tile<false>(p, acc1[i][j], acc2[i][j], em0 + (wm * 2 + i) * 32 + 4 * lhi, n, bv, emax);
         }
         if (!has_next) break;
         v = vnext;
@@ -233,7 +267,6 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
     // [hi plane (8) | lo plane (8)]
     int m0 = 0, n0 = 0;
     const float* asrc[2];
-    int kc[2];
     const _Float16* bsrc;
     auto setup_tile = [&](int v) {
         const int xcd = v & 7, j = v >> 3, q = ntiles >> 3, r = ntiles & 7;
@@ -246,7 +279,7 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
             const int row = 16 * wave + 8 * jj + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
             asrc[jj] = p.x + (size_t)min(m0 + row, p.M - 1) * p.xld;
-            kc[jj] = 4 * c;
+            (void)c;
         }
         const int brow = 16 * (wave & 7) + (lane >> 2);
         const int bc = (lane & 3) ^ ((brow >> 2) & 3);
@@ -256,7 +289,11 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
         const unsigned base = (unsigned)stage * D_STAGE;
         const int k0 = kt * DK;
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) dma16(asrc[jj] + min(k0 + kc[jj], K - 4), base + (unsigned)(2 * wave + jj) * 1024u, smem);
+        for (int jj = 0; jj < 2; ++jj) {   // the chunk's channel offset is recomputed here: this kernel has no register to spare
+            const int row = 16 * wave + 8 * jj + (lane >> 3);
+            const int kc = 4 * ((lane & 7) ^ ((row >> 1) & 7));
+            dma16(asrc[jj] + min(k0 + kc, K - 4), base + (unsigned)(2 * wave + jj) * 1024u, smem);
+        }
         dma16(bsrc + k0, base + D_A_BYTES + (unsigned)(wave >> 3) * D_B_BYTES + (unsigned)(wave & 7) * 1024u, smem);
     };
     int a_off[2][2], b_off[2];
@@ -322,7 +359,7 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
         if (n < p.Ng) {
             const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < 2; ++i) {      // element by element: 128 VGPRs leave no room for a 16-value staging array
                 const int mb = em0 + (wm * 2 + i) * 32 + 4 * lhi;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
