@@ -359,17 +359,42 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
         if (n < p.Ng) {
             const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {      // element by element: 128 VGPRs leave no room for a 16-value staging array
+            for (int i = 0; i < 2; ++i) {
                 const int mb = em0 + (wm * 2 + i) * 32 + 4 * lhi;
+                // eight values at a time (128 VGPRs leave no room for sixteen): activation switch and residual test outside
+                // the element loops, residual loads unconditional and batched ahead of the stores
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mb + (r & 3) + 8 * (r >> 2);
-                    if (m >= p.M) continue;
-                    const float pre = fmaf(acc2[i][r], 1.f / 2048.f, acc1[i][r]) + bv;
-                    emax = max(emax, __float_as_uint(pre) & 0x7fffffffu);
-                    float o = rd_act(pre, p.act);
-                    if (p.res) o += p.res[(size_t)m * p.rld + n];
-                    __builtin_nontemporal_store(o, &p.y[(size_t)m * p.yld + n]);
+                for (int half = 0; half < 2; ++half) {
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = half * 8 + e;
+                        o[e] = fmaf(acc2[i][r], 1.f / 2048.f, acc1[i][r]) + bv;
+                        emax = max(emax, __float_as_uint(o[e]) & 0x7fffffffu);
+                    }
+                    if (p.act == ACT_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = rd_gelu(o[e]);
+                    } else if (p.act != ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = rd_act(o[e], p.act);
+                    }
+                    if (p.res) {
+                        float rs[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int r = half * 8 + e;
+                            rs[e] = p.res[(size_t)min(mb + (r & 3) + 8 * (r >> 2), p.M - 1) * p.rld + n];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] += rs[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = half * 8 + e;
+                        const int m = mb + (r & 3) + 8 * (r >> 2);
+                        if (m < p.M) __builtin_nontemporal_store(o[e], &p.y[(size_t)m * p.yld + n]);
+                    }
                 }
             }
         }
