@@ -266,22 +266,56 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 && BM * BN >= 128 *
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mb = em0 + (wm * TM + i) * 32 + 4 * lhi;
+            if (p.out_mode == OUT_NHWC) {
+                // eight values at a time: the activation switch and the residual test stay outside the element loops and
+                // the residual loads are unconditional (clamped row) and batched ahead of the stores - a load issued behind
+                // a store otherwise waits for it (loads and stores share the vmcnt counter on this ISA)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+                for (int half = 0; half < 2; ++half) {
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = half * 8 + e;
+                        o[e] = fmaf(acc2[i][j][r], 1.f / 2048.f, acc1[i][j][r]) + bv;
+                        emax = max(emax, __float_as_uint(o[e]) & 0x7fffffffu);
+                    }
+                    if (p.act == ACT_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = rd_gelu(o[e]);
+                    } else if (p.act != ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = rd_act(o[e], p.act);
+                    }
+                    if (p.res) {
+                        float rs[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int r = half * 8 + e;
+                            rs[e] = p.res[(size_t)min(mb + (r & 3) + 8 * (r >> 2), p.M - 1) * p.rld + co];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] += rs[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = half * 8 + e;
+                        const int m = mb + (r & 3) + 8 * (r >> 2);
+                        if (m < p.M) p.y[(size_t)m * p.yld + co] = o[e];
+                    }
+                }
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {          // 2x2 transposed convolution: scatter to the upsampled grid
                 const int m = mb + (r & 3) + 8 * (r >> 2);
                 if (m >= p.M) continue;
                 const float pre = fmaf(acc2[i][j][r], 1.f / 2048.f, acc1[i][j][r]) + bv;
                 emax = max(emax, __float_as_uint(pre) & 0x7fffffffu);
-                float v = rd_act(pre, p.act);
-                if (p.out_mode == OUT_NHWC) {
-                    if (p.res) v += p.res[(size_t)m * p.rld + co];
-                    p.y[(size_t)m * p.yld + co] = v;
-                } else {
-                    const int b = m / ohw, rem = m - b * ohw;
-                    const int oh = rem / p.OW, ow = rem - oh * p.OW;
-                    const size_t pix = ((size_t)b * (2 * p.OH) + 2 * oh + dy) * (2 * p.OW) + 2 * ow + dx;
-                    p.y[pix * p.yld + co] = v;
-                }
+                const float v = rd_act(pre, p.act);
+                const int b = m / ohw, rem = m - b * ohw;
+                const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                const size_t pix = ((size_t)b * (2 * p.OH) + 2 * oh + dy) * (2 * p.OW) + 2 * ow + dx;
+                p.y[pix * p.yld + co] = v;
             }
         }
     }
