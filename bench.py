@@ -101,12 +101,14 @@ def main():
             dist_mod.init_process_group(backend)
         dist = dist_mod
 
+    # rank 0 (re)builds the library if it is missing or stale; EVERY rank then passes the same barrier, so no rank can
+    # dlopen a half-linked file or pair its first collective with rank 0's barrier (build() links to a temporary name
+    # and renames it into place)
     from rapiddoc_amd import build as rd_build
-    if not rd_build.OUT.exists():
-        if rank == 0:
-            rd_build.build()
-        if dist:
-            dist.barrier()
+    if rank == 0:
+        rd_build.build(verbose=False)
+    if dist:
+        dist.barrier()
     from rapiddoc_amd.pages import synth_batch
     from rapiddoc_amd.pipeline import PagePipelinePool, boxes_to_quads, render_text_maps
     from rapiddoc_amd.dist import gather_page_results

@@ -97,8 +97,7 @@ class RegionOcr:
         for i in range(b):   # DetPreProcess: BGR, (x/255 - 0.5)/0.5 (rapid_ocr.py:474-536)
             preproc_resize_norm(canvases[i], (dh, dw), mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), interp=1, swap_rb=True, out=x[i])
         maps = self.pipe.det.det_forward(x)
-        if self.pipe.det.precision != "fp32" and self.pipe.det.range_overflow():
-            self.pipe.det.set_precision("fp32")
+        if self.pipe.det.check_range_and_fallback():      # split-fp16 range guard (the pipeline's engines defer it)
             maps = self.pipe.det.det_forward(x)
         if maps_override is not None:
             assert tuple(maps_override.shape) == tuple(maps.shape)
@@ -136,21 +135,26 @@ class RegionOcr:
                                       det_batch_num=len(regions))
         for _lang, (gh, gw), members, _bs in groups:
             canv = torch.full((len(members), gh, gw, 3), 255, dtype=torch.uint8, device=pages.device)
+            # The reference whites the formula boxes out of a COPY that only the detector sees (`det_image`,
+            # analyze_utils.py:136-145); the line crops for the recogniser come from the unmasked region image
+            # (`bgr_image`, analyze_utils.py:199 -> ocr_utils.py:361-383).  Two canvases: `canv` unmasked, `det_canv` masked.
             for k, ridx in enumerate(members):
                 p, _r, (px, py, x0, y0, x1, y1, _nw, _nh), fboxes = regions[ridx]
                 x0c, y0c, x1c, y1c = max(0, x0), max(0, y0), min(W, x1), min(H, y1)      # numpy slicing clips the same way
                 if x1c > x0c and y1c > y0c:
                     canv[k, py + (y0c - y0): py + (y0c - y0) + (y1c - y0c), px + (x0c - x0): px + (x0c - x0) + (x1c - x0c)] = \
                         pages[p, y0c:y1c, x0c:x1c]
+            det_canv = canv.clone() if any(regions[ridx][3] for ridx in members) else canv
+            for k, ridx in enumerate(members):
                 nh, nw = regions[ridx][2][7], regions[ridx][2][6]
-                for fb in fboxes:                       # _apply_mask_boxes_to_image (analyze_utils.py:82-103)
+                for fb in regions[ridx][3]:             # _apply_mask_boxes_to_image (analyze_utils.py:82-103)
                     ib = _int_box(fb, nh, nw)
                     if ib:
-                        canv[k, ib[1]:ib[3], ib[0]:ib[2]] = 255
+                        det_canv[k, ib[1]:ib[3], ib[0]:ib[2]] = 255
             override = None
             if det_maps_fn is not None:
                 override = det_maps_fn([regions[i][:3] for i in members], (gh, gw), ocr_host.det_resize_shape(gh, gw, 960, "max"))
-            boxes_per_img = self._detect_group(canv, override)
+            boxes_per_img = self._detect_group(det_canv, override)
             spans_per_img: List[List[dict]] = []
             quads_per_img: List[np.ndarray] = []
             for k, ridx in enumerate(members):

@@ -49,10 +49,13 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(OUT)]
+    tmp = OUT.with_name(OUT.name + f".tmp{os.getpid()}")      # link aside, then rename: readers never see a partial file
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(tmp)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
+        tmp.unlink(missing_ok=True)
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    os.replace(tmp, OUT)
     if verbose:
         print(f"built {OUT} ({OUT.stat().st_size/1e6:.1f} MB)")
     return OUT

@@ -121,7 +121,8 @@ __global__ void __launch_bounds__(256) ctc_head_kernel(CtcParams p, int cls_per_
     const float om = __shfl_xor(m_run, 32, 64), os = __shfl_xor(s_run, 32, 64);
     const int oi = __shfl_xor(i_run, 32, 64);
     const float mm = fmaxf(m_run, om);
-    const float ss = s_run * __expf(m_run - mm) + os * __expf(om - mm);
+    // (a half that saw no class keeps m = -inf, s = 0: exp(-inf - -inf) would be NaN)
+    const float ss = (m_run > -INFINITY ? s_run * __expf(m_run - mm) : 0.f) + (om > -INFINITY ? os * __expf(om - mm) : 0.f);
     const int ii = (om > m_run || (om == m_run && oi < i_run)) ? oi : i_run;
     const int tok = tok0 + wave * 32 + l31;
     if (lhi == 0 && tok < p.M) {
@@ -264,7 +265,8 @@ __global__ void __launch_bounds__(256) ctc_head_h3_kernel(CtcParams p, int cls_p
     const float om = __shfl_xor(m_run, 32, 64), os = __shfl_xor(s_run, 32, 64);
     const int oi = __shfl_xor(i_run, 32, 64);
     const float mm = fmaxf(m_run, om);
-    const float ss = s_run * __expf(m_run - mm) + os * __expf(om - mm);
+    // (a half that saw no class keeps m = -inf, s = 0: exp(-inf - -inf) would be NaN)
+    const float ss = (m_run > -INFINITY ? s_run * __expf(m_run - mm) : 0.f) + (om > -INFINITY ? os * __expf(om - mm) : 0.f);
     const int ii = (om > m_run || (om == m_run && oi < i_run)) ? oi : i_run;
     const int tok = tok0 + wave * 32 + l31;
     if (lhi == 0 && tok < p.M) {
@@ -286,7 +288,8 @@ __global__ void __launch_bounds__(256) ctc_merge_kernel(const float* part, int M
         if (v > m) { m = v; best = __float_as_int(pr[s * 4 + 2]); }
     }
     float sum = 0.f;
-    for (int s = 0; s < nsplit; ++s) sum += pr[s * 4 + 1] * __expf(pr[s * 4] - m);
+    for (int s = 0; s < nsplit; ++s)
+        if (pr[s * 4] > -INFINITY) sum += pr[s * 4 + 1] * __expf(pr[s * 4] - m);   // an empty class split carries (-inf, 0)
     idx[tok] = best;
     prob[tok] = 1.f / sum;
 }
@@ -295,6 +298,8 @@ int ctc_head_nsplit(int M, int C) {
     const int tiles = (M + CT_TOK - 1) / CT_TOK;
     int ns = 8;
     while (tiles * ns < 256 && ns < 64 && (C / (ns * 2)) >= CT_CLS) ns *= 2;
+    // small dictionaries: every split must own at least one class (classes per split are rounded up to a multiple of 4)
+    while (ns > 1 && (((C + ns - 1) / ns + 3) / 4 * 4) * (ns - 1) >= C) --ns;
     return ns;
 }
 

@@ -25,9 +25,15 @@ def _stream_ptr() -> int:
 
 
 class RdEngine:
-    """One network on one GPU (`rd_handle`)."""
+    """One network on one GPU (`rd_handle`).
 
-    def __init__(self, kind: str, device: int = 0):
+    Range guard of the split-fp16 kernels (include/rapiddoc_mi355.h, rd_range_status) lives HERE, once, for every
+    forward of every network kind: with `guard="sync"` (default) a forward that raised the range flag is repeated in
+    native fp32 before it returns (one stream synchronisation per call); `guard="deferred"` is for callers that keep
+    several forwards in flight (PagePipeline) and promise to call `check_range_and_fallback()` before they use the
+    results; `guard="off"` leaves the flag to the caller (tests)."""
+
+    def __init__(self, kind: str, device: int = 0, guard: str = "sync"):
         if kind not in KINDS:
             raise ValueError(f"kind must be one of {KINDS}")
         if not torch.cuda.is_available():
@@ -39,6 +45,10 @@ class RdEngine:
             raise EngineError(self._l.rd_create_error().decode())
         self._tdev = torch.device("cuda", device)
         self._profiling = False
+        if guard not in ("sync", "deferred", "off"):
+            raise ValueError("guard must be 'sync', 'deferred' or 'off'")
+        self.guard = guard
+        self.range_fallbacks = 0
         self.precision = os.environ.get("RD_PRECISION", "auto")   # the library reads the same variable in rd_create
         self.profile_log: List[dict] = []
 
@@ -87,8 +97,11 @@ class RdEngine:
         x = self._prep(x)
         B, Cc, H, W_ = x.shape
         out = torch.empty((B, 1, H, W_), dtype=torch.float32, device=x.device)
-        self._chk(self._l.rd_det_forward(self._h, x.data_ptr(), B, H, W_, out.data_ptr(), None, 0, _stream_ptr()))
-        self._log()
+
+        def launch():
+            self._chk(self._l.rd_det_forward(self._h, x.data_ptr(), B, H, W_, out.data_ptr(), None, 0, _stream_ptr()))
+            self._log()
+        self._guarded(launch)
         return out
 
     def rec_forward(self, x: torch.Tensor, flags: int = 0) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
@@ -102,9 +115,12 @@ class RdEngine:
         full = None
         if flags & (REC_WANT_SOFTMAX | REC_WANT_LOGITS):
             full = torch.empty((B, T, self.num_classes), dtype=torch.float32, device=x.device)
-        self._chk(self._l.rd_rec_forward(self._h, x.data_ptr(), B, W_, idx.data_ptr(), prob.data_ptr(),
-                                         full.data_ptr() if full is not None else None, flags, None, 0, _stream_ptr()))
-        self._log()
+
+        def launch():
+            self._chk(self._l.rd_rec_forward(self._h, x.data_ptr(), B, W_, idx.data_ptr(), prob.data_ptr(),
+                                             full.data_ptr() if full is not None else None, flags, None, 0, _stream_ptr()))
+            self._log()
+        self._guarded(launch)
         return idx, prob, full
 
     def backbone_forward(self, x: torch.Tensor) -> List[torch.Tensor]:
@@ -114,8 +130,11 @@ class RdEngine:
         feats = [torch.empty((B, c, H // s, W_ // s), dtype=torch.float32, device=x.device)
                  for c, s in zip(chans, (4, 8, 16, 32))]
         arr = (C.c_void_p * 4)(*[f.data_ptr() for f in feats])
-        self._chk(self._l.rd_backbone_forward(self._h, x.data_ptr(), B, H, W_, arr, None, 0, _stream_ptr()))
-        self._log()
+
+        def launch():
+            self._chk(self._l.rd_backbone_forward(self._h, x.data_ptr(), B, H, W_, arr, None, 0, _stream_ptr()))
+            self._log()
+        self._guarded(launch)
         return feats
 
     def formula_encoder_forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -123,8 +142,11 @@ class RdEngine:
         x = self._prep(x)
         B, Cc, H, W_ = x.shape
         out = torch.empty((B, (H // 32) * (W_ // 32), 2048), dtype=torch.float32, device=x.device)
-        self._chk(self._l.rd_formula_encoder_forward(self._h, x.data_ptr(), B, Cc, H, W_, out.data_ptr(), None, 0, _stream_ptr()))
-        self._log()
+
+        def launch():
+            self._chk(self._l.rd_formula_encoder_forward(self._h, x.data_ptr(), B, Cc, H, W_, out.data_ptr(), None, 0, _stream_ptr()))
+            self._log()
+        self._guarded(launch)
         return out
 
     def formula_decode(self, enc: torch.Tensor, max_new_tokens: int) -> torch.Tensor:
@@ -146,6 +168,24 @@ class RdEngine:
         self._chk(self._l.rd_set_precision(self._h, mode.encode()))
         self.precision = mode
         return self
+
+    def _guarded(self, launch) -> None:
+        """Run `launch` (enqueue one forward); in "sync" mode repeat it in native fp32 if a split kernel flagged an
+        operand outside the fp16 range - a result is never silently wrong, whichever entry point produced it."""
+        launch()
+        if self.guard == "sync" and self.precision != "fp32" and self.range_overflow():
+            self.set_precision("fp32")
+            self.range_fallbacks += 1
+            launch()
+
+    def check_range_and_fallback(self) -> bool:
+        """Deferred guard: True when forwards since the last check overflowed; the handle is then switched to fp32 and
+        the CALLER must repeat those forwards."""
+        if self.precision != "fp32" and self.range_overflow():
+            self.set_precision("fp32")
+            self.range_fallbacks += 1
+            return True
+        return False
 
     def range_overflow(self) -> bool:
         """True when a split-fp16 kernel met an operand outside the fp16 range since the last call (synchronises the

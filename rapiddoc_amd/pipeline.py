@@ -92,20 +92,24 @@ class PagePipeline:
         bytes, or name->ndarray dict."""
         self.device = device
         self.tdev = torch.device("cuda", device)
-        self.det = RdEngine("ppocrv6_det", device).load_weights(states["ppocrv6_det"])
+        # several forwards are in flight at once here, so the engines defer the split-fp16 range guard: run_batch (det,
+        # layout) and rec_forward_lines (rec) call check_range_and_fallback() before any result is used
+        self.det = RdEngine("ppocrv6_det", device, guard="deferred").load_weights(states["ppocrv6_det"])
         # rec batches are independent: they alternate between `n_rec_streams` HIP streams (one engine handle = one
         # workspace per stream) so that the launch gaps / tails of one batch are filled by kernels of the other
-        self.rec_engines = [RdEngine("ppocrv6_rec", device).load_weights(states["ppocrv6_rec"]) for _ in range(max(1, n_rec_streams))]
+        self.rec_engines = [RdEngine("ppocrv6_rec", device, guard="deferred").load_weights(states["ppocrv6_rec"]) for _ in range(max(1, n_rec_streams))]
         self.rec = self.rec_engines[0]
         self.rec_streams = [torch.cuda.Stream(device=self.tdev) for _ in self.rec_engines]
         self.layout_stream = torch.cuda.Stream(device=self.tdev)
-        self.layout = RdEngine("pphgnetv2_b4", device).load_weights(states["pphgnetv2_b4"]) if "pphgnetv2_b4" in states else None
+        self.layout = RdEngine("pphgnetv2_b4", device, guard="deferred").load_weights(states["pphgnetv2_b4"]) if "pphgnetv2_b4" in states else None
         ncls = self.rec.num_classes
         self.characters = list(characters) if characters is not None else ["blank"] + [chr(0x4E00 + i) for i in range(ncls - 2)] + [" "]
         assert len(self.characters) == ncls, (len(self.characters), ncls)
         self.rec_batch_num = rec_batch_num
         self.rec_width_multiple = rec_width_multiple
         self.keep_feats = keep_feats
+        self.keep_rec_inputs = False      # tests: keep every rec batch's input tensor and raw (idx, prob) in last_rec_batches
+        self.last_rec_batches: List[Tuple[np.ndarray, torch.Tensor, torch.Tensor, torch.Tensor]] = []
         self._lib = _lib.load()
         self.stats: Dict[str, float] = {}
 
@@ -129,7 +133,16 @@ class PagePipeline:
 
     def rec_forward_lines(self, pages: torch.Tensor, quads_per_page: Sequence[np.ndarray]):
         """All text lines of the page batch -> [(text, score)] per page, reference batching order
-        (rapid_ocr.py:404-472) with a GPU-sized rec_batch_num."""
+        (rapid_ocr.py:404-472) with a GPU-sized rec_batch_num.  Carries the split-fp16 range guard of its rec engines
+        (every caller - run_batch, analyze.RegionOcr, RegionTextModel - gets it): a tripped engine is switched to native
+        fp32 and the lines are recognised again."""
+        out = self._rec_forward_lines_once(pages, quads_per_page)
+        if any([e.check_range_and_fallback() for e in self.rec_engines]):     # list, not generator: check every engine
+            self.stats["range_fallbacks"] = self.stats.get("range_fallbacks", 0) + 1
+            out = self._rec_forward_lines_once(pages, quads_per_page)
+        return out
+
+    def _rec_forward_lines_once(self, pages: torch.Tensor, quads_per_page: Sequence[np.ndarray]):
         P, H, W, _ = pages.shape
         t0 = time.perf_counter()
         counts = [len(np.asarray(q).reshape(-1, 4, 2)) for q in quads_per_page]
@@ -185,6 +198,8 @@ class PagePipeline:
         # D2H per batch result (small) as soon as that batch is done, host CTC decode (rapidocr CTCLabelDecode)
         # overlaps the GPU work of the batches still in flight
         t_dec = 0.0
+        if self.keep_rec_inputs:
+            self.last_rec_batches = [(np.asarray(chunk), x, idx, prob) for (chunk, _w), (idx, prob, _d, x) in zip(batches, outs)]
         for (chunk, wpad), (idx, prob, done, _x) in zip(batches, outs):
             done.synchronize()
             idx_h, prob_h = idx.cpu().numpy(), prob.cpu().numpy()
@@ -228,10 +243,9 @@ class PagePipeline:
         an engine that met an operand outside the fp16 range is switched to native fp32 for good and the batch is
         repeated, so a result is never silently wrong."""
         results = self._run_batch_once(pages, quads_per_page, det_maps_override)
-        tripped = [e for e in [self.det, *self.rec_engines] if e.precision != "fp32" and e.range_overflow()]
-        if tripped:
-            for e in tripped:
-                e.set_precision("fp32")
+        # det and the layout backbone (the rec engines are guarded inside rec_forward_lines)
+        engines = [self.det] + ([self.layout] if self.layout is not None else [])
+        if any([e.check_range_and_fallback() for e in engines]):
             self.stats["range_fallbacks"] = self.stats.get("range_fallbacks", 0) + 1
             results = self._run_batch_once(pages, quads_per_page, det_maps_override)
         return results

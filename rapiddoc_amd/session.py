@@ -50,13 +50,7 @@ class _BaseSession:
         return []
 
 
-def _guarded(engine, fn):
-    """Run `fn`; if a split-fp16 kernel flagged an out-of-range operand, switch the engine to fp32 and run it again."""
-    out = fn()
-    if engine.precision != "fp32" and engine.range_overflow():
-        engine.set_precision("fp32")
-        out = fn()
-    return out
+# The split-fp16 range guard (fp32 re-run) is part of every RdEngine forward (engine.RdEngine._guarded, guard="sync").
 
 
 class Mi355DetSession(_BaseSession):
@@ -65,7 +59,7 @@ class Mi355DetSession(_BaseSession):
 
     def __call__(self, img: np.ndarray) -> np.ndarray:
         x = self._to_dev(img)
-        return _guarded(self.engine, lambda: self.engine.det_forward(x).cpu().numpy())
+        return self.engine.det_forward(x).cpu().numpy()
 
 
 class Mi355RecSession(_BaseSession):
@@ -74,14 +68,12 @@ class Mi355RecSession(_BaseSession):
 
     def __call__(self, img: np.ndarray) -> np.ndarray:
         x = self._to_dev(img)
-        return _guarded(self.engine, lambda: self.engine.rec_forward(x, REC_WANT_SOFTMAX)[2].cpu().numpy())
+        return self.engine.rec_forward(x, REC_WANT_SOFTMAX)[2].cpu().numpy()
 
     def infer_indices(self, img: Union[np.ndarray, torch.Tensor]) -> Tuple[np.ndarray, np.ndarray]:
         x = img if isinstance(img, torch.Tensor) else self._to_dev(img)
-        def go():
-            idx, prob, _ = self.engine.rec_forward(x)
-            return idx.cpu().numpy(), prob.cpu().numpy()
-        return _guarded(self.engine, go)
+        idx, prob, _ = self.engine.rec_forward(x)
+        return idx.cpu().numpy(), prob.cpu().numpy()
 
 
 class Mi355LayoutBackboneSession(_BaseSession):

@@ -97,8 +97,8 @@ def test_b4_matches_oracle_batch(engines):
 
 def test_pipeline_end_to_end_boxes_from_db_postprocess(engines, golden_dir):
     """Whole device-resident path on 2 synthetic pages: det forward, DB post-process (on maps rendered from the
-    generator's boxes), crops, rec with fused CTC, decode.  The rec results must equal the oracle run on the very
-    same crops."""
+    generator's boxes), crops, rec with fused CTC, decode.  (That the rec results equal the oracle run on the very same
+    crops is asserted by tests/test_gpu_fullsize.py::test_pipeline_rec_equals_oracle_on_the_crops_it_made.)"""
     from rapiddoc_amd.pages import synth_batch
     from rapiddoc_amd.pipeline import PagePipeline, render_text_maps
     states = {k: W.synth_state_dict(W.load_manifest(golden_dir / f"manifest_{k}.json"), 0)
@@ -205,9 +205,9 @@ def test_range_guard_falls_back_to_fp32(golden_dir, monkeypatch):
     stem = [k for k in big if k.endswith("weight") and big[k].ndim == 4 and big[k].shape[1] == 3][0]
     big[stem] = big[stem] * 3.0e5          # blow the stem up: every later activation is ~1e5 x larger
     x = np.load(golden_dir / "det_seed0_64x96.npz")["x"]
-    ref_eng = RdEngine("ppocrv6_det").load_weights(big).set_precision("fp32")
+    ref_eng = RdEngine("ppocrv6_det", guard="off").load_weights(big).set_precision("fp32")
     ref = ref_eng.det_forward(torch.from_numpy(x).cuda()).cpu().numpy()
-    eng = RdEngine("ppocrv6_det").load_weights(big)
+    eng = RdEngine("ppocrv6_det", guard="off").load_weights(big)   # guard off: look at the raw flag
     eng.det_forward(torch.from_numpy(x).cuda())
     assert eng.range_overflow() and not eng.range_overflow()      # raised once, cleared by the read
     sess = Mi355DetSession(big)
