@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
@@ -430,11 +431,25 @@ TView Builder::mixer_fused(const std::string& prefix, const TView& x, const TVie
             pb_->add_u16(hkey + ".w1h", v[0]); pb_->add_u16(hkey + ".w1l", v[1]);
             pb_->add_u16(hkey + ".w2h", v[2]); pb_->add_u16(hkey + ".w2l", v[3]);
         }
+        if (!pb_->has(hkey + ".ws") && fits && mixer_ws_supported(C)) {   // weight stream image of the ws kernel
+            std::vector<uint16_t> img;
+            float inv[2];
+            prepare_mixer_weights_ws(f1, f2, C, img, inv);
+            pb_->add_u16(hkey + ".ws", img);
+            pb_->add(hkey + ".wsinv", std::vector<float>{inv[0], inv[1]});
+        }
         return y;
     }
     const bool split = (h3_ || mixer_h3_) && pb_->has(hkey + ".w1h");
+    static const bool ws_off = std::getenv("RD_MIXER_WS") && std::string(std::getenv("RD_MIXER_WS")) == "0";   // A/B switch
+    const bool ws = split && !ws_off && pb_->has(hkey + ".ws");
     MixerParams p{};
-    if (split) {
+    if (ws) {
+        p.w1h = reinterpret_cast<const uint16_t*>(pb_->ptr(hkey + ".ws"));
+        p.ws_inv1 = pb_->host_ptr(hkey + ".wsinv")[0];
+        p.ws_inv2 = pb_->host_ptr(hkey + ".wsinv")[1];
+        p.range_flag = range_flag_;
+    } else if (split) {
         p.w1h = reinterpret_cast<const uint16_t*>(pb_->ptr(hkey + ".w1h")); p.w1l = reinterpret_cast<const uint16_t*>(pb_->ptr(hkey + ".w1l"));
         p.w2h = reinterpret_cast<const uint16_t*>(pb_->ptr(hkey + ".w2h")); p.w2l = reinterpret_cast<const uint16_t*>(pb_->ptr(hkey + ".w2l"));
         p.range_flag = range_flag_;
@@ -446,7 +461,7 @@ TView Builder::mixer_fused(const std::string& prefix, const TView& x, const TVie
     p.w2 = pb_->ptr(w2 + "|" + bn2 + "#w"); p.b2 = pb_->ptr(w2 + "|" + bn2 + "#b");
     OpRecord r;
     r.name = prefix + ".mixer";
-    r.kind = split ? "mixer_fused_h3" : "mixer_fused";
+    r.kind = ws ? "mixer_fused_ws" : split ? "mixer_fused_h3" : "mixer_fused";
     r.cfg = "C" + std::to_string(C);
     r.shape = "M" + std::to_string(p.M) + "_C" + std::to_string(C);
     r.flops = 8.0 * p.M * (double)C * C;
@@ -454,12 +469,13 @@ TView Builder::mixer_fused(const std::string& prefix, const TView& x, const TVie
     const TView xv = x, yv = y;
     const bool has_gate = gate != nullptr;
     const TView gv = gate ? *gate : TView{};
-    r.run = [p, xv, yv, gv, has_gate, split](const Plan& pl, const RunCtx& c) {
+    r.run = [p, xv, yv, gv, has_gate, split, ws](const Plan& pl, const RunCtx& c) {
         MixerParams q = p;
         q.x = pl.vptr(xv, c);
         q.y = pl.vptr(yv, c);
         q.gate = has_gate ? pl.vptr(gv, c) : nullptr;
-        if (split) launch_mixer_fused_h3(q, c.stream);
+        if (ws) launch_mixer_fused_ws(q, c.stream);
+        else if (split) launch_mixer_fused_h3(q, c.stream);
         else launch_mixer_fused(q, c.stream);
     };
     emit(std::move(r));

@@ -1,0 +1,387 @@
+// Weight-streaming fused PPLCNetV4 channel mixer ("ws") on the split-fp16 matrix cores - round-2 replacement of
+// lc_mixer_h3_kernel for C = 96 / 192 (rec_lcnetv4.py:226-236:  Y = X' + W2 . GELU(W1 . X' + b1) + b2,  X' = X * gate).
+//
+// Why a new structure: the round-1 kernel kept a 128-pixel X tile in LDS (98 KB at C = 192), which left room
+// for ONE 4-wavefront workgroup per CU at 456 VGPRs: one wavefront per SIMD, every phase (tile load, GEMM1, GELU, GEMM2,
+// store) serialised, matrix pipe 22 % busy.  Here the ACTIVATIONS LIVE IN REGISTERS and LDS holds nothing but the weight
+// stream:
+//   * a wavefront owns 16 pixels.  Both GEMMs are computed transposed on v_mfma_f32_16x16x32_f16 with the weights as the A
+//     operand (rows = hidden units / output channels, straight from LDS) and the activations as the B operand (columns =
+//     pixels, from registers):  H^T[32 x 16] = W1c . X^T,   Y^T[C x 16] += W2c . GELU(H)^T.
+//     X^T as B fragments is C/4 VGPRs (48 at C = 192), Y^T accumulators C/4 x 2, so a wavefront needs < 256 VGPRs and
+//     EIGHT wavefronts (two per SIMD) share a CU: one wavefront's VALU (GELU, split) and waits hide under the other's MFMAs.
+//   * the k index of an MFMA is free as long as A and B agree, so W1's input channels are PERMUTED at weight-preparation
+//     time such that the 8 k-slots a lane feeds to GEMM1 are the same 2 x 4 contiguous channels it owns in the C/D layout
+//     of Y^T: one float4 load per 16-channel block serves the split, the same addresses serve the residual and the store.
+//     The C/D registers of H^T are directly the B fragment of GEMM2 (W2's hidden columns permuted to match), as before.
+//   * the weights are pre-arranged on the host as a stream of 1-KB MFMA fragments in exactly the order they are consumed:
+//     an LDS stage is filled by a LINEAR global_load_lds copy (no swizzle, no address arithmetic) and every fragment read
+//     is ds_read_b128 at stage + fragment * 1024 + lane * 16: conflict-free by construction.
+//   * persistent workgroups (one per CU) loop over pixel tiles while the weight stream cycles through a 3-stage LDS ring
+//     (2 stages = 96 KB in flight at C = 192): the pipeline never drains between tiles.  Stage q holds
+//     [W1 chunk q+1 | W2 chunk q]: a step runs GELU(chunk q) beside GEMM1(chunk q+1), then GEMM2(chunk q) - the MFMAs of the
+//     next chunk cover the VALU of this one inside a wavefront too.
+//   * optional stagger: wavefronts 4-7 (the second wavefront of every SIMD) start their tiles half a weight cycle later, so
+//     one half's epilogue / tile load runs under the other half's GEMMs.
+// Arithmetic ("scaled split", one accumulator): an operand v is carried as hi = fp16(v * s), lo = fp16(v * s - hi) with a
+// POWER-OF-TWO scale s, and a product is three MFMAs (hi.hi + hi.lo + lo.hi) into ONE fp32 accumulator that is multiplied by
+// the exact inverse scales in the epilogue.  The gfx950 fp16 matrix cores keep subnormal inputs (tools/probe_mfma.hip), so lo
+// needs no 2^11 pre-scale and the second accumulator of the round-1 kernels (half of the accumulator registers) goes away.
+// lo is a normal fp16 number - i.e. the operand keeps 22 significant bits - whenever |v * s| >= 2^-3, otherwise its absolute
+// error is <= 2^-25 / s.  Scales: weights per matrix, max |w| * s in [2^13, 2^14) (fixed at load time; elements down to
+// 2^-17 of the largest keep 22 bits); X' PER PIXEL, max over the pixel's channels scaled into [2^13, 2^14) (block floating
+// point: no activation of any magnitude can leave the fp16 range, and precision is relative to the pixel's own largest
+// channel); GELU outputs by a fixed 2^4 (guarded: |h| >= 4094 raises the range flag -> fp32 re-run, as in round 1).
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "rd_device.h"
+
+namespace rd {
+
+static constexpr int WS_PX = 16;      // pixels per wavefront
+static constexpr int WS_WAVES = 8;    // wavefronts per workgroup
+static constexpr int WS_HC = 32;      // hidden units per chunk
+static constexpr int WS_NSTAGE = 3;
+
+template <int C>
+struct WsGeom {
+    static constexpr int KS = C / 32;              // k-steps of GEMM1 (32 input channels each)
+    static constexpr int NB = C / 16;              // 16-channel output blocks of GEMM2
+    static constexpr int NC = 2 * C / WS_HC;       // hidden chunks = steps per tile
+    static constexpr int W1_FRAGS = 2 * KS * 2;    // (hidden block b, k-step s, plane)
+    static constexpr int W2_FRAGS = NB * 2;        // (output block n, plane)
+    static constexpr int STAGE_FRAGS = W1_FRAGS + W2_FRAGS;
+    static constexpr int STAGE_BYTES = STAGE_FRAGS * 1024;
+    static constexpr int PIECES = STAGE_FRAGS / WS_WAVES;   // DMA instructions per wavefront and stage
+    static_assert(STAGE_FRAGS % WS_WAVES == 0, "stage must split evenly over the wavefronts");
+    static constexpr size_t LDS_BYTES = (size_t)WS_NSTAGE * STAGE_BYTES + 3 * C * sizeof(float);
+};
+
+// one wait + workgroup barrier per step: my DMA pieces of the stage about to be read have landed (the PIECES issued
+// last step may still be in flight), then everybody's have, and everybody is done reading the stage about to be refilled
+template <int PIECES>
+__device__ __forceinline__ void ws_step_sync(bool next_in_flight) {
+    // (loads complete in issue order, so "at most PIECES operations outstanding" implies the older stage has landed
+    //  whatever the stores of an epilogue in between do; on the last step nothing younger is in flight: wait for all)
+    if (!next_in_flight) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    else if constexpr (PIECES == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    else if constexpr (PIECES == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+static constexpr float WS_SH = 16.f;   // fixed scale of the hidden activations (GELU outputs)
+
+// v -> (hi, lo) of v * s
+__device__ __forceinline__ void ws_split(float v, float s, _Float16& hi, _Float16& lo) {
+    const float vs = v * s;
+    hi = (_Float16)vs;
+    lo = (_Float16)(vs - (float)hi);   // exact difference, rounded once (only in the fp16 subnormal range)
+}
+
+// inv1 = 1 / scale(W1), inv2 = 1 / (scale(W2) * WS_SH): exact powers of two
+template <int C, bool GATED, bool STAGGER, bool KEEPX>
+__global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, const unsigned char* __restrict__ wimg, int n_wg_tiles,
+                                                             float inv1, float inv2) {
+    using G = WsGeom<C>;
+    constexpr int KS = G::KS, NB = G::NB, NC = G::NC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float* B1s = reinterpret_cast<float*>(lds + WS_NSTAGE * G::STAGE_BYTES);   // [2C] hidden biases, [C] output biases
+    float* B2s = B1s + 2 * C;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, g = lane >> 4;
+
+    for (int i = tid; i < 2 * C; i += 512) B1s[i] = p.b1[i];
+    for (int i = tid; i < C; i += 512) B2s[i] = p.b2[i];
+    __syncthreads();
+
+    // rounds of this workgroup: workgroup tiles blockIdx.x, + gridDim.x, ...; wavefront w owns pixels [16w, 16w + 16) of a tile
+    const int R = (n_wg_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int ph = (STAGGER && wave >= WS_WAVES / 2) ? NC / 2 : 0;
+    const int T_total = R * NC + 1 + (STAGGER ? NC / 2 : 0);
+
+    // ---- weight stream: stage q of the image = [W1 fragments of chunk (q+1) % NC | W2 fragments of chunk q]
+    auto issue_stage = [&](int t) {
+        const int q = (t + NC - 1) % NC;
+        const unsigned char* src = wimg + (size_t)q * G::STAGE_BYTES + (size_t)wave * 1024 + lane * 16;
+        unsigned char* dst = lds + (t % WS_NSTAGE) * G::STAGE_BYTES + wave * 1024;
+#pragma unroll
+        for (int u = 0; u < G::PIECES; ++u)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + u * WS_WAVES * 1024),
+                                             (__attribute__((address_space(3))) void*)(dst + u * WS_WAVES * 1024), 16, 0, 0);
+    };
+    issue_stage(0);
+    if (T_total > 1) issue_stage(1);
+
+    f16x8 xh[KS], xl[KS];            // X^T as B fragments of GEMM1 (hi / lo of x' * sx)
+    f32x4 xr[KEEPX ? NB : 1];        // KEEPX: the fp32 tile itself stays in registers for the residual
+    f32x4 y[NB];                     // Y^T accumulators
+    f32x4 hc[2];                     // H^T of the chunk being finished (GELU -> GEMM2)
+    f32x4 hn[2];                     // H^T of the next chunk (GEMM1 running)
+    float hfac = 0.f;                // inv1 / sx of this lane's pixel (set by load_x): H = acc * hfac + b1
+    float hfac_cur = 0.f;            // the factor that belongs to hc (the tile whose chunk is being finished)
+#pragma unroll
+    for (int n = 0; n < NB; ++n) y[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < (KEEPX ? NB : 1); ++n) xr[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 2; ++b) hc[b] = hn[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xh[s][e] = xl[s][e] = (_Float16)0.f;
+    float amax = 0.f;                // largest |GELU output| this lane split; X' can only fail by being non-finite
+    bool bad = false;
+
+    auto tile_m = [&](int r) { return (((int)blockIdx.x + r * (int)gridDim.x) * WS_WAVES + wave) * WS_PX + px; };
+
+    // X tile -> (gate) -> per-pixel scale -> split into the B fragments.  Lane (px, g) owns channels 16n + 4g .. + 4 of every
+    // block n; the four lanes px, px + 16, px + 32, px + 48 hold one pixel.
+    auto load_x = [&](int r) {
+        const int m = min(tile_m(r), p.M - 1);      // rows past M re-read the last row and are never stored
+        const float* xp = p.x + (size_t)m * p.xld + 4 * g;
+        const float* gp = GATED ? p.gate + (size_t)(m / p.HW) * C + 4 * g : nullptr;
+        f32x4 v[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) v[n] = *reinterpret_cast<const f32x4*>(xp + 16 * n);
+        if (GATED) {
+#pragma unroll
+            for (int n = 0; n < NB; ++n) v[n] *= *reinterpret_cast<const f32x4*>(gp + 16 * n);
+        }
+        float mx = 0.f;
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(v[n][e]));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        bad = bad || !(mx < INFINITY);               // inf / NaN input: let the fp32 path produce what fp32 produces
+        // sx = 2^(13 - floor(log2 mx)): mx * sx in [2^13, 2^14).  Exponent arithmetic on the bits; tiny / zero pixels clamp
+        // to 2^100 (everything then lands in the fp16 subnormal range or is 0: absolute error 2^-125, irrelevant)
+        const int ex = max((int)((__float_as_uint(mx) >> 23) & 0xffu), 40);
+        const float sx = __uint_as_float((unsigned)(267 - ex) << 23);
+        hfac = __uint_as_float((unsigned)(ex - 13) << 23) * inv1;      // (1 / sx) * inv1
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 a, b;
+                ws_split(v[n][e], sx, a, b);
+                xh[n >> 1][(n & 1) * 4 + e] = a;
+                xl[n >> 1][(n & 1) * 4 + e] = b;
+            }
+            if constexpr (KEEPX) xr[n] = v[n];
+        }
+    };
+
+    auto frag = [&](const unsigned char* stage, int f) {
+        return *reinterpret_cast<const f16x8*>(stage + f * 1024 + lane * 16);
+    };
+
+    // GEMM1 (transposed): hn = W1c . X^T   (A = weights from LDS, B = X fragments in registers)
+    auto gemm1 = [&](const unsigned char* stage) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) hn[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const f16x8 a0h = frag(stage, (0 * KS + s) * 2 + 0), a0l = frag(stage, (0 * KS + s) * 2 + 1);
+            const f16x8 a1h = frag(stage, (1 * KS + s) * 2 + 0), a1l = frag(stage, (1 * KS + s) * 2 + 1);
+            hn[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, xh[s], hn[0], 0, 0, 0);
+            hn[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, xh[s], hn[1], 0, 0, 0);
+            hn[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, xl[s], hn[0], 0, 0, 0);
+            hn[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, xl[s], hn[1], 0, 0, 0);
+            hn[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0l, xh[s], hn[0], 0, 0, 0);
+            hn[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l, xh[s], hn[1], 0, 0, 0);
+        }
+    };
+    // un-scale + bias + GELU in fp32 on the finished chunk, split (x 2^4) into the B fragment of GEMM2: C/D register r of
+    // hidden block b is hidden 16b + 4g + r = k-slot 4b + r (W2's hidden columns are permuted to this order on the host)
+    auto gelu_split = [&](int q, f16x8& hh, f16x8& hl) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(&B1s[q * WS_HC + 16 * b + 4 * g]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = rd_gelu(fmaf(hc[b][r], hfac_cur, bv[r]));
+                _Float16 a, c;
+                ws_split(v, WS_SH, a, c);
+                amax = fmaxf(amax, fabsf(v));
+                hh[4 * b + r] = a;
+                hl[4 * b + r] = c;
+            }
+        }
+    };
+    // GEMM2 (transposed): Y^T += W2c . H^T   (two output blocks interleaved)
+    auto gemm2 = [&](const unsigned char* stage, const f16x8& hh, const f16x8& hl) {
+#pragma unroll
+        for (int n = 0; n < NB; n += 2) {
+            const f16x8 w0h = frag(stage, G::W1_FRAGS + 2 * n + 0), w0l = frag(stage, G::W1_FRAGS + 2 * n + 1);
+            const f16x8 w1h = frag(stage, G::W1_FRAGS + 2 * n + 2), w1l = frag(stage, G::W1_FRAGS + 2 * n + 3);
+            y[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0h, hh, y[n], 0, 0, 0);
+            y[n + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h, hh, y[n + 1], 0, 0, 0);
+            y[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0h, hl, y[n], 0, 0, 0);
+            y[n + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h, hl, y[n + 1], 0, 0, 0);
+            y[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0l, hh, y[n], 0, 0, 0);
+            y[n + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1l, hh, y[n + 1], 0, 0, 0);
+        }
+    };
+    // un-scale + b2 + residual (exact fp32: kept in registers, or re-read from the same float4 addresses as the tile load),
+    // store, clear the accumulators
+    auto epilogue = [&](int r) {
+        const int mm = tile_m(r);
+        const int m = min(mm, p.M - 1);
+        f32x4 v[NB];
+        if constexpr (KEEPX) {
+#pragma unroll
+            for (int n = 0; n < NB; ++n) v[n] = xr[n];
+        } else {
+            const float* xp = p.x + (size_t)m * p.xld + 4 * g;
+            const float* gp = GATED ? p.gate + (size_t)(m / p.HW) * C + 4 * g : nullptr;
+#pragma unroll
+            for (int n = 0; n < NB; ++n) v[n] = *reinterpret_cast<const f32x4*>(xp + 16 * n);
+            if (GATED) {
+#pragma unroll
+                for (int n = 0; n < NB; ++n) v[n] *= *reinterpret_cast<const f32x4*>(gp + 16 * n);
+            }
+        }
+        float* yp = p.y + (size_t)m * p.yld + 4 * g;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(&B2s[16 * n + 4 * g]);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(y[n][e], inv2, bv[e]) + v[n][e];
+            if (mm < p.M) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(yp + 16 * n));
+            y[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    for (int t = 0; t < T_total; ++t) {
+        ws_step_sync<G::PIECES>(t + 1 < T_total);
+        if (t + 2 < T_total) issue_stage(t + 2);
+        const int u = t - ph;
+        if (u < 0 || u > R * NC) continue;               // (staggered half: idle head / tail; barriers and DMA above still run)
+        const unsigned char* stage = lds + (t % WS_NSTAGE) * G::STAGE_BYTES;
+        const int q = (t + NC - 1) % NC;                  // weight chunk finished this step
+        const bool has_cur = u >= 1;
+        const bool tile_end = has_cur && (u % NC == 0);
+        if (has_cur && !tile_end) {                       // common step: one straight-line region
+            f16x8 hh, hl;
+            gelu_split(q, hh, hl);
+            gemm1(stage);
+            gemm2(stage, hh, hl);
+        } else {
+            if (has_cur) {
+                f16x8 hh, hl;
+                gelu_split(q, hh, hl);
+                gemm2(stage, hh, hl);
+                epilogue(u / NC - 1);
+            }
+            if (u / NC < R) {                             // tile start (u % NC == 0 here)
+                load_x(u / NC);
+                gemm1(stage);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) hc[b] = hn[b];
+        hfac_cur = hfac;
+    }
+    if ((bad || !(amax * WS_SH < 65504.f)) && p.range_flag) atomicOr(p.range_flag, 1u);   // also catches NaN
+}
+
+bool mixer_ws_supported(int C) { return C == 96 || C == 192; }
+
+// largest power of two s with max|w| * s < 2^14 (1 for an all-zero matrix)
+static float ws_weight_scale(const float* w, size_t n) {
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) mx = std::fmax(mx, std::fabs(w[i]));
+    if (!(mx > 0.f) || !(mx < INFINITY)) return 1.f;
+    int e = 0;
+    (void)std::frexp(mx, &e);            // mx = f * 2^e, f in [0.5, 1)  ->  mx * 2^(14 - e) in [2^13, 2^14)
+    return std::ldexp(1.f, 14 - e);
+}
+
+// host: the weight stream image.  w1 [2C][C], w2 [C][2C] fp32 (BN folded).  img: NC stages of STAGE_BYTES;
+// inv[0] = 1 / scale(W1), inv[1] = 1 / (scale(W2) * WS_SH) - what the kernel multiplies its accumulators by.
+void prepare_mixer_weights_ws(const float* w1, const float* w2, int C, std::vector<uint16_t>& img, float inv[2]) {
+    const int KS = C / 32, NB = C / 16, NC = 2 * C / WS_HC, H2 = 2 * C;
+    const int w1_frags = 2 * KS * 2, w2_frags = NB * 2, stage_halfs = (w1_frags + w2_frags) * 512;
+    img.assign((size_t)NC * stage_halfs, 0);
+    const float s1 = ws_weight_scale(w1, (size_t)H2 * C), s2 = ws_weight_scale(w2, (size_t)H2 * C);
+    inv[0] = 1.f / s1;
+    inv[1] = 1.f / (s2 * WS_SH);
+    auto put = [](float v, float sc, uint16_t& hb, uint16_t& lb) {
+        const float vs = v * sc;
+        const _Float16 h = (_Float16)vs;
+        const _Float16 l = (_Float16)(vs - (float)h);
+        __builtin_memcpy(&hb, &h, 2);
+        __builtin_memcpy(&lb, &l, 2);
+    };
+    for (int q = 0; q < NC; ++q) {
+        uint16_t* st = img.data() + (size_t)q * stage_halfs;
+        const int c1 = (q + 1) % NC;   // W1 chunk of this stage
+        for (int b = 0; b < 2; ++b)
+            for (int s = 0; s < KS; ++s)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 8; ++e) {
+                        const int m = l & 15, g = l >> 4;
+                        const int hid = 32 * c1 + 16 * b + m, ch = 16 * (2 * s + e / 4) + 4 * g + (e & 3);
+                        const size_t f = (size_t)((b * KS + s) * 2) * 512 + l * 8 + e;
+                        put(w1[(size_t)hid * C + ch], s1, st[f], st[f + 512]);
+                    }
+        uint16_t* st2 = st + (size_t)w1_frags * 512;
+        for (int n = 0; n < NB; ++n)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e) {
+                    const int m = l & 15, g = l >> 4;
+                    const int out = 16 * n + m, hid = 32 * q + 16 * (e / 4) + 4 * g + (e & 3);
+                    const size_t f = (size_t)(2 * n) * 512 + l * 8 + e;
+                    put(w2[(size_t)out * H2 + hid], s2, st2[f], st2[f + 512]);
+                }
+    }
+}
+
+template <int C, bool GATED, bool STAGGER, bool KEEPX>
+static void launch_ws(const MixerParams& p, const unsigned char* wimg, int n_wg_tiles, int grid, hipStream_t s) {
+    static unsigned long long lds_ok = 0;
+    rd_allow_dynamic_lds((const void*)lc_mixer_ws_kernel<C, GATED, STAGGER, KEEPX>, WsGeom<C>::LDS_BYTES, lds_ok);
+    hipLaunchKernelGGL((lc_mixer_ws_kernel<C, GATED, STAGGER, KEEPX>), dim3(grid), dim3(512), WsGeom<C>::LDS_BYTES, s, p, wimg, n_wg_tiles,
+                       p.ws_inv1, p.ws_inv2);
+}
+
+// p.w1h carries the weight stream image, p.ws_inv1 / ws_inv2 its inverse scales (prepare_mixer_weights_ws);
+// p.dbg (microbenchmark A/B): bit 0 stagger off, bit 1 re-read X for the residual instead of keeping it in registers
+void launch_mixer_fused_ws(const MixerParams& p, hipStream_t s) {
+    if (p.M <= 0) return;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        (void)hipGetDevice(&dev);
+        n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    const int n_wg_tiles = (p.M + WS_PX * WS_WAVES - 1) / (WS_PX * WS_WAVES);
+    const int grid = n_wg_tiles < n_cu ? n_wg_tiles : n_cu;
+    const unsigned char* img = reinterpret_cast<const unsigned char*>(p.w1h);
+    const bool stagger = !(p.dbg & 1), keepx = !(p.dbg & 2);
+    const bool gated = p.gate != nullptr;
+#define RD_WS2(CC, GG, SS)                                                                \
+    do {                                                                                  \
+        if (keepx) launch_ws<CC, GG, SS, true>(p, img, n_wg_tiles, grid, s);              \
+        else launch_ws<CC, GG, SS, false>(p, img, n_wg_tiles, grid, s);                   \
+    } while (0)
+#define RD_WS(CC)                                                                         \
+    do {                                                                                  \
+        if (gated) { if (stagger) RD_WS2(CC, true, true); else RD_WS2(CC, true, false); } \
+        else { if (stagger) RD_WS2(CC, false, true); else RD_WS2(CC, false, false); }     \
+    } while (0)
+    if (p.C == 192) RD_WS(192);
+    else if (p.C == 96) RD_WS(96);
+#undef RD_WS
+#undef RD_WS2
+}
+
+}  // namespace rd

@@ -182,11 +182,17 @@ struct MixerParams {
     const uint16_t* w1h = nullptr; const uint16_t* w1l = nullptr; const uint16_t* w2h = nullptr; const uint16_t* w2l = nullptr;
     unsigned* range_flag = nullptr;   // raised when a split operand leaves the fp16 range (|v| >= 65504)
     int dbg = 0;   // microbenchmark ablation bits (h3 kernel): 1 no GELU, 2 no weight streaming, 4 skip GEMM1, 8 skip GEMM2
+    float ws_inv1 = 1.f, ws_inv2 = 1.f;   // ws kernel: inverse power-of-two scales of its weight stream image
 };
 bool mixer_fused_supported(int C);
 void launch_mixer_fused_h3(const MixerParams& p, hipStream_t s);
 void prepare_mixer_weights_h3(const float* w1, const float* w2, int C, std::vector<uint16_t>& w1h, std::vector<uint16_t>& w1l,
                               std::vector<uint16_t>& w2h, std::vector<uint16_t>& w2l);
 void launch_mixer_fused(const MixerParams& p, hipStream_t s);
+// round-2 weight-streaming variant (kernels_mixer_ws.hip; C = 96 / 192): activations in registers, LDS = weight stream only,
+// persistent 8-wavefront workgroups.  p.w1h carries the stream image built by prepare_mixer_weights_ws.
+bool mixer_ws_supported(int C);
+void prepare_mixer_weights_ws(const float* w1, const float* w2, int C, std::vector<uint16_t>& img, float inv[2]);
+void launch_mixer_fused_ws(const MixerParams& p, hipStream_t s);
 void launch_mixer_debug(const MixerParams& p, int variant, hipStream_t s);
 }  // namespace rd

@@ -209,8 +209,9 @@ def _blow_up_stem(st, gain):
 def test_range_guard_b4_and_b6_engines(golden_dir, monkeypatch):
     from rapiddoc_amd.engine import RdEngine
     monkeypatch.setenv("RD_PRECISION", "auto")
-    for kind, fwd, shape in (("pphgnetv2_b4", "backbone_forward", (1, 3, 128, 128)),
-                             ("pphgnetv2_b6_formula", "formula_encoder_forward", (1, 3, 96, 96))):
+    # 256x256: the split kernels only take layers with M >= 2048 pixels (stride-4 stage: 64x64 = 4096)
+    for kind, fwd, shape in (("pphgnetv2_b4", "backbone_forward", (1, 3, 256, 256)),
+                             ("pphgnetv2_b6_formula", "formula_encoder_forward", (1, 3, 256, 256))):
         big = _blow_up_stem(W.synth_state_dict(W.load_manifest(golden_dir / f"manifest_{kind}.json"), 0), 3.0e6)
         x = torch.from_numpy(np.random.default_rng(1).uniform(0, 1, shape).astype(np.float32)).cuda()
         ref_eng = RdEngine(kind, guard="off").load_weights(big).set_precision("fp32")

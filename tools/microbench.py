@@ -34,6 +34,14 @@ def mixer(C_, M, variant, iters=20, check=False):
     return ms, 8.0 * M * C_ * C_ / ms / 1e9
 
 
+if __name__ == "__main__" and "--mixer-ws" in sys.argv:
+    # round 2: weight-streaming mixer (variant 200 + bits: 1 stagger off, 2 residual re-read) vs the round-1 kernel (100)
+    for C_, M in ((192, 105600), (192, 131072), (192, 33000), (96, 211200), (96, 262144)):
+        for v in (100, 200, 201, 202, 203):
+            ms, tf, err = mixer(C_, M, v, check=True)
+            print(f"mixer C={C_} M={M} variant {v}: {ms*1e3:8.1f} us {tf:7.1f} TF/s  max abs err vs fp64 {err:.2e}", flush=True)
+    sys.exit(0)
+
 if __name__ == "__main__" and "--mixer-h3" in sys.argv:
     for C_ in (48, 96, 192):
         for M in (32768 + 77, 131072 * 192 // C_):
