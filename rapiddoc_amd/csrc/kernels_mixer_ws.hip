@@ -50,7 +50,7 @@ struct WsGeom {
     static constexpr int KS = C / 32;              // k-steps of GEMM1 (32 input channels each)
     static constexpr int NB = C / 16;              // 16-channel output blocks of GEMM2
     static constexpr int NC = 2 * C / WS_HC;       // hidden chunks = steps per tile
-    static constexpr int W1_FRAGS = 2 * KS * 2;    // (hidden block b, k-step s, plane)
+    static constexpr int W1_FRAGS = 2 * KS * 2;    // (k-step s, hidden block b, plane)
     static constexpr int W2_FRAGS = NB * 2;        // (output block n, plane)
     static constexpr int STAGE_FRAGS = W1_FRAGS + W2_FRAGS;
     static constexpr int STAGE_BYTES = STAGE_FRAGS * 1024;
@@ -81,7 +81,9 @@ __device__ __forceinline__ void ws_split(float v, float s, _Float16& hi, _Float1
 }
 
 // inv1 = 1 / scale(W1), inv2 = 1 / (scale(W2) * WS_SH): exact powers of two
-template <int C, bool GATED, bool STAGGER, bool KEEPX>
+// ABL: microbenchmark ablation bits (results are garbage): 1 no weight DMA after the first two stages, 2 no MFMAs,
+// 4 no fragment reads and no MFMAs, 8 no GELU, 16 no workgroup barrier
+template <int C, bool GATED, bool STAGGER, bool KEEPX, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, const unsigned char* __restrict__ wimg, int n_wg_tiles,
                                                              float inv1, float inv2) {
     using G = WsGeom<C>;
@@ -104,14 +106,20 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
     const int T_total = R * NC + 1 + (STAGGER ? NC / 2 : 0);
 
     // ---- weight stream: stage q of the image = [W1 fragments of chunk (q+1) % NC | W2 fragments of chunk q]
+    // Every CU streams the SAME bytes at about the same time; walking them in the same order would make all 32 CUs of an
+    // XCD hit the same L2 channel at the same moment.  Each workgroup therefore starts its walk at a different fragment.
+    const int rot = (int)((blockIdx.x * 7u) % (unsigned)G::STAGE_FRAGS);
     auto issue_stage = [&](int t) {
         const int q = (t + NC - 1) % NC;
-        const unsigned char* src = wimg + (size_t)q * G::STAGE_BYTES + (size_t)wave * 1024 + lane * 16;
-        unsigned char* dst = lds + (t % WS_NSTAGE) * G::STAGE_BYTES + wave * 1024;
+        const unsigned char* src = wimg + (size_t)q * G::STAGE_BYTES + lane * 16;
+        unsigned char* dst = lds + (t % WS_NSTAGE) * G::STAGE_BYTES;
 #pragma unroll
-        for (int u = 0; u < G::PIECES; ++u)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + u * WS_WAVES * 1024),
-                                             (__attribute__((address_space(3))) void*)(dst + u * WS_WAVES * 1024), 16, 0, 0);
+        for (int u = 0; u < G::PIECES; ++u) {
+            int f = wave + u * WS_WAVES + rot;
+            f = f >= G::STAGE_FRAGS ? f - G::STAGE_FRAGS : f;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 1024),
+                                             (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+        }
     };
     issue_stage(0);
     if (T_total > 1) issue_stage(1);
@@ -181,25 +189,51 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
         return *reinterpret_cast<const f16x8*>(stage + f * 1024 + lane * 16);
     };
 
-    // GEMM1 (transposed): hn = W1c . X^T   (A = weights from LDS, B = X fragments in registers)
-    auto gemm1 = [&](const unsigned char* stage) {
+    // ---- MFMA "units".  A stage is NU units of 4 fragments (4 KB): units 0 .. KS-1 are GEMM1 k-steps
+    // [hidden block 0 hi, lo, hidden block 1 hi, lo], units KS .. NU-1 GEMM2 output-block pairs [n hi, lo, n+1 hi, lo].
+    // Fragments run through a 3-deep register ring: the reads of unit i+2 are issued before the MFMAs of unit i, so an LDS
+    // round trip has two units (12 MFMAs) of cover, and a ring slot is rewritten a whole unit after its last reader (no
+    // MFMA-source hazard nops).
+    constexpr int NU = KS + NB / 2;
+    f16x8 fr[3][4] = {};
+    auto unit_load = [&](const unsigned char* stage, int i, int slot) {
+        if constexpr (ABL & 4) return;
 #pragma unroll
-        for (int b = 0; b < 2; ++b) hn[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const f16x8 a0h = frag(stage, (0 * KS + s) * 2 + 0), a0l = frag(stage, (0 * KS + s) * 2 + 1);
-            const f16x8 a1h = frag(stage, (1 * KS + s) * 2 + 0), a1l = frag(stage, (1 * KS + s) * 2 + 1);
-            hn[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, xh[s], hn[0], 0, 0, 0);
-            hn[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, xh[s], hn[1], 0, 0, 0);
-            hn[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, xl[s], hn[0], 0, 0, 0);
-            hn[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, xl[s], hn[1], 0, 0, 0);
-            hn[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0l, xh[s], hn[0], 0, 0, 0);
-            hn[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l, xh[s], hn[1], 0, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j) fr[slot][j] = frag(stage, 4 * i + j);
+    };
+    // GEMM1 (transposed): hn += W1c . X^T   (A = weights, B = X fragments in registers)
+    auto unit_g1 = [&](int s, int slot) {
+        if constexpr (ABL & 6) return;
+        hn[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[slot][0], xh[s], hn[0], 0, 0, 0);
+        hn[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[slot][2], xh[s], hn[1], 0, 0, 0);
+        hn[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[slot][0], xl[s], hn[0], 0, 0, 0);
+        hn[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[slot][2], xl[s], hn[1], 0, 0, 0);
+        hn[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[slot][1], xh[s], hn[0], 0, 0, 0);
+        hn[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[slot][3], xh[s], hn[1], 0, 0, 0);
+    };
+    // GEMM2 (transposed): Y^T += W2c . H^T
+    auto unit_g2 = [&](int n, int slot, const f16x8& hh, const f16x8& hl) {
+        if constexpr (ABL & 6) return;
+        y[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[slot][0], hh, y[n], 0, 0, 0);
+        y[n + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[slot][2], hh, y[n + 1], 0, 0, 0);
+        y[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[slot][0], hl, y[n], 0, 0, 0);
+        y[n + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[slot][2], hl, y[n + 1], 0, 0, 0);
+        y[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[slot][1], hh, y[n], 0, 0, 0);
+        y[n + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[slot][3], hh, y[n + 1], 0, 0, 0);
+    };
+    // pin the issue order of one pipeline iteration: 4 fragment reads (unit i+2), then the 6 MFMAs of unit i
+    auto pin_unit = [&](bool has_load) {
+        if (has_load) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
     };
     // un-scale + bias + GELU in fp32 on the finished chunk, split (x 2^4) into the B fragment of GEMM2: C/D register r of
     // hidden block b is hidden 16b + 4g + r = k-slot 4b + r (W2's hidden columns are permuted to this order on the host)
     auto gelu_split = [&](int q, f16x8& hh, f16x8& hl) {
+        if constexpr (ABL & 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hh[e] = hl[e] = (_Float16)hc[e >> 2][e & 3];
+            return;
+        }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(&B1s[q * WS_HC + 16 * b + 4 * g]);
@@ -212,20 +246,6 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
                 hh[4 * b + r] = a;
                 hl[4 * b + r] = c;
             }
-        }
-    };
-    // GEMM2 (transposed): Y^T += W2c . H^T   (two output blocks interleaved)
-    auto gemm2 = [&](const unsigned char* stage, const f16x8& hh, const f16x8& hl) {
-#pragma unroll
-        for (int n = 0; n < NB; n += 2) {
-            const f16x8 w0h = frag(stage, G::W1_FRAGS + 2 * n + 0), w0l = frag(stage, G::W1_FRAGS + 2 * n + 1);
-            const f16x8 w1h = frag(stage, G::W1_FRAGS + 2 * n + 2), w1l = frag(stage, G::W1_FRAGS + 2 * n + 3);
-            y[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0h, hh, y[n], 0, 0, 0);
-            y[n + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h, hh, y[n + 1], 0, 0, 0);
-            y[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0h, hl, y[n], 0, 0, 0);
-            y[n + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h, hl, y[n + 1], 0, 0, 0);
-            y[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0l, hh, y[n], 0, 0, 0);
-            y[n + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1l, hh, y[n + 1], 0, 0, 0);
         }
     };
     // un-scale + b2 + residual (exact fp32: kept in registers, or re-read from the same float4 addresses as the tile load),
@@ -259,30 +279,62 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
         }
     };
 
+    if (wave < WS_WAVES / 2) __builtin_amdgcn_s_setprio(1);   // static: the first wavefront of every SIMD wins arbitration
     for (int t = 0; t < T_total; ++t) {
-        ws_step_sync<G::PIECES>(t + 1 < T_total);
-        if (t + 2 < T_total) issue_stage(t + 2);
+        if constexpr (ABL & 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else ws_step_sync<G::PIECES>(t + 1 < T_total);
+        if (t + 2 < T_total && !(ABL & 1)) issue_stage(t + 2);
         const int u = t - ph;
         if (u < 0 || u > R * NC) continue;               // (staggered half: idle head / tail; barriers and DMA above still run)
         const unsigned char* stage = lds + (t % WS_NSTAGE) * G::STAGE_BYTES;
         const int q = (t + NC - 1) % NC;                  // weight chunk finished this step
         const bool has_cur = u >= 1;
         const bool tile_end = has_cur && (u % NC == 0);
-        if (has_cur && !tile_end) {                       // common step: one straight-line region
+        if (has_cur && !tile_end) {
+            // common step: GELU of this chunk (VALU), then one MFMA pipeline over GEMM1 of the next chunk and GEMM2 of this
+            // one.  The two wavefronts of a SIMD are kept out of phase by static priority (s_setprio above): the favoured
+            // one wins the matrix pipe, so the other's GELU falls under its MFMAs and vice versa.
             f16x8 hh, hl;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) hn[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            unit_load(stage, 0, 0);
+            unit_load(stage, 1, 1);
             gelu_split(q, hh, hl);
-            gemm1(stage);
-            gemm2(stage, hh, hl);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                if (i + 2 < NU) unit_load(stage, i + 2, (i + 2) % 3);
+                if (i < KS) unit_g1(i, i % 3);
+                else unit_g2(2 * (i - KS), i % 3, hh, hl);
+                pin_unit(i + 2 < NU);
+            }
         } else {
-            if (has_cur) {
+            if (has_cur) {                                // last chunk of a tile: GELU, GEMM2, epilogue
                 f16x8 hh, hl;
+                unit_load(stage, KS, 0);
+                unit_load(stage, KS + 1, 1);
                 gelu_split(q, hh, hl);
-                gemm2(stage, hh, hl);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = KS; i < NU; ++i) {
+                    if (i + 2 < NU) unit_load(stage, i + 2, (i + 2 - KS) % 3);
+                    unit_g2(2 * (i - KS), (i - KS) % 3, hh, hl);
+                    pin_unit(i + 2 < NU);
+                }
                 epilogue(u / NC - 1);
             }
-            if (u / NC < R) {                             // tile start (u % NC == 0 here)
+            if (u / NC < R) {                             // tile start (u % NC == 0 here): X tile, GEMM1 of its first chunk
                 load_x(u / NC);
-                gemm1(stage);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) hn[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+                unit_load(stage, 0, 0);
+                unit_load(stage, 1, 1);
+#pragma unroll
+                for (int i = 0; i < KS; ++i) {
+                    if (i + 2 < KS) unit_load(stage, i + 2, (i + 2) % 3);
+                    unit_g1(i, i % 3);
+                    pin_unit(i + 2 < KS);
+                }
             }
         }
 #pragma unroll
@@ -329,7 +381,7 @@ void prepare_mixer_weights_ws(const float* w1, const float* w2, int C, std::vect
                     for (int e = 0; e < 8; ++e) {
                         const int m = l & 15, g = l >> 4;
                         const int hid = 32 * c1 + 16 * b + m, ch = 16 * (2 * s + e / 4) + 4 * g + (e & 3);
-                        const size_t f = (size_t)((b * KS + s) * 2) * 512 + l * 8 + e;
+                        const size_t f = (size_t)((s * 2 + b) * 2) * 512 + l * 8 + e;   // unit s = [b0 hi, b0 lo, b1 hi, b1 lo]
                         put(w1[(size_t)hid * C + ch], s1, st[f], st[f + 512]);
                     }
         uint16_t* st2 = st + (size_t)w1_frags * 512;
@@ -368,6 +420,27 @@ void launch_mixer_fused_ws(const MixerParams& p, hipStream_t s) {
     const unsigned char* img = reinterpret_cast<const unsigned char*>(p.w1h);
     const bool stagger = !(p.dbg & 1), keepx = !(p.dbg & 2);
     const bool gated = p.gate != nullptr;
+    if (p.dbg >> 8) {   // microbenchmark ablations (C = 192, no gate, no stagger, residual re-read)
+        static unsigned long long ok = 0;
+        auto go = [&](auto kern) {
+            rd_allow_dynamic_lds((const void*)kern, WsGeom<192>::LDS_BYTES, ok);
+            ok = 0;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), WsGeom<192>::LDS_BYTES, s, p, img, n_wg_tiles, p.ws_inv1, p.ws_inv2);
+        };
+        switch (p.dbg >> 8) {
+            case 1: go(lc_mixer_ws_kernel<192, false, false, false, 1>); break;
+            case 2: go(lc_mixer_ws_kernel<192, false, false, false, 2>); break;
+            case 4: go(lc_mixer_ws_kernel<192, false, false, false, 4>); break;
+            case 5: go(lc_mixer_ws_kernel<192, false, false, false, 5>); break;
+            case 8: go(lc_mixer_ws_kernel<192, false, false, false, 8>); break;
+            case 12: go(lc_mixer_ws_kernel<192, false, false, false, 12>); break;
+            case 13: go(lc_mixer_ws_kernel<192, false, false, false, 13>); break;
+            case 16: go(lc_mixer_ws_kernel<192, false, false, false, 16>); break;
+            case 29: go(lc_mixer_ws_kernel<192, false, false, false, 29>); break;
+            default: break;
+        }
+        return;
+    }
 #define RD_WS2(CC, GG, SS)                                                                \
     do {                                                                                  \
         if (keepx) launch_ws<CC, GG, SS, true>(p, img, n_wg_tiles, grid, s);              \

@@ -34,6 +34,16 @@ def mixer(C_, M, variant, iters=20, check=False):
     return ms, 8.0 * M * C_ * C_ / ms / 1e9
 
 
+if __name__ == "__main__" and "--mixer-ws-abl" in sys.argv:
+    # ablations of the weight-streaming mixer (C = 192): variant 200 + 3 (no stagger, residual re-read) + 256 * bits
+    names = {0: "full", 1: "no DMA", 2: "no MFMA", 4: "no frag reads, no MFMA", 5: "no DMA, no reads, no MFMA", 8: "no GELU",
+             12: "no GELU / reads / MFMA (DMA + barriers only)", 13: "barriers only", 16: "no barrier", 29: "empty loop"}
+    for M in (105600,):
+        for bits in (0, 1, 2, 4, 5, 8, 12, 13, 16, 29):
+            ms, tf = mixer(192, M, 203 + 256 * bits)
+            print(f"ws ablation M={M} {names[bits]:45s}: {ms*1e3:8.1f} us", flush=True)
+    sys.exit(0)
+
 if __name__ == "__main__" and "--mixer-ws" in sys.argv:
     # round 2: weight-streaming mixer (variant 200 + bits: 1 stagger off, 2 residual re-read) vs the round-1 kernel (100)
     for C_, M in ((192, 105600), (192, 131072), (192, 33000), (96, 211200), (96, 262144)):
