@@ -183,7 +183,7 @@ float rd_debug_time_mixer(int C, int M, int variant, int iters, float* x, float*
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     void* hbuf[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (variant >= 200) {  // weight-streaming split mixer (kernels_mixer_ws.hip); bit 0: stagger off
+    if (variant >= 200) {  // weight-streaming split mixer (kernels_mixer_ws.hip)
         p.dbg = variant - 200;
         std::vector<float> hw1((size_t)2 * C * C), hw2((size_t)2 * C * C);
         (void)hipMemcpy(hw1.data(), w1, hw1.size() * 4, hipMemcpyDeviceToHost);

@@ -431,7 +431,7 @@ TView Builder::mixer_fused(const std::string& prefix, const TView& x, const TVie
             pb_->add_u16(hkey + ".w1h", v[0]); pb_->add_u16(hkey + ".w1l", v[1]);
             pb_->add_u16(hkey + ".w2h", v[2]); pb_->add_u16(hkey + ".w2l", v[3]);
         }
-        if (!pb_->has(hkey + ".ws") && fits && mixer_ws_supported(C)) {   // weight stream image of the ws kernel
+        if (!pb_->has(hkey + ".ws") && fits && mixer_ws_preferred(C)) {   // weight stream image of the ws kernel
             std::vector<uint16_t> img;
             float inv[2];
             prepare_mixer_weights_ws(f1, f2, C, img, inv);

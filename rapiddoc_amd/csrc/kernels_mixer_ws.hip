@@ -21,8 +21,13 @@
 //     (2 stages = 96 KB in flight at C = 192): the pipeline never drains between tiles.  Stage q holds
 //     [W1 chunk q+1 | W2 chunk q]: a step runs GELU(chunk q) beside GEMM1(chunk q+1), then GEMM2(chunk q) - the MFMAs of the
 //     next chunk cover the VALU of this one inside a wavefront too.
-//   * optional stagger: wavefronts 4-7 (the second wavefront of every SIMD) start their tiles half a weight cycle later, so
-//     one half's epilogue / tile load runs under the other half's GEMMs.
+//   * PER-WAVEFRONT PHASES: the weight stream is cyclic, so a wavefront may start a tile at any chunk.  Wavefront w of the
+//     grid starts its tiles at phase (5 w) mod NC of the weight cycle.  Measured reason (ablations of the lock-step
+//     version, M = 105 600): with every wavefront switching tiles at the same step the 243 MB of tile traffic arrives in
+//     four bursts during which nothing computes (40 of 168 us); spread over all NC phases the memory system sees a uniform
+//     ~2 TB/s and a wavefront's tile switch (epilogue, residual re-read, next X tile) runs under the GEMMs of the other
+//     wavefront of its SIMD.  Tiles are dealt statically: T steps give a wavefront of phase ph floor((T - 1 - ph) / NC)
+//     tiles, the host picks the smallest T that covers M (no more steps than the lock-step version needs).
 // Arithmetic ("scaled split", one accumulator): an operand v is carried as hi = fp16(v * s), lo = fp16(v * s - hi) with a
 // POWER-OF-TWO scale s, and a product is three MFMAs (hi.hi + hi.lo + lo.hi) into ONE fp32 accumulator that is multiplied by
 // the exact inverse scales in the epilogue.  The gfx950 fp16 matrix cores keep subnormal inputs (tools/probe_mfma.hip), so lo
@@ -83,9 +88,9 @@ __device__ __forceinline__ void ws_split(float v, float s, _Float16& hi, _Float1
 // inv1 = 1 / scale(W1), inv2 = 1 / (scale(W2) * WS_SH): exact powers of two
 // ABL: microbenchmark ablation bits (results are garbage): 1 no weight DMA after the first two stages, 2 no MFMAs,
 // 4 no fragment reads and no MFMAs, 8 no GELU, 16 no workgroup barrier
-template <int C, bool GATED, bool STAGGER, bool KEEPX, int ABL = 0>
-__global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, const unsigned char* __restrict__ wimg, int n_wg_tiles,
-                                                             float inv1, float inv2) {
+template <int C, bool GATED, bool KEEPX, int ABL = 0>
+__global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, const unsigned char* __restrict__ wimg, int n_tiles,
+                                                             int T_total, int ph_mul, float inv1, float inv2) {
     using G = WsGeom<C>;
     constexpr int KS = G::KS, NB = G::NB, NC = G::NC;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -100,10 +105,18 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
     for (int i = tid; i < C; i += 512) B2s[i] = p.b2[i];
     __syncthreads();
 
-    // rounds of this workgroup: workgroup tiles blockIdx.x, + gridDim.x, ...; wavefront w owns pixels [16w, 16w + 16) of a tile
-    const int R = (n_wg_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int ph = (STAGGER && wave >= WS_WAVES / 2) ? NC / 2 : 0;
-    const int T_total = R * NC + 1 + (STAGGER ? NC / 2 : 0);
+    // this wavefront's phase in the weight cycle and its (contiguous) run of 16-pixel tiles: a wavefront of phase ph' fits
+    // floor((T - 1 - ph') / NC) tiles into T steps; phases repeat every NC wavefronts, so the run start is a closed form
+    const int wg = (int)blockIdx.x * WS_WAVES + wave;
+    auto n_of = [&](int w) { return max(0, (T_total - 1 - (w * ph_mul) % NC) / NC); };
+    const int ph = (wg * ph_mul) % NC;
+    int per_cycle = 0, before = 0;
+    for (int j = 0; j < NC; ++j) {
+        per_cycle += n_of(j);
+        before += j < wg % NC ? n_of(j) : 0;
+    }
+    const int tile_base = (wg / NC) * per_cycle + before;
+    const int R = max(0, min(n_of(wg % NC), n_tiles - tile_base));    // tiles of this wavefront
 
     // ---- weight stream: stage q of the image = [W1 fragments of chunk (q+1) % NC | W2 fragments of chunk q]
     // Every CU streams the SAME bytes at about the same time; walking them in the same order would make all 32 CUs of an
@@ -122,7 +135,7 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
         }
     };
     issue_stage(0);
-    if (T_total > 1) issue_stage(1);
+    issue_stage(1);
 
     f16x8 xh[KS], xl[KS];            // X^T as B fragments of GEMM1 (hi / lo of x' * sx)
     f32x4 xr[KEEPX ? NB : 1];        // KEEPX: the fp32 tile itself stays in registers for the residual
@@ -144,7 +157,7 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
     float amax = 0.f;                // largest |GELU output| this lane split; X' can only fail by being non-finite
     bool bad = false;
 
-    auto tile_m = [&](int r) { return (((int)blockIdx.x + r * (int)gridDim.x) * WS_WAVES + wave) * WS_PX + px; };
+    auto tile_m = [&](int r) { return (tile_base + r) * WS_PX + px; };
 
     // X tile -> (gate) -> per-pixel scale -> split into the B fragments.  Lane (px, g) owns channels 16n + 4g .. + 4 of every
     // block n; the four lanes px, px + 16, px + 32, px + 48 hold one pixel.
@@ -285,7 +298,7 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
         else ws_step_sync<G::PIECES>(t + 1 < T_total);
         if (t + 2 < T_total && !(ABL & 1)) issue_stage(t + 2);
         const int u = t - ph;
-        if (u < 0 || u > R * NC) continue;               // (staggered half: idle head / tail; barriers and DMA above still run)
+        if (u < 0 || u > R * NC) continue;               // (idle head / tail of this phase; barriers and DMA above still run)
         const unsigned char* stage = lds + (t % WS_NSTAGE) * G::STAGE_BYTES;
         const int q = (t + NC - 1) % NC;                  // weight chunk finished this step
         const bool has_cur = u >= 1;
@@ -344,7 +357,10 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
     if ((bad || !(amax * WS_SH < 65504.f)) && p.range_flag) atomicOr(p.range_flag, 1u);   // also catches NaN
 }
 
+// C = 96 builds and passes the same tests, but measures level with the round-1 kernel (99 vs 97 us at M = 211 200): the
+// engine only routes C = 192 here
 bool mixer_ws_supported(int C) { return C == 96 || C == 192; }
+bool mixer_ws_preferred(int C) { return C == 192; }
 
 // largest power of two s with max|w| * s < 2^14 (1 for an all-zero matrix)
 static float ws_weight_scale(const float* w, size_t n) {
@@ -396,16 +412,31 @@ void prepare_mixer_weights_ws(const float* w1, const float* w2, int C, std::vect
     }
 }
 
-template <int C, bool GATED, bool STAGGER, bool KEEPX>
-static void launch_ws(const MixerParams& p, const unsigned char* wimg, int n_wg_tiles, int grid, hipStream_t s) {
+// smallest number of steps in which `waves` wavefronts with phases (w * ph_mul) mod NC cover n_tiles tiles
+static int ws_total_steps(int n_tiles, int waves, int NC, int ph_mul) {
+    for (int T = NC + 1;; ++T) {
+        long cap = 0;
+        for (int j = 0; j < NC; ++j) {
+            const long n = (T - 1 - (j * ph_mul) % NC) / NC;
+            if (n <= 0) continue;
+            cap += n * (waves / NC + (j < waves % NC ? 1 : 0));
+        }
+        if (cap >= n_tiles) return T;
+    }
+}
+
+template <int C, bool GATED, bool KEEPX, int ABL = 0>
+static void launch_ws(const MixerParams& p, const unsigned char* wimg, int n_tiles, int grid, int ph_mul, hipStream_t s) {
     static unsigned long long lds_ok = 0;
-    rd_allow_dynamic_lds((const void*)lc_mixer_ws_kernel<C, GATED, STAGGER, KEEPX>, WsGeom<C>::LDS_BYTES, lds_ok);
-    hipLaunchKernelGGL((lc_mixer_ws_kernel<C, GATED, STAGGER, KEEPX>), dim3(grid), dim3(512), WsGeom<C>::LDS_BYTES, s, p, wimg, n_wg_tiles,
-                       p.ws_inv1, p.ws_inv2);
+    rd_allow_dynamic_lds((const void*)lc_mixer_ws_kernel<C, GATED, KEEPX, ABL>, WsGeom<C>::LDS_BYTES, lds_ok);
+    const int T = ws_total_steps(n_tiles, grid * WS_WAVES, WsGeom<C>::NC, ph_mul);
+    hipLaunchKernelGGL((lc_mixer_ws_kernel<C, GATED, KEEPX, ABL>), dim3(grid), dim3(512), WsGeom<C>::LDS_BYTES, s, p, wimg, n_tiles, T,
+                       ph_mul, p.ws_inv1, p.ws_inv2);
 }
 
 // p.w1h carries the weight stream image, p.ws_inv1 / ws_inv2 its inverse scales (prepare_mixer_weights_ws);
-// p.dbg (microbenchmark A/B): bit 0 stagger off, bit 1 re-read X for the residual instead of keeping it in registers
+// p.dbg (microbenchmark A/B): bit 0 force lock step, bit 2 force per-wavefront phases, bit 1 flip the residual policy
+// (default: kept in registers at C = 96, re-read at C = 192 where keeping it spills); bits 8.. ablations (C = 192, garbage)
 void launch_mixer_fused_ws(const MixerParams& p, hipStream_t s) {
     if (p.M <= 0) return;
     static int n_cu = 0;
@@ -415,46 +446,45 @@ void launch_mixer_fused_ws(const MixerParams& p, hipStream_t s) {
         (void)hipGetDevice(&dev);
         n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
-    const int n_wg_tiles = (p.M + WS_PX * WS_WAVES - 1) / (WS_PX * WS_WAVES);
-    const int grid = n_wg_tiles < n_cu ? n_wg_tiles : n_cu;
+    const int n_tiles = (p.M + WS_PX - 1) / WS_PX;
+    const int n_wg = (n_tiles + WS_WAVES - 1) / WS_WAVES;
+    // persistent grid: as many rounds as a full machine needs, on the FEWEST workgroups that still manage in that many
+    // rounds (825 workgroup tiles on 256 CUs are 4 rounds either way; 207 workgroups leave 49 CUs to the kernels of the
+    // other streams instead of idling through the fourth round)
+    const int rounds = (n_wg + n_cu - 1) / n_cu;
+    const int grid = (n_wg + rounds - 1) / rounds;
     const unsigned char* img = reinterpret_cast<const unsigned char*>(p.w1h);
-    const bool stagger = !(p.dbg & 1), keepx = !(p.dbg & 2);
+    // Phases: lock step (every wavefront switches tiles at the same step) unless per-wavefront phases need fewer steps.
+    // Measured (tools/microbench.py --mixer-ws): with a barrier every step a wavefront in its tile switch holds up the
+    // whole workgroup, so spreading the switches over the cycle only pays when it shortens the schedule (M = 33 000:
+    // 64 vs 81 us; M = 105 600: 175 vs 169 us).
+    const int NC = 2 * p.C / WS_HC;
+    int ph_mul = 5;      // coprime to NC = 6 and 12: consecutive wavefronts walk through all phases
+    if ((p.dbg & 1) || ws_total_steps(n_tiles, grid * WS_WAVES, NC, 5) >= ws_total_steps(n_tiles, grid * WS_WAVES, NC, 0)) ph_mul = 0;
+    if (p.dbg & 4) ph_mul = 5;
     const bool gated = p.gate != nullptr;
-    if (p.dbg >> 8) {   // microbenchmark ablations (C = 192, no gate, no stagger, residual re-read)
-        static unsigned long long ok = 0;
-        auto go = [&](auto kern) {
-            rd_allow_dynamic_lds((const void*)kern, WsGeom<192>::LDS_BYTES, ok);
-            ok = 0;
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), WsGeom<192>::LDS_BYTES, s, p, img, n_wg_tiles, p.ws_inv1, p.ws_inv2);
-        };
+    if (p.dbg >> 8) {
         switch (p.dbg >> 8) {
-            case 1: go(lc_mixer_ws_kernel<192, false, false, false, 1>); break;
-            case 2: go(lc_mixer_ws_kernel<192, false, false, false, 2>); break;
-            case 4: go(lc_mixer_ws_kernel<192, false, false, false, 4>); break;
-            case 5: go(lc_mixer_ws_kernel<192, false, false, false, 5>); break;
-            case 8: go(lc_mixer_ws_kernel<192, false, false, false, 8>); break;
-            case 12: go(lc_mixer_ws_kernel<192, false, false, false, 12>); break;
-            case 13: go(lc_mixer_ws_kernel<192, false, false, false, 13>); break;
-            case 16: go(lc_mixer_ws_kernel<192, false, false, false, 16>); break;
-            case 29: go(lc_mixer_ws_kernel<192, false, false, false, 29>); break;
+            case 1: launch_ws<192, false, false, 1>(p, img, n_tiles, grid, ph_mul, s); break;
+            case 4: launch_ws<192, false, false, 4>(p, img, n_tiles, grid, ph_mul, s); break;
+            case 8: launch_ws<192, false, false, 8>(p, img, n_tiles, grid, ph_mul, s); break;
+            case 12: launch_ws<192, false, false, 12>(p, img, n_tiles, grid, ph_mul, s); break;
+            case 13: launch_ws<192, false, false, 13>(p, img, n_tiles, grid, ph_mul, s); break;
+            case 16: launch_ws<192, false, false, 16>(p, img, n_tiles, grid, ph_mul, s); break;
+            case 29: launch_ws<192, false, false, 29>(p, img, n_tiles, grid, ph_mul, s); break;
             default: break;
         }
         return;
     }
-#define RD_WS2(CC, GG, SS)                                                                \
-    do {                                                                                  \
-        if (keepx) launch_ws<CC, GG, SS, true>(p, img, n_wg_tiles, grid, s);              \
-        else launch_ws<CC, GG, SS, false>(p, img, n_wg_tiles, grid, s);                   \
-    } while (0)
-#define RD_WS(CC)                                                                         \
-    do {                                                                                  \
-        if (gated) { if (stagger) RD_WS2(CC, true, true); else RD_WS2(CC, true, false); } \
-        else { if (stagger) RD_WS2(CC, false, true); else RD_WS2(CC, false, false); }     \
+    const bool keepx = (p.C == 96) != ((p.dbg & 2) != 0);
+#define RD_WS(CC)                                                                                                \
+    do {                                                                                                         \
+        if (gated) { if (keepx) launch_ws<CC, true, true>(p, img, n_tiles, grid, ph_mul, s); else launch_ws<CC, true, false>(p, img, n_tiles, grid, ph_mul, s); } \
+        else { if (keepx) launch_ws<CC, false, true>(p, img, n_tiles, grid, ph_mul, s); else launch_ws<CC, false, false>(p, img, n_tiles, grid, ph_mul, s); } \
     } while (0)
     if (p.C == 192) RD_WS(192);
     else if (p.C == 96) RD_WS(96);
 #undef RD_WS
-#undef RD_WS2
 }
 
 }  // namespace rd

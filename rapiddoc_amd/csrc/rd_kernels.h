@@ -192,6 +192,7 @@ void launch_mixer_fused(const MixerParams& p, hipStream_t s);
 // round-2 weight-streaming variant (kernels_mixer_ws.hip; C = 96 / 192): activations in registers, LDS = weight stream only,
 // persistent 8-wavefront workgroups.  p.w1h carries the stream image built by prepare_mixer_weights_ws.
 bool mixer_ws_supported(int C);
+bool mixer_ws_preferred(int C);   // where it measures faster than the round-1 kernel
 void prepare_mixer_weights_ws(const float* w1, const float* w2, int C, std::vector<uint16_t>& img, float inv[2]);
 void launch_mixer_fused_ws(const MixerParams& p, hipStream_t s);
 void launch_mixer_debug(const MixerParams& p, int variant, hipStream_t s);

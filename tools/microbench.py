@@ -34,22 +34,18 @@ def mixer(C_, M, variant, iters=20, check=False):
     return ms, 8.0 * M * C_ * C_ / ms / 1e9
 
 
-if __name__ == "__main__" and "--mixer-ws-abl" in sys.argv:
-    # ablations of the weight-streaming mixer (C = 192): variant 200 + 3 (no stagger, residual re-read) + 256 * bits
-    names = {0: "full", 1: "no DMA", 2: "no MFMA", 4: "no frag reads, no MFMA", 5: "no DMA, no reads, no MFMA", 8: "no GELU",
-             12: "no GELU / reads / MFMA (DMA + barriers only)", 13: "barriers only", 16: "no barrier", 29: "empty loop"}
-    for M in (105600,):
-        for bits in (0, 1, 2, 4, 5, 8, 12, 13, 16, 29):
-            ms, tf = mixer(192, M, 203 + 256 * bits)
-            print(f"ws ablation M={M} {names[bits]:45s}: {ms*1e3:8.1f} us", flush=True)
-    sys.exit(0)
-
 if __name__ == "__main__" and "--mixer-ws" in sys.argv:
-    # round 2: weight-streaming mixer (variant 200 + bits: 1 stagger off, 2 residual re-read) vs the round-1 kernel (100)
-    for C_, M in ((192, 105600), (192, 131072), (192, 33000), (96, 211200), (96, 262144)):
-        for v in (100, 200, 201, 202, 203):
+    # round 2: weight-streaming mixer (variant 200 + bits: 1 lock step instead of per-wavefront phases, 2 flipped residual
+    # policy) vs the round-1 kernel (100); then ablations (+ 256 * bits, C = 192, garbage results)
+    for C_, M in ((192, 105600), (192, 131072), (192, 33000), (192, 4000), (96, 211200), (96, 262144)):
+        for v in (100, 200, 201, 204):
             ms, tf, err = mixer(C_, M, v, check=True)
             print(f"mixer C={C_} M={M} variant {v}: {ms*1e3:8.1f} us {tf:7.1f} TF/s  max abs err vs fp64 {err:.2e}", flush=True)
+    names = {1: "no DMA", 4: "no frag reads, no MFMA", 8: "no GELU", 12: "no GELU / reads / MFMA (DMA + barriers only)",
+             13: "barriers only", 16: "no barrier", 29: "empty loop"}
+    for bits in (1, 4, 8, 12, 13, 16, 29):
+        ms, tf = mixer(192, 105600, 200 + 256 * bits)
+        print(f"ws ablation M=105600 {names[bits]:45s}: {ms*1e3:8.1f} us", flush=True)
     sys.exit(0)
 
 if __name__ == "__main__" and "--mixer-h3" in sys.argv:
