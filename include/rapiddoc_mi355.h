@@ -87,7 +87,8 @@ int rd_formula_decode(rd_handle* h, const float* enc_dev, int B, int S, int max_
 int rd_formula_max_new_tokens(rd_handle* h);
 
 /* u8 HWC (3 channels) device image -> resize to OHxOW -> (v*scale - mean[c]) / std[c] -> CHW float32.
- * interp: 1 bilinear, 2 bicubic (a = -0.75, result rounded/saturated to u8 range like an 8-bit resize). */
+ * interp: 1 = cv2.INTER_LINEAR, 2 = cv2.INTER_CUBIC, both in OpenCV's 8-bit fixed-point arithmetic (11-bit coefficients,
+ * uint8 result) - bit-equal to oracle/cv2_ops.py; against cv2 itself parity is unpinned (package absent at build time). */
 int rd_preproc_resize_norm(int device_id, const uint8_t* hwc_u8_dev, int H, int W, int OH, int OW, const float mean[3],
                            const float std[3], float scale, int interp, int swap_rb, float* out_chw_dev, void* stream);
 
@@ -105,6 +106,24 @@ typedef struct rd_crop_desc {
 int rd_crop_resize_norm_batch(int device_id, const uint8_t* pages_u8_dev, int P, int H, int W,
                               const rd_crop_desc* descs_dev, int n, int out_h, int out_w_padded, const float mean[3],
                               const float std[3], float scale, int swap_rb, float* out_nchw_dev, void* stream);
+
+/* Reference-shaped text-line crops for one rec batch, in OpenCV's 8-bit arithmetic: cv2.warpPerspective(INTER_CUBIC,
+ * BORDER_REPLICATE) of every line to its integer-sized uint8 crop (rapid_doc/utils/ocr_utils.py:494-536), np.rot90 for tall
+ * crops, then rapidocr's resize_norm_img (linear resize to height out_h, /255, (x - 0.5) / 0.5, zero right-padding; called
+ * from rapid_doc/model/ocr/rapid_ocr.py:436-440).  scratch_u8_dev: device buffer holding the packed uint8 crops
+ * (desc.scratch_off, crop_w * crop_h * 3 bytes each); max_crop_pixels: largest crop_w * crop_h among the n lines.
+ * out: [n][3][out_h][out_w_padded] float32.  swap_rb = 1 when the pages are RGB (rapidocr works on BGR). */
+typedef struct rd_line_crop_desc {
+    int32_t page;          /* page index in the batch */
+    int32_t out_w;         /* resized width of this line (<= out_w_padded) */
+    int32_t crop_w, crop_h;/* rectified crop size in page pixels (before the optional rotation) */
+    int32_t rot90;         /* rotate the crop 90 deg CCW first (tall boxes) */
+    int32_t scratch_off;   /* byte offset of this crop in scratch_u8_dev */
+    double m[9];           /* crop (x, y, 1) -> page (X, Y, W) homography, row-major, float64 like cv2's */
+} rd_line_crop_desc;
+int rd_line_crops_batch(int device_id, const uint8_t* pages_u8_dev, int P, int H, int W, const rd_line_crop_desc* descs_dev,
+                        int n, int64_t max_crop_pixels, uint8_t* scratch_u8_dev, int out_h, int out_w_padded, int swap_rb,
+                        float* out_nchw_dev, void* stream);
 
 /* DB post-process (HOST pointers, runs on the host like the reference's): probability maps [B][H][W] -> text boxes.
  * Replaces rapidocr DBPostProcess.__call__ as patched in rapid_doc/model/ocr/ocr_patch.py:223-241 (box_type "quad",

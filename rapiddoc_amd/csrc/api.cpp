@@ -175,6 +175,20 @@ int rd_crop_resize_norm_batch(int device_id, const uint8_t* pages, int P, int H,
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+int rd_line_crops_batch(int device_id, const uint8_t* pages, int P, int H, int W, const rd_line_crop_desc* descs, int n,
+                        int64_t max_crop_pixels, uint8_t* scratch, int out_h, int out_w_padded, int swap_rb, float* out, void* stream) {
+    static_assert(sizeof(rd_line_crop_desc) == sizeof(rd::LineCropDesc), "rd_line_crop_desc layout");
+    if (!pages || !descs || !out || !scratch || P <= 0 || n < 0 || out_h <= 0 || out_w_padded <= 0 || max_crop_pixels <= 0) return 1;
+    if (hipSetDevice(device_id) != hipSuccess) return 1;
+    rd::LineCropParams p{};
+    p.pages = pages; p.H = H; p.W = W; p.page_stride = (size_t)H * W * 3;
+    p.descs = reinterpret_cast<const rd::LineCropDesc*>(descs); p.n = n;
+    p.scratch = scratch; p.max_crop_pixels = (long)max_crop_pixels;
+    p.dst = out; p.OH = out_h; p.OWp = out_w_padded; p.swap_rb = swap_rb;
+    if (rd::launch_line_crops(p, (hipStream_t)stream) != 0) return 1;
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 // ---- developer micro-benchmarks (not part of the public header): time one kernel on caller-provided buffers
 float rd_debug_time_mixer(int C, int M, int variant, int iters, float* x, float* y, float* w1, float* b1, float* w2, float* b2) {
     rd::MixerParams p{};

@@ -567,67 +567,8 @@ void launch_nchw_to_nhwc(const float* x, float* y, int yld, int N, int C, int H,
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + 31) / 32, (C + 31) / 32, N), dim3(256), 0, s, x, y, yld, HW, C);
 }
 
-// --------------------------------------------------------------------------------------------------
-// Pre-processing: u8 HWC page -> resized, normalised NCHW fp32 plane set.
-// interp 1: bilinear with half-pixel centres; interp 2: bicubic a = -0.75 (the OpenCV INTER_CUBIC kernel
-// the reference asks for in pp_doclayout/pre_process.py:35) evaluated in fp32 (cv2's 8-bit path uses
-// 11-bit fixed-point coefficients and rounds to u8 - see DESIGN.md).
-// --------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void cubic_coeffs(float t, float* w) {
-    const float A = -0.75f;
-    w[0] = ((A * (t + 1.f) - 5.f * A) * (t + 1.f) + 8.f * A) * (t + 1.f) - 4.f * A;
-    w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
-    w[2] = ((A + 2.f) * (1.f - t) - (A + 3.f)) * (1.f - t) * (1.f - t) + 1.f;
-    w[3] = 1.f - w[0] - w[1] - w[2];
-}
-__global__ void __launch_bounds__(256) preproc_kernel(PreprocParams p) {
-    const long total = (long)p.OH * p.OW;
-    const float sy = (float)p.H / p.OH, sx = (float)p.W / p.OW;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int ox = idx % p.OW, oy = idx / p.OW;
-        const float fy = (oy + 0.5f) * sy - 0.5f, fx = (ox + 0.5f) * sx - 0.5f;
-        float out[3] = {0.f, 0.f, 0.f};
-        if (p.interp == 2) {
-            const int iy = (int)floorf(fy), ix = (int)floorf(fx);
-            float wy[4], wx[4];
-            cubic_coeffs(fy - iy, wy);
-            cubic_coeffs(fx - ix, wx);
-            for (int a = 0; a < 4; ++a) {
-                const int yy = min(max(iy - 1 + a, 0), p.H - 1);
-                for (int b = 0; b < 4; ++b) {
-                    const int xx = min(max(ix - 1 + b, 0), p.W - 1);
-                    const uint8_t* px = p.src + ((size_t)yy * p.W + xx) * 3;
-                    const float w = wy[a] * wx[b];
-                    out[0] = fmaf(w, (float)px[0], out[0]);
-                    out[1] = fmaf(w, (float)px[1], out[1]);
-                    out[2] = fmaf(w, (float)px[2], out[2]);
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) out[c] = fminf(fmaxf(rintf(out[c]), 0.f), 255.f);  // saturate_cast<uchar>
-        } else {
-            const float cy = fminf(fmaxf(fy, 0.f), (float)(p.H - 1)), cx = fminf(fmaxf(fx, 0.f), (float)(p.W - 1));
-            const int y0 = (int)cy, x0 = (int)cx;
-            const int y1 = min(y0 + 1, p.H - 1), x1 = min(x0 + 1, p.W - 1);
-            const float ty = cy - y0, tx = cx - x0;
-            for (int c = 0; c < 3; ++c) {
-                const float v00 = p.src[((size_t)y0 * p.W + x0) * 3 + c], v01 = p.src[((size_t)y0 * p.W + x1) * 3 + c];
-                const float v10 = p.src[((size_t)y1 * p.W + x0) * 3 + c], v11 = p.src[((size_t)y1 * p.W + x1) * 3 + c];
-                out[c] = (v00 * (1.f - tx) + v01 * tx) * (1.f - ty) + (v10 * (1.f - tx) + v11 * tx) * ty;
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int sc = p.swap_rb ? 2 - c : c;
-            p.dst[(size_t)c * total + idx] = (out[sc] * p.scale - p.mean[c]) * p.inv_std[c];
-        }
-    }
-}
-void launch_preproc_resize_norm(const PreprocParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(preproc_kernel, dim3(grid_for((long)p.OH * p.OW)), dim3(256), 0, s, p);
-}
-
-
+// (image pre-processing - resize / normalise / text-line crops with OpenCV's 8-bit arithmetic - lives in kernels_image.hip;
+//  crop_batch_kernel below is the round-1 single-tap bilinear line crop, kept behind rd_crop_resize_norm_batch)
 __global__ void __launch_bounds__(256) crop_batch_kernel(CropBatchParams p) {
     const int i = blockIdx.y;
     const CropDesc d = p.descs[i];

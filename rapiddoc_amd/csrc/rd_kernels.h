@@ -164,6 +164,26 @@ struct CropBatchParams {
 };
 void launch_crop_resize_norm_batch(const CropBatchParams& p, hipStream_t s);
 
+// Reference-shaped text-line crops (kernels_image.hip): cubic perspective warp to the integer-sized uint8 crop
+// (cv2.warpPerspective INTER_CUBIC / BORDER_REPLICATE, utils/ocr_utils.py:523-529), 90-degree rotation of tall crops, linear
+// resize to height 48, /255, (x - 0.5) / 0.5, zero right-padding (rapidocr resize_norm_img) - two kernels per rec batch.
+struct LineCropDesc {
+    int32_t page;          // page index in the batch
+    int32_t out_w;         // resized width (<= padded batch width)
+    int32_t crop_w, crop_h;   // size of the rectified crop (before the optional rotation)
+    int32_t rot90;         // np.rot90 the crop first (h / w >= 2, ocr_utils.py:533-535)
+    int32_t scratch_off;   // byte offset of this crop's [crop_h][crop_w][3] uint8 image in the scratch buffer
+    double m[9];           // crop pixel (x, y, 1) -> page (X, Y, W), row-major (the inverse of getPerspectiveTransform's matrix)
+};
+struct LineCropParams {
+    const uint8_t* pages; int H, W; size_t page_stride;   // [P][H][W][3] u8
+    const LineCropDesc* descs; int n;
+    uint8_t* scratch; long max_crop_pixels;                // largest crop_w * crop_h of the batch (grid sizing)
+    float* dst; int OH, OWp;                               // [n][3][OH][OWp]
+    int swap_rb;
+};
+int launch_line_crops(const LineCropParams& p, hipStream_t s);
+
 }  // namespace rd
 
 namespace rd {

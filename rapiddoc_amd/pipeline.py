@@ -32,6 +32,11 @@ class CropDesc(C.Structure):
 CROP_DTYPE = np.dtype([("page", "<i4"), ("out_w", "<i4"), ("crop_w", "<f4"), ("crop_h", "<f4"), ("m", "<f4", (9,)),
                        ("rot90", "<i4"), ("pad_", "<i4")])
 assert CROP_DTYPE.itemsize == C.sizeof(CropDesc)
+# rd_line_crop_desc (include/rapiddoc_mi355.h): the reference-shaped two-stage crop (cubic warp to the integer-sized uint8
+# crop, rotation of tall crops, linear resize to height 48), homography in float64 like cv2's
+LINE_DTYPE = np.dtype([("page", "<i4"), ("out_w", "<i4"), ("crop_w", "<i4"), ("crop_h", "<i4"), ("rot90", "<i4"),
+                       ("scratch_off", "<i4"), ("m", "<f8", (9,))])
+assert LINE_DTYPE.itemsize == 96
 
 
 def quad_to_crop_matrix(quad: np.ndarray) -> Tuple[np.ndarray, float, float]:
@@ -54,7 +59,7 @@ def quad_to_crop_matrix(quad: np.ndarray) -> Tuple[np.ndarray, float, float]:
 
 
 def quads_to_crop_matrices(quads: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-    """Vectorised `quad_to_crop_matrix` for [n,4,2] quads -> ([n,9] float32, crop widths, crop heights)."""
+    """Vectorised `quad_to_crop_matrix` for [n,4,2] quads -> ([n,9] float64, crop widths, crop heights)."""
     q = np.asarray(quads, dtype=np.float64).reshape(-1, 4, 2)
     n = len(q)
     cw = np.maximum(np.linalg.norm(q[:, 0] - q[:, 1], axis=1), np.linalg.norm(q[:, 2] - q[:, 3], axis=1))
@@ -71,7 +76,7 @@ def quads_to_crop_matrices(quads: np.ndarray) -> Tuple[np.ndarray, np.ndarray, n
     A[:, 1::2, 6], A[:, 1::2, 7] = -v * x, -v * y
     b[:, 0::2], b[:, 1::2] = u, v
     h = np.linalg.solve(A, b[..., None])[..., 0]
-    return np.concatenate([h, np.ones((n, 1))], axis=1).astype(np.float32), cw, ch
+    return np.concatenate([h, np.ones((n, 1))], axis=1), cw, ch
 
 
 def boxes_to_quads(boxes_xyxy: np.ndarray) -> np.ndarray:
@@ -160,17 +165,29 @@ class PagePipeline:
         batches = ocr_host.rec_batches(ratios, self.rec_batch_num, width_multiple=self.rec_width_multiple)
         order_all = np.concatenate([c for c, _ in batches])
         wpad_all = np.concatenate([np.full(len(c), w) for c, w in batches])
-        descs = np.zeros(n, dtype=CROP_DTYPE)
+        descs = np.zeros(n, dtype=LINE_DTYPE)
         descs["page"] = page_of[order_all]
         descs["out_w"] = np.minimum(wpad_all, np.ceil(ocr_host.REC_IMG_H * (eff_w / eff_h)[order_all])).astype(np.int32)
-        descs["crop_w"] = cws_a[order_all]
-        descs["crop_h"] = chs_a[order_all]
+        descs["crop_w"] = cws_a[order_all].astype(np.int32)
+        descs["crop_h"] = chs_a[order_all].astype(np.int32)
         descs["m"] = mats[order_all]
         descs["rot90"] = rots_a[order_all]
+        # packed uint8 scratch of the rectified crops, one region per rec batch (batches run on different streams)
+        crop_bytes = (descs["crop_w"].astype(np.int64) * descs["crop_h"] * 3 + 15) // 16 * 16
+        batch_lens = [len(c) for c, _ in batches]
+        starts = np.cumsum([0] + batch_lens)
+        offs = np.zeros(n, np.int64)
+        batch_scratch = []
+        for b in range(len(batches)):
+            cb = crop_bytes[starts[b]:starts[b + 1]]
+            offs[starts[b]:starts[b + 1]] = np.cumsum(cb) - cb
+            batch_scratch.append(int(cb.sum()))
+        descs["scratch_off"] = offs.astype(np.int32)
+        batch_base = np.cumsum([0] + batch_scratch)
+        if getattr(self, "_crop_scratch", None) is None or self._crop_scratch.numel() < int(batch_base[-1]):
+            self._crop_scratch = torch.empty(int(batch_base[-1] * 1.25) + 1024, dtype=torch.uint8, device=pages.device)
         self.stats["t_descs_ms"] = (time.perf_counter() - t0) * 1e3
         descs_dev = torch.from_numpy(descs.view(np.uint8)).to(pages.device, non_blocking=True)
-        mean = (C.c_float * 3)(0.5, 0.5, 0.5)
-        std = (C.c_float * 3)(0.5, 0.5, 0.5)
         outs = []
         pos = 0
         main = torch.cuda.current_stream()
@@ -184,11 +201,13 @@ class PagePipeline:
                 st.wait_event(ready)          # descriptors (and the pages) are ready
             with torch.cuda.stream(st):
                 x = torch.empty((nb, 3, ocr_host.REC_IMG_H, wpad), dtype=torch.float32, device=pages.device)
-                rc = self._lib.rd_crop_resize_norm_batch(
-                    self.device, pages.data_ptr(), P, H, W, descs_dev.data_ptr() + pos * CROP_DTYPE.itemsize, nb,
-                    ocr_host.REC_IMG_H, wpad, mean, std, 1.0 / 255.0, 1, x.data_ptr(), st.cuda_stream)
+                d = descs[pos:pos + nb]
+                rc = self._lib.rd_line_crops_batch(
+                    self.device, pages.data_ptr(), P, H, W, descs_dev.data_ptr() + pos * LINE_DTYPE.itemsize, nb,
+                    int((d["crop_w"].astype(np.int64) * d["crop_h"]).max()), self._crop_scratch.data_ptr() + int(batch_base[bi]),
+                    ocr_host.REC_IMG_H, wpad, 1, x.data_ptr(), st.cuda_stream)
                 if rc != 0:
-                    raise RuntimeError("rd_crop_resize_norm_batch failed")
+                    raise RuntimeError("rd_line_crops_batch failed")
                 idx, prob, _ = self.rec_engines[k].rec_forward(x)
                 done = torch.cuda.Event()
                 done.record(st)

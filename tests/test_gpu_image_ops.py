@@ -1,0 +1,126 @@
+"""GPU: the image kernels (rapiddoc_amd/csrc/kernels_image.hip) against the numpy restatement of OpenCV's 8-bit arithmetic
+(oracle/cv2_ops.py): uint8 pixels must be IDENTICAL (compared through the normalised float outputs, which are exact
+functions of the uint8 value), plus the layout wrapper plumbing of BASELINE.json configs[0]."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cv2_ops as CV
+
+pytestmark = pytest.mark.gpu
+
+
+def _to_u8(x, scale=255.0):
+    return np.rint(x * scale).astype(np.int64)
+
+
+@pytest.mark.parametrize("hw,out_hw", [((1684, 1191), (800, 800)), ((300, 200), (480, 480)), ((97, 131), (64, 64)), ((50, 70), (50, 70))])
+def test_cubic_preprocess_is_pixel_exact(hw, out_hw):
+    """PPPreProcess resize (cv2 INTER_CUBIC, pp_doclayout/pre_process.py:35) -> /255, mean 0 / std 1."""
+    from rapiddoc_amd.engine import preproc_resize_norm
+    img = np.random.default_rng(hw[0]).integers(0, 256, (*hw, 3), dtype=np.uint8)
+    img[: hw[0] // 3, : hw[1] // 2] = 255                                # a hard edge: overshoot / saturation
+    got = preproc_resize_norm(torch.from_numpy(img).cuda(), out_hw, interp=2).cpu().numpy()
+    ref = CV.resize_cubic_u8(img, out_hw).transpose(2, 0, 1)
+    assert np.array_equal(_to_u8(got), ref.astype(np.int64))
+    assert np.abs(got - CV.layout_preprocess(img, out_hw[0])[0]).max() < 1e-6 if out_hw[0] == out_hw[1] else True
+
+
+@pytest.mark.parametrize("hw,out_hw", [((1784, 1291), (960, 704)), ((128, 448), (128, 448)), ((70, 333), (64, 320))])
+def test_linear_preprocess_is_pixel_exact(hw, out_hw):
+    """rapidocr DetPreProcess resize (cv2 INTER_LINEAR) -> BGR, (x / 255 - 0.5) / 0.5."""
+    from rapiddoc_amd.engine import preproc_resize_norm
+    img = np.random.default_rng(hw[1]).integers(0, 256, (*hw, 3), dtype=np.uint8)
+    got = preproc_resize_norm(torch.from_numpy(img).cuda(), out_hw, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), interp=1,
+                              swap_rb=True).cpu().numpy()
+    ref = CV.resize_linear_u8(img, out_hw)[:, :, ::-1].transpose(2, 0, 1)
+    assert np.array_equal(_to_u8((got * 0.5 + 0.5)), ref.astype(np.int64))
+
+
+def test_line_crops_match_get_rotate_crop_image_and_resize_norm_img():
+    """rd_line_crops_batch == get_rotate_crop_image (cubic warp, BORDER_REPLICATE, rot90 of tall crops, ocr_utils.py:494-536)
+    followed by rapidocr resize_norm_img, on axis-aligned, tilted, border-crossing and tall quads."""
+    from rapiddoc_amd import _lib
+    from rapiddoc_amd.pipeline import LINE_DTYPE, quads_to_crop_matrices
+    lib = _lib.load()
+    rng = np.random.default_rng(9)
+    pages = rng.integers(0, 256, (2, 400, 600, 3), dtype=np.uint8)
+    quads = np.array([
+        [[40, 50], [440, 50], [440, 82], [40, 82]],                      # axis-aligned line
+        [[30, 120], [520, 150], [518, 182], [28, 152]],                  # tilted
+        [[-6, 300], [200, 296], [201, 330], [-5, 334]],                  # crosses the left page border
+        [[500, 20], [530, 20], [530, 200], [500, 200]],                  # tall: rotated by 90 degrees
+        [[100, 350], [595, 352], [596.5, 391], [100.5, 389]],            # long
+    ], np.float64)
+    page_of = np.array([0, 1, 0, 1, 0])
+    mats, cws, chs = quads_to_crop_matrices(quads)
+    rot = (chs / cws >= 2.0).astype(np.int32)
+    eff_w, eff_h = np.where(rot == 1, chs, cws), np.where(rot == 1, cws, chs)
+    wpad = 608
+    n = len(quads)
+    d = np.zeros(n, dtype=LINE_DTYPE)
+    d["page"], d["crop_w"], d["crop_h"], d["rot90"], d["m"] = page_of, cws.astype(np.int32), chs.astype(np.int32), rot, mats
+    d["out_w"] = np.minimum(wpad, np.ceil(48 * eff_w / eff_h)).astype(np.int32)
+    nbytes = (d["crop_w"].astype(np.int64) * d["crop_h"] * 3 + 15) // 16 * 16
+    d["scratch_off"] = (np.cumsum(nbytes) - nbytes).astype(np.int32)
+    dd = torch.from_numpy(d.view(np.uint8)).cuda()
+    pg = torch.from_numpy(pages).cuda()
+    scratch = torch.zeros(int(nbytes.sum()) + 64, dtype=torch.uint8, device="cuda")
+    out = torch.full((n, 3, 48, wpad), 7.0, device="cuda")
+    rc = lib.rd_line_crops_batch(0, pg.data_ptr(), 2, 400, 600, dd.data_ptr(), n, int((d["crop_w"].astype(np.int64) * d["crop_h"]).max()),
+                                 scratch.data_ptr(), 48, wpad, 0, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    got = out.cpu().numpy()
+    sc = scratch.cpu().numpy()
+    for i in range(n):
+        crop = CV.get_rotate_crop_image(pages[page_of[i]], quads[i].astype(np.float32))
+        M, cw, ch = CV.perspective_dst_to_src(quads[i])
+        raw = CV.warp_perspective_cubic_u8(pages[page_of[i]], M, (cw, ch))
+        mine = sc[d["scratch_off"][i]: d["scratch_off"][i] + cw * ch * 3].reshape(ch, cw, 3)
+        assert (cw, ch) == (d["crop_w"][i], d["crop_h"][i])
+        assert np.array_equal(mine, raw), f"warp {i}: {np.abs(mine.astype(int) - raw.astype(int)).max()}"
+        ref = CV.resize_norm_img(crop, wpad / 48.0)
+        assert np.array_equal(got[i], ref), f"line {i}: {np.abs(got[i] - ref).max()}"
+
+
+def test_layout_model_plumbing_config1():
+    """BASELINE.json configs[0]: PP-DocLayout-S on 4 x 1684 x 1191 pages through the wrapper with a synthetic-box session:
+    chunks of `batch_size`, [b,3,480,480] ImageNet-normalised inputs, scale_factor = [S/H, S/W], post-process, layout_dets
+    schema (rapid_layout.py:55-108, pp_doclayout/main.py:38-80)."""
+    import json
+    from pathlib import Path
+    from rapiddoc_amd.layout_host import LayoutPostProcess, to_layout_dets
+    from rapiddoc_amd.layout_model import IMAGENET_MEAN, IMAGENET_STD, LayoutModel, SyntheticBoxSession, split_session_output
+    from rapiddoc_amd.pages import synth_batch
+    maps = json.loads((Path(__file__).resolve().parent / "golden" / "layout_category_maps.json").read_text())
+    labels = list(maps["label_to_category"]["pp_doclayout"])
+    sess = SyntheticBoxSession(labels, boxes_per_page=60, ncol=6, size=480)
+    model = LayoutModel(sess, "pp_doclayout_s")
+    pages_np, _ = synth_batch(0, 4)
+    out = model.batch_predict([p for p in pages_np], batch_size=3)
+    assert [c[0] for c in sess.calls] == [(3, 3, 480, 480), (1, 3, 480, 480)]
+    assert np.allclose(sess.calls[0][1], [[480 / 1684, 480 / 1191]] * 3)
+    assert len(out) == 4 and all(len(o) > 0 for o in out)
+    for dets in out:
+        for d in dets:
+            assert set(d) == {"category_id", "original_label", "original_order", "poly", "polygon_points", "score"}
+            assert d["original_order"] == -1 and d["polygon_points"] is None and d["score"] == round(d["score"], 3)
+            x0, y0, x1, y1 = d["poly"][0], d["poly"][1], d["poly"][4], d["poly"][5]
+            assert d["poly"] == [x0, y0, x1, y0, x1, y1, x0, y1] and 0 <= x0 < x1 <= 1191 and 0 <= y0 < y1 <= 1684
+            assert d["category_id"] == (2 if d["original_label"] in model.ignore else maps["label_to_category"]["pp_doclayout"][d["original_label"]]) \\
+                or d["category_id"] == 13
+    # the wrapper is exactly: session boxes -> LayoutPostProcess(conf 0.2 for S) -> to_layout_dets
+    x, sf = model.preprocess([pages_np[0]])
+    ref_in = CV.layout_preprocess(pages_np[0], 480, IMAGENET_MEAN, IMAGENET_STD)
+    assert np.abs(x.cpu().numpy() - ref_in).max() < 1e-5
+    boxes = split_session_output(SyntheticBoxSession(labels, 60, 6, size=480)(x.cpu().numpy()[:1].repeat(3, 0), np.repeat(sf, 3, 0)))[0]["boxes"]
+    want = to_layout_dets(LayoutPostProcess(labels, 0.2, 0.5)(boxes, [1191, 1684], None, "rect"), "pp_doclayout", False, model.ignore)
+    got0 = [dict(d, category_id=d["category_id"]) for d in out[0]]
+    assert [d["poly"] for d in got0] == [d["poly"] for d in want] and [d["original_label"] for d in got0] == [d["original_label"] for d in want]
+    # V3: ordered output, 7-column boxes, 800 x 800, mean 0 / std 1, per-class merge table
+    labels_v2 = list(maps["label_to_category"]["pp_doclayoutv2"])
+    m3 = LayoutModel(SyntheticBoxSession(labels_v2, 50, 7), "pp_doclayoutv3")
+    o3 = m3.batch_predict([pages_np[1]], 1)[0]
+    assert m3.session.calls[0][0] == (1, 3, 800, 800) and [d["original_order"] for d in o3] == list(range(len(o3)))
