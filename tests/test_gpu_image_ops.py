@@ -109,8 +109,8 @@ def test_layout_model_plumbing_config1():
             assert d["original_order"] == -1 and d["polygon_points"] is None and d["score"] == round(d["score"], 3)
             x0, y0, x1, y1 = d["poly"][0], d["poly"][1], d["poly"][4], d["poly"][5]
             assert d["poly"] == [x0, y0, x1, y0, x1, y1, x0, y1] and 0 <= x0 < x1 <= 1191 and 0 <= y0 < y1 <= 1684
-            assert d["category_id"] == (2 if d["original_label"] in model.ignore else maps["label_to_category"]["pp_doclayout"][d["original_label"]]) \\
-                or d["category_id"] == 13
+            want_cat = 2 if d["original_label"] in model.ignore else maps["label_to_category"]["pp_doclayout"][d["original_label"]]
+            assert d["category_id"] in (want_cat, 13)
     # the wrapper is exactly: session boxes -> LayoutPostProcess(conf 0.2 for S) -> to_layout_dets
     x, sf = model.preprocess([pages_np[0]])
     ref_in = CV.layout_preprocess(pages_np[0], 480, IMAGENET_MEAN, IMAGENET_STD)
