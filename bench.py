@@ -65,12 +65,76 @@ def cpu_baseline(states, threads):
                       "1x3x960x704 (%.3fs) + rec 6x3x48x1088 (%.3fs) scaled x45/6" % (t_b4, t_det, t_rec)}
 
 
+def bench_backbone(args, pool, pages, rank, world, dist, backend):
+    """--only backbone: PP-DocLayout's PPHGNetV2-B4 backbone alone on this rank's pages (pre-process + forward), as
+    pages/s, TFLOP/s and the fraction of the peak of the arithmetic ACTUALLY ISSUED: every layer's FLOPs are priced at the
+    dense fp16 MFMA peak / 3 when it ran on the split-fp16 kernels and at the fp32 MFMA peak otherwise."""
+    pipe = pool.pipes[0]
+    eng = pipe.layout
+
+    def step():
+        feats = pipe.layout_forward(pages)
+        if eng.check_range_and_fallback():
+            feats = pipe.layout_forward(pages)
+        return feats
+    for _ in range(max(1, args.warmup)):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    eng.set_profiling(True)
+    eng.profile_log = []
+    step()
+    torch.cuda.synchronize()
+    eng.set_profiling(False)
+    ops = eng.profile_log
+    split = [o for o in ops if o["cfg"].endswith("/h3") or "_h3" in o["kind"] or "_ws" in o["kind"]]
+    dense = [o for o in ops if o["flops"] > 0 and o not in split]
+    fl_split, fl_dense = sum(o["flops"] for o in split), sum(o["flops"] for o in dense)
+    ms_all = sum(o["ms"] for o in ops)
+    t_ideal = fl_split / (F16_MFMA_PEAK_TFLOPS / 3.0 * 1e12) + fl_dense / (FP32_MFMA_PEAK_TFLOPS * 1e12)
+    P = pages.shape[0]
+    if rank == 0:
+        rec = {"metric": "pages/sec (PP-DocLayout backbone only)", "value": round(P * world * args.steps / dt, 3), "unit": "pages/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "PPHGNetV2-B4 @800x800 (pre-process + backbone) on %d synthetic pages per GPU" % P,
+                          "gflop_per_page": round((fl_split + fl_dense) / P / 1e9, 3)},
+               "roofline": {"bound": "mfma", "kernel": "PPHGNetV2-B4 backbone (all layers)",
+                            "achieved": round((fl_split + fl_dense) / (ms_all * 1e-3) / 1e12, 3), "unit": "TFLOP/s",
+                            "peak": round((fl_split + fl_dense) / t_ideal / 1e12, 1),
+                            "frac": round(t_ideal / (ms_all * 1e-3), 4), "traffic": None,
+                            "split_fp16_flop_share": round(fl_split / (fl_split + fl_dense), 3), "kernel_ms": round(ms_all, 3),
+                            "note": "peak = FLOP-weighted harmonic mix of 838.9 (split-fp16 layers) and 157.3 TFLOP/s (fp32-MFMA layers)"}}
+        print(json.dumps(rec), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pages", type=int, default=PAGES_PER_GPU)
+    ap.add_argument("--pages", type=int, default=PAGES_PER_GPU, help="pages per GPU and step (weak scaling)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: the global document has --pages x N pages; strong: it has --global-pages whatever N is.  Either way "
+                         "rank r takes pages {i : i mod N = r} of ONE global list (rapiddoc_amd.dist.shard_pages)")
+    ap.add_argument("--global-pages", type=int, default=256)
+    ap.add_argument("--only", choices=("all", "backbone"), default="all",
+                    help="backbone: time the PPHGNetV2-B4 layout backbone alone (north_star's >= 40 %% MFMA item)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-profile", type=str, default="")
     ap.add_argument("--rec-batch", type=int, default=64)
@@ -121,9 +185,15 @@ def main():
                                     rec_width_multiple=args.rec_width_multiple,
                                     n_rec_streams=max(1, args.rec_streams // max(1, args.workers))) for _ in range(max(1, args.inflight) - 1)]
     pools = [pool] + extra_pools
-    P = args.pages
-    pages_np, boxes = synth_batch(rank * P, P)
+    from rapiddoc_amd.dist import shard_pages
+    from rapiddoc_amd.pages import synth_pages
+    n_global = args.global_pages if args.scaling == "strong" else args.pages * world
+    my_pages = shard_pages(n_global, rank, world)          # interleaved split of ONE document list
+    P = len(my_pages)
+    pages_np, boxes = synth_pages(my_pages)
     pages = torch.from_numpy(pages_np).cuda()
+    if args.only == "backbone":
+        return bench_backbone(args, pool, pages, rank, world, dist, backend)
     # random-weight det maps carry no text, so the DB post-process stage gets maps rendered from the generator's own
     # line boxes (the det network still runs every step); its boxes then drive cropping and recognition
     det_hw = pipe.det_forward(pages[:1])[1]
@@ -132,7 +202,7 @@ def main():
 
     def compute(k=0):
         res = pools[k].run_batch(pages, quads, det_maps_override=text_maps)
-        return [(rank * P + i, [(t, s) for _, t, s in r.lines]) for i, r in enumerate(res)]
+        return [(my_pages[i], [(t, s) for _, t, s in r.lines]) for i, r in enumerate(res)]
 
     def step():
         return gather_page_results(compute(0), dist)
@@ -190,6 +260,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_lines = sum(len(l) for _, l in out)
+    import zlib
+    from rapiddoc_amd.dist import encode_page_results
+    result_crc = zlib.crc32(encode_page_results(out))      # of the gathered, page-ordered result: equal for every N (strong)
     host_stats = {k: round(v, 2) for k, v in pool.stats.items()}
 
     # ---- roofline of the dominant kernel: per-op HIP events (recorded by the library on the launch stream)
@@ -215,6 +288,8 @@ def main():
                     name = "lc_mixer_kernel<%s>" % op["cfg"][1:]
                 elif op["kind"] == "mixer_fused_h3":
                     name = "lc_mixer_h3_kernel<%s>" % op["cfg"][1:]
+                elif op["kind"] == "mixer_fused_ws":
+                    name = "lc_mixer_ws_kernel<%s>" % op["cfg"][1:]
                 elif op["kind"] == "ctc_head_fused_h3":
                     name = "ctc_head_h3_kernel"
                 elif op["kind"] == "ctc_head_fused":
@@ -227,15 +302,21 @@ def main():
         dom = max(mfma, key=lambda k: mfma[k][2])
         fl, by, ms, n = mfma[dom]
         ach = fl / (ms * 1e-3) / 1e12
-        traffic = None
-        tf = ROOT / "profiles" / "pmc_traffic.json"   # HBM bytes per launch from the last rocprofv3 --pmc passes
+        # HBM bytes per launch: NOT measured in this run - read from the committed summary of the last rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE passes (tools/collect_profiles.sh -> profiles/pmc_traffic.json); null if that file has no
+        # row for today's dominant kernel.  `traffic_source` says which file / collection the number comes from.
+        traffic, traffic_source = None, None
+        tf = ROOT / "profiles" / "pmc_traffic.json"
         if tf.exists():
-            traffic = json.loads(tf.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
+            tj = json.loads(tf.read_text())
+            traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
+            if traffic is not None:
+                traffic_source = "profiles/pmc_traffic.json (%s)" % tj.get("_collected", "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes")
         # a split-fp16 kernel issues 3 fp16 MFMAs per fp32 product: its ceiling in algorithmic (fp32) FLOPs is the dense
         # fp16 MFMA peak / 3
-        peak = F16_MFMA_PEAK_TFLOPS / 3.0 if "_h3_" in dom else FP32_MFMA_PEAK_TFLOPS   # gemm_h3_dma_kernel, *_h3_kernel
+        peak = F16_MFMA_PEAK_TFLOPS / 3.0 if ("_h3_" in dom or "_ws_" in dom) else FP32_MFMA_PEAK_TFLOPS   # split-fp16 kernels
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic,
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": round(by / n), "launches_per_step": n,
                 "avg_launch_us": round(ms * 1e3 / n, 2), "avg_gflop_per_launch": round(fl / n / 1e9, 4),
                 "all_mfma_kernels_tflops": round(sum(v[0] for v in mfma.values()) / (sum(v[2] for v in mfma.values()) * 1e-3) / 1e12, 3),
@@ -252,20 +333,21 @@ def main():
                     f.write("%s,%d,%.3f,%.2f,%.1f,%.2f,%.1f\n" % (k, n_, ms_, gf, mb, gf / ms_ if ms_ else 0, mb / ms_ if ms_ else 0))
 
     if rank == 0:
-        total_pages = P * world * args.steps
+        total_pages = n_global * args.steps
         rec = {
             "metric": "pages/sec (layout+OCR det/rec)", "value": round(total_pages / dt, 3), "unit": "pages/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "PP-DocLayout backbone (PPHGNetV2-B4 @800x800) + PP-OCRv6-small det (960x704) + rec "
-                                   "(45 lines/page, fused CTC) on %d synthetic 1684x1191 pages per GPU" % P,
+                                   "(45 lines/page, fused CTC) on %d synthetic 1684x1191 pages per GPU (rank r takes pages r, r+N, ... of one %d-page list)" % (P, n_global),
                        "precision": "auto: fp32 in / fp32 accumulate / fp32 out; products of the channel mixers, the CTC head and the "
                                     "wide convs on split-fp16 MFMA (x = hi + lo*2^-11, 3 MFMAs per product, error vs fp64 <= the fp32 "
                                     "MFMA kernels': mixer 8.6e-8 vs 2.1e-7 max abs, GEMM 1.8e-7..1.1e-6 vs 4.8e-7..1.1e-6 max rel, "
                                     "tools/microbench.py + tests/test_gpu_parity.py), fp32 MFMA for the rest; range-guarded with fp32 "
                                     "fallback (DESIGN.md s3); RD_PRECISION=fp32 (native fp32 MFMA only) measures 179 pages/s"
                                     if pipe.det.precision == "auto" else pipe.det.precision,
-                       "pages_per_gpu": P, "lines_per_step": n_lines, "host_stage_ms": host_stats, "parallelism": "page-sharded dp%d; %d page batch(es) in flight per GPU" % (world, len(pools)),
+                       "pages_per_gpu": P, "global_pages": n_global, "pages_gathered": len(out), "result_crc32": result_crc,
+                       "lines_per_step": n_lines, "host_stage_ms": host_stats, "parallelism": "page-sharded dp%d; %d page batch(es) in flight per GPU" % (world, len(pools)),
                        "layout_head": "absent (ONNX-only in the reference; backbone only)",
                        "det_postprocess": "DB post-process (host C++) runs on maps rendered from the generator's line boxes "
                                           "(random-weight det output has no text); its boxes drive crop+rec"},

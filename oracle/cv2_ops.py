@@ -19,7 +19,7 @@ Fixed-point conventions restated (OpenCV): resize coefficients are 11-bit (`INTE
 and rounded half-to-even to int16; the horizontal pass keeps int32 rows, the vertical pass of the cubic kernel rounds
 (v + 2^21) >> 22, that of the linear kernel uses ((b0 (S0 >> 4)) >> 16) + ((b1 (S1 >> 4)) >> 16) + 2) >> 2; remap-based warps
 quantise source positions to 1/32 pixel (`INTER_BITS` = 5) and use a 32 x 32 table of 4 x 4 weights in 15-bit fixed point
-whose sum is forced to 2^15 by adjusting one of the four centre weights.
+whose sum is forced to 2^15 by adjusting the largest / smallest weight of its lower-right 2 x 2 quadrant.
 """
 from __future__ import annotations
 
@@ -125,9 +125,11 @@ def cubic_remap_table() -> np.ndarray:
             it = np.clip(_round_half_even_i(v * np.float32(REMAP_SCALE)), -32768, 32767)
             diff = int(it.sum()) - REMAP_SCALE
             if diff != 0:
-                mk, Mk = (1, 1), (1, 1)
-                for k1 in (1, 2):
-                    for k2 in (1, 2):
+                # initInterTab2D searches rows / columns ksize/2 .. ksize/2 + 1 (= 2, 3 for the 4-tap kernel), starting from
+                # (2, 2).  (With the centre block an integer position - one weight of 32767 - would overflow int16.)
+                mk, Mk = (2, 2), (2, 2)
+                for k1 in (2, 3):
+                    for k2 in (2, 3):
                         if it[k1, k2] < it[mk]:
                             mk = (k1, k2)
                         elif it[k1, k2] > it[Mk]:

@@ -10,6 +10,8 @@
 // rounding rules, 1/32-pixel remap positions with a 15-bit 4x4 weight table whose sum is forced to 2^15) is the public OpenCV
 // 4.x algorithm; oracle/cv2_ops.py is its numpy twin and tests/test_gpu_image_ops.py demands bit-equality with it.
 // cv2 itself is absent from the build container, so against the real library this is PARITY UNPINNED.
+// OpenCV's scalar code rounds every float operation separately: no FMA contraction in this file.
+#pragma clang fp contract(off)
 #include <cmath>
 #include <mutex>
 #include <vector>
@@ -135,10 +137,10 @@ static std::vector<int16_t> build_cubic_remap_table() {
                     sum += (int)r;
                 }
             const int diff = sum - 32768;
-            if (diff != 0) {   // force the sum: adjust the smallest / largest of the four centre weights
-                int mk1 = 1, mk2 = 1, Mk1 = 1, Mk2 = 1;
-                for (int k1 = 1; k1 < 3; ++k1)
-                    for (int k2 = 1; k2 < 3; ++k2) {
+            if (diff != 0) {   // force the sum: adjust the smallest / largest weight of rows / columns ksize/2 .. ksize/2 + 1
+                int mk1 = 2, mk2 = 2, Mk1 = 2, Mk2 = 2;
+                for (int k1 = 2; k1 < 4; ++k1)
+                    for (int k2 = 2; k2 < 4; ++k2) {
                         if (it[k1][k2] < it[mk1][mk2]) { mk1 = k1; mk2 = k2; }
                         else if (it[k1][k2] > it[Mk1][Mk2]) { Mk1 = k1; Mk2 = k2; }
                     }

@@ -45,3 +45,13 @@ def synth_batch(first_idx: int, n: int):
         pages.append(p)
         boxes.append(b)
     return np.stack(pages), boxes
+
+
+def synth_pages(indices):
+    """Pages of a global document list by index (what a rank gets from `dist.shard_pages`)."""
+    pages, boxes = [], []
+    for i in indices:
+        p, b = synth_page(int(i))
+        pages.append(p)
+        boxes.append(b)
+    return np.stack(pages), boxes

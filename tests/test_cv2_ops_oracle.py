@@ -31,7 +31,7 @@ def test_cubic_resize_overshoots_and_saturates():
 def test_remap_table_blocks_sum_to_one():
     tab = CV.cubic_remap_table()
     assert tab.shape == (1024, 4, 4) and (tab.reshape(1024, 16).sum(1) == 32768).all()
-    assert tab[0, 1, 1] == 32768 and (tab[0].sum() == 32768)            # integer position: the centre tap only
+    assert tab[0, 1, 1] == 32767 and tab[0, 2, 2] == 1 and tab[0].sum() == 32768     # integer position: centre tap (int16 max) + 1
 
 
 def test_identity_warp_and_integer_shift():

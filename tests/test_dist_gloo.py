@@ -48,3 +48,16 @@ def test_shard_pages_partition():
     for world in (1, 2, 4, 8):
         seen = sorted(i for r in range(world) for i in shard_pages(37, r, world))
         assert seen == list(range(37))
+
+
+def test_wire_format_roundtrip_and_rejects_garbage():
+    import pytest
+    from rapiddoc_amd.dist import decode_page_results, encode_page_results
+    pages = [(3, [("\u6587\u5b57 abc", 0.987), ("", 0.0)]), (10 ** 12, []), (0, [("x" * 3000, 1.0)])]
+    blob = encode_page_results(pages)
+    assert decode_page_results(blob) == pages
+    assert decode_page_results(encode_page_results([])) == []
+    with pytest.raises(Exception):
+        decode_page_results(blob[:-3])
+    with pytest.raises(ValueError):
+        decode_page_results(blob + b"\0")
