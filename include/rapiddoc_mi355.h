@@ -125,6 +125,14 @@ int rd_line_crops_batch(int device_id, const uint8_t* pages_u8_dev, int P, int H
                         int n, int64_t max_crop_pixels, uint8_t* scratch_u8_dev, int out_h, int out_w_padded, int swap_rb,
                         float* out_nchw_dev, void* stream);
 
+/* CTC greedy decode on the device (replaces rapidocr CTCLabelDecode's per-line loop, called from
+ * rapid_doc/model/ocr/rapid_ocr.py:444-449): idx / prob [B][T] as rd_rec_forward wrote them -> per line, at out + b * row_bytes:
+ * int32 n_text_bytes, float32 confidence (the float32 np.mean of the kept max-probabilities, bit for bit), int32 n_kept,
+ * int32 0, then the UTF-8 text.  char_table_dev: [n_classes][1 + max_len] bytes = (length, UTF-8 bytes) of every dictionary
+ * entry, entry 0 = blank.  row_bytes >= 16 + T * max_len. */
+int rd_ctc_collapse(int device_id, const int32_t* idx_bt_dev, const float* prob_bt_dev, int B, int T, const uint8_t* char_table_dev,
+                    int max_len, int n_classes, uint8_t* out_dev, int row_bytes, void* stream);
+
 /* DB post-process (HOST pointers, runs on the host like the reference's): probability maps [B][H][W] -> text boxes.
  * Replaces rapidocr DBPostProcess.__call__ as patched in rapid_doc/model/ocr/ocr_patch.py:223-241 (box_type "quad",
  * score_mode "fast"), called from rapid_doc/model/ocr/rapid_ocr.py:537-538.  src_hw[b] = (height, width) of the image

@@ -189,6 +189,14 @@ int rd_line_crops_batch(int device_id, const uint8_t* pages, int P, int H, int W
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+int rd_ctc_collapse(int device_id, const int32_t* idx, const float* prob, int B, int T, const uint8_t* ctab, int max_len, int n_classes,
+                    uint8_t* out, int row_bytes, void* stream) {
+    if (!idx || !prob || !ctab || !out || B < 0 || T <= 0 || max_len <= 0 || n_classes <= 0) return 1;
+    if (hipSetDevice(device_id) != hipSuccess) return 1;
+    if (rd::launch_ctc_collapse(idx, prob, B, T, ctab, max_len, n_classes, out, row_bytes, (hipStream_t)stream) != 0) return 1;
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 // ---- developer micro-benchmarks (not part of the public header): time one kernel on caller-provided buffers
 float rd_debug_time_mixer(int C, int M, int variant, int iters, float* x, float* y, float* w1, float* b1, float* w2, float* b2) {
     rd::MixerParams p{};

@@ -252,3 +252,106 @@ int launch_line_crops(const LineCropParams& p, hipStream_t s) {
 }
 
 }  // namespace rd
+
+// ---------------------------------------------------------------------------------------------------------------------
+// CTC greedy decode on the device (rapidocr CTCLabelDecode as called from rapid_doc/model/ocr/rapid_ocr.py:444-449):
+// per text line collapse repeated indices, drop the blank (0), map the kept indices to the UTF-8 bytes of their dictionary
+// entries and average the kept max-probabilities - so that only the finished strings cross PCIe and the host loop over
+// [B][T] indices (14 ms per 32-page step in round 1) disappears.
+// The confidence reproduces numpy's float32 `np.mean` bit for bit: add.reduce starts from the identity 0 and sums with the
+// pairwise scheme of numpy/core/src/umath/loops_utils.h (n < 8: a plain loop; n <= 128: eight strided partial sums
+// combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus a tail loop; larger n: split at (n/2 rounded down to a multiple of 8)),
+// then one float32 division by the count (tests/test_ocr_host.py pins the scheme against np.mean on the CPU).
+// Row layout of `out` (stride row_bytes): int32 n_text_bytes, float32 confidence, int32 n_kept, int32 pad, then the text.
+// ---------------------------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+__device__ float np_pairwise_sum_f32(const float* a, int n) {
+    if (n < 8) {
+        float res = 0.f;
+        for (int i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        float r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum_f32(a, n2) + np_pairwise_sum_f32(a + n2, n - n2);
+}
+
+__global__ void __launch_bounds__(256) ctc_collapse_kernel(const int32_t* __restrict__ idx, const float* __restrict__ prob, int T,
+                                                           const uint8_t* __restrict__ ctab, int max_len, int n_classes,
+                                                           uint8_t* __restrict__ out, int row_bytes) {
+    extern __shared__ unsigned char smem[];
+    float* kept = reinterpret_cast<float*>(smem);                  // [T] kept probabilities, compacted
+    int* scan = reinterpret_cast<int*>(smem + (size_t)T * 4);      // [2][256] scan scratch
+    __shared__ int carry_k, carry_b;
+    const int line = blockIdx.x, tid = threadIdx.x;
+    const int32_t* row = idx + (size_t)line * T;
+    const float* prow = prob + (size_t)line * T;
+    uint8_t* orow = out + (size_t)line * row_bytes;
+    if (tid == 0) carry_k = carry_b = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < T; t0 += 256) {
+        const int t = t0 + tid;
+        int id = 0, keep = 0, len = 0;
+        if (t < T) {
+            id = row[t];
+            keep = id != 0 && (t == 0 || id != row[t - 1]);
+            if (keep && id > 0 && id < n_classes) len = ctab[(size_t)id * (max_len + 1)];
+        }
+        // block-wide inclusive scans of `keep` and `len` (Hillis-Steele over 256 entries)
+        int* sk = scan;
+        int* sb = scan + 256;
+        sk[tid] = keep;
+        sb[tid] = len;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int vk = tid >= off ? sk[tid - off] : 0, vb = tid >= off ? sb[tid - off] : 0;
+            __syncthreads();
+            sk[tid] += vk;
+            sb[tid] += vb;
+            __syncthreads();
+        }
+        const int pos_k = carry_k + sk[tid] - keep, pos_b = carry_b + sb[tid] - len;
+        if (keep) {
+            kept[pos_k] = prow[t];
+            const uint8_t* src = ctab + (size_t)id * (max_len + 1) + 1;
+            for (int b = 0; b < len; ++b) orow[16 + pos_b + b] = src[b];
+        }
+        __syncthreads();
+        if (tid == 255) {
+            carry_k += sk[255];
+            carry_b += sb[255];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int n = carry_k;
+        float conf = 0.f;
+        if (n > 0) conf = (0.f + np_pairwise_sum_f32(kept, n)) / (float)n;
+        reinterpret_cast<int32_t*>(orow)[0] = carry_b;
+        reinterpret_cast<float*>(orow)[1] = conf;
+        reinterpret_cast<int32_t*>(orow)[2] = n;
+        reinterpret_cast<int32_t*>(orow)[3] = 0;
+    }
+}
+
+namespace rd {
+int launch_ctc_collapse(const int32_t* idx, const float* prob, int B, int T, const uint8_t* ctab, int max_len, int n_classes,
+                        uint8_t* out, int row_bytes, hipStream_t s) {
+    if (B <= 0 || T <= 0) return 0;
+    if (row_bytes < 16 + T * max_len) return 1;
+    const size_t sh = (size_t)T * 4 + 2 * 256 * sizeof(int);
+    if (sh > 60000) return 1;
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(B), dim3(256), sh, s, idx, prob, T, ctab, max_len, n_classes, out, row_bytes);
+    return 0;
+}
+}  // namespace rd

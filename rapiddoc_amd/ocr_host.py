@@ -99,6 +99,27 @@ def ctc_decode(idx: np.ndarray, prob: np.ndarray, characters: Sequence[str]) -> 
     return out
 
 
+def char_table(characters: Sequence[str]):
+    """Dictionary as the byte table `rd_ctc_collapse` reads: [n_classes][1 + max_len] uint8 = (UTF-8 length, bytes)."""
+    enc = [c.encode("utf-8") for c in characters]
+    max_len = max(1, max(len(b) for b in enc))
+    tab = np.zeros((len(enc), 1 + max_len), np.uint8)
+    for i, b in enumerate(enc):
+        tab[i, 0] = len(b)
+        tab[i, 1:1 + len(b)] = np.frombuffer(b, np.uint8)
+    return tab, max_len
+
+
+def parse_ctc_rows(rows: np.ndarray) -> List[Tuple[str, float]]:
+    """Rows written by `rd_ctc_collapse` (int32 n_text_bytes, float32 confidence, int32 n_kept, int32 0, UTF-8 text) ->
+    [(text, confidence)] - what `ctc_decode` returns for the same (idx, prob)."""
+    rows = np.ascontiguousarray(rows)
+    head = rows[:, :8].copy()
+    nbytes = head[:, :4].view("<i4")[:, 0]
+    conf = head[:, 4:8].view("<f4")[:, 0]
+    return [(rows[b, 16:16 + int(nbytes[b])].tobytes().decode("utf-8"), float(conf[b])) for b in range(rows.shape[0])]
+
+
 def format_score(score: float) -> float:
     """analyze_utils.py:280: float(f'{score:.3f}')"""
     return float(f"{score:.3f}")

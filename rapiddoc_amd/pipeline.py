@@ -113,6 +113,10 @@ class PagePipeline:
         self.rec_batch_num = rec_batch_num
         self.rec_width_multiple = rec_width_multiple
         self.keep_feats = keep_feats
+        # CTC greedy decode on the device (rd_ctc_collapse): only finished strings + confidences cross PCIe
+        tab, self._ctc_max_len = ocr_host.char_table(self.characters)
+        self._ctc_table = torch.from_numpy(tab).to(self.tdev)
+        self.device_ctc = True
         self.keep_rec_inputs = False      # tests: keep every rec batch's input tensor and raw (idx, prob) in last_rec_batches
         self.last_rec_batches: List[Tuple[np.ndarray, torch.Tensor, torch.Tensor, torch.Tensor]] = []
         self._lib = _lib.load()
@@ -209,21 +213,37 @@ class PagePipeline:
                 if rc != 0:
                     raise RuntimeError("rd_line_crops_batch failed")
                 idx, prob, _ = self.rec_engines[k].rec_forward(x)
+                rows = None
+                if self.device_ctc:
+                    T = idx.shape[1]
+                    row_bytes = (16 + T * self._ctc_max_len + 15) // 16 * 16
+                    rows = torch.empty((nb, row_bytes), dtype=torch.uint8, device=pages.device)
+                    rc = self._lib.rd_ctc_collapse(self.device, idx.data_ptr(), prob.data_ptr(), nb, T, self._ctc_table.data_ptr(),
+                                                   self._ctc_max_len, len(self.characters), rows.data_ptr(), row_bytes, st.cuda_stream)
+                    if rc != 0:
+                        raise RuntimeError("rd_ctc_collapse failed")
+                    rows_h = torch.empty((nb, row_bytes), dtype=torch.uint8, pin_memory=True)
+                    rows_h.copy_(rows, non_blocking=True)
+                    rows = rows_h
                 done = torch.cuda.Event()
                 done.record(st)
-            outs.append((idx, prob, done, x))
+            outs.append((idx, prob, done, x, rows))
             pos += nb
         self.stats["t_rec_enqueue_ms"] = (time.perf_counter() - t0) * 1e3 - self.stats["t_descs_ms"]
         # D2H per batch result (small) as soon as that batch is done, host CTC decode (rapidocr CTCLabelDecode)
         # overlaps the GPU work of the batches still in flight
         t_dec = 0.0
         if self.keep_rec_inputs:
-            self.last_rec_batches = [(np.asarray(chunk), x, idx, prob) for (chunk, _w), (idx, prob, _d, x) in zip(batches, outs)]
-        for (chunk, wpad), (idx, prob, done, _x) in zip(batches, outs):
+            self.last_rec_batches = [(np.asarray(chunk), x, idx, prob) for (chunk, _w), (idx, prob, _d, x, _r) in zip(batches, outs)]
+        for (chunk, wpad), (idx, prob, done, _x, rows) in zip(batches, outs):
             done.synchronize()
-            idx_h, prob_h = idx.cpu().numpy(), prob.cpu().numpy()
-            t1 = time.perf_counter()
-            dec = ocr_host.ctc_decode(idx_h, prob_h, self.characters)
+            if rows is not None:
+                t1 = time.perf_counter()
+                dec = ocr_host.parse_ctc_rows(rows.numpy())
+            else:
+                idx_h, prob_h = idx.cpu().numpy(), prob.cpu().numpy()
+                t1 = time.perf_counter()
+                dec = ocr_host.ctc_decode(idx_h, prob_h, self.characters)
             for j, i in enumerate(chunk):
                 t, s = dec[j]
                 texts[i] = (t, ocr_host.format_score(s))

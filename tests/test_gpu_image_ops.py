@@ -124,3 +124,30 @@ def test_layout_model_plumbing_config1():
     m3 = LayoutModel(SyntheticBoxSession(labels_v2, 50, 7), "pp_doclayoutv3")
     o3 = m3.batch_predict([pages_np[1]], 1)[0]
     assert m3.session.calls[0][0] == (1, 3, 800, 800) and [d["original_order"] for d in o3] == list(range(len(o3)))
+
+
+@pytest.mark.parametrize("B,T", [(1, 2), (7, 40), (64, 136), (3, 400), (2, 700)])
+def test_device_ctc_collapse_equals_host_decode(B, T):
+    """rd_ctc_collapse (collapse repeats, drop blank, dictionary bytes, float32 np.mean of the kept probabilities) must give
+    exactly what the host decode of the same (idx, prob) gives - strings AND confidences, bit for bit."""
+    from rapiddoc_amd import _lib, ocr_host
+    lib = _lib.load()
+    rng = np.random.default_rng(B * 1000 + T)
+    chars = ["blank"] + [chr(0x4E00 + i) for i in range(300)] + ["a", "é", "\U0001f600", " "]
+    idx = rng.integers(0, len(chars), (B, T)).astype(np.int32)
+    idx[rng.random((B, T)) < 0.45] = 0                            # blanks
+    rep = rng.random((B, T)) < 0.3
+    idx[:, 1:][rep[:, 1:]] = idx[:, :-1][rep[:, 1:]]              # repeats
+    if B > 1:
+        idx[1] = 0                                               # an empty line
+    prob = rng.uniform(0.05, 1.0, (B, T)).astype(np.float32)
+    tab, max_len = ocr_host.char_table(chars)
+    row_bytes = (16 + T * max_len + 15) // 16 * 16
+    out = torch.zeros((B, row_bytes), dtype=torch.uint8, device="cuda")
+    ti, tp, tt = torch.from_numpy(idx).cuda(), torch.from_numpy(prob).cuda(), torch.from_numpy(tab).cuda()
+    assert lib.rd_ctc_collapse(0, ti.data_ptr(), tp.data_ptr(), B, T, tt.data_ptr(), max_len, len(chars), out.data_ptr(), row_bytes,
+                               torch.cuda.current_stream().cuda_stream) == 0
+    got = ocr_host.parse_ctc_rows(out.cpu().numpy())
+    ref = ocr_host.ctc_decode(idx, prob, chars)
+    assert [g[0] for g in got] == [r[0] for r in ref]
+    assert [np.float32(g[1]).tobytes() for g in got] == [np.float32(r[1]).tobytes() for r in ref]

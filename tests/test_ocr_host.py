@@ -102,3 +102,49 @@ def test_det_buckets_follow_reference_grouping():
     pad = H.pad_to_bucket(img, (64, 64))
     assert pad.shape == (64, 64, 3) and (pad[:2, :3] == img).all() and pad[2:].min() == 255 and pad[:, 3:].min() == 255
 
+
+
+def test_numpy_float32_mean_scheme_is_the_one_the_ctc_kernel_implements():
+    """rd_ctc_collapse reproduces np.mean of a float32 vector bit for bit by restating numpy's pairwise summation
+    (kernels_image.hip: np_pairwise_sum_f32).  This is the same scheme in Python, pinned against np.mean itself."""
+    def pairwise(a):
+        n = len(a)
+        if n < 8:
+            r = np.float32(0)
+            for v in a:
+                r = np.float32(r + v)
+            return r
+        if n <= 128:
+            r = [np.float32(v) for v in a[:8]]
+            i = 8
+            while i < n - (n % 8):
+                for j in range(8):
+                    r[j] = np.float32(r[j] + a[i + j])
+                i += 8
+            res = np.float32(np.float32(np.float32(r[0] + r[1]) + np.float32(r[2] + r[3])) + np.float32(np.float32(r[4] + r[5]) + np.float32(r[6] + r[7])))
+            while i < n:
+                res = np.float32(res + a[i])
+                i += 1
+            return res
+        n2 = n // 2
+        n2 -= n2 % 8
+        return np.float32(pairwise(a[:n2]) + pairwise(a[n2:]))
+    rng = np.random.default_rng(0)
+    for n in list(range(1, 40)) + [63, 64, 65, 100, 127, 128, 129, 136, 200, 255, 256, 257, 400]:
+        for _ in range(6):
+            a = rng.uniform(0.05, 1.0, n).astype(np.float32)
+            mine = np.float32(np.float32(np.float32(0) + pairwise(a)) / np.float32(n))
+            assert mine.tobytes() == np.mean(a).astype(np.float32).tobytes(), (n, mine, np.mean(a))
+
+
+def test_char_table_and_row_parser_roundtrip():
+    from rapiddoc_amd import ocr_host
+    chars = ["blank", "a", "\u6587", "\u00e9", " ", "\U0001f600"]
+    tab, max_len = ocr_host.char_table(chars)
+    assert tab.shape == (6, 1 + max_len) and max_len == 5 and tab[2, 0] == 3 and bytes(tab[5, 1:5]) == "\U0001f600".encode()
+    rows = np.zeros((2, 48), np.uint8)
+    t = "a\u6587 ".encode()
+    rows[0, :4] = np.frombuffer(np.int32(len(t)).tobytes(), np.uint8)
+    rows[0, 4:8] = np.frombuffer(np.float32(0.875).tobytes(), np.uint8)
+    rows[0, 16:16 + len(t)] = np.frombuffer(t, np.uint8)
+    assert ocr_host.parse_ctc_rows(rows) == [("a\u6587 ", 0.875), ("", 0.0)]
