@@ -228,3 +228,77 @@ class RegionTextModel:
             for k, i in enumerate(ids):
                 texts[i] = "\n".join(t for t, s in lines[k] if s >= MIN_CONFIDENCE and t)
         return texts
+
+
+class PageAnalyzer:
+    """Stage sequencing of `BatchAnalyze.__call__` (rapid_doc/backend/pipeline/batch_analyze.py:78-164) for one page batch
+    resident on the GPU:
+
+        1. layout        `layout_model.batch_predict(pages, batch_size)`  (:165-189: + `filter_overlap_boxes`, inline formulas
+                         dropped when formulas are disabled or formula_level == 1)
+        2. collection    OCR / table / formula regions per page (`split_regions` = get_res_list_from_layout_res)
+        3. formulas      `recognise_formulas` (:258-283) when a formula model is given
+        4. OCR           det + rec of every text region (`RegionOcr`), or the custom-OCR seam (`RegionTextModel`-shaped object:
+                         one string per region, :286-333) when `custom_ocr` is given
+        5. tables        `table_model.batch_predict(table crops)` (seam S1, :375-377) when a table model is given - the
+                         reference's own table networks are ONNX-only and not built
+        6. (rec post-process is part of RegionOcr here: spans get text / score / LowScoreText demotion, analyze_utils.py:216-292)
+
+    Every page is processed independently (`pages[p]` only feeds `out[p]`); the result is the reference's
+    `images_layout_res`: per page the filtered layout detections, formula `latex` fields filled in place, followed by the
+    OcrText spans.  Not built (reference sub-stages outside SURVEY 8): orientation classification, checkbox detection, seal
+    OCR, the 'txt' det mode (PDF text layer)."""
+
+    def __init__(self, layout_model, pipeline, formula_model=None, table_model=None, custom_ocr=None, layout_batch_size: int = 1,
+                 formula_level: int = 0, box_thresh: float = 0.3, unclip_ratio: float = 1.8):
+        self.layout_model, self.pipe = layout_model, pipeline
+        self.formula_model, self.table_model, self.custom_ocr = formula_model, table_model, custom_ocr
+        self.layout_batch_size, self.formula_level = layout_batch_size, formula_level
+        self.ocr = RegionOcr(pipeline, box_thresh, unclip_ratio)
+
+    def __call__(self, pages: torch.Tensor, det_maps_fn=None) -> List[List[dict]]:
+        assert pages.is_cuda and pages.dtype == torch.uint8 and pages.dim() == 4
+        P, H, W, _ = pages.shape
+        use_custom = self.custom_ocr is not None
+        # 1. layout (+ overlap filter, formula level)
+        dets = self.layout_model.batch_predict([pages[i] for i in range(P)], self.layout_batch_size)
+        dets = [layout_host.filter_overlap_boxes(d, use_custom) for d in dets]
+        if self.formula_model is None or self.formula_level == 1:
+            inline = layout_host.CATEGORY_ID["InlineEquation"]
+            dets = [[d for d in page if d["category_id"] != inline] for page in dets]
+        # 3. formulas (region collection happens inside the helpers, per page)
+        if self.formula_model is not None:
+            recognise_formulas(pages, dets, self.formula_model)
+        # 4. OCR
+        if use_custom:
+            out = [list(d) for d in dets]
+            for p in range(P):
+                regions, _t, _f = layout_host.split_regions(dets[p])
+                crops, owners = [], []
+                for r in regions:
+                    x0, y0, x1, y1 = (int(v) for v in (r["poly"][0], r["poly"][1], r["poly"][4], r["poly"][5]))
+                    x0, y0, x1, y1 = max(0, x0), max(0, y0), min(W, x1), min(H, y1)
+                    if x1 > x0 and y1 > y0:
+                        crops.append(np.ascontiguousarray(pages[p, y0:y1, x0:x1].cpu().numpy()[:, :, ::-1]))   # BGR (batch_analyze.py:300-304)
+                        owners.append(r)
+                for r, text in zip(owners, self.custom_ocr.batch_predict(crops) if crops else []):
+                    out[p].append({"category_id": OCR_TEXT, "original_label": r.get("original_label"),
+                                   "original_order": r.get("original_order", -1), "poly": list(r["poly"]), "score": 1,
+                                   "text": text, "vl_ocr": True})
+        else:
+            out = self.ocr(pages, dets, det_maps_fn=det_maps_fn)
+        # 5. tables through the CustomBaseModel seam
+        if self.table_model is not None:
+            for p in range(P):
+                _o, tables, _f = layout_host.split_regions(dets[p])
+                crops, owners = [], []
+                for t in tables:
+                    x0, y0, x1, y1 = (int(v) for v in (t["poly"][0], t["poly"][1], t["poly"][4], t["poly"][5]))
+                    x0, y0, x1, y1 = max(0, x0), max(0, y0), min(W, x1), min(H, y1)
+                    if x1 > x0 and y1 > y0:
+                        crops.append(pages[p, y0:y1, x0:x1].cpu().numpy())
+                        owners.append(t)
+                for t, html in zip(owners, self.table_model.batch_predict(crops) if crops else []):
+                    if html:
+                        t["html"] = html
+        return out

@@ -151,3 +151,71 @@ def test_device_ctc_collapse_equals_host_decode(B, T):
     ref = ocr_host.ctc_decode(idx, prob, chars)
     assert [g[0] for g in got] == [r[0] for r in ref]
     assert [np.float32(g[1]).tobytes() for g in got] == [np.float32(r[1]).tobytes() for r in ref]
+
+
+def test_page_analyzer_runs_the_reference_stage_order(golden_dir):
+    """BatchAnalyze.__call__ sequencing (batch_analyze.py:78-164) on 2 synthetic pages: layout (synthetic-box session through
+    the real wrapper) -> overlap filter -> formulas -> OCR det/rec spans -> table seam; pages independent; schema kept."""
+    import json
+    from rapiddoc_amd import weights as W
+    from rapiddoc_amd.analyze import LOW_SCORE_TEXT, OCR_TEXT, PageAnalyzer
+    from rapiddoc_amd.layout_model import LayoutModel
+    from rapiddoc_amd.pages import synth_batch
+    from rapiddoc_amd.pipeline import PagePipeline
+    maps = json.loads((golden_dir / "layout_category_maps.json").read_text())
+    labels = list(maps["label_to_category"]["pp_doclayoutv2"])
+
+    class FixedSession:          # page-pixel boxes: two text regions, one table, one display formula (7-column V3 rows)
+        characters = labels
+        accepts_device_tensors = False
+        calls = 0
+
+        def __call__(self, x, sf):
+            FixedSession.calls += 1
+            rows = []
+            for b in range(x.shape[0]):
+                def row(label, score, x0, y0, x1, y1, order):
+                    return [labels.index(label), score, x0, y0, x1, y1, order]
+                rows += [row("text", 0.9, 80, 50, 1150, 500, 0), row("text", 0.8, 80, 520, 640, 980, 1),
+                         row("table", 0.9, 650, 1000, 1150, 1400, 2), row("display_formula" if "display_formula" in labels else "formula", 0.9, 100, 1450, 600, 1520, 3)]
+            return [np.asarray(rows, np.float32), np.full(x.shape[0], 4, np.int32)]
+
+    class Formula:
+        def batch_predict(self, imgs, batch_size=16):
+            return ["x^{%d}" % im.shape[1] for im in imgs]
+
+    class Table:
+        def batch_predict(self, imgs, **kw):
+            return ["<table><tr><td>%dx%d</td></tr></table>" % im.shape[:2] for im in imgs]
+
+    states = {k: W.synth_state_dict(W.load_manifest(golden_dir / f"manifest_{k}.json"), 0) for k in ("ppocrv6_det", "ppocrv6_rec")}
+    pipe = PagePipeline(states, rec_batch_num=32, n_rec_streams=2)
+    an = PageAnalyzer(LayoutModel(FixedSession(), "pp_doclayoutv3"), pipe, formula_model=Formula(), table_model=Table(), layout_batch_size=2)
+    pages_np, boxes = synth_batch(0, 2)
+
+    def maps_fn(regions, ghw, dhw):
+        (gh, gw), (dh, dw) = ghw, dhw
+        m = torch.zeros((len(regions), 1, dh, dw), dtype=torch.float32)
+        for k, (p, r, useful) in enumerate(regions):
+            px, py, x0, y0 = useful[:4]
+            for lb in np.asarray(boxes[p], dtype=np.float64).reshape(-1, 4):
+                if lb[0] >= r["poly"][0] and lb[2] <= r["poly"][4] and lb[1] >= r["poly"][1] and lb[3] <= r["poly"][5]:
+                    cx0, cy0, cx1, cy1 = lb[0] - x0 + px, lb[1] - y0 + py, lb[2] - x0 + px, lb[3] - y0 + py
+                    d = 0.32 * min(cx1 - cx0, cy1 - cy0)
+                    m[k, 0, int(round((cy0 + d) * dh / gh)):int(round((cy1 - d) * dh / gh)), int(round((cx0 + d) * dw / gw)):int(round((cx1 - d) * dw / gw))] = 0.95
+        return m.cuda()
+
+    out = an(torch.from_numpy(pages_np).cuda(), det_maps_fn=maps_fn)
+    assert FixedSession.calls == 1 and len(out) == 2
+    for p in range(2):
+        layout = [d for d in out[p] if d["category_id"] not in (OCR_TEXT, LOW_SCORE_TEXT)]
+        spans = [d for d in out[p] if d["category_id"] in (OCR_TEXT, LOW_SCORE_TEXT)]
+        assert [d["original_label"] for d in layout][:2] == ["text", "text"] and [d["original_order"] for d in layout] == list(range(len(layout)))
+        table = [d for d in layout if d["category_id"] == 5]
+        formula = [d for d in layout if d["category_id"] in (8, 14)]
+        assert len(table) == 1 and table[0]["html"] == "<table><tr><td>400x500</td></tr></table>"
+        assert len(formula) == 1 and formula[0]["latex"].startswith("x^{")
+        lines = np.asarray(boxes[p]).reshape(-1, 4)
+        inside = sum(1 for lb in lines if (lb[1] >= 50 and lb[3] <= 500 and lb[2] <= 1150) or (lb[1] >= 520 and lb[3] <= 980 and lb[2] <= 640))
+        assert len(spans) == inside and inside > 10
+        assert all(isinstance(s["text"], str) and s["score"] == float(f"{s['score']:.3f}") for s in spans)
