@@ -71,8 +71,40 @@ def preprocess(imgs: Sequence[np.ndarray]) -> List[Optional[np.ndarray]]:
     return out
 
 
+def make_token_decoder(tokenizer_json, fix_text="auto") -> Callable[[List[int]], str]:
+    """ids -> LaTeX string exactly as UniMERNetDecode.token2str produces it after its EOS cut
+    (pp_formulanet_plus/post_process.py:92-94 builds `tokenizers.Tokenizer.from_buffer(fast_tokenizer_file JSON)`, :277-296
+    `tokenizer.decode(ids, skip_special_tokens=True)`, :350-381 LaTeX fix-ups then `ftfy.fix_text`).
+
+    tokenizer_json: path to / str of / dict of the `fast_tokenizer_file` JSON the reference downloads with the model
+    (`PP-FormulaNet_plus-M_inference.yml` -> PostProcess.character_dict).  fix_text: a callable, None, or "auto" =
+    `ftfy.fix_text` when that package is importable (it is not part of this container; the reference imports it lazily)."""
+    import json
+    import os
+    from tokenizers import Tokenizer
+    from .latex_post import latex_postprocess
+    if isinstance(tokenizer_json, dict):
+        tok = Tokenizer.from_str(json.dumps(tokenizer_json))
+    elif isinstance(tokenizer_json, (str, os.PathLike)) and os.path.exists(str(tokenizer_json)):
+        tok = Tokenizer.from_file(str(tokenizer_json))
+    else:
+        tok = Tokenizer.from_str(str(tokenizer_json))
+    if fix_text == "auto":
+        try:
+            from ftfy import fix_text as _ft   # noqa: WPS433
+            fix_text = _ft
+        except ImportError:
+            fix_text = None
+
+    def decode(ids: List[int]) -> str:
+        text = latex_postprocess(tok.decode([int(i) for i in ids], skip_special_tokens=True))
+        return fix_text(text) if fix_text else text
+    return decode
+
+
 class FormulaRecognizer:
-    """`batch_predict(image_list, batch_size) -> list` like rapid_doc.model.custom.CustomBaseModel / RapidFormulaModel.
+    """`batch_predict(image_list, batch_size) -> list[str]` like rapid_doc.model.custom.CustomBaseModel / RapidFormulaModel
+    when a tokenizer is given (`tokenizer_json=`, see `make_token_decoder`).
 
     Returns one entry per input image: the decoded string when `token_decoder` (ids -> str, e.g. the reference's
     UniMERNetDecode.token2str with its downloaded tokenizer) is given, otherwise the list of generated token ids with the
@@ -83,7 +115,7 @@ class FormulaRecognizer:
     def __init__(self, weights, device: int = 0, max_new_tokens: Optional[int] = None,
                  token_decoder: Optional[Callable[[List[int]], str]] = None,
                  bpe_decode: Optional[Callable[[List[int]], str]] = None,
-                 fix_text: Optional[Callable[[str], str]] = None):
+                 fix_text: Optional[Callable[[str], str]] = None, tokenizer_json=None):
         import torch  # noqa: F401  (device memory + stream only)
         from . import weights as W
         from .engine import RdEngine
@@ -95,6 +127,8 @@ class FormulaRecognizer:
         self.encoder = RdEngine("pphgnetv2_b6_formula", device).load_weights({k: v for k, v in state.items() if k.startswith("backbone.")})
         self.decoder = RdEngine("ppformulanet_head", device).load_weights({k: v for k, v in state.items() if k.startswith("head.")})
         self.max_new_tokens = max_new_tokens or self.decoder.formula_max_new_tokens
+        if token_decoder is None and tokenizer_json is not None:
+            token_decoder = make_token_decoder(tokenizer_json, fix_text if fix_text is not None else "auto")
         if token_decoder is None and bpe_decode is not None:
             from .latex_post import latex_postprocess
 

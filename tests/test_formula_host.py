@@ -44,3 +44,34 @@ def test_normalisation_and_latex_format():
 def test_preprocess_batch_shapes():
     xs = F.preprocess([_img(100, 300, (30, 40, 70, 260)), _img(400, 100, (10, 10, 390, 90))])
     assert all(x.shape == (1, 1, 384, 384) for x in xs)
+
+
+def test_token_decoder_from_tokenizer_json(tmp_path):
+    """a16: ids -> str through `tokenizers` (the library the reference's UniMERNetDecode wraps) + the LaTeX fix-ups.  The
+    shipped tokenizer JSON is download-only, so a small BPE tokenizer of the same kind (byte-level, <s>/<pad>/</s>/<unk> =
+    0/1/2/3) is built here; the oracle for the decode stage is the library itself."""
+    import json
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers
+    from rapiddoc_amd.latex_post import latex_postprocess
+    vocab = {"<s>": 0, "<pad>": 1, "</s>": 2, "<unk>": 3}
+    for t in ["\\", "f", "r", "a", "c", "{", "}", "x", "y", "^", "2", "\u0120", "\\f", "\\fr", "\\fra", "\\frac", "\u0120{", "\u0120}",
+              "l", "e", "t", "i", "g", "h", "\\l", "\\le", "\\lef", "\\left", "(", ")", "\u0120(", "\u0120)"]:
+        vocab.setdefault(t, len(vocab))
+    merges = [("\\", "f"), ("\\f", "r"), ("\\fr", "a"), ("\\fra", "c"), ("\u0120", "{"), ("\u0120", "}"), ("\\", "l"), ("\\l", "e"),
+              ("\\le", "f"), ("\\lef", "t"), ("\u0120", "("), ("\u0120", ")")]
+    tok = Tokenizer(models.BPE(vocab=vocab, merges=merges, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False)
+    tok.decoder = decoders.ByteLevel()
+    tok.add_special_tokens(["<s>", "<pad>", "</s>", "<unk>"])
+    path = tmp_path / "tokenizer.json"
+    tok.save(str(path))
+    text = "\\frac {x} {y}^2"
+    ids = [0] + tok.encode(text).ids + [2]
+    for src in (str(path), json.loads(path.read_text()), path.read_text()):
+        dec = F.make_token_decoder(src, fix_text=None)
+        assert dec(ids) == latex_postprocess(tok.decode(ids, skip_special_tokens=True)) == latex_postprocess(text)
+    upper = F.make_token_decoder(str(path), fix_text=str.upper)      # the ftfy hook is applied last
+    assert upper(ids) == latex_postprocess(text).upper()
+    # an unbalanced \\left( is repaired by the LaTeX stage between tokenizer and fix_text (post_process.py:350-381)
+    ids2 = [0] + tok.encode("\\left (x").ids + [2]
+    assert F.make_token_decoder(str(path), None)(ids2) == latex_postprocess(tok.decode(ids2, skip_special_tokens=True))
