@@ -102,8 +102,9 @@ class RegionOcr:
         if maps_override is not None:
             assert tuple(maps_override.shape) == tuple(maps.shape)
             maps = maps_override
-        res = ocr_host.db_postprocess(maps.cpu().numpy(), [(H, W)] * b, thresh=0.3, box_thresh=self.box_thresh,
-                                      unclip_ratio=self.unclip_ratio)
+        # DB post-process with the maps staying in HBM (runs + scores on the device, labelling / rectangles on the host)
+        res = ocr_host.db_postprocess_device(maps.contiguous(), [(H, W)] * b, thresh=0.3, box_thresh=self.box_thresh,
+                                             unclip_ratio=self.unclip_ratio)
         out = []
         for boxes, _scores in res:
             if len(boxes) == 0:

@@ -130,6 +130,68 @@ static double box_score_fast(const float* pred, int H, int W, const P2 box[4]) {
 
 struct Params { float thresh, box_thresh, unclip_ratio; int use_dilation, max_candidates, min_size; };
 
+struct Cand { Rect r; P2 box[4]; };
+
+// border pixels (or any point set with the same convex hull) of one region -> min-area rectangle candidate
+static bool make_candidate(const std::vector<P2>& border, const Params& pr, Cand& c) {
+    if (!min_area_rect(border, c.r)) return false;
+    if (std::min(c.r.w, c.r.h) < pr.min_size) return false;
+    order_mini_box(c.r.c, c.box);
+    return true;
+}
+
+// score filter, unclip, second min-area rectangle, scale to the source image, filter_det_res.  Returns 1 if a box was written.
+static int finish_candidate(const Cand& c, double score, int H, int W, int src_h, int src_w, const Params& pr, rd_text_box* out) {
+    if (pr.box_thresh > score) return 0;
+    // unclip: Polygon(box).area * ratio / Polygon(box).length; pyclipper works on integer coordinates
+    const Rect& r = c.r;
+    const P2* box = c.box;
+    const double area = r.w * r.h, perim = 2.0 * (r.w + r.h);
+    if (perim <= 0) return 0;
+    const double dist = area * pr.unclip_ratio / perim;
+    std::vector<P2> ip(4);
+    for (int i = 0; i < 4; ++i) ip[i] = {(double)(long)box[i].x, (double)(long)box[i].y};
+    Rect ri;
+    if (!min_area_rect(ip, ri) || ri.w <= 0 || ri.h <= 0) return 0;
+    // grow the rectangle by `dist` on every side (== min-area rect of the round-join offset polygon)
+    P2 cen = {0, 0};
+    for (auto& c : ri.c) { cen.x += c.x * 0.25; cen.y += c.y * 0.25; }
+    double ux = ri.c[1].x - ri.c[0].x, uy = ri.c[1].y - ri.c[0].y;
+    double vx = ri.c[3].x - ri.c[0].x, vy = ri.c[3].y - ri.c[0].y;
+    const double ul = std::sqrt(ux * ux + uy * uy), vl = std::sqrt(vx * vx + vy * vy);
+    ux /= ul; uy /= ul; vx /= vl; vy /= vl;
+    const double hu = ul * 0.5 + dist, hv = vl * 0.5 + dist;
+    P2 ex[4] = {{cen.x - hu * ux - hv * vx, cen.y - hu * uy - hv * vy}, {cen.x + hu * ux - hv * vx, cen.y + hu * uy - hv * vy},
+                {cen.x + hu * ux + hv * vx, cen.y + hu * uy + hv * vy}, {cen.x - hu * ux + hv * vx, cen.y - hu * uy + hv * vy}};
+    if (std::min(2 * hu, 2 * hv) < pr.min_size + 2) return 0;
+    P2 eb[4];
+    order_mini_box(ex, eb);
+    // scale to the source image: np.clip(np.round(x / width * dest_width), 0, dest_width) -> int32
+    long bx[4], by[4];
+    for (int i = 0; i < 4; ++i) {
+        bx[i] = (long)std::min(std::max(std::nearbyint(eb[i].x / W * src_w), 0.0), (double)src_w);
+        by[i] = (long)std::min(std::max(std::nearbyint(eb[i].y / H * src_h), 0.0), (double)src_h);
+    }
+    // filter_det_res: order_points_clockwise, clip to the image, drop tiny boxes
+    int idx[4] = {0, 1, 2, 3};
+    std::stable_sort(idx, idx + 4, [&](int a, int b) { return bx[a] < bx[b]; });
+    int l0 = idx[0], l1 = idx[1], r0 = idx[2], r1 = idx[3];
+    if (by[l1] < by[l0]) std::swap(l0, l1);
+    if (by[r1] < by[r0]) std::swap(r0, r1);
+    const int ord[4] = {l0, r0, r1, l1};  // tl, tr, br, bl
+    float pts[8];
+    for (int i = 0; i < 4; ++i) {
+        pts[2 * i] = (float)std::min(std::max(bx[ord[i]], 0L), (long)src_w - 1);
+        pts[2 * i + 1] = (float)std::min(std::max(by[ord[i]], 0L), (long)src_h - 1);
+    }
+    const int rw = (int)std::sqrt((pts[0] - pts[2]) * (pts[0] - pts[2]) + (pts[1] - pts[3]) * (pts[1] - pts[3]));
+    const int rh = (int)std::sqrt((pts[0] - pts[6]) * (pts[0] - pts[6]) + (pts[1] - pts[7]) * (pts[1] - pts[7]));
+    if (rw <= 3 || rh <= 3) return 0;
+    std::memcpy(out->pts, pts, sizeof(pts));
+    out->score = (float)score;
+    return 1;
+}
+
 static int process_one(const float* pred, int H, int W, int src_h, int src_w, const Params& pr, rd_text_box* out, int max_out) {
     const size_t n = (size_t)H * W;
     std::vector<uint8_t> bin(n), bm(n);
@@ -181,63 +243,105 @@ static int process_one(const float* pred, int H, int W, int src_h, int src_w, co
                 if (edge) border.push_back({(double)qx, (double)qy});
             }
             if (++n_cand > pr.max_candidates) return n_out;
-            Rect r;
-            if (!min_area_rect(border, r)) continue;
-            if (std::min(r.w, r.h) < pr.min_size) continue;
-            P2 box[4];
-            order_mini_box(r.c, box);
-            const double score = box_score_fast(pred, H, W, box);
-            if (pr.box_thresh > score) continue;
-            // unclip: Polygon(box).area * ratio / Polygon(box).length; pyclipper works on integer coordinates
-            const double area = r.w * r.h, perim = 2.0 * (r.w + r.h);
-            if (perim <= 0) continue;
-            const double dist = area * pr.unclip_ratio / perim;
-            std::vector<P2> ip(4);
-            for (int i = 0; i < 4; ++i) ip[i] = {(double)(long)box[i].x, (double)(long)box[i].y};
-            Rect ri;
-            if (!min_area_rect(ip, ri) || ri.w <= 0 || ri.h <= 0) continue;
-            // grow the rectangle by `dist` on every side (== min-area rect of the round-join offset polygon)
-            P2 cen = {0, 0};
-            for (auto& c : ri.c) { cen.x += c.x * 0.25; cen.y += c.y * 0.25; }
-            double ux = ri.c[1].x - ri.c[0].x, uy = ri.c[1].y - ri.c[0].y;
-            double vx = ri.c[3].x - ri.c[0].x, vy = ri.c[3].y - ri.c[0].y;
-            const double ul = std::sqrt(ux * ux + uy * uy), vl = std::sqrt(vx * vx + vy * vy);
-            ux /= ul; uy /= ul; vx /= vl; vy /= vl;
-            const double hu = ul * 0.5 + dist, hv = vl * 0.5 + dist;
-            P2 ex[4] = {{cen.x - hu * ux - hv * vx, cen.y - hu * uy - hv * vy}, {cen.x + hu * ux - hv * vx, cen.y + hu * uy - hv * vy},
-                        {cen.x + hu * ux + hv * vx, cen.y + hu * uy + hv * vy}, {cen.x - hu * ux + hv * vx, cen.y - hu * uy + hv * vy}};
-            if (std::min(2 * hu, 2 * hv) < pr.min_size + 2) continue;
-            P2 eb[4];
-            order_mini_box(ex, eb);
-            // scale to the source image: np.clip(np.round(x / width * dest_width), 0, dest_width) -> int32
-            long bx[4], by[4];
-            for (int i = 0; i < 4; ++i) {
-                bx[i] = (long)std::min(std::max(std::nearbyint(eb[i].x / W * src_w), 0.0), (double)src_w);
-                by[i] = (long)std::min(std::max(std::nearbyint(eb[i].y / H * src_h), 0.0), (double)src_h);
-            }
-            // filter_det_res: order_points_clockwise, clip to the image, drop tiny boxes
-            int idx[4] = {0, 1, 2, 3};
-            std::stable_sort(idx, idx + 4, [&](int a, int b) { return bx[a] < bx[b]; });
-            int l0 = idx[0], l1 = idx[1], r0 = idx[2], r1 = idx[3];
-            if (by[l1] < by[l0]) std::swap(l0, l1);
-            if (by[r1] < by[r0]) std::swap(r0, r1);
-            const int ord[4] = {l0, r0, r1, l1};  // tl, tr, br, bl
-            float pts[8];
-            for (int i = 0; i < 4; ++i) {
-                pts[2 * i] = (float)std::min(std::max(bx[ord[i]], 0L), (long)src_w - 1);
-                pts[2 * i + 1] = (float)std::min(std::max(by[ord[i]], 0L), (long)src_h - 1);
-            }
-            const int rw = (int)std::sqrt((pts[0] - pts[2]) * (pts[0] - pts[2]) + (pts[1] - pts[3]) * (pts[1] - pts[3]));
-            const int rh = (int)std::sqrt((pts[0] - pts[6]) * (pts[0] - pts[6]) + (pts[1] - pts[7]) * (pts[1] - pts[7]));
-            if (rw <= 3 || rh <= 3) continue;
-            std::memcpy(out[n_out].pts, pts, sizeof(pts));
-            out[n_out].score = (float)score;
-            ++n_out;
+            Cand c;
+            if (!make_candidate(border, pr, c)) continue;
+            const double score = box_score_fast(pred, H, W, c.box);
+            n_out += finish_candidate(c, score, H, W, src_h, src_w, pr, out + n_out);
         }
     return n_out;
 }
 
 }  // namespace
+
+// ---- device-assisted path: the GPU thresholds / dilates the maps and emits the horizontal RUNS of the bitmap
+// (rd_db_runs), scores the candidate rectangles (rd_db_scores); the host only sees a few thousand runs per page.
+struct Run { int16_t y, x0, x1, pad; };
+
+// runs of one page -> 8-connected regions in raster order of their first pixel -> candidates (same rectangles as the
+// flood fill above: a region's convex hull is the hull of its run end points)
+static int candidates_from_runs(std::vector<Run>& runs, int max_cand, const Params& pr, rd_db_candidate* out) {
+    std::sort(runs.begin(), runs.end(), [](const Run& a, const Run& b) { return a.y < b.y || (a.y == b.y && a.x0 < b.x0); });
+    const int n = (int)runs.size();
+    std::vector<int> parent(n);
+    for (int i = 0; i < n; ++i) parent[i] = i;
+    auto find = [&](int i) { while (parent[i] != i) { parent[i] = parent[parent[i]]; i = parent[i]; } return i; };
+    int prev_b = 0, prev_e = 0;   // [prev_b, prev_e): runs of the previous row
+    for (int i = 0; i < n;) {
+        int j = i;
+        while (j < n && runs[j].y == runs[i].y) ++j;
+        if (prev_e > prev_b && runs[prev_b].y == runs[i].y - 1) {
+            int q = prev_b;
+            for (int k = i; k < j; ++k) {
+                while (q < prev_e && runs[q].x1 + 1 < runs[k].x0) ++q;           // runs entirely to the left
+                for (int t = q; t < prev_e && runs[t].x0 <= runs[k].x1 + 1; ++t) {  // 8-connected: columns may differ by one
+                    const int a = find(t), b = find(k);
+                    if (a != b) parent[std::max(a, b)] = std::min(a, b);           // root = earliest run = first pixel in raster order
+                }
+            }
+        }
+        prev_b = i;
+        prev_e = j;
+        i = j;
+    }
+    // regions in order of their root run (runs are sorted in raster order, the root is the smallest index)
+    std::vector<std::vector<P2>> pts;
+    std::vector<int> slot(n, -1);
+    for (int i = 0; i < n; ++i) {
+        const int r = find(i);
+        if (slot[r] < 0) { slot[r] = (int)pts.size(); pts.emplace_back(); }
+        pts[slot[r]].push_back({(double)runs[i].x0, (double)runs[i].y});
+        if (runs[i].x1 != runs[i].x0) pts[slot[r]].push_back({(double)runs[i].x1, (double)runs[i].y});
+    }
+    int n_out = 0, n_cand = 0;
+    for (auto& border : pts) {
+        if (++n_cand > pr.max_candidates || n_out >= max_cand) break;
+        Cand c;
+        if (!make_candidate(border, pr, c)) continue;
+        for (int k = 0; k < 4; ++k) {
+            out[n_out].box[2 * k] = c.box[k].x; out[n_out].box[2 * k + 1] = c.box[k].y;
+            out[n_out].rect[2 * k] = c.r.c[k].x; out[n_out].rect[2 * k + 1] = c.r.c[k].y;
+        }
+        out[n_out].w = c.r.w;
+        out[n_out].h = c.r.h;
+        ++n_out;
+    }
+    return n_out;
+}
+
+extern "C" int rd_db_candidates(const void* runs_host, const int32_t* n_runs, int B, int max_runs, int max_candidates,
+                                rd_db_candidate* out, int max_out, int32_t* n_out) {
+    if (!runs_host || !n_runs || !out || !n_out || B < 0 || max_runs <= 0 || max_out <= 0) return 1;
+    Params pr{0.f, 0.f, 0.f, 0, max_candidates > 0 ? max_candidates : 1000, 3};
+    for (int b = 0; b < B; ++b) {
+        if (n_runs[b] < 0 || n_runs[b] > max_runs) return 2;      // the device buffer overflowed: caller falls back to the host path
+        const Run* r = reinterpret_cast<const Run*>(runs_host) + (size_t)b * max_runs;
+        std::vector<Run> runs(r, r + n_runs[b]);
+        n_out[b] = candidates_from_runs(runs, max_out, pr, out + (size_t)b * max_out);
+    }
+    return 0;
+}
+
+extern "C" int rd_db_finish(const rd_db_candidate* cand, const double* scores, const int32_t* n_cand, int B, int max_cand, int H, int W,
+                            const int32_t* src_hw, float box_thresh, float unclip_ratio, rd_text_box* out, int max_out, int32_t* n_out) {
+    if (!cand || !scores || !n_cand || !src_hw || !out || !n_out || B < 0) return 1;
+    Params pr{0.f, box_thresh, unclip_ratio, 0, 0, 3};
+    for (int b = 0; b < B; ++b) {
+        int n = 0;
+        for (int i = 0; i < n_cand[b] && n < max_out; ++i) {
+            const rd_db_candidate& q = cand[(size_t)b * max_cand + i];
+            Cand c;
+            for (int k = 0; k < 4; ++k) {
+                c.box[k] = {q.box[2 * k], q.box[2 * k + 1]};
+                c.r.c[k] = {q.rect[2 * k], q.rect[2 * k + 1]};
+            }
+            c.r.w = q.w;
+            c.r.h = q.h;
+            n += finish_candidate(c, scores[(size_t)b * max_cand + i], H, W, src_hw[2 * b], src_hw[2 * b + 1], pr, out + (size_t)b * max_out + n);
+        }
+        n_out[b] = n;
+    }
+    return 0;
+}
 
 extern "C" int rd_db_postprocess(const float* prob_host, int B, int H, int W, const int32_t* src_hw, float thresh, float box_thresh,
                                  float unclip_ratio, int use_dilation, int max_candidates, rd_text_box* out, int max_out,

@@ -355,3 +355,96 @@ int launch_ctc_collapse(const int32_t* idx, const float* prob, int B, int T, con
     return 0;
 }
 }  // namespace rd
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Device half of the DB post-process (ocr_patch.py:223-241): bitmap runs and box scores, see include/rapiddoc_mi355.h.
+// ---------------------------------------------------------------------------------------------------------------------
+struct DbRun { int16_t y, x0, x1, pad; };
+
+__global__ void __launch_bounds__(256) db_runs_kernel(const float* __restrict__ prob, int H, int W, float thresh, int dilate, DbRun* runs,
+                                                      int32_t* n_runs, int max_runs) {
+    extern __shared__ unsigned char rowm[];     // dilated bitmap of this row
+    const int y = blockIdx.x, b = blockIdx.y;
+    const float* p1 = prob + ((size_t)b * H + y) * W;
+    const float* p0 = p1 - W;
+    for (int x = threadIdx.x; x < W; x += 256) {
+        bool v = p1[x] > thresh;
+        if (dilate) {      // cv2.dilate 2x2, anchor (1,1): max over (y-1..y, x-1..x)
+            if (x > 0) v = v || p1[x - 1] > thresh;
+            if (y > 0) {
+                v = v || p0[x] > thresh;
+                if (x > 0) v = v || p0[x - 1] > thresh;
+            }
+        }
+        rowm[x] = v;
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < W; x += 256) {
+        if (rowm[x] && (x == 0 || !rowm[x - 1])) {
+            int x1 = x;
+            while (x1 + 1 < W && rowm[x1 + 1]) ++x1;
+            const int slot = atomicAdd(&n_runs[b], 1);
+            if (slot < max_runs) runs[(size_t)b * max_runs + slot] = DbRun{(int16_t)y, (int16_t)x, (int16_t)x1, 0};
+        }
+    }
+}
+
+struct DbCand { double box[8], rect[8], w, h; };
+
+__global__ void __launch_bounds__(256) db_scores_kernel(const float* __restrict__ prob, int H, int W, const DbCand* cand, const int32_t* n_cand,
+                                                        int max_cand, double* scores) {
+    const int i = blockIdx.x, b = blockIdx.y;
+    if (i >= n_cand[b]) return;
+    const DbCand& c = cand[(size_t)b * max_cand + i];
+    const float* pred = prob + (size_t)b * H * W;
+    double xmn = 1e300, xmx = -1e300, ymn = 1e300, ymx = -1e300;
+    for (int k = 0; k < 4; ++k) {
+        xmn = fmin(xmn, c.box[2 * k]); xmx = fmax(xmx, c.box[2 * k]);
+        ymn = fmin(ymn, c.box[2 * k + 1]); ymx = fmax(ymx, c.box[2 * k + 1]);
+    }
+    const int x0 = min(max((int)floor(xmn), 0), W - 1), x1 = min(max((int)ceil(xmx), 0), W - 1);
+    const int y0 = min(max((int)floor(ymn), 0), H - 1), y1 = min(max((int)ceil(ymx), 0), H - 1);
+    long qx[4], qy[4];
+    for (int k = 0; k < 4; ++k) { qx[k] = (long)(c.box[2 * k] - x0); qy[k] = (long)(c.box[2 * k + 1] - y0); }
+    long area2 = 0;
+    for (int k = 0; k < 4; ++k) area2 += qx[k] * qy[(k + 1) & 3] - qx[(k + 1) & 3] * qy[k];
+    const int sgn = area2 >= 0 ? 1 : -1;
+    const int bw = x1 - x0 + 1;
+    const long total = (long)bw * (y1 - y0 + 1);
+    double sum = 0.0;
+    long cnt = 0;
+    for (long t = threadIdx.x; t < total; t += 256) {
+        const long px = t % bw, py = t / bw;
+        bool in = true;
+        for (int k = 0; k < 4 && in; ++k) {
+            const long cr = (qx[(k + 1) & 3] - qx[k]) * (py - qy[k]) - (qy[(k + 1) & 3] - qy[k]) * (px - qx[k]);
+            in = (cr * sgn) >= 0;
+        }
+        if (in) { sum += (double)pred[(size_t)(y0 + py) * W + x0 + px]; ++cnt; }
+    }
+    __shared__ double ssum[256];
+    __shared__ long scnt[256];
+    ssum[threadIdx.x] = sum;
+    scnt[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { ssum[threadIdx.x] += ssum[threadIdx.x + off]; scnt[threadIdx.x] += scnt[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scores[(size_t)b * max_cand + i] = scnt[0] ? ssum[0] / (double)scnt[0] : 0.0;
+}
+
+namespace rd {
+int launch_db_runs(const float* prob, int B, int H, int W, float thresh, int dilate, void* runs, int32_t* n_runs, int max_runs, hipStream_t s) {
+    if (B <= 0) return 0;
+    if (W > 32767 || H > 32767 || W > 60000) return 1;
+    (void)hipMemsetAsync(n_runs, 0, (size_t)B * sizeof(int32_t), s);
+    hipLaunchKernelGGL(db_runs_kernel, dim3(H, B), dim3(256), (size_t)W, s, prob, H, W, thresh, dilate, reinterpret_cast<DbRun*>(runs), n_runs, max_runs);
+    return 0;
+}
+int launch_db_scores(const float* prob, int B, int H, int W, const void* cand, const int32_t* n_cand, int max_cand, double* scores, hipStream_t s) {
+    if (B <= 0 || max_cand <= 0) return 0;
+    hipLaunchKernelGGL(db_scores_kernel, dim3(max_cand, B), dim3(256), 0, s, prob, H, W, reinterpret_cast<const DbCand*>(cand), n_cand, max_cand, scores);
+    return 0;
+}
+}  // namespace rd

@@ -186,6 +186,9 @@ int launch_line_crops(const LineCropParams& p, hipStream_t s);
 // CTC greedy decode on the device: idx / prob [B][T] -> per line (row stride row_bytes): int32 n_text_bytes, float32
 // confidence (numpy float32 mean of the kept probabilities), int32 n_kept, int32 0, UTF-8 text.  ctab: [n_classes][1 + max_len]
 // bytes (length, then the entry's UTF-8 bytes).
+// device half of the DB post-process (bitmap runs, candidate scores): include/rapiddoc_mi355.h rd_db_runs / rd_db_scores
+int launch_db_runs(const float* prob, int B, int H, int W, float thresh, int dilate, void* runs, int32_t* n_runs, int max_runs, hipStream_t s);
+int launch_db_scores(const float* prob, int B, int H, int W, const void* cand, const int32_t* n_cand, int max_cand, double* scores, hipStream_t s);
 int launch_ctc_collapse(const int32_t* idx, const float* prob, int B, int T, const uint8_t* ctab, int max_len, int n_classes,
                         uint8_t* out, int row_bytes, hipStream_t s);
 

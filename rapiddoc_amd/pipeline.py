@@ -117,6 +117,7 @@ class PagePipeline:
         tab, self._ctc_max_len = ocr_host.char_table(self.characters)
         self._ctc_table = torch.from_numpy(tab).to(self.tdev)
         self.device_ctc = True
+        self.device_db = True            # DB post-process with the maps staying in HBM (ocr_host.db_postprocess_device)
         self.keep_rec_inputs = False      # tests: keep every rec batch's input tensor and raw (idx, prob) in last_rec_batches
         self.last_rec_batches: List[Tuple[np.ndarray, torch.Tensor, torch.Tensor, torch.Tensor]] = []
         self._lib = _lib.load()
@@ -275,6 +276,34 @@ class PagePipeline:
             out.append(np.asarray(b, dtype=np.float32).reshape(-1, 4, 2))
         return out
 
+    def boxes_from_maps_device(self, maps_dev: torch.Tensor, page_hw: Tuple[int, int], box_thresh: float = 0.3,
+                               unclip_ratio: float = 1.8) -> List[np.ndarray]:
+        """`boxes_from_maps` with the maps staying in HBM (ocr_host.db_postprocess_device)."""
+        P = maps_dev.shape[0]
+        res = ocr_host.db_postprocess_device(maps_dev, [page_hw] * P, thresh=0.3, box_thresh=box_thresh, unclip_ratio=unclip_ratio,
+                                             stats=self.stats)
+        out = []
+        for boxes, _scores in res:
+            if len(boxes) == 0:
+                out.append(np.zeros((0, 4, 2), np.float32))
+                continue
+            b = ocr_host.merge_det_boxes(ocr_host.sorted_boxes(boxes.astype(np.float32)))
+            out.append(np.asarray(b, dtype=np.float32).reshape(-1, 4, 2))
+        return out
+
+    def _boxes_via_host_maps(self, src: torch.Tensor, page_hw: Tuple[int, int]) -> List[np.ndarray]:
+        """Round-1 path: the float maps cross PCIe (pinned buffer) and the whole post-process runs on the host."""
+        if getattr(self, "_maps_host", None) is None or self._maps_host.shape != src.shape:
+            self._maps_host = torch.empty(src.shape, dtype=torch.float32, pin_memory=True)
+        t0 = time.perf_counter()
+        self._maps_host.copy_(src, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        t1 = time.perf_counter()
+        quads = self.boxes_from_maps(self._maps_host.numpy(), page_hw)
+        self.stats["t_wait_maps_ms"] = (t1 - t0) * 1e3
+        self.stats["t_db_post_ms"] = (time.perf_counter() - t1) * 1e3
+        return quads
+
     # ---------------------------------------------------------------- whole batch
     def run_batch(self, pages: torch.Tensor, quads_per_page: Optional[Sequence[np.ndarray]] = None,
                   det_maps_override: Optional[torch.Tensor] = None) -> List[PageResult]:
@@ -300,21 +329,11 @@ class PagePipeline:
         results = [PageResult() for _ in range(P)]
         prob_maps, det_hw = self.det_forward(pages)
         self.last_det = (prob_maps, det_hw)
-        copy_done = None
+        src = None
         if quads_per_page is None:
             src = det_maps_override if det_maps_override is not None else prob_maps
-            if getattr(self, "_maps_host", None) is None or self._maps_host.shape != src.shape:
-                self._maps_host = torch.empty(src.shape, dtype=torch.float32, pin_memory=True)
-                self._copy_stream = torch.cuda.Stream(device=pages.device)
-            ready = torch.cuda.Event()
-            ready.record()
-            with torch.cuda.stream(self._copy_stream):
-                self._copy_stream.wait_event(ready)
-                self._maps_host.copy_(src, non_blocking=True)
-                copy_done = torch.cuda.Event()
-                copy_done.record()
-        # the layout backbone keeps the GPU busy while the host turns the det maps into boxes
-        # ... on its own stream, so it also overlaps the recognition batches that follow
+        # the layout backbone keeps the GPU busy (on its own stream, so it also overlaps the recognition batches that follow)
+        # while the host turns the det maps into boxes
         if self.layout is not None:
             self.layout_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.layout_stream):
@@ -323,12 +342,7 @@ class PagePipeline:
                 for i in range(P):
                     results[i].layout_feats = [f[i] for f in feats]
         if quads_per_page is None:
-            t0 = time.perf_counter()
-            copy_done.synchronize()
-            t1 = time.perf_counter()
-            quads_per_page = self.boxes_from_maps(self._maps_host.numpy(), (H, W))
-            self.stats["t_wait_maps_ms"] = (t1 - t0) * 1e3
-            self.stats["t_db_post_ms"] = (time.perf_counter() - t1) * 1e3
+            quads_per_page = self.boxes_from_maps_device(src.contiguous(), (H, W)) if self.device_db else self._boxes_via_host_maps(src, (H, W))
         texts = self.rec_forward_lines(pages, quads_per_page)
         if self.layout is not None:
             torch.cuda.current_stream().wait_stream(self.layout_stream)

@@ -219,3 +219,46 @@ def test_page_analyzer_runs_the_reference_stage_order(golden_dir):
         inside = sum(1 for lb in lines if (lb[1] >= 50 and lb[3] <= 500 and lb[2] <= 1150) or (lb[1] >= 520 and lb[3] <= 980 and lb[2] <= 640))
         assert len(spans) == inside and inside > 10
         assert all(isinstance(s["text"], str) and s["score"] == float(f"{s['score']:.3f}") for s in spans)
+
+
+@pytest.mark.parametrize("kind", ["lines", "blobs", "empty", "full"])
+def test_device_db_postprocess_equals_host_path(kind):
+    """rd_db_runs + rd_db_candidates + rd_db_scores + rd_db_finish == rd_db_postprocess (flood fill on the host), box for box:
+    text-line maps, irregular blobs (touching the borders, diagonal 8-connections, holes), an empty and a full map."""
+    from rapiddoc_amd import ocr_host
+    rng = np.random.default_rng(5)
+    B, H, W = 3, 320, 448
+    m = np.full((B, H, W), 0.02, np.float32)
+    if kind == "lines":
+        for b in range(B):
+            y = 10
+            while y + 30 < H:
+                w = int(rng.integers(60, W - 20))
+                m[b, y + 6: y + 20, 10: 10 + w] = rng.uniform(0.5, 0.99, (14, w))
+                y += int(rng.integers(30, 44))
+    elif kind == "blobs":
+        f = rng.standard_normal((B, H // 8 + 2, W // 8 + 2)).astype(np.float32)
+        f = np.kron(f, np.ones((8, 8), np.float32))[:, :H, :W]
+        f = (f + np.roll(f, 3, 1) + np.roll(f, 5, 2)) / 3
+        m = (1 / (1 + np.exp(-3 * f))).astype(np.float32)
+        for k in range(40):                                   # diagonal staircases: 8- but not 4-connected pixels
+            m[0, 100 + k, 200 + k] = 0.9
+        m[1, 50:90, 300:380] = 0.9
+        m[1, 60:80, 320:360] = 0.01                            # a hole
+    elif kind == "full":
+        m[:] = 0.8
+    hw = [(640, 896)] * B
+    host = ocr_host.db_postprocess(m, hw, thresh=0.3, box_thresh=0.3, unclip_ratio=1.8)
+    dev = ocr_host.db_postprocess_device(torch.from_numpy(m).cuda(), hw, thresh=0.3, box_thresh=0.3, unclip_ratio=1.8)
+    assert len(host) == len(dev) == B
+    for (hb, hs), (db, ds) in zip(host, dev):
+        assert hb.shape == db.shape and np.array_equal(hb, db)
+        assert np.allclose(hs, ds, rtol=0, atol=1e-6)
+    if kind == "lines":
+        assert all(len(b) >= 5 for b, _ in dev)
+    if kind == "empty":
+        assert all(len(b) == 0 for b, _ in dev)
+    # overflow of the run buffer falls back to the host path with identical results
+    small = ocr_host.db_postprocess_device(torch.from_numpy(m).cuda(), hw, thresh=0.3, box_thresh=0.3, unclip_ratio=1.8, max_runs=4)
+    for (hb, _), (sb, _) in zip(host, small):
+        assert np.array_equal(hb, sb)
