@@ -22,6 +22,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/p_${c}_$TAG -o a -- $B > /tmp/p.log 2>&1
   python $R/tools/pmc_summary.py $(find /tmp/p_${c}_$TAG -name "*counter_collection.csv" | head -1) $O/${TAG}_pmc_$c.csv > /dev/null
 done
-python $R/tools/pmc_traffic.py $O/${TAG}_pmc_FETCH_SIZE.csv $O/${TAG}_pmc_WRITE_SIZE.csv $O/${TAG}_pmc_traffic.json > /dev/null
+python $R/tools/pmc_traffic.py $O/${TAG}_pmc_FETCH_SIZE.csv $O/${TAG}_pmc_WRITE_SIZE.csv $O/${TAG}_pmc_traffic.json "collection ${TAG}, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bench.py --steps 1 --rec-streams 1" > /dev/null
+timeout 200 python $R/bench.py --only backbone 2>/dev/null | tail -1 > $O/${TAG}_bench_backbone.json
 cat $O/${TAG}_bench.json | cut -c1-900
 head -8 $O/${TAG}_rocprofv3_kernel_stats.csv | cut -c1-140

@@ -29,6 +29,9 @@ def canon(name):
     m = re.match(r"lc_mixer_h3_kernel<(\d+),0>", name)
     if m:
         return "lc_mixer_h3_kernel<%s>" % m.group(1)
+    m = re.match(r"lc_mixer_ws_kernel<(\d+),", name)
+    if m:
+        return "lc_mixer_ws_kernel<%s>" % m.group(1)
     m = re.match(r"lc_mixer_kernel<(\d+),0>", name)
     if m:
         return "lc_mixer_kernel<%s>" % m.group(1)
@@ -36,14 +39,18 @@ def canon(name):
 
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-res = {}
+acc = {}
 for k in fetch:
     if k not in write:
         continue
     f, n = fetch[k]
     w, _ = write[k]
-    res[canon(k)] = {"dispatches": n, "fetch_KiB_raw": f, "write_KiB_raw": w,
-                     "hbm_bytes_per_launch": round((2.0 * f + w) * 1024.0 / n),
-                     "note": "FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE as counted"}
+    a = acc.setdefault(canon(k), [0, 0.0, 0.0])     # template variants of one kernel (gated / ungated) are pooled
+    a[0] += n; a[1] += f; a[2] += w
+res = {"_collected": sys.argv[4] if len(sys.argv) > 4 else "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes"}
+for k, (n, f, w) in acc.items():
+    res[k] = {"dispatches": n, "fetch_KiB_raw": f, "write_KiB_raw": w,
+              "hbm_bytes_per_launch": round((2.0 * f + w) * 1024.0 / n),
+              "note": "FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE as counted"}
 json.dump(res, open(sys.argv[3], "w"), indent=1)
-print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in list(res.items())[:8]}, indent=1))
+print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in list(res.items())[1:9]}, indent=1))
