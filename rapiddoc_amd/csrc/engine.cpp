@@ -622,7 +622,7 @@ TView Builder::dwconv(const std::string& wname, const std::string& bname, const 
     if (gap) {
         DwParams gp{};
         gp.N = x.n; gp.H = x.h; gp.W = x.w; gp.C = c; gp.OH = oh; gp.OW = ow;
-        gp.KH = kh; gp.KW = kw; gp.SH = g.sh; gp.SW = g.sw;
+        gp.KH = kh; gp.KW = kw; gp.SH = g.sh; gp.SW = g.sw; gp.PT = g.pt; gp.PL = g.pl;
         gap->chunks = dwconv_gap_chunks(gp);
         if (gap->chunks > 0) gap->partial = alloc_raw((size_t)x.n * gap->chunks * c);
     }

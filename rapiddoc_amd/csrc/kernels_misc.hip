@@ -2,6 +2,9 @@
 // nearest upsample (FPN), LayerNorm, the small LightSVTR attention, CTC row statistics, layout
 // conversion at the C-ABI boundary and the image resize+normalise pre-processing.
 // Everything is NHWC fp32 with the channel dimension innermost => 16-byte coalesced accesses.
+#include <cstdlib>
+#include <string>
+
 #include "rd_device.h"
 
 namespace rd {
@@ -121,6 +124,103 @@ __global__ void __launch_bounds__(256) dwconv_tiled_kernel(DwParams p, int c4n, 
     }
 }
 
+// Column-strip variant for 3x3 / stride 1 (the depthwise conv of every PPLCNetV4 block, rec_lcnetv4.py:187-206): one thread =
+// TW consecutive output columns x 4 channels x ALL output rows.  It walks down its strip with a three-row register window, so
+// every input row is loaded ONCE (1.5 loads per output at TW = 4 instead of 3.75 for the row-tiled kernel above, whose three
+// kernel rows re-read their input from L1 / L2): round 1 measured the row-tiled kernel at 3.2 TB/s = 0.40 of HBM with the
+// L1 request rate as the suspected limiter.  MEASURED (round 2, bench.py): 17.6 ms per step against 16.5 for the row-tiled kernel
+// (TW = 8 without prefetch: 20.3) - fewer, longer threads hide latency worse than the L1 re-reads cost; kept behind RD_DW_COL=1.
+// Same optional squeeze-excite partial sums.
+template <int TW>
+__global__ void __launch_bounds__(256) dwconv3x3_col_kernel(DwParams p, int c4n, int groups_w, int gpb) {
+    constexpr int NCOL = TW + 2;
+    __shared__ f32x4 red[256];
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int lanes_p = blockDim.x / c4n;
+    const int c4 = threadIdx.x % c4n, pl = threadIdx.x / c4n;
+    const int c = c4 << 2;
+    const float* xb = p.x + (size_t)n * p.H * p.W * p.xld + c;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 bias = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c) : zero4;
+    f32x4 wv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[k] = *reinterpret_cast<const f32x4*>(p.w + (size_t)k * p.C + c);
+    f32x4 gsum = zero4;
+    const int g_end = min(groups_w, (chunk + 1) * gpb);
+    for (int g = chunk * gpb + pl; g < g_end; g += lanes_p) {
+        const int ow0 = g * TW, iw0 = ow0 - 1;
+        size_t coff[NCOL];
+        bool cok[NCOL];
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) {
+            coff[j] = (size_t)min(max(iw0 + j, 0), p.W - 1) * p.xld;      // unconditional loads from clamped columns, masked after
+            cok[j] = (unsigned)(iw0 + j) < (unsigned)p.W;
+        }
+        auto load_row = [&](int ih, f32x4* row) {
+            const float* xr = xb + (size_t)ih * p.W * p.xld;
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) row[j] = *reinterpret_cast<const f32x4*>(xr + coff[j]);
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) row[j] = cok[j] ? row[j] : zero4;
+        };
+        // four-row window: r0..r2 feed output row oh while r3 = input row oh + 2 is already in flight
+        f32x4 r0[NCOL], r1[NCOL], r2[NCOL], r3[NCOL];
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) r0[j] = r2[j] = r3[j] = zero4;           // row -1: padding
+        load_row(0, r1);
+        if (p.H > 1) load_row(1, r2);
+        for (int oh = 0; oh < p.OH; ++oh) {
+            if (oh + 2 < p.H) load_row(oh + 2, r3);
+            else {
+#pragma unroll
+                for (int j = 0; j < NCOL; ++j) r3[j] = zero4;
+            }
+            const size_t pix0 = ((size_t)n * p.OH + oh) * p.OW + ow0;
+#pragma unroll
+            for (int t = 0; t < TW; ++t) {
+                f32x4 a = bias;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) a += r0[t + kw] * wv[kw];
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) a += r1[t + kw] * wv[3 + kw];
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) a += r2[t + kw] * wv[6 + kw];
+                if (ow0 + t < p.OW) {
+                    f32x4 v = act4(a, p.act);
+                    if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (pix0 + t) * p.rld + c);
+                    *reinterpret_cast<f32x4*>(p.y + (pix0 + t) * p.yld + c) = v;
+                    gsum += v;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) { r0[j] = r1[j]; r1[j] = r2[j]; r2[j] = r3[j]; }
+        }
+    }
+    if (p.gap_partial) {
+        red[threadIdx.x] = gsum;
+        __syncthreads();
+        if (pl == 0) {
+            for (int r = 1; r < lanes_p; ++r) gsum += red[r * c4n + c4];
+            *reinterpret_cast<f32x4*>(p.gap_partial + ((size_t)n * gridDim.x + chunk) * p.C + c) = gsum;
+        }
+    }
+}
+// column-strip geometry: groups are the W / TW column strips of one image
+static inline bool dw_col_applies(const DwParams& p) {
+    static const bool off = std::getenv("RD_DW_COL") && std::string(std::getenv("RD_DW_COL")) == "0";
+    static const bool on = std::getenv("RD_DW_COL") && std::string(std::getenv("RD_DW_COL")) == "1";   // measured 17.6 vs 16.5 ms per step: OFF by default
+    return on && !off && p.KH == 3 && p.KW == 3 && p.SH == 1 && p.SW == 1 && p.PT == 1 && p.PL == 1 && p.OH == p.H && p.OW == p.W &&
+           p.C % 4 == 0 && (p.C >> 2) <= 256;
+}
+static inline void dw_col_geom(const DwParams& p, int& c4n, int& threads, int& groups_w, int& gpb, int& chunks) {
+    constexpr int TW = 4;
+    c4n = p.C >> 2;
+    threads = (256 / c4n) * c4n;
+    groups_w = (p.OW + TW - 1) / TW;
+    gpb = threads / c4n;             // one strip per pixel lane: as many blocks as the geometry allows
+    chunks = (groups_w + gpb - 1) / gpb;
+}
+
 // chunk geometry shared by the launcher and by the planner (which sizes the partial-sum buffer)
 static inline void dw_tiled_geom(const DwParams& p, int TW, int& c4n, int& threads, int& groups_w, int& groups, int& gpb,
                                  int& chunks) {
@@ -142,6 +242,11 @@ static inline int dw_tiled_tw(const DwParams& p) {
     return 0;
 }
 int dwconv_gap_chunks(const DwParams& p) {
+    if (dw_col_applies(p)) {
+        int c4n, threads, gw, gpb, chunks;
+        dw_col_geom(p, c4n, threads, gw, gpb, chunks);
+        return chunks;
+    }
     const int tw = dw_tiled_tw(p);
     if (!tw) return 0;
     int c4n, threads, gw, g, gpb, chunks;
@@ -150,6 +255,12 @@ int dwconv_gap_chunks(const DwParams& p) {
 }
 
 void launch_dwconv(const DwParams& p, hipStream_t s) {
+    if (dw_col_applies(p)) {
+        int c4n, threads, gw, gpb, chunks;
+        dw_col_geom(p, c4n, threads, gw, gpb, chunks);
+        hipLaunchKernelGGL((dwconv3x3_col_kernel<4>), dim3(chunks, p.N), dim3(threads), 0, s, p, c4n, gw, gpb);
+        return;
+    }
     const int tw = dw_tiled_tw(p);
     if (tw) {
         int c4n, threads, gw, g, gpb, chunks;

@@ -90,7 +90,7 @@ __device__ __forceinline__ void ws_split(float v, float s, _Float16& hi, _Float1
 // 4 no fragment reads and no MFMAs, 8 no GELU, 16 no workgroup barrier
 template <int C, bool GATED, bool KEEPX, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, const unsigned char* __restrict__ wimg, int n_tiles,
-                                                             int T_total, int ph_mul, float inv1, float inv2) {
+                                                             int T_total, int ph_mul, int ph_unit, float inv1, float inv2) {
     using G = WsGeom<C>;
     constexpr int KS = G::KS, NB = G::NB, NC = G::NC;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -107,16 +107,20 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
 
     // this wavefront's phase in the weight cycle and its (contiguous) run of 16-pixel tiles: a wavefront of phase ph' fits
     // floor((T - 1 - ph') / NC) tiles into T steps; phases repeat every NC wavefronts, so the run start is a closed form
-    const int wg = (int)blockIdx.x * WS_WAVES + wave;
+    // dealing unit: a wavefront (ph_unit = 1) or a whole workgroup (ph_unit = 8: its wavefronts switch tiles together, so a
+    // switch stalls nobody else at the step barrier, while different workgroups - nothing couples them - switch at different
+    // steps and the tile traffic of the chip is spread over the weight cycle instead of arriving in bursts)
+    const int du = ((int)blockIdx.x * WS_WAVES + wave) / ph_unit, sub = ((int)blockIdx.x * WS_WAVES + wave) % ph_unit;
     auto n_of = [&](int w) { return max(0, (T_total - 1 - (w * ph_mul) % NC) / NC); };
-    const int ph = (wg * ph_mul) % NC;
+    const int ph = (du * ph_mul) % NC;
     int per_cycle = 0, before = 0;
     for (int j = 0; j < NC; ++j) {
         per_cycle += n_of(j);
-        before += j < wg % NC ? n_of(j) : 0;
+        before += j < du % NC ? n_of(j) : 0;
     }
-    const int tile_base = (wg / NC) * per_cycle + before;
-    const int R = max(0, min(n_of(wg % NC), n_tiles - tile_base));    // tiles of this wavefront
+    const int tile_base = (du / NC) * per_cycle + before;            // in unit tiles (ph_unit wavefront tiles each)
+    const int n_unit_tiles = (n_tiles + ph_unit - 1) / ph_unit;
+    const int R = max(0, min(n_of(du % NC), n_unit_tiles - tile_base));    // tiles of this wavefront
 
     // ---- weight stream: stage q of the image = [W1 fragments of chunk (q+1) % NC | W2 fragments of chunk q]
     // Every CU streams the SAME bytes at about the same time; walking them in the same order would make all 32 CUs of an
@@ -157,7 +161,7 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
     float amax = 0.f;                // largest |GELU output| this lane split; X' can only fail by being non-finite
     bool bad = false;
 
-    auto tile_m = [&](int r) { return (tile_base + r) * WS_PX + px; };
+    auto tile_m = [&](int r) { return ((tile_base + r) * ph_unit + sub) * WS_PX + px; };
 
     // X tile -> (gate) -> per-pixel scale -> split into the B fragments.  Lane (px, g) owns channels 16n + 4g .. + 4 of every
     // block n; the four lanes px, px + 16, px + 32, px + 48 hold one pixel.
@@ -426,16 +430,16 @@ static int ws_total_steps(int n_tiles, int waves, int NC, int ph_mul) {
 }
 
 template <int C, bool GATED, bool KEEPX, int ABL = 0>
-static void launch_ws(const MixerParams& p, const unsigned char* wimg, int n_tiles, int grid, int ph_mul, hipStream_t s) {
+static void launch_ws(const MixerParams& p, const unsigned char* wimg, int n_tiles, int grid, int ph_mul, int ph_unit, hipStream_t s) {
     static unsigned long long lds_ok = 0;
     rd_allow_dynamic_lds((const void*)lc_mixer_ws_kernel<C, GATED, KEEPX, ABL>, WsGeom<C>::LDS_BYTES, lds_ok);
-    const int T = ws_total_steps(n_tiles, grid * WS_WAVES, WsGeom<C>::NC, ph_mul);
+    const int T = ws_total_steps((n_tiles + ph_unit - 1) / ph_unit, grid * WS_WAVES / ph_unit, WsGeom<C>::NC, ph_mul);
     hipLaunchKernelGGL((lc_mixer_ws_kernel<C, GATED, KEEPX, ABL>), dim3(grid), dim3(512), WsGeom<C>::LDS_BYTES, s, p, wimg, n_tiles, T,
-                       ph_mul, p.ws_inv1, p.ws_inv2);
+                       ph_mul, ph_unit, p.ws_inv1, p.ws_inv2);
 }
 
 // p.w1h carries the weight stream image, p.ws_inv1 / ws_inv2 its inverse scales (prepare_mixer_weights_ws);
-// p.dbg (microbenchmark A/B): bit 0 force lock step, bit 2 force per-wavefront phases, bit 1 flip the residual policy
+// p.dbg (microbenchmark A/B): bit 0 force lock step, bit 2 force per-wavefront phases, bit 3 force per-workgroup phases, bit 1 flip the residual policy
 // (default: kept in registers at C = 96, re-read at C = 192 where keeping it spills); bits 8.. ablations (C = 192, garbage)
 void launch_mixer_fused_ws(const MixerParams& p, hipStream_t s) {
     if (p.M <= 0) return;
@@ -454,24 +458,31 @@ void launch_mixer_fused_ws(const MixerParams& p, hipStream_t s) {
     const int rounds = (n_wg + n_cu - 1) / n_cu;
     const int grid = (n_wg + rounds - 1) / rounds;
     const unsigned char* img = reinterpret_cast<const unsigned char*>(p.w1h);
-    // Phases: lock step (every wavefront switches tiles at the same step) unless per-wavefront phases need fewer steps.
-    // Measured (tools/microbench.py --mixer-ws): with a barrier every step a wavefront in its tile switch holds up the
-    // whole workgroup, so spreading the switches over the cycle only pays when it shortens the schedule (M = 33 000:
-    // 64 vs 81 us; M = 105 600: 175 vs 169 us).
+    // Phases.  Lock step (every wavefront of the chip switches tiles at the same step) puts the tile traffic into bursts
+    // during which nothing computes (ablation: 40 of 168 us at M = 105 600); per-WAVEFRONT phases spread it, but with a barrier
+    // every step a wavefront in its tile switch holds up its whole workgroup (175 vs 169 us); per-WORKGROUP phases spread the
+    // traffic over the chip without that coupling.  Phases cost up to NC - 1 extra steps when the tiles divide evenly, so the
+    // launcher takes them when the schedule grows by at most 1/8.
     const int NC = 2 * p.C / WS_HC;
-    int ph_mul = 5;      // coprime to NC = 6 and 12: consecutive wavefronts walk through all phases
-    if ((p.dbg & 1) || ws_total_steps(n_tiles, grid * WS_WAVES, NC, 5) >= ws_total_steps(n_tiles, grid * WS_WAVES, NC, 0)) ph_mul = 0;
-    if (p.dbg & 4) ph_mul = 5;
+    const int t_lock = ws_total_steps(n_tiles, grid * WS_WAVES, NC, 0);
+    const int t_wg = ws_total_steps((n_tiles + WS_WAVES - 1) / WS_WAVES, grid, NC, 5);     // 5: coprime to NC = 6 and 12
+    const int t_wave = ws_total_steps(n_tiles, grid * WS_WAVES, NC, 5);
+    int ph_mul = 0, ph_unit = 1;
+    if (t_wave < t_lock) { ph_mul = 5; ph_unit = 1; }
+    else if (t_wg * 8 <= t_lock * 9) { ph_mul = 5; ph_unit = WS_WAVES; }
+    if (p.dbg & 1) { ph_mul = 0; ph_unit = 1; }
+    if (p.dbg & 4) { ph_mul = 5; ph_unit = 1; }
+    if (p.dbg & 8) { ph_mul = 5; ph_unit = WS_WAVES; }
     const bool gated = p.gate != nullptr;
     if (p.dbg >> 8) {
         switch (p.dbg >> 8) {
-            case 1: launch_ws<192, false, false, 1>(p, img, n_tiles, grid, ph_mul, s); break;
-            case 4: launch_ws<192, false, false, 4>(p, img, n_tiles, grid, ph_mul, s); break;
-            case 8: launch_ws<192, false, false, 8>(p, img, n_tiles, grid, ph_mul, s); break;
-            case 12: launch_ws<192, false, false, 12>(p, img, n_tiles, grid, ph_mul, s); break;
-            case 13: launch_ws<192, false, false, 13>(p, img, n_tiles, grid, ph_mul, s); break;
-            case 16: launch_ws<192, false, false, 16>(p, img, n_tiles, grid, ph_mul, s); break;
-            case 29: launch_ws<192, false, false, 29>(p, img, n_tiles, grid, ph_mul, s); break;
+            case 1: launch_ws<192, false, false, 1>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
+            case 4: launch_ws<192, false, false, 4>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
+            case 8: launch_ws<192, false, false, 8>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
+            case 12: launch_ws<192, false, false, 12>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
+            case 13: launch_ws<192, false, false, 13>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
+            case 16: launch_ws<192, false, false, 16>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
+            case 29: launch_ws<192, false, false, 29>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
             default: break;
         }
         return;
@@ -479,8 +490,8 @@ void launch_mixer_fused_ws(const MixerParams& p, hipStream_t s) {
     const bool keepx = (p.C == 96) != ((p.dbg & 2) != 0);
 #define RD_WS(CC)                                                                                                \
     do {                                                                                                         \
-        if (gated) { if (keepx) launch_ws<CC, true, true>(p, img, n_tiles, grid, ph_mul, s); else launch_ws<CC, true, false>(p, img, n_tiles, grid, ph_mul, s); } \
-        else { if (keepx) launch_ws<CC, false, true>(p, img, n_tiles, grid, ph_mul, s); else launch_ws<CC, false, false>(p, img, n_tiles, grid, ph_mul, s); } \
+        if (gated) { if (keepx) launch_ws<CC, true, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s); else launch_ws<CC, true, false>(p, img, n_tiles, grid, ph_mul, ph_unit, s); } \
+        else { if (keepx) launch_ws<CC, false, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s); else launch_ws<CC, false, false>(p, img, n_tiles, grid, ph_mul, ph_unit, s); } \
     } while (0)
     if (p.C == 192) RD_WS(192);
     else if (p.C == 96) RD_WS(96);

@@ -319,11 +319,11 @@ def test_split_gemm_tails_match_fp64(M, K, N):
 
 
 @pytest.mark.parametrize("C_,M", [(48, 1000), (96, 4097), (192, 333), (192, 12800 + 5), (192, 70001), (96, 40000 + 3)])
-@pytest.mark.parametrize("variant", [0, 100, 200, 201, 202, 204])
+@pytest.mark.parametrize("variant", [0, 100, 200, 201, 202, 204, 208])
 def test_fused_mixer_kernels_match_fp64(C_, M, variant):
     """Fused channel mixer x + W2 gelu(W1 x + b1) + b2 (rec_lcnetv4.py:226-236): fp32-MFMA kernel (variant 0, C = 192
-    only in the debug entry), round-1 split-fp16 kernel (variant 100) and the weight-streaming kernel (200; +1 lock step instead of
-    per-wavefront phases, +2 flipped residual policy) on ragged pixel counts incl. several persistent rounds, against fp64."""
+    only in the debug entry), round-1 split-fp16 kernel (variant 100) and the weight-streaming kernel (200; +1 lock step, +4 per-wavefront
+    phases, +8 per-workgroup phases, +2 flipped residual policy) on ragged pixel counts incl. several persistent rounds, against fp64."""
     import ctypes as C
     from rapiddoc_amd import _lib
     if variant == 0 and C_ != 192:

@@ -38,7 +38,7 @@ if __name__ == "__main__" and "--mixer-ws" in sys.argv:
     # round 2: weight-streaming mixer (variant 200 + bits: 1 lock step instead of per-wavefront phases, 2 flipped residual
     # policy) vs the round-1 kernel (100); then ablations (+ 256 * bits, C = 192, garbage results)
     for C_, M in ((192, 105600), (192, 131072), (192, 33000), (192, 4000), (96, 211200), (96, 262144)):
-        for v in (100, 200, 201, 204):
+        for v in (100, 200, 201, 204, 208):
             ms, tf, err = mixer(C_, M, v, check=True)
             print(f"mixer C={C_} M={M} variant {v}: {ms*1e3:8.1f} us {tf:7.1f} TF/s  max abs err vs fp64 {err:.2e}", flush=True)
     names = {1: "no DMA", 4: "no frag reads, no MFMA", 8: "no GELU", 12: "no GELU / reads / MFMA (DMA + barriers only)",
