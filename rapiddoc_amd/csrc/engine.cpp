@@ -306,7 +306,9 @@ static inline int out_dim(int in, int k, int s, int p0, int p1) { return (in + p
 // "auto" precision: wide pointwise convolutions also run on the split-fp16 matrix-core path (256x128 tile; measured
 // 1.2x the fp32 MFMA kernel at K = 192, 2x at K >= 768 - table in kernels_conv_h3.hip)
 static inline bool auto_split_conv(int kh, int kw, int K, int cout) {
-    return (kh == 1 && kw == 1) ? (K >= 96 && cout >= 96) : (K >= 288 && cout >= 48);
+    static const int kxk_k = std::getenv("RD_H3_KXK_MIN_K") ? std::atoi(std::getenv("RD_H3_KXK_MIN_K")) : 96;   // round 2: 96 / 24 (round 1: 288 / 48) measured +2.8 % pages/s
+    static const int kxk_n = std::getenv("RD_H3_KXK_MIN_N") ? std::atoi(std::getenv("RD_H3_KXK_MIN_N")) : 24;
+    return (kh == 1 && kw == 1) ? (K >= 96 && cout >= 96) : (K >= kxk_k && cout >= kxk_n);
 }
 
 // =================================================================================================

@@ -514,49 +514,67 @@ void launch_layernorm(const float* x, int xld, float* y, int yld, const float* g
 // --------------------------------------------------------------------------------------------------
 template <int HD>
 __global__ void __launch_bounds__(256) attention_kernel(const float* qkv, float* o, int T, int heads, float scale) {
+    // K / V rows are padded to HDP = 16 / 32 floats in LDS so that a key costs HDP / 4 ds_read_b128 (every lane reads the same
+    // address: a broadcast) instead of HD ds_read_b32 - round 1's 15 scalar reads per dot product made this kernel LDS-issue
+    // bound (51 us per launch for 0.4 GFLOP); same two-pass max-subtracted softmax, same operation order per element.
+    constexpr int HDP = (HD + 3) / 4 * 4;
+    constexpr int NV = HDP / 4;
     extern __shared__ float sm[];
-    float* Ks = sm;               // [T][HD]
-    float* Vs = sm + (size_t)T * HD;
+    f32x4* Ks = reinterpret_cast<f32x4*>(sm);               // [T][NV]
+    f32x4* Vs = Ks + (size_t)T * NV;
     const int b = blockIdx.x, h = blockIdx.y;
     const int C = heads * HD;
     const float* base = qkv + (size_t)b * T * 3 * C;
-    for (int i = threadIdx.x; i < T * HD; i += 256) {
-        const int t = i / HD, d = i - t * HD;
-        Ks[i] = base[(size_t)t * 3 * C + C + h * HD + d];
-        Vs[i] = base[(size_t)t * 3 * C + 2 * C + h * HD + d];
+    for (int i = threadIdx.x; i < T * HDP; i += 256) {
+        const int t = i / HDP, d = i - t * HDP;
+        reinterpret_cast<float*>(Ks)[i] = d < HD ? base[(size_t)t * 3 * C + C + h * HD + d] : 0.f;
+        reinterpret_cast<float*>(Vs)[i] = d < HD ? base[(size_t)t * 3 * C + 2 * C + h * HD + d] : 0.f;
     }
     __syncthreads();
     for (int t = threadIdx.x; t < T; t += 256) {
-        float q[HD];
+        f32x4 q[NV];
 #pragma unroll
-        for (int d = 0; d < HD; ++d) q[d] = base[(size_t)t * 3 * C + h * HD + d] * scale;
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[v][e] = (4 * v + e < HD) ? base[(size_t)t * 3 * C + h * HD + 4 * v + e] * scale : 0.f;
+        auto dot = [&](int j) {
+            float sdot = 0.f;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const f32x4 kv = Ks[(size_t)j * NV + v];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * v + e < HD) sdot = fmaf(q[v][e], kv[e], sdot);
+            }
+            return sdot;
+        };
         float mx = -INFINITY;
+        for (int j = 0; j < T; ++j) mx = fmaxf(mx, dot(j));
+        float l = 0.f;
+        f32x4 acc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int j = 0; j < T; ++j) {
-            float sdot = 0.f;
-#pragma unroll
-            for (int d = 0; d < HD; ++d) sdot = fmaf(q[d], Ks[j * HD + d], sdot);
-            mx = fmaxf(mx, sdot);
-        }
-        float l = 0.f, acc[HD];
-#pragma unroll
-        for (int d = 0; d < HD; ++d) acc[d] = 0.f;
-        for (int j = 0; j < T; ++j) {
-            float sdot = 0.f;
-#pragma unroll
-            for (int d = 0; d < HD; ++d) sdot = fmaf(q[d], Ks[j * HD + d], sdot);
-            const float e = __expf(sdot - mx);
+            const float e = __expf(dot(j) - mx);
             l += e;
 #pragma unroll
-            for (int d = 0; d < HD; ++d) acc[d] = fmaf(e, Vs[j * HD + d], acc[d]);
+            for (int v = 0; v < NV; ++v) {
+                const f32x4 vv = Vs[(size_t)j * NV + v];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[v][c] = fmaf(e, vv[c], acc[v][c]);
+            }
         }
         const float inv = 1.f / l;
         float* op = o + ((size_t)b * T + t) * C + h * HD;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) op[d] = acc[d] * inv;
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (4 * v + c < HD) op[4 * v + c] = acc[v][c] * inv;
     }
 }
 void launch_attention(const float* qkv, float* o, int B, int T, int heads, int hd, float scale, hipStream_t s) {
-    const size_t sh = (size_t)2 * T * hd * sizeof(float);
+    const size_t sh = (size_t)2 * T * ((hd + 3) / 4 * 4) * sizeof(float);
     if (hd == 15)
         hipLaunchKernelGGL(attention_kernel<15>, dim3(B, heads), dim3(256), sh, s, qkv, o, T, heads, scale);
     else if (hd == 16)
