@@ -282,6 +282,29 @@ float rd_debug_time_gemm(int M, int K, int N, int act, int iters, float* x, floa
     return ms / iters;
 }
 
+// developer timing of the fused CTC head on prepared weights: wp = W' [C][128] fp32 (bias in column K), wh / wl its fp16 split
+// (null: fp32 MFMA kernel); part = workspace of M * 64 * 4 floats.  Returns ms per launch; *nsplit_out = the split count used.
+float rd_debug_time_ctc(int M, int K, int Ccls, int iters, float* x, float* wp, void* wh, void* wl, float* part, int32_t* idx, float* prob,
+                        int nsplit_override, int* nsplit_out) {
+    rd::CtcParams p{};
+    p.x = x; p.xld = K; p.w = wp; p.M = M; p.K = K; p.C = Ccls; p.part = part;
+    p.nsplit = nsplit_override > 0 ? nsplit_override : rd::ctc_head_nsplit(M, Ccls, wh != nullptr);
+    p.idx = idx; p.prob = prob;
+    p.wh = (const uint16_t*)wh; p.wl = (const uint16_t*)wl;
+    if (nsplit_out) *nsplit_out = p.nsplit;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    rd::launch_ctc_head(p, nullptr);
+    (void)hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters; ++i) rd::launch_ctc_head(p, nullptr);
+    (void)hipEventRecord(e1, nullptr);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return ms / iters;
+}
+
 int rd_set_precision(rd_handle* h, const char* mode) {
     return guarded(h, [&] {
         RD_CHECK(h->eng, "precision modes apply to the network engines");

@@ -914,8 +914,9 @@ void Builder::ctc_head(const std::string& prefix, const TView& x, const TView& i
     const int C = (int)w.shape[0], K = (int)w.shape[1];
     RD_CHECK(K == x.c && K % 4 == 0, "ctc head width");
     const int M = (int)x.pixels();
-    const int nsplit = ctc_head_nsplit(M, C);
-    TView part = alloc_raw((size_t)M * nsplit * 4);
+    // the two kernels tile differently, so their class-split counts differ: the workspace is sized for either
+    const int ns_f32 = ctc_head_nsplit(M, C, false), ns_h3 = ctc_head_nsplit(M, C, true);
+    TView part = alloc_raw((size_t)M * std::max(ns_f32, ns_h3) * 4);
     if (!planning()) {
         if (!pb_->has(prefix + "|ctc#w")) {
             // W' [C][128]: columns 0..K-1 = W, column K = bias (the kernel feeds X[:,K] = 1), rest 0
@@ -941,8 +942,9 @@ void Builder::ctc_head(const std::string& prefix, const TView& x, const TView& i
     p.xld = plan_->ld(x);
     p.w = pb_->ptr(prefix + "|ctc#w");
     p.bias = nullptr;
-    p.M = M; p.K = K; p.C = C; p.nsplit = nsplit;
+    p.M = M; p.K = K; p.C = C;
     const bool split = (h3_ || mixer_h3_) && pb_->has(prefix + "|ctc#wh");
+    p.nsplit = split ? ns_h3 : ns_f32;
     if (split) {
         p.wh = reinterpret_cast<const uint16_t*>(pb_->ptr(prefix + "|ctc#wh"));
         p.wl = reinterpret_cast<const uint16_t*>(pb_->ptr(prefix + "|ctc#wl"));

@@ -11,6 +11,9 @@
 //   * the bias rides in the padded K column (K=120 -> 128: X[:,120] = 1, W'[:,120] = bias)
 //   * class ranges are split across blocks so that split s runs on XCD s%8: each XCD keeps its ~1.2 MB slice
 //     of W' resident in its private L2 while the token tiles stream past
+#include <cstdlib>
+#include <type_traits>
+
 #include "rd_device.h"
 
 namespace rd {
@@ -135,133 +138,179 @@ __global__ void __launch_bounds__(256) ctc_head_kernel(CtcParams p, int cls_per_
 
 
 // ------------------------------------------------------------------------------------------------------------------
-// Split-fp16 variant (precision "auto" / "h3"): same tiling, split and statistics, but the products run on the fp16 matrix
-// cores with (hi, lo) operands - 3 x v_mfma_f32_32x32x16_f16 per 16-wide k-step instead of 8 fp32 MFMAs, fp32 accumulate
-// (arithmetic as in kernels_conv_h3.hip).  The token tile is split once per block, the weights once at load time.
-static constexpr int CH_LD = CT_K + 8;   // LDS row stride in halfs (272 B): conflict-free ds_read_b128
+// Split-fp16 variant (precision "auto" / "h3"): same split and statistics, but the products run on the fp16 matrix cores with
+// (hi, lo) operands - 3 x v_mfma_f32_32x32x16_f16 per 16-wide k-step instead of 8 fp32 MFMAs, fp32 accumulate (arithmetic as in
+// kernels_conv_h3.hip).  The weights are split once at load time.
+//
+// Round 2 restructuring.  The round-1 kernel (128 tokens x 128 classes per step, 4 wavefronts, token tile and one class tile
+// in LDS) measured 204-270 us per launch against ~30 us of MFMA issue.  Ablations of an intermediate version showed its phases
+// simply ADD UP per class tile: MFMA 3070 cycles + statistics ~3800 cycles of VALU (merge, max / argmax, 64 exp per lane) +
+// ~1500 cycles of LDS-DMA issue and wait: with one wavefront per SIMD nothing runs under anything else unless a single
+// instruction stream interleaves it, and the compiler does not (sched_group_barrier pipelines were ignored, it clusters the
+// MFMAs of a k-step and then runs the VALU work with the matrix pipe idle).  So the overlap is left to the hardware:
+//   * 8 wavefronts x 32 tokens per workgroup, TWO per SIMD, 64 classes per step; the token tile lives in REGISTERS as the MFMA
+//     B operand (8 k-steps x (hi, lo) x f16x8 = 64 VGPRs, split once);
+//   * wavefronts 0-3 run [MFMAs of tile s, statistics of tile s], wavefronts 4-7 run [statistics of tile s-1, MFMAs of tile s]
+//     between the same two barriers: each SIMD hosts one wavefront of either kind, so its matrix pipe and its VALU are busy
+//     with different wavefronts at the same time;
+//   * class tiles (32 KB: hi and lo planes of 64 classes) are double-buffered by LDS-DMA, four 1-KB pieces per wavefront and
+//     step, requested one full step ahead; one barrier per step; a 256-token workgroup also halves the L2 -> LDS weight stream;
+//   * statistics in slices of 8 classes with an online softmax (one extra exp per slice), exp as one fma + v_exp, class masking
+//     only in a split's last tile, the running argmax as selects of uniform class codes (no divergent branch);
+//   * blocks are dealt to XCDs in contiguous runs of the (class split, token tile) list, so an XCD's L2 holds the one or two
+//     class slices it works on whatever the split count is, and
+//   * the split count is chosen to minimise rounds x steps (ctc_head_nsplit): 34 token tiles x 8 splits = 272 blocks used to take
+//     two rounds on 256 CUs with the second one 6 % full.
+static constexpr int CH_TOK = 256;   // tokens per block (8 wavefronts x 32)
+static constexpr int CH_CLS = 64;    // classes per step (2 MFMA tiles)
 
-__global__ void __launch_bounds__(256) ctc_head_h3_kernel(CtcParams p, int cls_per_split) {
+template <int MODE>   // developer variants (RD_CTC_MODE): 1 pair by wave parity, 2 no skew, 3 s_setprio around the MFMAs
+__global__ void __launch_bounds__(512) ctc_head_h3_kernel(CtcParams p, int cls_per_split, int tiles, int per_xcd) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    _Float16* Xh = reinterpret_cast<_Float16*>(smem);
-    _Float16* Xl = Xh + CT_TOK * CH_LD;
-    _Float16* Wh = Xl + CT_TOK * CH_LD;         // [128 classes][128] UNPADDED: filled by LDS-DMA, 16-byte chunk c of row r
-    _Float16* Wl = Wh + CT_CLS * CT_K;          // sits at chunk c ^ (r & 15) (rows are 256 B = a whole bank sweep apart)
+    _Float16* Wbuf = reinterpret_cast<_Float16*>(smem);   // 2 x [hi plane 64 x 128 | lo plane]: filled by LDS-DMA, 16-byte chunk c of
+                                                          // row r sits at chunk c ^ (r & 15) (rows are 256 B = a whole bank sweep apart)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool late = MODE == 2 ? false : MODE == 1 ? (wave & 1) != 0 : wave >= 4;   // statistics one tile late (see above)
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int split = blockIdx.x % p.nsplit, ttile = blockIdx.x / p.nsplit;
-    const int tok0 = ttile * CT_TOK;
+    // workgroup b runs on XCD b % 8: XCD x takes entries [x * per_xcd, (x + 1) * per_xcd) of the split-major block list
+    const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || lin >= tiles * p.nsplit) return;
+    const int split = lin / tiles, ttile = lin - split * tiles;
+    const int tok0 = ttile * CH_TOK;
     const int c_begin = split * cls_per_split;
     const int c_end = min(p.C, c_begin + cls_per_split);
-    const int nit = (c_end - c_begin + CT_CLS - 1) / CT_CLS;
+    const int nit = (c_end - c_begin + CH_CLS - 1) / CH_CLS;
     const _Float16* wh_g = reinterpret_cast<const _Float16*>(p.wh);
     const _Float16* wl_g = reinterpret_cast<const _Float16*>(p.wl);
 
-    // ---- X tile (tokens): bias column appended, split once
-    float amax = 0.f;
-    {
-        const int lrow = tid >> 5, lkq = tid & 31;
-#pragma unroll 4
-        for (int r = lrow; r < CT_TOK; r += 8) {
-            const int tok = min(tok0 + r, p.M - 1), k = 4 * lkq;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < p.K) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)tok * p.xld + k);
-            else if (k == p.K) v[0] = 1.f;
-            f16x4 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                _Float16 h, l;
-                rd_split(v[e], h, l);
-                hi[e] = h;
-                lo[e] = l;
-                amax = fmaxf(amax, fabsf(v[e]));
-            }
-            *reinterpret_cast<f16x4*>(&Xh[r * CH_LD + k]) = hi;
-            *reinterpret_cast<f16x4*>(&Xl[r * CH_LD + k]) = lo;
-        }
-    }
-    // W tile by LDS-DMA: 64 KB = 64 instructions of 1 KB per iteration, 16 per wavefront (no staging registers, no
-    // ds_write).  Instruction q covers bytes [q*1024, +1024) of [hi plane | lo plane]; lane -> (row, chunk position).
+    // W tile by LDS-DMA: 32 KB = 32 instructions of 1 KB, 4 per wavefront (no staging registers, no ds_write).  Instruction
+    // q = wave + 8 u covers bytes [q*1024, +1024) of [hi plane | lo plane] (u >= 2: lo plane): lane -> row rbase + 32 (u & 1),
+    // 16-byte chunk position lane & 15, which holds source chunk (lane & 15) ^ (row & 15) = a constant.
     unsigned char* lds_bytes = reinterpret_cast<unsigned char*>(smem);
-    const unsigned w_base = (unsigned)((Wh - Xh) * 2);
-    int woff[16];            // element offset of this lane's source chunk inside a 128-class block of W
+    const int rbase = 4 * wave + (lane >> 4);
+    const int koff = 8 * ((lane & 15) ^ (rbase & 15));
+    auto dma_tile = [&](int tile) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const int q = wave + 4 * u;                       // 0..63
-        const int o = (q & 31) * 1024 + lane * 16;        // byte offset inside the plane
-        const int row = o >> 8, cp = (o & 255) >> 4;
-        woff[u] = row * CT_K + 8 * (cp ^ (row & 15));
-    }
-    auto issue_w = [&](int it) {
-        const int cb = c_begin + it * CT_CLS;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int q = wave + 4 * u;
-            const int row = woff[u] / CT_K;
-            // classes past the end of this split re-read its last class; their logits are masked to -inf below
-            const int cls = min(cb + row, c_end - 1);
-            const _Float16* src = ((q >> 5) ? wl_g : wh_g) + (size_t)cls * CT_K + (woff[u] - row * CT_K);
+        for (int u = 0; u < 4; ++u) {
+            // classes past the end of this split re-read its last class; their logits are masked to -inf in the statistics
+            const int cls = min(c_begin + tile * CH_CLS + rbase + 32 * (u & 1), c_end - 1);
+            const unsigned off = (unsigned)cls * CT_K + (unsigned)koff;
+            const _Float16* src = ((u >= 2) ? wl_g : wh_g) + off;
+            const unsigned dst = (unsigned)(tile & 1) * (unsigned)(2 * CH_CLS * CT_K * 2) + (unsigned)(wave + 8 * u) * 1024u;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lds_bytes + w_base + (unsigned)q * 1024u), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(lds_bytes + dst), 16, 0, 0);
         }
     };
-    issue_w(0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    dma_tile(0);
+
+    // ---- this wavefront's 32 tokens as B operands: lane (l31, lhi) holds X[token l31][16 ks + 8 lhi .. + 8]; bias column appended
+    float amax = 0.f;
+    f16x8 xh[CT_K / 16], xl[CT_K / 16];
+    {
+        const int tok = min(tok0 + wave * 32 + l31, p.M - 1);
+        const float* xr = p.x + (size_t)tok * p.xld;
+#pragma unroll
+        for (int ks = 0; ks < CT_K / 16; ++ks)
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {
+                const int k = ks * 16 + 8 * lhi + 4 * hq;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k < p.K) v = *reinterpret_cast<const f32x4*>(xr + k);
+                else if (k == p.K) v[0] = 1.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 h, l;
+                    rd_split(v[e], h, l);
+                    xh[ks][4 * hq + e] = h;
+                    xl[ks][4 * hq + e] = l;
+                    amax = fmaxf(amax, fabsf(v[e]));
+                }
+            }
+    }
 
     float m_run = -INFINITY, s_run = 0.f;
-    int i_run = 0;
-    const int xo = (wave * 32 + l31) * CH_LD + 8 * lhi;
+    int i_run = 0;                                   // class code: class - c_begin - 4 lhi
     const int wrow = l31 * CT_K, wkey = l31 & 15;
-    for (int it = 0; it < nit; ++it) {
-        const bool more = it + 1 < nit;
-        f32x16 acc1[4], acc2[4];
+    constexpr float LOG2E = 1.4426950408889634f;
+    f32x16 zero16;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    float vals[32];                                  // merged logits of one tile: this lane's 32 classes of its token
+
+    auto mfma_tile = [&](int s) {
+        const _Float16* Wh = Wbuf + (size_t)(s & 1) * (2 * CH_CLS * CT_K);
+        const _Float16* Wl = Wh + CH_CLS * CT_K;
+        f32x16 acc1[2], acc2[2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[ct][r] = acc2[ct][r] = 0.f;
-#pragma unroll 2
-        for (int ks = 0; ks < CT_K / 16; ++ks) {
-            const f16x8 bh = *reinterpret_cast<const f16x8*>(&Xh[xo + ks * 16]);
-            const f16x8 bl = *reinterpret_cast<const f16x8*>(&Xl[xo + ks * 16]);
+        for (int ks = 0; ks < CT_K / 16; ++ks)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
+            for (int ct = 0; ct < 2; ++ct) {
                 const int wa = ct * 32 * CT_K + wrow + (((2 * ks + lhi) ^ wkey) << 3);
                 const f16x8 ah = *reinterpret_cast<const f16x8*>(&Wh[wa]);
                 const f16x8 al = *reinterpret_cast<const f16x8*>(&Wl[wa]);
-                acc1[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[ct], 0, 0, 0);
-                acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[ct], 0, 0, 0);
-                acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[ct], 0, 0, 0);
+                // (the first k-step starts from a constant zero C operand instead of zero-filled accumulators)
+                acc1[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh[ks], ks ? acc1[ct] : zero16, 0, 0, 0);
+                acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl[ks], ks ? acc2[ct] : zero16, 0, 0, 0);
+                acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh[ks], acc2[ct], 0, 0, 0);
             }
-        }
-        // every wavefront is done with this W tile: request the next one, it lands under the statistics below
-        asm volatile("s_barrier" ::: "memory");
-        if (more) issue_w(it + 1);
-        const int cb = c_begin + it * CT_CLS + 4 * lhi;
-        float lm = -INFINITY;
-        int li = 0;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = cb + ct * 32 + (r & 3) + 8 * (r >> 2);
-                const float v = (c < c_end) ? fmaf(acc2[ct][r], 1.f / 2048.f, acc1[ct][r]) : -INFINITY;
-                acc1[ct][r] = v;
-                if (v > lm) { lm = v; li = c; }
+            for (int r = 0; r < 16; ++r) vals[ct * 16 + r] = fmaf(acc2[ct][r], 1.f / 2048.f, acc1[ct][r]);
+    };
+    // running (max, argmax, sum-exp) over `vals` = tile t; TAIL: the tile may be partial (a split's last tile)
+    auto stats = [&](auto tail_t, int t) {
+        constexpr bool TAIL = decltype(tail_t)::value;
+        const int cb = c_begin + t * CH_CLS + 4 * lhi;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            // slice sl: this lane's classes cb + ct * 32 + {0..3, 8..11} (+16 for the odd slice)
+            const int ct = sl >> 1, r0 = (sl & 1) * 8;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = vals[ct * 16 + r0 + j];
+                if (TAIL && cb + ct * 32 + ((r0 + j) & 3) + 8 * ((r0 + j) >> 2) >= c_end) v[j] = -INFINITY;
             }
-        const float m_new = fmaxf(m_run, lm);
-        if (m_new > -INFINITY) {
-            float s = 0.f;
+            const float lm = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+            // argmax: lowest class of the slice that attains its maximum, taken if that maximum beats the running one (what a
+            // strict `>` scan in class order finds).  Eight selects of UNIFORM class codes straight into the running index (a
+            // select chain feeding one final select is turned into a divergent branch by the compiler)
+            const bool beats = lm > m_run;
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
+            for (int j = 7; j >= 0; --j)
+                i_run = (beats && v[j] == lm) ? t * CH_CLS + ct * 32 + ((r0 + j) & 3) + 8 * ((r0 + j) >> 2) : i_run;
+            const float m_new = fmaxf(m_run, lm);
+            // (TAIL: a masked slice in front of any real class has m_new = -inf, exp(-inf - -inf) would be NaN)
+            const float nm = (TAIL && !(m_new > -INFINITY)) ? 0.f : -m_new * LOG2E;
+            float sum = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s += __expf(acc1[ct][r] - m_new);
-            s_run = s_run * __expf(m_run - m_new) + s;
-            if (lm > m_run) i_run = li;
+            for (int j = 0; j < 8; ++j) sum += __builtin_amdgcn_exp2f(fmaf(v[j], LOG2E, nm));
+            s_run = fmaf(s_run, __builtin_amdgcn_exp2f(fmaf(m_run, LOG2E, nm)), sum);
             m_run = m_new;
         }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    for (int s = 0; s < nit; ++s) {
+        // class tile s has landed (every wavefront's pieces) and every wavefront is past the MFMAs of step s-1, which read the
+        // buffer that tile s+1 goes to
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (s + 1 < nit) dma_tile(s + 1);
+        if (late && s > 0) stats(F{}, s - 1);
+        if (MODE == 3) __builtin_amdgcn_s_setprio(1);
+        mfma_tile(s);
+        if (MODE == 3) __builtin_amdgcn_s_setprio(0);
+        if (!late) {
+            if (s + 1 < nit) stats(F{}, s);
+            else stats(T{}, s);
+        }
     }
+    if (late) stats(T{}, nit - 1);
+
     if (!(amax < 65504.f) && p.range_flag) atomicOr(p.range_flag, 1u);
+    i_run += c_begin + 4 * lhi;        // class code -> class
     const float om = __shfl_xor(m_run, 32, 64), os = __shfl_xor(s_run, 32, 64);
     const int oi = __shfl_xor(i_run, 32, 64);
     const float mm = fmaxf(m_run, om);
@@ -294,27 +343,48 @@ __global__ void __launch_bounds__(256) ctc_merge_kernel(const float* part, int M
     prob[tok] = 1.f / sum;
 }
 
-int ctc_head_nsplit(int M, int C) {
-    const int tiles = (M + CT_TOK - 1) / CT_TOK;
-    int ns = 8;
-    while (tiles * ns < 256 && ns < 64 && (C / (ns * 2)) >= CT_CLS) ns *= 2;
-    // small dictionaries: every split must own at least one class (classes per split are rounded up to a multiple of 4)
-    while (ns > 1 && (((C + ns - 1) / ns + 3) / 4 * 4) * (ns - 1) >= C) --ns;
-    return ns;
+// class splits: one block = (split, token tile); blocks run one per CU, so a launch costs rounds x (steps per block + a
+// fixed part for the token tile and the first class tile).  Pick the split count that minimises it; every split must own at
+// least one class (classes per split are rounded up to a multiple of 4).
+static int ctc_pick_nsplit(int M, int C, int tok_per_block, int cls_per_step, int fixed_steps) {
+    const int tiles = (M + tok_per_block - 1) / tok_per_block;
+    int best = 1;
+    long best_cost = -1;
+    for (int ns = 1; ns <= 64; ++ns) {
+        const int cps = ((C + ns - 1) / ns + 3) / 4 * 4;
+        if (ns > 1 && (long)cps * (ns - 1) >= C) continue;
+        const long rounds = ((long)tiles * ns + 255) / 256;
+        const long its = (cps + cls_per_step - 1) / cls_per_step;
+        const long cost = rounds * (its + fixed_steps);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ns; }
+    }
+    return best;
+}
+int ctc_head_nsplit(int M, int C, bool split_fp16) {
+    return split_fp16 ? ctc_pick_nsplit(M, C, CH_TOK, CH_CLS, 3) : ctc_pick_nsplit(M, C, CT_TOK, CT_CLS, 2);
 }
 
 void launch_ctc_head(const CtcParams& p, hipStream_t s) {
     if (p.M <= 0) return;
-    const int tiles = (p.M + CT_TOK - 1) / CT_TOK;
     int cps = (p.C + p.nsplit - 1) / p.nsplit;
     cps = (cps + 3) / 4 * 4;
-    const size_t sh = (size_t)(CT_TOK + CT_CLS) * CT_LD * sizeof(float);
-    const size_t sh3 = (size_t)(2 * CT_TOK * CH_LD + 2 * CT_CLS * CT_K) * sizeof(_Float16);
     static unsigned long long lds_ok = 0, lds_ok3 = 0;
-    rd_allow_dynamic_lds((const void*)ctc_head_kernel, sh, lds_ok);
-    rd_allow_dynamic_lds((const void*)ctc_head_h3_kernel, sh3, lds_ok3);
-    if (p.wh) hipLaunchKernelGGL(ctc_head_h3_kernel, dim3(tiles * p.nsplit), dim3(256), sh3, s, p, cps);
-    else hipLaunchKernelGGL(ctc_head_kernel, dim3(tiles * p.nsplit), dim3(256), sh, s, p, cps);
+    if (p.wh) {
+        const int tiles = (p.M + CH_TOK - 1) / CH_TOK;
+        const size_t sh3 = (size_t)(2 * 2 * CH_CLS * CT_K) * sizeof(_Float16);   // two (hi, lo) class tiles
+        const int per_xcd = (tiles * p.nsplit + 7) / 8;
+        static const int mode = std::getenv("RD_CTC_MODE") ? atoi(std::getenv("RD_CTC_MODE")) : 0;
+        static unsigned long long okm[4] = {};
+#define RD_CTC_CASE(A) case A: rd_allow_dynamic_lds((const void*)ctc_head_h3_kernel<A>, sh3, okm[A]); \
+        hipLaunchKernelGGL(ctc_head_h3_kernel<A>, dim3(per_xcd * 8), dim3(512), sh3, s, p, cps, tiles, per_xcd); break;
+        switch (mode) { RD_CTC_CASE(1) RD_CTC_CASE(2) RD_CTC_CASE(3) default: RD_CTC_CASE(0) }
+#undef RD_CTC_CASE
+    } else {
+        const int tiles = (p.M + CT_TOK - 1) / CT_TOK;
+        const size_t sh = (size_t)(CT_TOK + CT_CLS) * CT_LD * sizeof(float);
+        rd_allow_dynamic_lds((const void*)ctc_head_kernel, sh, lds_ok);
+        hipLaunchKernelGGL(ctc_head_kernel, dim3(tiles * p.nsplit), dim3(256), sh, s, p, cps);
+    }
     hipLaunchKernelGGL(ctc_merge_kernel, dim3((p.M + 255) / 256), dim3(256), 0, s, p.part, p.M, p.nsplit, p.idx, p.prob);
 }
 

@@ -229,8 +229,15 @@ static inline void dw_tiled_geom(const DwParams& p, int TW, int& c4n, int& threa
     groups_w = (p.OW + TW - 1) / TW;
     groups = p.OH * groups_w;
     const int lanes_p = threads / c4n;
-    gpb = lanes_p * 4;
-    // enough blocks to fill the chip a few times over, but not so many that the SE partial buffer explodes
+    // groups per pixel lane: 4 on the large maps (fewer, longer blocks), down to 1 when that would leave the chip under-filled:
+    // the recogniser's 6 x 68 x 192 maps gave 192 blocks of 4 wavefronts (under one wavefront per SIMD) with a fixed 4, and the
+    // kernel ran latency-bound at 2.3 TB/s
+    static const int k_env = std::getenv("RD_DW_GPL") ? atoi(std::getenv("RD_DW_GPL")) : 0;
+    int k = 4;
+    while (k > 1 && (long)((groups + lanes_p * k - 1) / (lanes_p * k)) * p.N < 4096) --k;
+    if (k_env > 0) k = k_env;
+    gpb = lanes_p * k;
+    // ... but not so many blocks that the SE partial buffer explodes
     while ((long)((groups + gpb - 1) / gpb) * p.N > 8192) gpb += lanes_p;
     chunks = (groups + gpb - 1) / gpb;
 }

@@ -128,7 +128,7 @@ struct CtcParams {
     unsigned* range_flag = nullptr;
 };
 void launch_ctc_head(const CtcParams& p, hipStream_t s);   // dispatches on p.wh
-int ctc_head_nsplit(int M, int C);
+int ctc_head_nsplit(int M, int C, bool split_fp16);   // class splits the kernel that launch_ctc_head picks (p.wh set or not) wants
 
 // layout conversion at the C-ABI boundary
 void launch_nhwc_to_nchw(const float* x, int xld, float* y, int N, int H, int W, int C, hipStream_t s);

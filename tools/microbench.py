@@ -34,6 +34,38 @@ def mixer(C_, M, variant, iters=20, check=False):
     return ms, 8.0 * M * C_ * C_ / ms / 1e9
 
 
+def ctc(M, Ccls=18385, K=120, nsplit=0, iters=20, split=True):
+    """Fused CTC head in isolation (weights prepared here the way engine.cpp does: bias in column K, hi/lo fp16 split)."""
+    lib.rd_debug_time_ctc.restype = C.c_float
+    lib.rd_debug_time_ctc.argtypes = [C.c_int] * 4 + [C.c_void_p] * 7 + [C.c_int, C.c_void_p]
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.rand((M, K), device="cuda", generator=g) - 0.5
+    wp = torch.zeros((Ccls, 128), device="cuda")
+    wp[:, :K] = (torch.rand((Ccls, K), device="cuda", generator=g) - 0.5) * 0.2
+    wp[:, K] = torch.rand((Ccls,), device="cuda", generator=g) - 0.5
+    hi = wp.half()
+    lo = ((wp - hi.float()) * 2048.0).half()
+    part = torch.empty((M * 64 * 4,), device="cuda")
+    idx = torch.empty((M,), dtype=torch.int32, device="cuda")
+    prob = torch.empty((M,), device="cuda")
+    ns = C.c_int(0)
+    ms = lib.rd_debug_time_ctc(M, K, Ccls, iters, x.data_ptr(), wp.data_ptr(), hi.data_ptr() if split else None, lo.data_ptr() if split else None,
+                               part.data_ptr(), idx.data_ptr(), prob.data_ptr(), nsplit, C.byref(ns))
+    lg = (x.double() @ wp[:, :K].double().t() + wp[:, K].double())[:512]
+    ok = bool((lg.argmax(1).int() == idx[:512]).all())
+    perr = float((torch.softmax(lg, 1).max(1).values - prob[:512].double()).abs().max())
+    return ms, 2.0 * M * K * Ccls / ms / 1e9, ns.value, ok, perr
+
+
+if __name__ == "__main__" and "--ctc" in sys.argv:
+    for M in (2176, 4352, 6528, 8704, 4352 * 23):
+        for ns in (0, 8):
+            ms, tf, n, ok, perr = ctc(M, nsplit=ns)
+            print(f"ctc head M={M} nsplit {n:2d}: {ms*1e3:8.1f} us {tf:7.1f} TF/s  argmax ok {ok}  prob err {perr:.1e}", flush=True)
+    ms, tf, n, ok, perr = ctc(4352, split=False)
+    print(f"ctc head fp32 MFMA M=4352 nsplit {n}: {ms*1e3:8.1f} us {tf:7.1f} TF/s  argmax ok {ok}  prob err {perr:.1e}")
+    sys.exit(0)
+
 if __name__ == "__main__" and "--mixer-ws" in sys.argv:
     # round 2: weight-streaming mixer (variant 200 + bits: 1 lock step instead of per-wavefront phases, 2 flipped residual
     # policy) vs the round-1 kernel (100); then ablations (+ 256 * bits, C = 192, garbage results)
