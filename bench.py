@@ -324,7 +324,7 @@ def main():
         if args.dump_profile:
             with open(args.dump_profile + ".ops.json", "w") as f:
                 json.dump({"det": sum((q.det.profile_log for q in pool.pipes), []),
-                           "rec": sum((e.profile_log for q in pool.pipes for e in q.rec_engines), []),
+                           "rec": sum((e.profile_log for q in pool.pipes for e in q.rec_engines + [q.rec_tail]), []),
                            "layout": sum((q.layout.profile_log for q in pool.pipes), [])}, f)
             table = sorted(((k, v[3], v[2], v[0] / 1e9, v[1] / 1e6) for k, v in agg.items()), key=lambda r: -r[2])
             with open(args.dump_profile, "w") as f:

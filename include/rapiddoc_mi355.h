@@ -61,6 +61,22 @@ int rd_det_forward(rd_handle* h, const float* x_nchw_dev, int B, int H, int W, f
 int rd_rec_forward(rd_handle* h, const float* x_nchw_dev, int B, int W, int32_t* idx_bt_dev, float* prob_bt_dev,
                    float* full_btc_dev, int flags, void* ws_dev, size_t ws_bytes, void* stream);
 int rd_rec_num_classes(rd_handle* h);
+/* The same network in two stages, for a pipeline that recognises the lines of many batches (rapid_ocr.py:430-449 loops over
+ * `rec_batch_num` chunks and calls the session once per chunk): the neck and the CTC head of one chunk are ~25 launches on a few
+ * thousand tokens - launch latency - so the chunks run only the backbone, each writing its tokens into ONE buffer, and the tail
+ * runs once over all of them.  The results are those of rd_rec_forward chunk by chunk.
+ *   rd_rec_backbone_forward: x [B,3,48,W] -> tokens [B][T = rd_rec_seq_len(W)][rd_rec_token_dim()] float32
+ *   rd_rec_tail_forward:     tokens [n_tokens][dim] of n_lines text lines (any mix of lengths) -> idx / prob [n_tokens];
+ *                            seg_dev = int32 [n_lines][2] (first token, tokens) per line, tokinfo_dev = int32 [n_tokens]
+ *                            (position in its line | tokens of the line << 16), max_tokens = the longest line (< 32768)
+ * rd_query_workspace(h, B, 0, W, RD_REC_STAGE_BACKBONE) resp. (h, n_lines, max_tokens, n_tokens, RD_REC_STAGE_TAIL) size them. */
+#define RD_REC_STAGE_BACKBONE 8
+#define RD_REC_STAGE_TAIL 16
+int rd_rec_token_dim(rd_handle* h);
+int rd_rec_backbone_forward(rd_handle* h, const float* x_nchw_dev, int B, int W, float* tokens_btd_dev, void* ws_dev, size_t ws_bytes,
+                            void* stream);
+int rd_rec_tail_forward(rd_handle* h, const float* tokens_dev, int n_tokens, int n_lines, int max_tokens, const int32_t* seg_dev,
+                        const int32_t* tokinfo_dev, int32_t* idx_dev, float* prob_dev, void* ws_dev, size_t ws_bytes, void* stream);
 /* number of CTC time steps the rec network emits for input width W (stride-2 stem x2, then avg-pool (3,2)) */
 int rd_rec_seq_len(int W);
 

@@ -89,7 +89,7 @@ int rd_query_workspace(rd_handle* h, int B, int H, int W, int flags, size_t* ws_
     return guarded(h, [&] {
         RD_CHECK(ws_bytes, "ws_bytes is NULL");
         RD_CHECK(h->eng, "this model kind owns its workspace");
-        if (h->eng->kind() == "ppocrv6_rec") H = 48;
+        if (h->eng->kind() == "ppocrv6_rec" && !(flags & rd::REC_STAGE_TAIL)) H = 48;
         *ws_bytes = h->eng->workspace_bytes(B, H, W, flags);
     });
 }
@@ -110,6 +110,23 @@ int rd_rec_forward(rd_handle* h, const float* x, int B, int W, int32_t* idx, flo
         if (flags & (RD_REC_WANT_SOFTMAX | RD_REC_WANT_LOGITS)) RD_CHECK(full, "full_btc_dev is NULL");
         RD_CHECK(!((flags & RD_REC_WANT_SOFTMAX) && (flags & RD_REC_WANT_LOGITS)), "choose softmax OR logits");
         h->eng->run(B, 48, W, flags, {(void*)x, (void*)idx, (void*)prob, (void*)full}, ws, ws_bytes, (hipStream_t)stream);
+    });
+}
+int rd_rec_token_dim(rd_handle* h) { return (h && h->eng && h->eng->kind() == "ppocrv6_rec") ? h->eng->rec_token_dim() : -1; }
+int rd_rec_backbone_forward(rd_handle* h, const float* x, int B, int W, float* tokens, void* ws, size_t ws_bytes, void* stream) {
+    return guarded(h, [&] {
+        RD_CHECK(h->eng && h->eng->kind() == "ppocrv6_rec", "handle is not a ppocrv6_rec model");
+        RD_CHECK(x && tokens && B > 0, "null input/output");
+        h->eng->run(B, 48, W, rd::REC_STAGE_BACKBONE, {(void*)x, (void*)tokens}, ws, ws_bytes, (hipStream_t)stream);
+    });
+}
+int rd_rec_tail_forward(rd_handle* h, const float* tokens, int n_tokens, int n_lines, int max_tokens, const int32_t* seg,
+                        const int32_t* tokinfo, int32_t* idx, float* prob, void* ws, size_t ws_bytes, void* stream) {
+    return guarded(h, [&] {
+        RD_CHECK(h->eng && h->eng->kind() == "ppocrv6_rec", "handle is not a ppocrv6_rec model");
+        RD_CHECK(tokens && seg && tokinfo && idx && prob && n_tokens > 0 && n_lines > 0 && max_tokens > 0, "null input/output");
+        h->eng->run(n_lines, max_tokens, n_tokens, rd::REC_STAGE_TAIL,
+                    {(void*)tokens, (void*)idx, (void*)prob, nullptr, (void*)seg, (void*)tokinfo}, ws, ws_bytes, (hipStream_t)stream);
     });
 }
 int rd_rec_seq_len(int W) {

@@ -613,7 +613,7 @@ TView Builder::stem3x3s2(const std::string& wname, const std::string& bn, const 
 }
 
 TView Builder::dwconv(const std::string& wname, const std::string& bname, const std::string& bn, const TView& x,
-                      const ConvGeom& g, int act, const TView* out, const TView* res, GapOut* gap) {
+                      const ConvGeom& g, int act, const TView* out, const TView* res, GapOut* gap, const TView* tokinfo) {
     const HostTensor& w = ws_->get(wname);
     RD_CHECK(w.shape.size() == 4 && w.shape[1] == 1, "depthwise weight shape: " + wname);
     const int c = (int)w.shape[0], kh = (int)w.shape[2], kw = (int)w.shape[3];
@@ -668,12 +668,16 @@ TView Builder::dwconv(const std::string& wname, const std::string& bname, const 
     const TView rv = res ? *res : TView{};
     const bool has_gap = gap && gap->chunks > 0;
     const TView gpv = has_gap ? gap->partial : TView{};
-    r.run = [p, xv, yv, rv, has_res, has_gap, gpv](const Plan& pl, const RunCtx& cx) {
+    const bool ragged = tokinfo != nullptr;
+    RD_CHECK(!ragged || (kh == 1 && g.sw == 1 && x.n == 1 && x.h == 1 && x.w < (1 << 30)), "ragged depthwise conv: 1 x k over one token row");
+    const TView tiv = ragged ? *tokinfo : TView{};
+    r.run = [p, xv, yv, rv, has_res, has_gap, gpv, ragged, tiv](const Plan& pl, const RunCtx& cx) {
         DwParams q = p;
         q.x = pl.vptr(xv, cx);
         q.y = pl.vptr(yv, cx);
         q.res = has_res ? pl.vptr(rv, cx) : nullptr;
         q.gap_partial = has_gap ? pl.vptr(gpv, cx) : nullptr;
+        q.tokinfo = ragged ? reinterpret_cast<const int32_t*>(pl.vptr(tiv, cx)) : nullptr;
         launch_dwconv(q, cx.stream);
     };
     emit(std::move(r));
@@ -694,9 +698,11 @@ void Builder::maxpool2x2s1(const TView& x, const TView& out) {
     emit(std::move(r));
 }
 
-TView Builder::avgpool3x2(const TView& x) {
+TView Builder::avgpool3x2(const TView& x, const TView* out) {
     RD_CHECK(x.h >= 3 && x.w >= 2, "avg_pool2d([3,2]): feature map too small");  // rec_lcnetv4.py:309-310
-    TView y = alloc(x.n, (x.h - 3) / 3 + 1, (x.w - 2) / 2 + 1, x.c);
+    const int oh = (x.h - 3) / 3 + 1, ow = (x.w - 2) / 2 + 1;
+    TView y = out ? *out : alloc(x.n, oh, ow, x.c);
+    RD_CHECK(y.n == x.n && y.h == oh && y.w == ow && y.c == x.c, "avgpool3x2: output view mismatch");
     if (!planning()) return y;
     OpRecord r;
     r.name = "avgpool3x2";
@@ -821,7 +827,7 @@ TView Builder::layernorm(const std::string& prefix, const TView& x, float eps) {
     return y;
 }
 
-TView Builder::attention(const TView& qkv, int B, int T, int heads, int hd) {
+TView Builder::attention(const TView& qkv, int B, int T, int heads, int hd, const TView* seg) {
     RD_CHECK(qkv.c == 3 * heads * hd && qkv.coff == 0 && plan_->ld(qkv) == qkv.c, "attention: packed qkv expected");
     RD_CHECK(hd == 15 || hd == 16 || hd == 32, "attention: head_dim 15/16/32");
     RD_CHECK((size_t)2 * T * hd * sizeof(float) <= 160 * 1024 - 1024, "attention: sequence too long for LDS");
@@ -833,8 +839,11 @@ TView Builder::attention(const TView& qkv, int B, int T, int heads, int hd) {
     r.kind = "attention";
     r.flops = 4.0 * B * heads * (double)T * T * hd;
     const TView qv = qkv, ov = o;
-    r.run = [qv, ov, B, T, heads, hd, sc](const Plan& pl, const RunCtx& c) {
-        launch_attention(pl.vptr(qv, c), pl.vptr(ov, c), B, T, heads, hd, sc, c.stream);
+    const bool ragged = seg != nullptr;
+    const TView sv = ragged ? *seg : TView{};
+    r.run = [qv, ov, B, T, heads, hd, sc, ragged, sv](const Plan& pl, const RunCtx& c) {
+        launch_attention(pl.vptr(qv, c), pl.vptr(ov, c), B, T, heads, hd, sc, c.stream,
+                         ragged ? reinterpret_cast<const int32_t*>(pl.vptr(sv, c)) : nullptr);
     };
     emit(std::move(r));
     return o;
@@ -1005,7 +1014,10 @@ void Engine::load_weights(const void* blob, size_t nbytes) {
     RD_HIP(hipSetDevice(device_));
     RD_CHECK(!loaded_, "weights already loaded for this handle");
     store_.load_safetensors(blob, nbytes);
-    if (kind_ == "ppocrv6_rec") n_classes_ = (int)store_.get("head.head.weight").shape[0];  // torch.py:112-116
+    if (kind_ == "ppocrv6_rec") {
+        n_classes_ = (int)store_.get("head.head.weight").shape[0];  // torch.py:112-116
+        rec_token_dim_ = (int)store_.get("head.encoder.conv_block.0.convolution.weight").shape[1];
+    }
     Plan dummy;
     h3_prepared_ = precision_ == PREC_H3;
     RD_HIP(hipMalloc((void**)&range_flag_, sizeof(unsigned)));
@@ -1075,7 +1087,14 @@ void Engine::run(int B, int H, int W, int flags, const std::vector<void*>& ext, 
     for (const Buf& b : plan.bufs)
         if (b.external >= 0) RD_CHECK(b.external < (int)ext.size() && ext[b.external], "missing external buffer");
     if (!profiling_) {
-        for (const OpRecord& op : plan.ops) op.run(plan, ctx);
+        // developer what-if (timing only, results are garbage): RD_SKIP_KIND=<op kind> leaves those launches out
+        static const char* skip_kind = std::getenv("RD_SKIP_KIND");
+        if (skip_kind) {
+            for (const OpRecord& op : plan.ops)
+                if (op.kind != skip_kind) op.run(plan, ctx);
+        } else {
+            for (const OpRecord& op : plan.ops) op.run(plan, ctx);
+        }
         RD_HIP(hipGetLastError());
         return;
     }

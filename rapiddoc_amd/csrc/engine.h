@@ -158,16 +158,18 @@ class Builder {
     TView stem3x3s2(const std::string& wname, const std::string& bn, const TView& x_nchw, int act);
     struct GapOut { TView partial; int chunks = 0; };  // per-image partial sums of a layer's output (SE pooling)
     TView dwconv(const std::string& wname, const std::string& bname, const std::string& bn, const TView& x,
-                 const ConvGeom& g, int act, const TView* out = nullptr, const TView* res = nullptr, GapOut* gap = nullptr);
+                 const ConvGeom& g, int act, const TView* out = nullptr, const TView* res = nullptr, GapOut* gap = nullptr,
+                 const TView* tokinfo = nullptr);   // tokinfo: ragged rows (DwParams::tokinfo), an int32 external of x.pixels() entries
     void maxpool2x2s1(const TView& x, const TView& out);
-    TView avgpool3x2(const TView& x);
+    TView avgpool3x2(const TView& x, const TView* out = nullptr);
     // squeeze-excite gate s[n][c]; `w1/b1/w2/b2` full tensor names
     TView se_gate(const std::string& w1, const std::string& b1, const std::string& w2, const std::string& b2,
                   const TView& x, int gate_act, const GapOut* pre = nullptr);
     void scale(const TView& x, const TView& gate, float alpha, const TView& out);
     void upsample(const TView& x, const TView& out, int f, bool accumulate);
     TView layernorm(const std::string& prefix, const TView& x, float eps);
-    TView attention(const TView& qkv, int B, int T, int heads, int hd);
+    // seg: ragged batch - int32 external [B][2] = (first token, tokens) of every sequence; T = the longest sequence
+    TView attention(const TView& qkv, int B, int T, int heads, int hd, const TView* seg = nullptr);
     TView add(const TView& a, const TView& b);
     void to_nchw(const TView& x, const TView& out_ext);
     void copy(const TView& x, const TView& out);   // same geometry, possibly different channel strides
@@ -213,6 +215,7 @@ class Engine {
     const std::vector<ProfileEntry>& last_profile() const { return profile_; }
     std::string profile_json() const;
     int n_classes() const { return n_classes_; }
+    int rec_token_dim() const { return rec_token_dim_; }   // channels of the rec backbone's pooled tokens (two-stage form)
     bool h3() const { return precision_ == PREC_H3; }
     int device() const { return device_; }
     // Arithmetic of the dense layers.  Every mode returns fp32 results with fp32-level error:
@@ -239,6 +242,7 @@ class Engine {
     bool h3_prepared_ = false;
     unsigned* range_flag_ = nullptr;
     int n_classes_ = 0;
+    int rec_token_dim_ = 0;
     ParamBlock params_;
     WeightStore store_;
     std::map<std::tuple<int, int, int, int>, std::unique_ptr<Plan>> plans_;
@@ -250,7 +254,10 @@ class Engine {
 
 // model builders (models.cpp)
 void build_ppocrv6_det(Builder& b, int B, int H, int W);
-enum RecFlags : int { REC_UNFUSED_CTC = 1, REC_WANT_SOFTMAX = 2, REC_WANT_LOGITS = 4 };
+// REC_STAGE_BACKBONE: image -> pooled tokens only (ext[1] = [B][T][C] out).  REC_STAGE_TAIL: the LightSVTR neck + CTC head over
+// the tokens of MANY batches at once (B = text lines, H = longest line in tokens, W = all tokens; ext: 0 tokens, 1 idx,
+// 2 prob, 4 seg int32 [B][2], 5 tokinfo int32 [W]) - see build_ppocrv6_rec
+enum RecFlags : int { REC_UNFUSED_CTC = 1, REC_WANT_SOFTMAX = 2, REC_WANT_LOGITS = 4, REC_STAGE_BACKBONE = 8, REC_STAGE_TAIL = 16 };
 void build_ppocrv6_rec(Builder& b, int B, int H, int W, int flags);
 void build_pphgnetv2_b4(Builder& b, int B, int H, int W);
 // PP-FormulaNet_plus encoder; flags bit 0: the caller's image has 1 channel (replicated to 3 like the reference)

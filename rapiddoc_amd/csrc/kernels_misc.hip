@@ -40,12 +40,18 @@ __global__ void __launch_bounds__(256) dwconv_kernel(DwParams p) {
         f32x4 acc = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         const float* xb = p.x + (size_t)b * p.H * p.W * p.xld + c;
         const int ih0 = oh * p.SH - p.PT, iw0 = ow * p.SW - p.PL;
+        int w_lo = 0, w_hi = p.W;                 // valid input columns: the row, or this token's text line (ragged rows)
+        if (p.tokinfo) {
+            const int ti = p.tokinfo[pix];
+            w_lo = ow - (ti & 0xffff);
+            w_hi = w_lo + (ti >> 16);
+        }
         for (int kh = 0; kh < p.KH; ++kh) {
             const int ih = ih0 + kh;
             if ((unsigned)ih >= (unsigned)p.H) continue;
             for (int kw = 0; kw < p.KW; ++kw) {
                 const int iw = iw0 + kw;
-                if ((unsigned)iw >= (unsigned)p.W) continue;
+                if (iw < w_lo || iw >= w_hi) continue;
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + ((size_t)ih * p.W + iw) * p.xld);
                 const f32x4 wv = *reinterpret_cast<const f32x4*>(p.w + (size_t)(kh * p.KW + kw) * p.C + c);
                 acc += xv * wv;
@@ -262,6 +268,11 @@ int dwconv_gap_chunks(const DwParams& p) {
 }
 
 void launch_dwconv(const DwParams& p, hipStream_t s) {
+    if (p.tokinfo) {      // ragged rows: only the per-pixel kernel knows about line ends
+        const long total = (long)p.N * p.OH * p.OW * (p.C >> 2);
+        hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for(total)), dim3(256), 0, s, p);
+        return;
+    }
     if (dw_col_applies(p)) {
         int c4n, threads, gw, gpb, chunks;
         dw_col_geom(p, c4n, threads, gw, gpb, chunks);
@@ -520,7 +531,7 @@ void launch_layernorm(const float* x, int xld, float* y, int yld, const float* g
 // (row max, then exp/sum/PV) exactly like a max-subtracted softmax.
 // --------------------------------------------------------------------------------------------------
 template <int HD>
-__global__ void __launch_bounds__(256) attention_kernel(const float* qkv, float* o, int T, int heads, float scale) {
+__global__ void __launch_bounds__(256) attention_kernel(const float* qkv, float* o, int T, int heads, float scale, const int32_t* seg) {
     // K / V rows are padded to HDP = 16 / 32 floats in LDS so that a key costs HDP / 4 ds_read_b128 (every lane reads the same
     // address: a broadcast) instead of HD ds_read_b32 - round 1's 15 scalar reads per dot product made this kernel LDS-issue
     // bound (51 us per launch for 0.4 GFLOP); same two-pass max-subtracted softmax, same operation order per element.
@@ -531,7 +542,12 @@ __global__ void __launch_bounds__(256) attention_kernel(const float* qkv, float*
     f32x4* Vs = Ks + (size_t)T * NV;
     const int b = blockIdx.x, h = blockIdx.y;
     const int C = heads * HD;
-    const float* base = qkv + (size_t)b * T * 3 * C;
+    size_t tok0 = (size_t)b * T;
+    if (seg) {                 // ragged batch: this sequence's own offset and length (T was the longest: it sized the LDS)
+        tok0 = (size_t)seg[2 * b];
+        T = seg[2 * b + 1];
+    }
+    const float* base = qkv + tok0 * 3 * C;
     for (int i = threadIdx.x; i < T * HDP; i += 256) {
         const int t = i / HDP, d = i - t * HDP;
         reinterpret_cast<float*>(Ks)[i] = d < HD ? base[(size_t)t * 3 * C + C + h * HD + d] : 0.f;
@@ -572,7 +588,7 @@ __global__ void __launch_bounds__(256) attention_kernel(const float* qkv, float*
             }
         }
         const float inv = 1.f / l;
-        float* op = o + ((size_t)b * T + t) * C + h * HD;
+        float* op = o + (tok0 + t) * C + h * HD;
 #pragma unroll
         for (int v = 0; v < NV; ++v)
 #pragma unroll
@@ -580,14 +596,14 @@ __global__ void __launch_bounds__(256) attention_kernel(const float* qkv, float*
                 if (4 * v + c < HD) op[4 * v + c] = acc[v][c] * inv;
     }
 }
-void launch_attention(const float* qkv, float* o, int B, int T, int heads, int hd, float scale, hipStream_t s) {
+void launch_attention(const float* qkv, float* o, int B, int T, int heads, int hd, float scale, hipStream_t s, const int32_t* seg) {
     const size_t sh = (size_t)2 * T * ((hd + 3) / 4 * 4) * sizeof(float);
     if (hd == 15)
-        hipLaunchKernelGGL(attention_kernel<15>, dim3(B, heads), dim3(256), sh, s, qkv, o, T, heads, scale);
+        hipLaunchKernelGGL(attention_kernel<15>, dim3(B, heads), dim3(256), sh, s, qkv, o, T, heads, scale, seg);
     else if (hd == 16)
-        hipLaunchKernelGGL(attention_kernel<16>, dim3(B, heads), dim3(256), sh, s, qkv, o, T, heads, scale);
+        hipLaunchKernelGGL(attention_kernel<16>, dim3(B, heads), dim3(256), sh, s, qkv, o, T, heads, scale, seg);
     else if (hd == 32)
-        hipLaunchKernelGGL(attention_kernel<32>, dim3(B, heads), dim3(256), sh, s, qkv, o, T, heads, scale);
+        hipLaunchKernelGGL(attention_kernel<32>, dim3(B, heads), dim3(256), sh, s, qkv, o, T, heads, scale, seg);
 }
 
 // --------------------------------------------------------------------------------------------------

@@ -174,20 +174,53 @@ void build_ppocrv6_det(Builder& b, int B, int H, int W) {
 // ---------------------------------------------------------------------------------------------------
 // PP-OCRv6 rec small.  ext[0] = x NCHW [B,3,48,W]; ext[1] = idx i32 [B*T]; ext[2] = prob f32 [B*T];
 // ext[3] = optional [B,T,C] softmax probabilities or raw logits (flags)
+//
+// Two-stage form for the page pipeline (the neck + head of one 64-line batch is ~25 launches of 17-30 us on 4352 tokens:
+// pure launch latency, ~45 % of a batch's kernel count for ~3 % of its FLOPs):
+//   REC_STAGE_BACKBONE   x -> avg-pooled backbone tokens only: ext[1] = [B][T][384] f32 out (the caller points it INTO one
+//                        token buffer shared by all batches of the page group)
+//   REC_STAGE_TAIL       LightSVTR neck + CTC head ONCE over the tokens of all batches: B = text lines, H = the longest
+//                        line in tokens, W = all tokens; ext[0] = tokens [W][384], ext[1] / ext[2] = idx / prob [W],
+//                        ext[4] = seg i32 [B][2] (first token, tokens per line), ext[5] = tokinfo i32 [W] (position in the
+//                        line | tokens of the line << 16).  Every layer of the neck is row-wise except the 1x7 depthwise
+//                        conv and the attention, which take the line structure from those two tables; lines of different
+//                        batches (different widths) simply have different lengths.
 // ---------------------------------------------------------------------------------------------------
 void build_ppocrv6_rec(Builder& b, int B, int H, int W, int flags) {
-    RD_CHECK(H == 48, "rec input height must be 48");
-    RD_CHECK(W >= 16, "rec input width must be >= 16");
-    TView x = b.external(0, B, H, W, 3);
-    std::vector<TView> f = lcnetv4(b, x, kRecSmall, 48, 96, false);
-    TView pooled = b.avgpool3x2(f[0]);  // [B,1,W/8,384]
-    b.release(f[0]);
-    const int T = pooled.w;
-    RD_CHECK(pooled.h == 1, "rec: pooled height");
-
+    const bool tail_only = (flags & REC_STAGE_TAIL) != 0, backbone_only = (flags & REC_STAGE_BACKBONE) != 0;
+    RD_CHECK(!(tail_only && backbone_only), "rec: choose one stage");
     const std::string e = "head.encoder";
     auto cw = [&](int i) { return e + ".conv_block." + std::to_string(i) + ".convolution.weight"; };
     auto cbn = [&](int i) { return e + ".conv_block." + std::to_string(i) + ".normalization"; };
+    TView pooled, seg, tokinfo;
+    int T, n_seq = B;
+    if (tail_only) {
+        RD_CHECK((flags & ~REC_STAGE_TAIL) == 0, "rec tail: fused CTC only");
+        RD_CHECK(B >= 1 && H >= 1 && H < 32768 && W >= B, "rec tail: B lines, H = longest line (tokens), W = all tokens");
+        pooled = b.external(0, 1, 1, W, b.weight_dim(cw(0), 1));
+        seg = b.external(4, B, 1, 1, 2);
+        tokinfo = b.external(5, 1, 1, W, 1);
+        T = H;
+    } else {
+        RD_CHECK(H == 48, "rec input height must be 48");
+        RD_CHECK(W >= 16, "rec input width must be >= 16");
+        TView x = b.external(0, B, H, W, 3);
+        std::vector<TView> f = lcnetv4(b, x, kRecSmall, 48, 96, false);
+        if (backbone_only) {
+            RD_CHECK((flags & ~REC_STAGE_BACKBONE) == 0, "rec backbone stage takes no other flag");
+            TView out = b.external(1, B, 1, (f[0].w - 2) / 2 + 1, f[0].c);
+            b.avgpool3x2(f[0], &out);
+            b.release(f[0]);
+            return;
+        }
+        pooled = b.avgpool3x2(f[0]);  // [B,1,W/8,384]
+        b.release(f[0]);
+        T = pooled.w;
+        RD_CHECK(pooled.h == 1, "rec: pooled height");
+    }
+    const TView* ti = tail_only ? &tokinfo : nullptr;
+    const TView* sg = tail_only ? &seg : nullptr;
+
     TView res = b.conv(cw(0), "", cbn(0), pooled, geom(1), ACT_SILU);
     TView h = b.conv(cw(1), "", cbn(1), pooled, geom(1), ACT_SILU);
     b.release(pooled);
@@ -195,7 +228,7 @@ void build_ppocrv6_rec(Builder& b, int B, int H, int W, int flags) {
     g17.kh = 1;
     g17.kw = b.weight_dim(cw(2), 3);
     g17.pl = g17.pr = g17.kw / 2;
-    TView t = b.dwconv(cw(2), "", cbn(2), h, g17, ACT_SILU, nullptr, &h);  // h + silu(bn(dw(h)))
+    TView t = b.dwconv(cw(2), "", cbn(2), h, g17, ACT_SILU, nullptr, &h, nullptr, ti);  // h + silu(bn(dw(h)))
     b.release(h);
     const int C = t.c, heads = 8, hd = C / heads;
     int depth = 0;
@@ -205,7 +238,7 @@ void build_ppocrv6_rec(Builder& b, int B, int H, int W, int flags) {
         TView y = b.layernorm(p + ".layer_norm1", t, 1e-6f);
         TView qkv = b.linear(p + ".self_attn.qkv", y, ACT_NONE);
         b.release(y);
-        TView a = b.attention(qkv, B, T, heads, hd);
+        TView a = b.attention(qkv, n_seq, T, heads, hd, sg);
         b.release(qkv);
         TView t2 = b.linear(p + ".self_attn.projection", a, ACT_NONE, nullptr, &t);
         b.release(a);
@@ -224,7 +257,8 @@ void build_ppocrv6_rec(Builder& b, int B, int H, int W, int flags) {
     b.release(res);
 
     const int ncls = b.weight_dim("head.head.weight", 0);
-    TView idx = b.external(1, B, 1, T, 1), prob = b.external(2, B, 1, T, 1);
+    TView idx = tail_only ? b.external(1, 1, 1, W, 1) : b.external(1, B, 1, T, 1);
+    TView prob = tail_only ? b.external(2, 1, 1, W, 1) : b.external(2, B, 1, T, 1);
     const bool want_full = (flags & (REC_WANT_SOFTMAX | REC_WANT_LOGITS)) != 0;
     if ((flags & REC_UNFUSED_CTC) || want_full) {
         if (flags & REC_WANT_LOGITS) {

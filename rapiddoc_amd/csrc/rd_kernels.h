@@ -74,6 +74,9 @@ struct DwParams {
     const float* res; int rld;  // added after activation
     float* gap_partial;         // optional [N][gap_chunks][C] partial sums of the OUTPUT (SE fusion), or nullptr
     int gap_chunks;
+    // ragged rows (the recogniser's batched tail): the tensor is [1][1][W = all tokens][C], token i sits at position
+    // tokinfo[i] & 0xffff of a text line of tokinfo[i] >> 16 tokens and the kernel's horizontal taps stop at the line's ends
+    const int32_t* tokinfo = nullptr;
 };
 void launch_dwconv(const DwParams& p, hipStream_t s);
 // number of per-image partial-sum chunks launch_dwconv writes to p.gap_partial for this geometry (0 = the fused
@@ -105,7 +108,8 @@ void launch_upsample(const float* x, int xld, float* y, int yld, int N, int H, i
 void launch_layernorm(const float* x, int xld, float* y, int yld, const float* g, const float* b, int M, int C,
                       float eps, hipStream_t s);
 // qkv: [B*T][3*heads*hd] (q|k|v, head-major) -> o: [B*T][heads*hd]
-void launch_attention(const float* qkv, float* o, int B, int T, int heads, int hd, float scale, hipStream_t s);
+// seg != nullptr: ragged batch - sequence b is seg[2b+1] tokens starting at token seg[2b]; T is then the longest one
+void launch_attention(const float* qkv, float* o, int B, int T, int heads, int hd, float scale, hipStream_t s, const int32_t* seg = nullptr);
 
 // y = a + b (same geometry, views)
 void launch_add(const float* a, int ald, const float* b, int bld, float* y, int yld, int M, int C, hipStream_t s);

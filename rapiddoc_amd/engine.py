@@ -16,6 +16,16 @@ REC_UNFUSED_CTC, REC_WANT_SOFTMAX, REC_WANT_LOGITS = 1, 2, 4
 KINDS = ("ppocrv6_det", "ppocrv6_rec", "pphgnetv2_b4", "pphgnetv2_b6_formula", "ppformulanet_head")
 
 
+def ragged_tables(line_lengths: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """(seg int32 [n][2] = (first token, tokens) per line, tokinfo int32 [n_tokens] = position | tokens << 16)."""
+    lens = np.asarray(line_lengths, dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    seg = np.stack([off, lens], axis=1).astype(np.int32)
+    pos = np.arange(int(lens.sum()), dtype=np.int64) - np.repeat(off, lens)
+    tokinfo = (pos | (np.repeat(lens, lens) << 16)).astype(np.int32)
+    return seg, tokinfo
+
+
 class EngineError(RuntimeError):
     pass
 
@@ -122,6 +132,57 @@ class RdEngine:
             self._log()
         self._guarded(launch)
         return idx, prob, full
+
+    # two-stage form of the recogniser (include/rapiddoc_mi355.h: rd_rec_backbone_forward / rd_rec_tail_forward)
+    @property
+    def rec_token_dim(self) -> int:
+        return self._l.rd_rec_token_dim(self._h)
+
+    def rec_backbone_forward(self, x: torch.Tensor, tokens_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x [B,3,48,W] -> pooled backbone tokens [B, T, dim]; `tokens_out`: a contiguous float32 view to write them into."""
+        x = self._prep(x)
+        B, Cc, H, W_ = x.shape
+        if H != 48:
+            raise EngineError("rec input height must be 48")
+        T = self._l.rd_rec_seq_len(W_)
+        if tokens_out is None:
+            tokens_out = torch.empty((B, T, self.rec_token_dim), dtype=torch.float32, device=x.device)
+        if tokens_out.numel() != B * T * self.rec_token_dim or not tokens_out.is_contiguous() or tokens_out.dtype != torch.float32:
+            raise EngineError("tokens_out must be a contiguous float32 tensor of B*T*dim elements")
+
+        def launch():
+            self._chk(self._l.rd_rec_backbone_forward(self._h, x.data_ptr(), B, W_, tokens_out.data_ptr(), None, 0, _stream_ptr()))
+            self._log()
+        self._guarded(launch)
+        return tokens_out
+
+    def rec_tail_tables(self, line_lengths, device) -> torch.Tensor:
+        """The two int32 tables rd_rec_tail_forward wants, as one device tensor [2 * n_lines + n_tokens] (seg, then tokinfo)."""
+        seg_h, tokinfo_h = ragged_tables(np.asarray(line_lengths, dtype=np.int64))
+        host = torch.from_numpy(np.concatenate([seg_h.reshape(-1), tokinfo_h])).pin_memory()
+        return host.to(device, non_blocking=True)
+
+    def rec_tail_forward(self, tokens: torch.Tensor, line_lengths, tables: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """tokens [n_tokens, dim] = the text lines back to back, `line_lengths` their token counts -> (idx, prob) [n_tokens].
+        `tables`: rec_tail_tables(line_lengths) uploaded earlier (e.g. before the backbones were enqueued)."""
+        lens = np.asarray(line_lengths, dtype=np.int64)
+        n_tokens = int(lens.sum())
+        if tokens.numel() != n_tokens * self.rec_token_dim or lens.min() < 1 or lens.max() >= 32768:
+            raise EngineError("rec tail: token count / line lengths mismatch")
+        dev = tokens.device
+        if tables is None:
+            tables = self.rec_tail_tables(lens, dev)
+        seg, tokinfo = tables[: 2 * len(lens)], tables[2 * len(lens):]
+        idx = torch.empty((n_tokens,), dtype=torch.int32, device=dev)
+        prob = torch.empty((n_tokens,), dtype=torch.float32, device=dev)
+
+        def launch():
+            self._chk(self._l.rd_rec_tail_forward(self._h, tokens.data_ptr(), n_tokens, len(lens), int(lens.max()), seg.data_ptr(),
+                                                  tokinfo.data_ptr(), idx.data_ptr(), prob.data_ptr(), None, 0, _stream_ptr()))
+            self._log()
+        self._guarded(launch)
+        self._keep = (tables,)          # the tables must outlive the asynchronous launch
+        return idx, prob
 
     def backbone_forward(self, x: torch.Tensor) -> List[torch.Tensor]:
         x = self._prep(x)

@@ -8,6 +8,7 @@ boxes cross PCIe.
 """
 from __future__ import annotations
 
+import os
 import time
 import ctypes as C
 from concurrent.futures import ThreadPoolExecutor
@@ -105,6 +106,9 @@ class PagePipeline:
         self.rec_engines = [RdEngine("ppocrv6_rec", device, guard="deferred").load_weights(states["ppocrv6_rec"]) for _ in range(max(1, n_rec_streams))]
         self.rec = self.rec_engines[0]
         self.rec_streams = [torch.cuda.Stream(device=self.tdev) for _ in self.rec_engines]
+        # neck + CTC head of the two-stage recogniser: own handle (own workspace) and stream, it runs under the next backbones
+        self.rec_tail = RdEngine("ppocrv6_rec", device, guard="deferred").load_weights(states["ppocrv6_rec"])
+        self.tail_stream = torch.cuda.Stream(device=self.tdev)
         self.layout_stream = torch.cuda.Stream(device=self.tdev)
         self.layout = RdEngine("pphgnetv2_b4", device, guard="deferred").load_weights(states["pphgnetv2_b4"]) if "pphgnetv2_b4" in states else None
         ncls = self.rec.num_classes
@@ -118,6 +122,10 @@ class PagePipeline:
         self._ctc_table = torch.from_numpy(tab).to(self.tdev)
         self.device_ctc = True
         self.device_db = True            # DB post-process with the maps staying in HBM (ocr_host.db_postprocess_device)
+        # recogniser in two stages: the batches run only the backbone (each into its slice of one token buffer) on their
+        # streams, then the LightSVTR neck + CTC head run ONCE over all lines (rd_rec_tail_forward); RD_REC_TWO_STAGE=0: whole
+        # network batch by batch
+        self.rec_two_stage = os.environ.get("RD_REC_TWO_STAGE", "1") != "0"
         self.keep_rec_inputs = False      # tests: keep every rec batch's input tensor and raw (idx, prob) in last_rec_batches
         self.last_rec_batches: List[Tuple[np.ndarray, torch.Tensor, torch.Tensor, torch.Tensor]] = []
         self._lib = _lib.load()
@@ -147,10 +155,36 @@ class PagePipeline:
         (every caller - run_batch, analyze.RegionOcr, RegionTextModel - gets it): a tripped engine is switched to native
         fp32 and the lines are recognised again."""
         out = self._rec_forward_lines_once(pages, quads_per_page)
-        if any([e.check_range_and_fallback() for e in self.rec_engines]):     # list, not generator: check every engine
+        # a pass can trip a LATER stage only once the earlier one runs in fp32 (an overflowed backbone feeds the tail NaNs or
+        # finite-but-huge tokens), so check after every pass; a tripped engine stays in fp32, which bounds the loop
+        for _ in range(3):
+            if not any([e.check_range_and_fallback() for e in self.rec_engines + [self.rec_tail]]):     # list: check every engine
+                break
             self.stats["range_fallbacks"] = self.stats.get("range_fallbacks", 0) + 1
             out = self._rec_forward_lines_once(pages, quads_per_page)
         return out
+
+    def _collapse_rows(self, idx: torch.Tensor, prob: torch.Tensor, nb: int, st, record: bool = True):
+        """Device CTC collapse of one batch's (idx, prob) [nb, T] on stream `st` + the D2H of its rows into pinned memory;
+        returns (rows or None, event recorded after it or None)."""
+        rows = None
+        with torch.cuda.stream(st):
+            if self.device_ctc:
+                T = idx.shape[1]
+                row_bytes = (16 + T * self._ctc_max_len + 15) // 16 * 16
+                rows = torch.empty((nb, row_bytes), dtype=torch.uint8, device=idx.device)
+                rc = self._lib.rd_ctc_collapse(self.device, idx.data_ptr(), prob.data_ptr(), nb, T, self._ctc_table.data_ptr(),
+                                               self._ctc_max_len, len(self.characters), rows.data_ptr(), row_bytes, st.cuda_stream)
+                if rc != 0:
+                    raise RuntimeError("rd_ctc_collapse failed")
+                rows_h = torch.empty((nb, row_bytes), dtype=torch.uint8, pin_memory=True)
+                rows_h.copy_(rows, non_blocking=True)
+                rows = rows_h
+            done = None
+            if record:
+                done = torch.cuda.Event()
+                done.record(st)
+        return rows, done
 
     def _rec_forward_lines_once(self, pages: torch.Tensor, quads_per_page: Sequence[np.ndarray]):
         P, H, W, _ = pages.shape
@@ -198,12 +232,44 @@ class PagePipeline:
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(main)
+        two_stage = self.rec_two_stage
+        S = len(self.rec_engines)
+        if two_stage:
+            # the batches run the backbone only, each into its slice of one token buffer; the neck + CTC head then run once per
+            # GROUP of S consecutive batches (one per stream) on the tail stream, under the backbones of the next group
+            seq = [self._lib.rd_rec_seq_len(int(w)) for _c, w in batches]
+            tok_off = np.cumsum([0] + [len(c) * t for (c, _w), t in zip(batches, seq)])
+            tokens = torch.empty((int(tok_off[-1]), self.rec.rec_token_dim), dtype=torch.float32, device=pages.device)
+            groups = [list(range(g, min(g + S, len(batches)))) for g in range(0, len(batches), S)]
+            group_lens = [np.concatenate([np.full(len(batches[bi][0]), seq[bi], dtype=np.int64) for bi in grp]) for grp in groups]
+            group_tables = [self.rec_tail.rec_tail_tables(l, pages.device) for l in group_lens]   # uploaded now, used later
+            ready.record(main)
+            self.tail_stream.wait_event(ready)
+
+        def run_tail(gi):
+            grp = groups[gi]
+            t_lo, t_hi = int(tok_off[grp[0]]), int(tok_off[grp[-1] + 1])
+            for bi in grp:
+                self.tail_stream.wait_event(outs[bi][2])
+            with torch.cuda.stream(self.tail_stream):
+                idx_all, prob_all = self.rec_tail.rec_tail_forward(tokens[t_lo:t_hi], group_lens[gi], group_tables[gi])
+            done = None
+            for bi in grp:
+                nb, t = len(batches[bi][0]), seq[bi]
+                lo, hi = int(tok_off[bi]) - t_lo, int(tok_off[bi + 1]) - t_lo
+                idx, prob = idx_all[lo:hi].view(nb, t), prob_all[lo:hi].view(nb, t)
+                rows, ev = self._collapse_rows(idx, prob, nb, self.tail_stream, record=bi == grp[-1])
+                done = ev or done
+                outs[bi] = (idx, prob, None, outs[bi][3], rows)
+            for bi in grp:
+                outs[bi] = outs[bi][:2] + (done,) + outs[bi][3:]
+
         for bi, (chunk, wpad) in enumerate(batches):
             nb = len(chunk)
-            k = bi % len(self.rec_engines)
+            k = bi % S
             st = self.rec_streams[k]
-            if bi < len(self.rec_engines):
-                st.wait_event(ready)          # descriptors (and the pages) are ready
+            if bi < S:
+                st.wait_event(ready)          # descriptors (and the pages, the token buffer) are ready
             with torch.cuda.stream(st):
                 x = torch.empty((nb, 3, ocr_host.REC_IMG_H, wpad), dtype=torch.float32, device=pages.device)
                 d = descs[pos:pos + nb]
@@ -213,23 +279,20 @@ class PagePipeline:
                     ocr_host.REC_IMG_H, wpad, 1, x.data_ptr(), st.cuda_stream)
                 if rc != 0:
                     raise RuntimeError("rd_line_crops_batch failed")
-                idx, prob, _ = self.rec_engines[k].rec_forward(x)
-                rows = None
-                if self.device_ctc:
-                    T = idx.shape[1]
-                    row_bytes = (16 + T * self._ctc_max_len + 15) // 16 * 16
-                    rows = torch.empty((nb, row_bytes), dtype=torch.uint8, device=pages.device)
-                    rc = self._lib.rd_ctc_collapse(self.device, idx.data_ptr(), prob.data_ptr(), nb, T, self._ctc_table.data_ptr(),
-                                                   self._ctc_max_len, len(self.characters), rows.data_ptr(), row_bytes, st.cuda_stream)
-                    if rc != 0:
-                        raise RuntimeError("rd_ctc_collapse failed")
-                    rows_h = torch.empty((nb, row_bytes), dtype=torch.uint8, pin_memory=True)
-                    rows_h.copy_(rows, non_blocking=True)
-                    rows = rows_h
-                done = torch.cuda.Event()
-                done.record(st)
-            outs.append((idx, prob, done, x, rows))
+                if two_stage:
+                    self.rec_engines[k].rec_backbone_forward(x, tokens[int(tok_off[bi]): int(tok_off[bi + 1])])
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    outs.append((None, None, ev, x, None))
+                else:
+                    idx, prob, _ = self.rec_engines[k].rec_forward(x)
+                    rows, done = self._collapse_rows(idx, prob, nb, st)
+                    outs.append((idx, prob, done, x, rows))
             pos += nb
+            if two_stage and (bi + 1) % S == 0:
+                run_tail(bi // S)
+        if two_stage and len(batches) % S:
+            run_tail(len(groups) - 1)
         self.stats["t_rec_enqueue_ms"] = (time.perf_counter() - t0) * 1e3 - self.stats["t_descs_ms"]
         # D2H per batch result (small) as soon as that batch is done, host CTC decode (rapidocr CTCLabelDecode)
         # overlaps the GPU work of the batches still in flight
@@ -250,7 +313,7 @@ class PagePipeline:
                 texts[i] = (t, ocr_host.format_score(s))
             t_dec += time.perf_counter() - t1
         self.stats["t_decode_ms"] = t_dec * 1e3
-        for st in self.rec_streams:
+        for st in self.rec_streams + [self.tail_stream]:
             main.wait_stream(st)
         per_page: List[List[Tuple[str, float]]] = [[] for _ in range(P)]
         for i, pi in enumerate(page_of.tolist()):
@@ -388,7 +451,7 @@ class PagePipelinePool:
     def engines(self) -> List[RdEngine]:
         out = []
         for p in self.pipes:
-            out += [p.det, *([p.layout] if p.layout is not None else []), *p.rec_engines]
+            out += [p.det, *([p.layout] if p.layout is not None else []), *p.rec_engines, p.rec_tail]
         return out
 
     def run_batch(self, pages: torch.Tensor, quads_per_page: Optional[Sequence[np.ndarray]] = None,

@@ -237,7 +237,7 @@ def test_range_guard_on_rec_forward_lines_path(golden_dir, monkeypatch):
     out = pipe.rec_forward_lines(pages, quads)
     assert len(out[0]) == 10
     assert pipe.stats.get("range_fallbacks", 0) >= 1
-    assert all(e.precision == "fp32" for e in pipe.rec_engines if e.range_fallbacks)
+    assert all(e.precision == "fp32" for e in pipe.rec_engines + [pipe.rec_tail] if e.range_fallbacks)
     assert any(e.range_fallbacks for e in pipe.rec_engines)
     again = pipe.rec_forward_lines(pages, quads)      # now in fp32: stable, no further fallbacks
     assert again == out

@@ -489,3 +489,61 @@ def test_region_text_model_is_a_custom_ocr_model(golden_dir):
     assert out[3] == ""
     for (n, _), text in zip(want, out[:3]):
         assert len(text.split("\n")) <= n                           # never more lines than text lines in the region
+
+
+def test_rec_two_stage_equals_single_stage(engines):
+    """rd_rec_backbone_forward per batch into one token buffer + ONE rd_rec_tail_forward over the lines of all batches
+    (different widths => different line lengths) == rd_rec_forward batch by batch."""
+    eng, _ = engines["ppocrv6_rec"]
+    rng = np.random.default_rng(21)
+    shapes = [(5, 3, 48, 328), (3, 3, 48, 96), (2, 3, 48, 1200), (1, 3, 48, 16)]
+    xs = [torch.from_numpy(rng.uniform(-1, 1, s).astype(np.float32)).cuda() for s in shapes]
+    singles = [eng.rec_forward(x) for x in xs]
+    dim = eng.rec_token_dim
+    lens = []
+    for x, (idx, _p, _f) in zip(xs, singles):
+        lens += [idx.shape[1]] * x.shape[0]
+    tokens = torch.empty((sum(lens), dim), dtype=torch.float32, device="cuda")
+    pos = 0
+    for x, (idx, _p, _f) in zip(xs, singles):
+        n = x.shape[0] * idx.shape[1]
+        out = eng.rec_backbone_forward(x, tokens[pos: pos + n])
+        assert out.data_ptr() == tokens[pos: pos + n].data_ptr()
+        pos += n
+    idx2, prob2 = eng.rec_tail_forward(tokens, lens)
+    pos = 0
+    for x, (idx, prob, _f) in zip(xs, singles):
+        n = idx.numel()
+        assert (idx2[pos: pos + n].cpu().numpy() == idx.reshape(-1).cpu().numpy()).all()
+        assert np.abs(prob2[pos: pos + n].cpu().numpy() - prob.reshape(-1).cpu().numpy()).max() < 1e-5
+        pos += n
+
+
+def test_pipeline_two_stage_rec_gives_the_single_stage_results(engines, golden_dir):
+    """PagePipeline with the recogniser in two stages (backbone per batch, neck + CTC head once per group of batches, the
+    default) decodes the same strings as the whole network batch by batch.  The confidences agree to kernel precision, not to
+    the bit: the planner picks the matrix kernels by row count (a 16-line batch has < 2048 tokens => native fp32 MFMA, the
+    group of three batches gets the split-fp16 kernels), and the class split of the fused CTC head depends on the token count."""
+    from rapiddoc_amd.pages import synth_batch
+    from rapiddoc_amd.pipeline import PagePipeline, render_text_maps
+    states = {k: W.synth_state_dict(W.load_manifest(golden_dir / f"manifest_{k}.json"), 0)
+              for k in ("ppocrv6_det", "ppocrv6_rec")}
+    pipe = PagePipeline(states, rec_batch_num=16, n_rec_streams=3)
+    pages_np, boxes = synth_batch(11, 2)
+    pages = torch.from_numpy(pages_np).cuda()
+    det_hw = pipe.det_forward(pages[:1])[1]
+    maps = render_text_maps(boxes, pages_np.shape[1:3], det_hw, pages.device)
+    out = {}
+    for two in (True, False):
+        pipe.rec_two_stage = two
+        pipe.keep_rec_inputs = True
+        res = pipe.run_batch(pages, None, det_maps_override=maps)
+        out[two] = ([[(t, s) for _q, t, s in r.lines] for r in res],
+                    [(c.copy(), i.cpu().numpy().copy(), p.cpu().numpy().copy()) for c, _x, i, p in pipe.last_rec_batches])
+    assert [len(p) for p in out[True][0]] == [45, 45]
+    for (ca, ia, pa), (cb, ib, pb) in zip(out[True][1], out[False][1]):
+        assert (ca == cb).all() and (ia == ib).all()
+        assert np.abs(pa - pb).max() < TOL
+    for pa, pb in zip(out[True][0], out[False][0]):
+        assert [t for t, _ in pa] == [t for t, _ in pb]
+        assert max(abs(sa - sb) for (_, sa), (_, sb) in zip(pa, pb)) < TOL
