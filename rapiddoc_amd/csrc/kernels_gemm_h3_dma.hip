@@ -249,15 +249,17 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// 16-wavefront variant of the same pipeline: 256x128 tile, wavefronts as 4 x 4 with 64x32 each (64 accumulator registers
-// instead of 128), so FOUR wavefronts share a SIMD instead of two.  The 8-wavefront kernel spends its time in phases that
+// 16-wavefront variant of the same pipeline: 256x128 tile, wavefronts as 8 x 2 with 32x64 each (64 accumulator registers
+// instead of 128), so FOUR wavefronts share a SIMD instead of two.  (Round 1 had them 4 x 4 with 64x32: every A row tile was
+// split - 2 VALU per element - by four wavefronts; VALU work does not run under another wavefront's MFMAs on this chip
+// (tools/probe_mfma_valu.hip), so the redundant splits were 2/3 of the MFMA time.  32x64 halves them at the same LDS traffic.)  The 8-wavefront kernel spends its time in phases that
 // do not overlap inside one wavefront (fragment read -> split -> MFMA); with twice the wavefronts the SIMD has another
 // wavefront's MFMAs to issue while one splits.  Costs: every A row tile is read and split by 4 wavefronts instead of 2.
 __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int ntn, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..15
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave >> 1, wn = wave & 1;     // 8 x 2 wavefronts of 32 x 64: an A row tile is split by TWO wavefronts (4 x 4 of 64 x 32: four)
     const int l31 = lane & 31, lhi = lane >> 5;
     const int K = p.K, KT = (K + DK - 1) / DK, Kp = KT * DK;
     const _Float16* wh = reinterpret_cast<const _Float16*>(p.wh);
@@ -296,16 +298,16 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
         }
         dma16(bsrc + k0, base + D_A_BYTES + (unsigned)(wave >> 3) * D_B_BYTES + (unsigned)(wave & 7) * 1024u, smem);
     };
-    int a_off[2][2], b_off[2];
+    int a_off[2], b_off[2][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+        const int R = wm * 32 + l31;
+        a_off[ks] = R * 128 + (((2 * (lhi + 2 * ks)) ^ ((R >> 1) & 7)) << 4);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int R = (wm * 2 + i) * 32 + l31;
-            a_off[i][ks] = R * 128 + (((2 * (lhi + 2 * ks)) ^ ((R >> 1) & 7)) << 4);
+        for (int j = 0; j < 2; ++j) {
+            const int Rn = wn * 64 + j * 32 + l31;
+            b_off[j][ks] = D_A_BYTES + Rn * 64 + (((lhi + 2 * ks) ^ ((Rn >> 2) & 3)) << 4);
         }
-        const int Rn = wn * 32 + l31;
-        b_off[ks] = D_A_BYTES + Rn * 64 + (((lhi + 2 * ks) ^ ((Rn >> 2) & 3)) << 4);
     }
 
     unsigned emax = 0;
@@ -328,20 +330,17 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
             const unsigned char* st = smem + stage * D_STAGE;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                f16x8 ah[2], al[2];
+                f16x8 ah, al;
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(st + a_off[ks]);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(st + (a_off[ks] ^ 16));
+                split8(x0, x1, ah, al);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(st + a_off[i][ks]);
-                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(st + (a_off[i][ks] ^ 16));
-                    split8(x0, x1, ah[i], al[i]);
-                }
-                const f16x8 bh = *reinterpret_cast<const f16x8*>(st + b_off[ks]);
-                const f16x8 bl = *reinterpret_cast<const f16x8*>(st + b_off[ks] + D_B_BYTES);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc1[i], 0, 0, 0);
-                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc2[i], 0, 0, 0);
-                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc2[i], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) {
+                    const f16x8 bh = *reinterpret_cast<const f16x8*>(st + b_off[j][ks]);
+                    const f16x8 bl = *reinterpret_cast<const f16x8*>(st + b_off[j][ks] + D_B_BYTES);
+                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[j], 0, 0, 0);
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[j], 0, 0, 0);
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[j], 0, 0, 0);
                 }
             }
             stage = stage == 2 ? 0 : stage + 1;
@@ -355,46 +354,45 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
             issue_tile(0, 0);
             if (KT > 1) issue_tile(1, 1);
         }
-        const int n = en0 + wn * 32 + l31;
-        if (n < p.Ng) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {           // the wavefront's two 32-column blocks
+            const int n = en0 + wn * 64 + i * 32 + l31;
+            if (n >= p.Ng) continue;
             const float bv = p.bias ? p.bias[n] : 0.f;
+            const int mb = em0 + wm * 32 + 4 * lhi;
+            // eight values at a time (128 VGPRs leave no room for sixteen): activation switch and residual test outside
+            // the element loops, residual loads unconditional and batched ahead of the stores
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int mb = em0 + (wm * 2 + i) * 32 + 4 * lhi;
-                // eight values at a time (128 VGPRs leave no room for sixteen): activation switch and residual test outside
-                // the element loops, residual loads unconditional and batched ahead of the stores
+            for (int half = 0; half < 2; ++half) {
+                float o[8];
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    float o[8];
+                for (int e = 0; e < 8; ++e) {
+                    const int r = half * 8 + e;
+                    o[e] = fmaf(acc2[i][r], 1.f / 2048.f, acc1[i][r]) + bv;
+                    emax = max(emax, __float_as_uint(o[e]) & 0x7fffffffu);
+                }
+                if (p.act == ACT_GELU) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int r = half * 8 + e;
-                        o[e] = fmaf(acc2[i][r], 1.f / 2048.f, acc1[i][r]) + bv;
-                        emax = max(emax, __float_as_uint(o[e]) & 0x7fffffffu);
-                    }
-                    if (p.act == ACT_GELU) {
+                    for (int e = 0; e < 8; ++e) o[e] = rd_gelu(o[e]);
+                } else if (p.act != ACT_NONE) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = rd_gelu(o[e]);
-                    } else if (p.act != ACT_NONE) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = rd_act(o[e], p.act);
-                    }
-                    if (p.res) {
-                        float rs[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const int r = half * 8 + e;
-                            rs[e] = p.res[(size_t)min(mb + (r & 3) + 8 * (r >> 2), p.M - 1) * p.rld + n];
-                        }
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] += rs[e];
-                    }
+                    for (int e = 0; e < 8; ++e) o[e] = rd_act(o[e], p.act);
+                }
+                if (p.res) {
+                    float rs[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int r = half * 8 + e;
-                        const int m = mb + (r & 3) + 8 * (r >> 2);
-                        if (m < p.M) __builtin_nontemporal_store(o[e], &p.y[(size_t)m * p.yld + n]);
+                        rs[e] = p.res[(size_t)min(mb + (r & 3) + 8 * (r >> 2), p.M - 1) * p.rld + n];
                     }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += rs[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r = half * 8 + e;
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (m < p.M) __builtin_nontemporal_store(o[e], &p.y[(size_t)m * p.yld + n]);
                 }
             }
         }

@@ -122,6 +122,14 @@ if __name__ == "__main__" and "--small" in sys.argv:
             print(f"small gemm M={M} K={K} N={N} {'h3  ' if h3 else 'fp32'}: {ms*1e3:7.1f} us  {tf:6.1f} TF/s  err {err:.1e}")
     sys.exit(0)
 
+if __name__ == "__main__" and "--rec-gemms" in sys.argv:
+    # the pointwise layers of one 64-line recogniser batch (stage 2 / 3 of PPLCNetV4 + the LightSVTR neck's first layer)
+    for (M, K, N, act) in ((52224, 96, 192, 4), (52224, 192, 192, 0), (26112, 192, 384, 4), (26112, 384, 384, 0), (26112, 384, 768, 4),
+                           (26112, 768, 384, 0), (4352, 384, 120, 0), (104448, 384, 768, 4)):
+        ms, tf, err = gemm(M, K, N, act, iters=50, h3=True, check=(act == 0))
+        print(f"rec gemm M={M} K={K} N={N} act {act}: {ms*1e3:7.1f} us  {tf:6.1f} TF/s  err {err}", flush=True)
+    sys.exit(0)
+
 if __name__ == "__main__" and "--h3only" in sys.argv:
     for (M, K, N) in ((131072, 192, 384), (131072, 384, 768), (131072, 768, 384), (81920, 2176, 512), (32768, 4096, 4096)):
         ms, tf, err = gemm(M, K, N, 0, h3=True, check=True)
