@@ -212,8 +212,13 @@ def main():
         result collectives are issued from this thread in step order."""
         if len(pools) == 1:
             out = None
+            trace = os.environ.get("RD_BENCH_STEP_TIMES") == "1"      # developer: per-step host times on stderr
             for _ in range(n):
+                ts = time.perf_counter()
                 out = step()
+                if trace:
+                    torch.cuda.synchronize()
+                    print("step %.1f ms" % ((time.perf_counter() - ts) * 1e3), file=sys.stderr)
             return out
         from concurrent.futures import ThreadPoolExecutor
         streams = [torch.cuda.Stream() for _ in pools]
@@ -282,6 +287,8 @@ def main():
                 if op["kind"].startswith(("conv", "deconv")):  # name = the HIP kernel instantiation rocprofv3 reports
                     split = op["cfg"].endswith("/h3")
                     name = "conv_igemm%s_kernel<%s,%s>" % ("_h3" if split else "", op["cfg"].replace("/h3", ""), "1x1" if op["kind"] == "conv1x1" else "kxk")
+                    if op["cfg"].startswith("direct"):
+                        name = "conv_direct_h3_kernel"
                     if op["cfg"].startswith("dma"):   # LDS-DMA GEMM: 8-wavefront kernel, 16-wavefront one for K <= 384
                         name = "gemm_h3_dma16_kernel" if op["cfg"].startswith("dma16w") else "gemm_h3_dma_kernel"
                 elif op["kind"] == "mixer_fused":

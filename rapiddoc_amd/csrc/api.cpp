@@ -299,6 +299,39 @@ float rd_debug_time_gemm(int M, int K, int N, int act, int iters, float* x, floa
     return ms / iters;
 }
 
+// developer entry: one dense convolution on prepared operands (x NHWC fp32 [N][H][W][Cin]; w folded [Cout][K], k = (kh*KW+kw)*Cin+ci;
+// wh / wl its fp16 split with rows padded to Kp = ceil32(K), or null for the fp32 MFMA kernels; y NHWC [N][OH][OW][Cout]).
+// Returns ms per launch (iters timed launches after one untimed).  *used_direct: in = 1 forces the direct k x k kernel when it
+// supports the geometry; out = 1 when that kernel ran.
+float rd_debug_conv(int N, int H, int W, int Cin, int Cout, int KH, int KW, int S, int PT, int PL, int PB, int PR, int act, int iters,
+                    float* x, float* w, void* wh, void* wl, float* bias, float* res, float* y, int* used_direct) {
+    rd::ConvParams p{};
+    p.x = x; p.xld = Cin; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.w = w; p.bias = bias; p.y = y; p.yld = Cout;
+    p.wh = (const uint16_t*)wh; p.wl = (const uint16_t*)wl;
+    p.OH = (H + PT + PB - KH) / S + 1; p.OW = (W + PL + PR - KW) / S + 1; p.Cout = Cout;
+    p.KH = KH; p.KW = KW; p.SH = p.SW = S; p.PT = PT; p.PL = PL; p.act = act; p.out_mode = rd::OUT_NHWC;
+    p.res = res; p.rld = Cout;
+    p.M = N * p.OH * p.OW; p.K = KH * KW * Cin; p.Ng = Cout;
+    const bool force = used_direct && *used_direct == 1 && wh && rd::conv_direct_h3_supported(p);
+    if (used_direct) *used_direct = (force || (wh && rd::conv_direct_h3_applies(p))) ? 1 : 0;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    auto go = [&] {
+        if (force) rd::launch_conv_direct_h3(p, nullptr);
+        else if (wh) rd::launch_conv_igemm_h3(p, nullptr);
+        else rd::launch_conv_igemm(p, nullptr);
+    };
+    go();
+    (void)hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters; ++i) go();
+    (void)hipEventRecord(e1, nullptr);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return iters > 0 ? ms / iters : 0.f;
+}
+
 // developer timing of the fused CTC head on prepared weights: wp = W' [C][128] fp32 (bias in column K), wh / wl its fp16 split
 // (null: fp32 MFMA kernel); part = workspace of M * 64 * 4 floats.  Returns ms per launch; *nsplit_out = the split count used.
 float rd_debug_time_ctc(int M, int K, int Ccls, int iters, float* x, float* wp, void* wh, void* wl, float* part, int32_t* idx, float* prob,

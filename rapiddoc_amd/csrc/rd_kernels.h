@@ -49,6 +49,10 @@ bool skinny_gemm_applies(int M, int K);   // true when launch_conv_igemm will ta
 bool gemm_h3_dma_applies(const ConvParams& p);
 void launch_gemm_h3_dma(const ConvParams& p, hipStream_t s);
 void launch_conv_igemm_h3(const ConvParams& p, hipStream_t s);
+// direct 2x2 / 3x3 stride-1 convolution for narrow outputs (kernels_conv_direct_h3.hip); launch_conv_igemm_h3 dispatches to it
+bool conv_direct_h3_supported(const ConvParams& p);   // geometry
+bool conv_direct_h3_applies(const ConvParams& p);     // geometry + routing policy
+void launch_conv_direct_h3(const ConvParams& p, hipStream_t s);
 // a short human-readable tag of the tile configuration chosen for p (for the per-op profile)
 const char* conv_igemm_config_name(const ConvParams& p);
 

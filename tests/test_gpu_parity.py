@@ -547,3 +547,61 @@ def test_pipeline_two_stage_rec_gives_the_single_stage_results(engines, golden_d
     for pa, pb in zip(out[True][0], out[False][0]):
         assert [t for t, _ in pa] == [t for t, _ in pb]
         assert max(abs(sa - sb) for (_, sa), (_, sb) in zip(pa, pb)) < TOL
+
+
+def _debug_conv(x_nhwc, w_oihw, bias, stride, pads, act=0, res=None, split=True, iters=0, force_direct=False):
+    """One convolution through the library's dense-conv launcher on prepared operands (api.cpp rd_debug_conv)."""
+    import ctypes as C
+    from rapiddoc_amd import _lib
+    lib = _lib.load()
+    lib.rd_debug_conv.restype = C.c_float
+    lib.rd_debug_conv.argtypes = [C.c_int] * 14 + [C.c_void_p] * 7 + [C.c_void_p]
+    N, H, W_, Cin = x_nhwc.shape
+    Cout, _, KH, KW = w_oihw.shape
+    K = KH * KW * Cin
+    wf = w_oihw.permute(0, 2, 3, 1).reshape(Cout, K).contiguous()          # k = (kh * KW + kw) * Cin + ci
+    Kp = (K + 31) // 32 * 32
+    wh = wl = None
+    if split:
+        hi = wf.half()
+        lo = ((wf - hi.float()) * 2048.0).half()
+        wh = torch.zeros((Cout, Kp), dtype=torch.float16, device="cuda"); wh[:, :K] = hi
+        wl = torch.zeros((Cout, Kp), dtype=torch.float16, device="cuda"); wl[:, :K] = lo
+    pt, pl, pb, pr = pads
+    OH, OW = (H + pt + pb - KH) // stride + 1, (W_ + pl + pr - KW) // stride + 1
+    y = torch.full((N, OH, OW, Cout), float("nan"), device="cuda")
+    used = C.c_int(1 if force_direct else 0)
+    ms = lib.rd_debug_conv(N, H, W_, Cin, Cout, KH, KW, stride, pt, pl, pb, pr, act, iters, x_nhwc.data_ptr(), wf.data_ptr(),
+                           wh.data_ptr() if split else None, wl.data_ptr() if split else None, bias.data_ptr(),
+                           res.data_ptr() if res is not None else None, y.data_ptr(), C.byref(used))
+    torch.cuda.synchronize()
+    return y, used.value, ms
+
+
+@pytest.mark.parametrize("N,H,W_,Cin,Cout,k,pads,act,with_res", [
+    (2, 50, 67, 48, 48, 3, (1, 1, 1, 1), 1, False),      # B4 stages.0 3x3: two 32-blocks, the second half empty
+    (2, 41, 90, 96, 96, 3, (1, 1, 1, 1), 1, True),       # B4 stages.1: two channel passes, three blocks, residual
+    (3, 24, 130, 48, 24, 2, (0, 0, 1, 1), 1, False),     # rec stem2a: 2x2, pad right / bottom only
+    (3, 24, 130, 24, 48, 2, (0, 0, 1, 1), 1, False),     # rec stem2b: Cin 24 padded to 32 in LDS
+    (2, 12, 333, 64, 32, 3, (1, 1, 1, 1), 0, False),     # 4-row tiles (OH = 12), Cin 64 in one pass
+    (1, 96, 96, 192, 24, 3, (1, 1, 1, 1), 3, False),     # Cin 192 = 3 passes of 64, SiLU
+])
+def test_direct_conv_matches_fp64(N, H, W_, Cin, Cout, k, pads, act, with_res):
+    """kernels_conv_direct_h3.hip against torch conv2d in float64: fp32-class error (the split keeps 22 of 24 mantissa bits
+    per operand, fp32 accumulate) at ragged sizes (tile edges in both directions, partial channel blocks)."""
+    g = torch.Generator(device="cuda").manual_seed(N * 1000 + Cin)
+    x = torch.rand((N, H, W_, Cin), device="cuda", generator=g) * 2 - 1
+    w = (torch.rand((Cout, Cin, k, k), device="cuda", generator=g) - 0.5) * 0.2
+    b = torch.rand((Cout,), device="cuda", generator=g) - 0.5
+    pt, pl, pb, pr = pads
+    xp = torch.nn.functional.pad(x.permute(0, 3, 1, 2).double(), (pl, pr, pt, pb))
+    ref = torch.nn.functional.conv2d(xp, w.double(), b.double())
+    ref = {0: ref, 1: torch.relu(ref), 3: torch.nn.functional.silu(ref)}[act]
+    res = None
+    if with_res:
+        res = torch.rand((N, ref.shape[2], ref.shape[3], Cout), device="cuda", generator=g)
+        ref = ref + res.permute(0, 3, 1, 2).double()
+    y, used, _ = _debug_conv(x, w, b, 1, pads, act, res, force_direct=True)
+    assert used == 1, "the direct kernel did not take this geometry"
+    err = (y.permute(0, 3, 1, 2).double() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err

@@ -130,6 +130,23 @@ if __name__ == "__main__" and "--rec-gemms" in sys.argv:
         print(f"rec gemm M={M} K={K} N={N} act {act}: {ms*1e3:7.1f} us  {tf:6.1f} TF/s  err {err}", flush=True)
     sys.exit(0)
 
+if __name__ == "__main__" and "--kxk" in sys.argv:
+    # the k x k layers of the step (NHWC geometry, Cin, Cout, k, pads): direct split kernel vs the fp32 MFMA implicit GEMM
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tests"))
+    from test_gpu_parity import _debug_conv
+    cases = (("B4 stages.0 3x3", 32, 200, 200, 48, 48, 3, (1, 1, 1, 1)), ("B4 stages.1 3x3", 32, 100, 100, 96, 96, 3, (1, 1, 1, 1)),
+             ("rec stem2a 2x2", 64, 24, 272, 48, 24, 2, (0, 0, 1, 1)), ("rec stem2b 2x2", 64, 24, 272, 24, 48, 2, (0, 0, 1, 1)),
+             ("det conv_down 3x3", 32, 240, 176, 96, 24, 3, (1, 1, 1, 1)), ("layout stem2b 2x2", 32, 400, 400, 16, 32, 2, (0, 0, 1, 1)))
+    for name, N, H, W_, Cin, Cout, k, pads in cases:
+        x = torch.rand((N, H, W_, Cin), device="cuda") - 0.5
+        w = (torch.rand((Cout, Cin, k, k), device="cuda") - 0.5) * 0.1
+        b = torch.zeros(Cout, device="cuda")
+        for split in (True, False):
+            y, used, ms = _debug_conv(x, w, b, 1, pads, 1, None, split=split, iters=20, force_direct="--force-direct" in sys.argv)
+            fl = 2.0 * y.numel() * Cin * k * k
+            print(f"{name:20s} M={y.numel() // Cout:8d} K={Cin * k * k:4d} N={Cout:3d} {'split' if split else 'fp32 '} direct={used}: {ms * 1e3:8.1f} us {fl / ms / 1e9:7.1f} TF/s", flush=True)
+    sys.exit(0)
+
 if __name__ == "__main__" and "--h3only" in sys.argv:
     for (M, K, N) in ((131072, 192, 384), (131072, 384, 768), (131072, 768, 384), (81920, 2176, 512), (32768, 4096, 4096)):
         ms, tf, err = gemm(M, K, N, 0, h3=True, check=True)
