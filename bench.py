@@ -287,6 +287,8 @@ def main():
                 if op["kind"].startswith(("conv", "deconv")):  # name = the HIP kernel instantiation rocprofv3 reports
                     split = op["cfg"].endswith("/h3")
                     name = "conv_igemm%s_kernel<%s,%s>" % ("_h3" if split else "", op["cfg"].replace("/h3", ""), "1x1" if op["kind"] == "conv1x1" else "kxk")
+                    if op["cfg"].startswith("stream"):
+                        name = "conv_stream_h3_kernel"
                     if op["cfg"].startswith("direct"):
                         name = "conv_direct_h3_kernel"
                     if op["cfg"].startswith("dma"):   # LDS-DMA GEMM: 8-wavefront kernel, 16-wavefront one for K <= 384
@@ -354,7 +356,9 @@ def main():
                                     "fallback (DESIGN.md s3); RD_PRECISION=fp32 (native fp32 MFMA only) measures 179 pages/s"
                                     if pipe.det.precision == "auto" else pipe.det.precision,
                        "pages_per_gpu": P, "global_pages": n_global, "pages_gathered": len(out), "result_crc32": result_crc,
-                       "lines_per_step": n_lines, "host_stage_ms": host_stats, "parallelism": "page-sharded dp%d; %d page batch(es) in flight per GPU" % (world, len(pools)),
+                       "lines_per_step": n_lines, "host_stage_ms": host_stats,
+                       "range_fallbacks": int(sum(e.range_fallbacks for q in pools for e in q.engines)),   # engines that left the split-fp16 mode (0 = the dtype claim holds)
+                       "parallelism": "page-sharded dp%d; %d page batch(es) in flight per GPU" % (world, len(pools)),
                        "layout_head": "absent (ONNX-only in the reference; backbone only)",
                        "det_postprocess": "DB post-process (host C++) runs on maps rendered from the generator's line boxes "
                                           "(random-weight det output has no text); its boxes drive crop+rec"},

@@ -302,7 +302,7 @@ float rd_debug_time_gemm(int M, int K, int N, int act, int iters, float* x, floa
 // developer entry: one dense convolution on prepared operands (x NHWC fp32 [N][H][W][Cin]; w folded [Cout][K], k = (kh*KW+kw)*Cin+ci;
 // wh / wl its fp16 split with rows padded to Kp = ceil32(K), or null for the fp32 MFMA kernels; y NHWC [N][OH][OW][Cout]).
 // Returns ms per launch (iters timed launches after one untimed).  *used_direct: in = 1 forces the direct k x k kernel when it
-// supports the geometry; out = 1 when that kernel ran.
+// supports the geometry, in = 2 the small-K streaming kernel; out = 1 / 2 when the direct / streaming kernel ran.
 float rd_debug_conv(int N, int H, int W, int Cin, int Cout, int KH, int KW, int S, int PT, int PL, int PB, int PR, int act, int iters,
                     float* x, float* w, void* wh, void* wl, float* bias, float* res, float* y, int* used_direct) {
     rd::ConvParams p{};
@@ -313,11 +313,14 @@ float rd_debug_conv(int N, int H, int W, int Cin, int Cout, int KH, int KW, int 
     p.res = res; p.rld = Cout;
     p.M = N * p.OH * p.OW; p.K = KH * KW * Cin; p.Ng = Cout;
     const bool force = used_direct && *used_direct == 1 && wh && rd::conv_direct_h3_supported(p);
-    if (used_direct) *used_direct = (force || (wh && rd::conv_direct_h3_applies(p))) ? 1 : 0;
+    const bool force_stream = used_direct && *used_direct == 2 && wh && rd::conv_stream_h3_supported(p);
+    if (used_direct) *used_direct = force_stream ? 2 : (force || (wh && !rd::conv_stream_h3_applies(p) && rd::conv_direct_h3_applies(p))) ? 1
+                                    : (wh && rd::conv_stream_h3_applies(p)) ? 2 : 0;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     auto go = [&] {
-        if (force) rd::launch_conv_direct_h3(p, nullptr);
+        if (force_stream) rd::launch_conv_stream_h3(p, nullptr);
+        else if (force) rd::launch_conv_direct_h3(p, nullptr);
         else if (wh) rd::launch_conv_igemm_h3(p, nullptr);
         else rd::launch_conv_igemm(p, nullptr);
     };

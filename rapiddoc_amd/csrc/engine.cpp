@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
@@ -310,6 +311,9 @@ static inline bool auto_split_conv(int kh, int kw, int K, int cout) {
     static const int kxk_n = std::getenv("RD_H3_KXK_MIN_N") ? std::atoi(std::getenv("RD_H3_KXK_MIN_N")) : 24;
     static const int pw_k = std::getenv("RD_H3_1X1_MIN_K") ? std::atoi(std::getenv("RD_H3_1X1_MIN_K")) : 96;
     static const int pw_n = std::getenv("RD_H3_1X1_MIN_N") ? std::atoi(std::getenv("RD_H3_1X1_MIN_N")) : 96;
+    static const bool stream_off = std::getenv("RD_CONV_STREAM") && std::getenv("RD_CONV_STREAM")[0] == '0';
+    // small-K layers: the streaming split kernel (kernels_conv_stream_h3.hip) takes them whatever the thresholds below say
+    if (!stream_off && cout >= 12 && conv_stream_h3_shape_ok(kh, kw, K / (kh * kw), cout)) return true;
     return (kh == 1 && kw == 1) ? (K >= pw_k && cout >= pw_n) : (K >= kxk_k && cout >= kxk_n);
 }
 
@@ -363,7 +367,7 @@ TView Builder::conv(const std::string& wname, const std::string& bname, const st
         p.wh = reinterpret_cast<const uint16_t*>(pb_->ptr(key + "#wh"));
         p.wl = reinterpret_cast<const uint16_t*>(pb_->ptr(key + "#wl"));
         p.range_flag = range_flag_;
-        r.cfg = std::string(conv_direct_h3_applies(p) ? "direct" : gemm_h3_dma_applies(p) ? (K <= 384 ? "dma16w256x128" : "dma256x128") : cout > 96 ? "256x128" : cout > 64 ? "128x96"
+        r.cfg = std::string(conv_stream_h3_applies(p) ? "stream" : conv_direct_h3_applies(p) ? "direct" : gemm_h3_dma_applies(p) ? (K <= 384 ? "dma16w256x128" : "dma256x128") : cout > 96 ? "256x128" : cout > 64 ? "128x96"
                             : (cout > 32 && p.M >= 65536) ? "256x64" : K <= 256 || cout <= 32 ? "128x32" : "128x64") + "/h3";
     }
     r.run = [p, xv, yv, rv, av, has_res, has_as, h3](const Plan& pl, const RunCtx& c) mutable {
@@ -1021,7 +1025,12 @@ void Engine::load_weights(const void* blob, size_t nbytes) {
     Plan dummy;
     h3_prepared_ = precision_ == PREC_H3;
     RD_HIP(hipMalloc((void**)&range_flag_, sizeof(unsigned)));
-    RD_HIP(hipMemset(range_flag_, 0, sizeof(unsigned)));
+    {   // a synchronous copy, not hipMemset: the fill kernel of a memset runs on the null stream and is not ordered against the
+        // non-blocking streams the forwards are launched on (a stale non-zero word would read as "range overflow")
+        const unsigned zero = 0;
+        RD_HIP(hipMemcpy(range_flag_, &zero, sizeof(zero), hipMemcpyHostToDevice));
+        RD_HIP(hipDeviceSynchronize());
+    }
     Builder b(Mode::PREPARE, &store_, &params_, &dummy, h3_prepared_, true);
     // smallest legal geometry; only weight names/shapes matter in PREPARE mode
     if (kind_ == "ppocrv6_rec") build(b, 1, 48, 64, 0), build(b, 1, 48, 64, REC_UNFUSED_CTC);
@@ -1081,12 +1090,39 @@ void Engine::run(int B, int H, int W, int flags, const std::vector<void*>& ext, 
             arena_bytes_ = 0;
             RD_HIP(hipMalloc((void**)&arena_, plan.arena_bytes));
             arena_bytes_ = plan.arena_bytes;
+            // developer check (RD_POISON_ARENA=1): fresh workspace filled with NaN bit patterns - no kernel may let workspace bytes
+            // it did not write reach a result or the range guard
+            static const bool poison = std::getenv("RD_POISON_ARENA") && std::getenv("RD_POISON_ARENA")[0] == '1';
+            if (poison) {     // on the launch stream: a null-stream memset is not ordered against a non-blocking stream
+                RD_HIP(hipMemsetAsync(arena_, 0xFF, arena_bytes_, s));
+                RD_HIP(hipStreamSynchronize(s));
+            }
         }
         ctx.arena = arena_;
     }
     for (const Buf& b : plan.bufs)
         if (b.external >= 0) RD_CHECK(b.external < (int)ext.size() && ext[b.external], "missing external buffer");
     if (!profiling_) {
+        // developer trace (RD_RANGE_TRACE=1): which op raises the split-fp16 range flag (synchronises after every op)
+        static const bool range_trace = std::getenv("RD_RANGE_TRACE") && std::getenv("RD_RANGE_TRACE")[0] == '1';
+        if (range_trace && range_flag_) {
+            for (const OpRecord& op : plan.ops) {
+                op.run(plan, ctx);
+                unsigned v = 0;
+                RD_HIP(hipMemcpyAsync(&v, range_flag_, sizeof(v), hipMemcpyDeviceToHost, s));
+                RD_HIP(hipStreamSynchronize(s));
+                if (v) {
+                    fprintf(stderr, "[range] %s: op '%s' kind %s cfg %s shape %s raised the flag (B=%d H=%d W=%d flags=%d)\n", kind_.c_str(),
+                            op.name.c_str(), op.kind.c_str(), op.cfg.c_str(), op.shape.c_str(), B, H, W, flags);
+                    RD_HIP(hipMemsetAsync(range_flag_, 0, sizeof(unsigned), s));
+                    v = 1;
+                    RD_HIP(hipMemcpyAsync(range_flag_, &v, sizeof(v), hipMemcpyHostToDevice, s));   // keep it raised for the caller
+                    RD_HIP(hipStreamSynchronize(s));
+                    break;
+                }
+            }
+            return;
+        }
         // developer what-if (timing only, results are garbage): RD_SKIP_KIND=<op kind> leaves those launches out
         static const char* skip_kind = std::getenv("RD_SKIP_KIND");
         if (skip_kind) {

@@ -365,6 +365,10 @@ static void h3_launch_cfg(const ConvParams& p, hipStream_t s) {
 
 void launch_conv_igemm_h3(const ConvParams& p, hipStream_t s) {
     if (p.M <= 0) return;
+    if (conv_stream_h3_applies(p)) {   // small K (stems): HBM-bound, operands streamed from global memory at high occupancy
+        launch_conv_stream_h3(p, s);
+        return;
+    }
     if (conv_direct_h3_applies(p)) {   // 2x2 / 3x3 stride 1, <= 96 output channels: patch in LDS, taps as address offsets
         launch_conv_direct_h3(p, s);
         return;

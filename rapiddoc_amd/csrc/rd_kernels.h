@@ -53,6 +53,14 @@ void launch_conv_igemm_h3(const ConvParams& p, hipStream_t s);
 bool conv_direct_h3_supported(const ConvParams& p);   // geometry
 bool conv_direct_h3_applies(const ConvParams& p);     // geometry + routing policy
 void launch_conv_direct_h3(const ConvParams& p, hipStream_t s);
+// small-K layers (padded K <= 256, <= 96 output channels), operands streamed from global memory (kernels_conv_stream_h3.hip)
+bool conv_stream_h3_supported(const ConvParams& p);
+bool conv_stream_h3_applies(const ConvParams& p);
+void launch_conv_stream_h3(const ConvParams& p, hipStream_t s);
+// host-side twin of conv_stream_h3_supported for the weight preparation (no ConvParams yet)
+inline bool conv_stream_h3_shape_ok(int kh, int kw, int cin, int cout) {
+    return cin % 4 == 0 && cin <= 64 && kh * kw * ((cin + 15) / 16 * 16) <= 256 && cout <= 96;
+}
 // a short human-readable tag of the tile configuration chosen for p (for the per-op profile)
 const char* conv_igemm_config_name(const ConvParams& p);
 

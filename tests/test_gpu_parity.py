@@ -549,7 +549,7 @@ def test_pipeline_two_stage_rec_gives_the_single_stage_results(engines, golden_d
         assert max(abs(sa - sb) for (_, sa), (_, sb) in zip(pa, pb)) < TOL
 
 
-def _debug_conv(x_nhwc, w_oihw, bias, stride, pads, act=0, res=None, split=True, iters=0, force_direct=False):
+def _debug_conv(x_nhwc, w_oihw, bias, stride, pads, act=0, res=None, split=True, iters=0, force_direct=False, force_stream=False):
     """One convolution through the library's dense-conv launcher on prepared operands (api.cpp rd_debug_conv)."""
     import ctypes as C
     from rapiddoc_amd import _lib
@@ -570,7 +570,7 @@ def _debug_conv(x_nhwc, w_oihw, bias, stride, pads, act=0, res=None, split=True,
     pt, pl, pb, pr = pads
     OH, OW = (H + pt + pb - KH) // stride + 1, (W_ + pl + pr - KW) // stride + 1
     y = torch.full((N, OH, OW, Cout), float("nan"), device="cuda")
-    used = C.c_int(1 if force_direct else 0)
+    used = C.c_int(2 if force_stream else 1 if force_direct else 0)
     ms = lib.rd_debug_conv(N, H, W_, Cin, Cout, KH, KW, stride, pt, pl, pb, pr, act, iters, x_nhwc.data_ptr(), wf.data_ptr(),
                            wh.data_ptr() if split else None, wl.data_ptr() if split else None, bias.data_ptr(),
                            res.data_ptr() if res is not None else None, y.data_ptr(), C.byref(used))
@@ -603,5 +603,32 @@ def test_direct_conv_matches_fp64(N, H, W_, Cin, Cout, k, pads, act, with_res):
         ref = ref + res.permute(0, 3, 1, 2).double()
     y, used, _ = _debug_conv(x, w, b, 1, pads, act, res, force_direct=True)
     assert used == 1, "the direct kernel did not take this geometry"
+    err = (y.permute(0, 3, 1, 2).double() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("N,H,W_,Cin,Cout,k,stride,pads,act,with_res", [
+    (3, 24, 130, 48, 24, 2, 1, (0, 0, 1, 1), 1, False),     # rec stem2a
+    (3, 24, 130, 24, 48, 2, 1, (0, 0, 1, 1), 1, False),     # rec stem2b: Cin 24 -> two k-steps, the second half masked
+    (2, 33, 71, 12, 24, 2, 1, (0, 0, 1, 1), 1, False),      # det stem2b: Cin 12
+    (2, 40, 57, 48, 96, 1, 1, (0, 0, 0, 0), 1, True),       # stem4 1x1, three output blocks, residual
+    (2, 37, 53, 16, 32, 3, 2, (1, 1, 1, 1), 3, False),      # 3x3 stride 2 (any geometry is address arithmetic here)
+])
+def test_stream_conv_matches_fp64(N, H, W_, Cin, Cout, k, stride, pads, act, with_res):
+    """kernels_conv_stream_h3.hip (small-K layers, operands streamed from global memory) against torch conv2d in float64."""
+    g = torch.Generator(device="cuda").manual_seed(N * 77 + Cin)
+    x = torch.rand((N, H, W_, Cin), device="cuda", generator=g) * 2 - 1
+    w = (torch.rand((Cout, Cin, k, k), device="cuda", generator=g) - 0.5) * 0.2
+    b = torch.rand((Cout,), device="cuda", generator=g) - 0.5
+    pt, pl, pb, pr = pads
+    xp = torch.nn.functional.pad(x.permute(0, 3, 1, 2).double(), (pl, pr, pt, pb))
+    ref = torch.nn.functional.conv2d(xp, w.double(), b.double(), stride=stride)
+    ref = {0: ref, 1: torch.relu(ref), 3: torch.nn.functional.silu(ref)}[act]
+    res = None
+    if with_res:
+        res = torch.rand((N, ref.shape[2], ref.shape[3], Cout), device="cuda", generator=g)
+        ref = ref + res.permute(0, 3, 1, 2).double()
+    y, used, _ = _debug_conv(x, w, b, stride, pads, act, res, force_stream=True)
+    assert used == 2, "the streaming kernel did not take this geometry"
     err = (y.permute(0, 3, 1, 2).double() - ref).abs().max().item()
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err

@@ -136,7 +136,8 @@ if __name__ == "__main__" and "--kxk" in sys.argv:
     from test_gpu_parity import _debug_conv
     cases = (("B4 stages.0 3x3", 32, 200, 200, 48, 48, 3, (1, 1, 1, 1)), ("B4 stages.1 3x3", 32, 100, 100, 96, 96, 3, (1, 1, 1, 1)),
              ("rec stem2a 2x2", 64, 24, 272, 48, 24, 2, (0, 0, 1, 1)), ("rec stem2b 2x2", 64, 24, 272, 24, 48, 2, (0, 0, 1, 1)),
-             ("det conv_down 3x3", 32, 240, 176, 96, 24, 3, (1, 1, 1, 1)), ("layout stem2b 2x2", 32, 400, 400, 16, 32, 2, (0, 0, 1, 1)))
+             ("det conv_down 3x3", 32, 240, 176, 96, 24, 3, (1, 1, 1, 1)), ("layout stem2b 2x2", 32, 400, 400, 16, 32, 2, (0, 0, 1, 1)),
+             ("rec stem4 1x1", 64, 12, 136, 48, 96, 1, (0, 0, 0, 0)), ("det stem2a 2x2", 32, 480, 352, 24, 12, 2, (0, 0, 1, 1)))
     for name, N, H, W_, Cin, Cout, k, pads in cases:
         x = torch.rand((N, H, W_, Cin), device="cuda") - 0.5
         w = (torch.rand((Cout, Cin, k, k), device="cuda") - 0.5) * 0.1
