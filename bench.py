@@ -297,6 +297,8 @@ def main():
                     name = "lc_mixer_kernel<%s>" % op["cfg"][1:]
                 elif op["kind"] == "mixer_fused_h3":
                     name = "lc_mixer_h3_kernel<%s>" % op["cfg"][1:]
+                elif op["kind"] == "mixer_fused_res":
+                    name = "lc_mixer_res_kernel<%s>" % op["cfg"][1:]
                 elif op["kind"] == "mixer_fused_ws":
                     name = "lc_mixer_ws_kernel<%s>" % op["cfg"][1:]
                 elif op["kind"] == "ctc_head_fused_h3":

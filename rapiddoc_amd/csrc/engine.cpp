@@ -439,6 +439,11 @@ TView Builder::mixer_fused(const std::string& prefix, const TView& x, const TVie
             pb_->add_u16(hkey + ".w1h", v[0]); pb_->add_u16(hkey + ".w1l", v[1]);
             pb_->add_u16(hkey + ".w2h", v[2]); pb_->add_u16(hkey + ".w2l", v[3]);
         }
+        if (!pb_->has(hkey + ".res") && fits && mixer_res_supported(C)) {   // fragment image of the resident-weights kernel
+            std::vector<uint16_t> img;
+            prepare_mixer_weights_res(f1, f2, C, img);
+            pb_->add_u16(hkey + ".res", img);
+        }
         if (!pb_->has(hkey + ".ws") && fits && mixer_ws_preferred(C)) {   // weight stream image of the ws kernel
             std::vector<uint16_t> img;
             float inv[2];
@@ -451,8 +456,12 @@ TView Builder::mixer_fused(const std::string& prefix, const TView& x, const TVie
     const bool split = (h3_ || mixer_h3_) && pb_->has(hkey + ".w1h");
     static const bool ws_off = std::getenv("RD_MIXER_WS") && std::string(std::getenv("RD_MIXER_WS")) == "0";   // A/B switch
     const bool ws = split && !ws_off && pb_->has(hkey + ".ws");
+    const bool res_k = split && !ws && mixer_res_supported(C) && pb_->has(hkey + ".res");
     MixerParams p{};
-    if (ws) {
+    if (res_k) {
+        p.w1h = reinterpret_cast<const uint16_t*>(pb_->ptr(hkey + ".res"));
+        p.range_flag = range_flag_;
+    } else if (ws) {
         p.w1h = reinterpret_cast<const uint16_t*>(pb_->ptr(hkey + ".ws"));
         p.ws_inv1 = pb_->host_ptr(hkey + ".wsinv")[0];
         p.ws_inv2 = pb_->host_ptr(hkey + ".wsinv")[1];
@@ -469,7 +478,7 @@ TView Builder::mixer_fused(const std::string& prefix, const TView& x, const TVie
     p.w2 = pb_->ptr(w2 + "|" + bn2 + "#w"); p.b2 = pb_->ptr(w2 + "|" + bn2 + "#b");
     OpRecord r;
     r.name = prefix + ".mixer";
-    r.kind = ws ? "mixer_fused_ws" : split ? "mixer_fused_h3" : "mixer_fused";
+    r.kind = res_k ? "mixer_fused_res" : ws ? "mixer_fused_ws" : split ? "mixer_fused_h3" : "mixer_fused";
     r.cfg = "C" + std::to_string(C);
     r.shape = "M" + std::to_string(p.M) + "_C" + std::to_string(C);
     r.flops = 8.0 * p.M * (double)C * C;
@@ -477,12 +486,13 @@ TView Builder::mixer_fused(const std::string& prefix, const TView& x, const TVie
     const TView xv = x, yv = y;
     const bool has_gate = gate != nullptr;
     const TView gv = gate ? *gate : TView{};
-    r.run = [p, xv, yv, gv, has_gate, split, ws](const Plan& pl, const RunCtx& c) {
+    r.run = [p, xv, yv, gv, has_gate, split, ws, res_k](const Plan& pl, const RunCtx& c) {
         MixerParams q = p;
         q.x = pl.vptr(xv, c);
         q.y = pl.vptr(yv, c);
         q.gate = has_gate ? pl.vptr(gv, c) : nullptr;
-        if (ws) launch_mixer_fused_ws(q, c.stream);
+        if (res_k) launch_mixer_fused_res(q, c.stream);
+        else if (ws) launch_mixer_fused_ws(q, c.stream);
         else if (split) launch_mixer_fused_h3(q, c.stream);
         else launch_mixer_fused(q, c.stream);
     };
@@ -1030,6 +1040,9 @@ void Engine::load_weights(const void* blob, size_t nbytes) {
         const unsigned zero = 0;
         RD_HIP(hipMemcpy(range_flag_, &zero, sizeof(zero), hipMemcpyHostToDevice));
         RD_HIP(hipDeviceSynchronize());
+        unsigned back = 1;
+        RD_HIP(hipMemcpy(&back, range_flag_, sizeof(back), hipMemcpyDeviceToHost));
+        RD_CHECK(back == 0, "range flag did not initialise");
     }
     Builder b(Mode::PREPARE, &store_, &params_, &dummy, h3_prepared_, true);
     // smallest legal geometry; only weight names/shapes matter in PREPARE mode

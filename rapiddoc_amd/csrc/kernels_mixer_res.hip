@@ -1,0 +1,222 @@
+// Fused PPLCNetV4 channel mixer (rec_lcnetv4.py:226-236: y = xg + W2 * GELU(W1 * xg + b1) + b2, xg = x * SE gate) for the NARROW
+// blocks (C = 96; any multiple of 32 whose weights fit in LDS) - split-fp16 arithmetic as in kernels_mixer_h3.hip (x = hi + lo * 2^-11, three MFMAs per product, two fp32
+// accumulators).
+//
+// At C = 96 a mixer is HBM-bound: 8 M C^2 = 7.7 GFLOP against 80 MB of activations (M = 104 448): ~12 us of MFMA issue, ~16 us of
+// VALU (GELU) and 20 us of HBM at 4 TB/s.  The round-1 kernel (one wavefront per SIMD, phases separated by barriers) and the
+// weight-streaming kernel of round 2 (kernels_mixer_ws.hip) both measured 97-105 us there.  What this width allows and C = 192
+// does not: ALL weights (hi and lo of W1 and W2: 147 KB at C = 96) fit in LDS.  So:
+//   * one 16-wavefront workgroup per CU copies the weight image (pre-arranged as MFMA A fragments, 1 KB each) into LDS once, one
+//     barrier, and after that NO wavefront ever waits for another: each loops over its own 16-pixel tiles;
+//   * activations never touch LDS: X^T is the MFMA B operand from registers (16x16x32, lane = pixel, 8 channels), the hidden block's
+//     C/D registers ARE the next B fragment (W2's columns are permuted to match), Y^T's C/D registers are four consecutive output
+//     channels of the lane's pixel: residual and store are float4 at the addresses the tile was loaded from;
+//   * four wavefronts per SIMD (<= 128 VGPRs) hide the tile loads and the LDS fragment reads of one another.
+#include <cstdlib>
+#include <vector>
+
+#include "rd_device.h"
+
+namespace rd {
+
+static constexpr int MR_WAVES = 16;
+
+template <int C>
+struct ResGeom {
+    static constexpr int H2 = 2 * C;            // hidden width
+    static constexpr int KS1 = C / 32;          // k-steps of GEMM1
+    static constexpr int HB = H2 / 16;          // hidden blocks of 16
+    static constexpr int NQ = H2 / 32;          // pairs of hidden blocks = k-steps of GEMM2
+    static constexpr int OB = C / 16;           // output blocks of 16
+    static constexpr int F1 = HB * KS1;         // W1 fragments per plane
+    static constexpr int F2 = OB * NQ;          // W2 fragments per plane
+    static constexpr size_t IMG_BYTES = (size_t)2 * (F1 + F2) * 1024;
+    static constexpr size_t LDS_BYTES = IMG_BYTES + (size_t)(H2 + C) * sizeof(float);
+};
+
+// image layout: [W1 hi: F1 fragments][W1 lo][W2 hi: F2][W2 lo]; W1 fragment (hb, ks), W2 fragment (ob, q)
+template <int C, bool GATED>
+__global__ void __launch_bounds__(1024) lc_mixer_res_kernel(MixerParams p, const unsigned char* __restrict__ wimg, int n_tiles) {
+    using G = ResGeom<C>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float* B1s = reinterpret_cast<float*>(lds + G::IMG_BYTES);
+    float* B2s = B1s + G::H2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(wimg);
+        u32x4* dst = reinterpret_cast<u32x4*>(lds);
+        for (int i = tid; i < (int)(G::IMG_BYTES / 16); i += 1024) dst[i] = src[i];
+        for (int i = tid; i < G::H2; i += 1024) B1s[i] = p.b1[i];
+        for (int i = tid; i < C; i += 1024) B2s[i] = p.b2[i];
+    }
+    __syncthreads();
+    const unsigned char* W1h = lds;
+    const unsigned char* W1l = lds + (size_t)G::F1 * 1024;
+    const unsigned char* W2h = lds + (size_t)2 * G::F1 * 1024;
+    const unsigned char* W2l = W2h + (size_t)G::F2 * 1024;
+    const int px = lane & 15, kg = lane >> 4;
+    const unsigned lo16 = (unsigned)lane * 16u;
+    float amax = 0.f;
+
+    for (int tile = (int)blockIdx.x * MR_WAVES + wave; tile < n_tiles; tile += (int)gridDim.x * MR_WAVES) {
+        const int mm = tile * 16 + px;
+        const int m = min(mm, p.M - 1);                 // rows past M re-read the last row and are never stored
+        const float* xp = p.x + (size_t)m * p.xld + 8 * kg;
+        const float* gp = GATED ? p.gate + (size_t)(m / p.HW) * C + 8 * kg : nullptr;
+        // ---- X^T as B fragments: k-step ks, lane (px, kg) = channels 32 ks + 8 kg .. + 8
+        f16x8 xh[G::KS1], xl[G::KS1];
+#pragma unroll
+        for (int ks = 0; ks < G::KS1; ++ks) {
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(xp + 32 * ks);
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(xp + 32 * ks + 4);
+            if (GATED) {
+                v0 *= *reinterpret_cast<const f32x4*>(gp + 32 * ks);
+                v1 *= *reinterpret_cast<const f32x4*>(gp + 32 * ks + 4);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 h0, l0, h1, l1;
+                rd_split(v0[e], h0, l0);
+                rd_split(v1[e], h1, l1);
+                xh[ks][e] = h0; xh[ks][4 + e] = h1;
+                xl[ks][e] = l0; xl[ks][4 + e] = l1;
+                amax = fmaxf(amax, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
+            }
+        }
+        f32x4 y1[G::OB], y2[G::OB];
+#pragma unroll
+        for (int ob = 0; ob < G::OB; ++ob) y1[ob] = y2[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+        for (int q = 0; q < G::NQ; ++q) {
+            // ---- GEMM1: hidden blocks 2q, 2q+1 (16 hidden x 16 pixels each)
+            f16x8 hh, hl;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+                const int hb = 2 * q + b;
+#pragma unroll
+                for (int ks = 0; ks < G::KS1; ++ks) {
+                    const unsigned fo = (unsigned)(hb * G::KS1 + ks) * 1024u + lo16;
+                    const f16x8 wh = *reinterpret_cast<const f16x8*>(W1h + fo);
+                    const f16x8 wl = *reinterpret_cast<const f16x8*>(W1l + fo);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[ks], a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[ks], a2, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[ks], a2, 0, 0, 0);
+                }
+                // bias, GELU, split: C/D rows 4 kg + r of block hb = hidden 16 hb + 4 kg + r -> B slot 4 b + r of k-step q
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(&B1s[16 * hb + 4 * kg]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = rd_gelu(fmaf(a2[r], 1.f / 2048.f, a1[r]) + bv[r]);
+                    _Float16 h, l;
+                    rd_split(v, h, l);
+                    hh[4 * b + r] = h;
+                    hl[4 * b + r] = l;
+                    amax = fmaxf(amax, fabsf(v));
+                }
+            }
+            // ---- GEMM2: every output block takes k-step q
+#pragma unroll
+            for (int ob = 0; ob < G::OB; ++ob) {
+                const unsigned fo = (unsigned)(ob * G::NQ + q) * 1024u + lo16;
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(W2h + fo);
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(W2l + fo);
+                y1[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hh, y1[ob], 0, 0, 0);
+                y2[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hl, y2[ob], 0, 0, 0);
+                y2[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, hh, y2[ob], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: C/D rows 4 kg + r of output block ob = channels 16 ob + 4 kg .. + 4 of pixel px: + b2 + gated x, float4 store
+        if (mm < p.M) {
+            const float* xr = p.x + (size_t)m * p.xld + 4 * kg;
+            const float* gr = GATED ? p.gate + (size_t)(m / p.HW) * C + 4 * kg : nullptr;
+            float* yp = p.y + (size_t)m * p.yld + 4 * kg;
+#pragma unroll
+            for (int ob = 0; ob < G::OB; ++ob) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(xr + 16 * ob);
+                if (GATED) v *= *reinterpret_cast<const f32x4*>(gr + 16 * ob);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(&B2s[16 * ob + 4 * kg]);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaf(y2[ob][e], 1.f / 2048.f, y1[ob][e]) + bv[e] + v[e];
+                __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(yp + 16 * ob));
+            }
+        }
+    }
+    if (!(amax < 65504.f) && p.range_flag) atomicOr(p.range_flag, 1u);   // also catches NaN
+}
+
+bool mixer_res_supported(int C) {
+    static const bool off = [] { const char* e = getenv("RD_MIXER_RES"); return e && e[0] == '0'; }();
+    return !off && (C == 64 || C == 96);       // multiples of 32 whose image fits in LDS (C = 128: 256 KB)
+}
+
+// w1 [2C][C], w2 [C][2C] (BN folded) -> fragment image (layout above).  A fragment of v_mfma_f32_16x16x32_f16: lane l holds row
+// l % 16, k = 8 (l / 16) + e.  W2's k-slot e of k-step q is hidden unit 16 (2q + e / 4) + 4 (l / 16) + e % 4 (the C/D registers of
+// the two hidden blocks, see the kernel).
+void prepare_mixer_weights_res(const float* w1, const float* w2, int C, std::vector<uint16_t>& img) {
+    const int H2 = 2 * C, KS1 = C / 32, HB = H2 / 16, NQ = H2 / 32, OB = C / 16;
+    const int F1 = HB * KS1, F2 = OB * NQ;
+    img.assign((size_t)2 * (F1 + F2) * 512, 0);
+    auto put = [](float v, uint16_t& hb, uint16_t& lb) {
+        const _Float16 h = (_Float16)v;
+        const _Float16 l = (_Float16)((v - (float)h) * 2048.f);
+        __builtin_memcpy(&hb, &h, 2);
+        __builtin_memcpy(&lb, &l, 2);
+    };
+    uint16_t* w1h = img.data();
+    uint16_t* w1l = w1h + (size_t)F1 * 512;
+    uint16_t* w2h = w1l + (size_t)F1 * 512;
+    uint16_t* w2l = w2h + (size_t)F2 * 512;
+    for (int hb = 0; hb < HB; ++hb)
+        for (int ks = 0; ks < KS1; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e) {
+                    const int row = 16 * hb + (l & 15), k = 32 * ks + 8 * (l >> 4) + e;
+                    const size_t o = ((size_t)(hb * KS1 + ks) * 64 + l) * 8 + e;
+                    put(w1[(size_t)row * C + k], w1h[o], w1l[o]);
+                }
+    for (int ob = 0; ob < OB; ++ob)
+        for (int q = 0; q < NQ; ++q)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e) {
+                    const int row = 16 * ob + (l & 15);
+                    const int hid = 16 * (2 * q + (e >> 2)) + 4 * (l >> 4) + (e & 3);
+                    const size_t o = ((size_t)(ob * NQ + q) * 64 + l) * 8 + e;
+                    put(w2[(size_t)row * H2 + hid], w2h[o], w2l[o]);
+                }
+}
+
+template <int C>
+static void launch_res(const MixerParams& p, hipStream_t s) {
+    using G = ResGeom<C>;
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    const int n_tiles = (p.M + 15) / 16;
+    const int n_wg = (n_tiles + MR_WAVES - 1) / MR_WAVES;
+    const int grid = n_wg < n_cu ? n_wg : n_cu;
+    const unsigned char* img = reinterpret_cast<const unsigned char*>(p.w1h);
+    static unsigned long long ok0 = 0, ok1 = 0;
+    if (p.gate) {
+        rd_allow_dynamic_lds((const void*)lc_mixer_res_kernel<C, true>, G::LDS_BYTES, ok1);
+        hipLaunchKernelGGL((lc_mixer_res_kernel<C, true>), dim3(grid), dim3(1024), G::LDS_BYTES, s, p, img, n_tiles);
+    } else {
+        rd_allow_dynamic_lds((const void*)lc_mixer_res_kernel<C, false>, G::LDS_BYTES, ok0);
+        hipLaunchKernelGGL((lc_mixer_res_kernel<C, false>), dim3(grid), dim3(1024), G::LDS_BYTES, s, p, img, n_tiles);
+    }
+}
+
+// p.w1h = the fragment image of prepare_mixer_weights_res
+void launch_mixer_fused_res(const MixerParams& p, hipStream_t s) {
+    if (p.M <= 0) return;
+    if (p.C == 96) launch_res<96>(p, s);
+    else launch_res<64>(p, s);
+}
+
+}  // namespace rd

@@ -177,7 +177,8 @@ def test_native_fp32_precision_mode_matches_golden(golden_dir, monkeypatch):
     eng.set_precision("fp32")
     nat = eng.rec_forward(x, REC_WANT_LOGITS)[2].cpu().numpy()
     kinds_nat = {r["kind"] for r in _profile(eng, lambda: eng.rec_forward(x))}
-    assert "mixer_fused_h3" in kinds_auto and "mixer_fused_h3" not in kinds_nat and "mixer_fused" in kinds_nat
+    split_kinds = {"mixer_fused_h3", "mixer_fused_ws", "mixer_fused_res"}     # round-1 / weight-streaming / resident-weights kernels
+    assert kinds_auto & split_kinds and not (kinds_nat & split_kinds) and "mixer_fused" in kinds_nat
     assert not eng.range_overflow()
     assert np.abs(nat[:, 0, :] - g["logits_t0"]).max() < TOL
     assert np.abs(auto - nat).max() < 2e-4
@@ -319,15 +320,17 @@ def test_split_gemm_tails_match_fp64(M, K, N):
 
 
 @pytest.mark.parametrize("C_,M", [(48, 1000), (96, 4097), (192, 333), (192, 12800 + 5), (192, 70001), (96, 40000 + 3)])
-@pytest.mark.parametrize("variant", [0, 100, 200, 201, 202, 204, 208])
+@pytest.mark.parametrize("variant", [0, 100, 200, 201, 202, 204, 208, 300])
 def test_fused_mixer_kernels_match_fp64(C_, M, variant):
     """Fused channel mixer x + W2 gelu(W1 x + b1) + b2 (rec_lcnetv4.py:226-236): fp32-MFMA kernel (variant 0, C = 192
     only in the debug entry), round-1 split-fp16 kernel (variant 100) and the weight-streaming kernel (200; +1 lock step, +4 per-wavefront
-    phases, +8 per-workgroup phases, +2 flipped residual policy) on ragged pixel counts incl. several persistent rounds, against fp64."""
+    phases, +8 per-workgroup phases, +2 flipped residual policy) and the resident-weights kernel of the narrow blocks (300) on ragged pixel counts incl. several persistent rounds, against fp64."""
     import ctypes as C
     from rapiddoc_amd import _lib
     if variant == 0 and C_ != 192:
         pytest.skip("the fp32 debug entry is instantiated for C = 192")
+    if variant >= 300 and C_ != 96:
+        pytest.skip("the resident-weights kernel (300) covers C = 96")
     if variant >= 200 and C_ == 48:
         pytest.skip("the weight-streaming kernel covers C = 96 / 192")
     lib = _lib.load()

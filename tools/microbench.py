@@ -66,6 +66,14 @@ if __name__ == "__main__" and "--ctc" in sys.argv:
     print(f"ctc head fp32 MFMA M=4352 nsplit {n}: {ms*1e3:8.1f} us {tf:7.1f} TF/s  argmax ok {ok}  prob err {perr:.1e}")
     sys.exit(0)
 
+if __name__ == "__main__" and "--mixer-res" in sys.argv:
+    # narrow blocks: resident-weights kernel (300) vs weight-streaming (200) vs the round-1 split kernel (100)
+    for C_, M in ((96, 104448), (96, 211200), (96, 26112), (96, 5000)):
+        for v in (100, 200, 300):
+            ms, tf, err = mixer(C_, M, v, check=True)
+            print(f"mixer C={C_} M={M} variant {v}: {ms*1e3:8.1f} us {tf:7.1f} TF/s  max abs err vs fp64 {err:.2e}", flush=True)
+    sys.exit(0)
+
 if __name__ == "__main__" and "--mixer-ws" in sys.argv:
     # round 2: weight-streaming mixer (variant 200 + bits: 1 lock step instead of per-wavefront phases, 2 flipped residual
     # policy) vs the round-1 kernel (100); then ablations (+ 256 * bits, C = 192, garbage results)
