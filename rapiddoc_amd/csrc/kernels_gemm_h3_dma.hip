@@ -13,7 +13,7 @@
 //   * a DMA writes wave-uniform base + lane*16, so the LDS images are unpadded; bank conflicts are avoided by XOR-swizzling
 //     the 16-byte chunk index with the row on the SOURCE address (A: chunk ^ ((row >> 1) & 7) in 128-byte rows, B:
 //     chunk ^ ((row >> 2) & 3) in 64-byte rows - both conflict-free for the ds_read_b128 lane groups of gfx950).
-// 256x128 output tile, 8 wavefronts (4 x 2, 64x64 each), persistent workgroups, XCD-contiguous tile order, epilogue and
+// 256x128 output tile, 8 wavefronts (8 x 1, 32x128 each), persistent workgroups, XCD-contiguous tile order, epilogue and
 // range guard as in kernels_conv_h3.hip.
 // Tried and dropped: the same pipeline as an implicit GEMM for k x k convolutions (every lane's 16-byte chunk gathered by
 // the DMA from its tap, padding taps from a zero page, BN = 32 / 64 / 128): no faster than the register-staged kernel on
@@ -100,7 +100,8 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave;      // 8 x 1 wavefronts of 32 x 128: every A row tile is split (2 VALU per element) by ONE wavefront
+                              // (round 1: 4 x 2 of 64 x 64, split twice; VALU time is not hidden on this chip)
     const int l31 = lane & 31, lhi = lane >> 5;
     const int K = p.K, KT = (K + DK - 1) / DK, Kp = KT * DK;   // weight rows are zero padded to Kp (split_weights_h3)
     const _Float16* wh = reinterpret_cast<const _Float16*>(p.wh);
@@ -144,15 +145,16 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
     };
 
     // ---- fragment addressing (byte offsets inside a stage)
-    int a_off[2][2], b_off[2][2];   // [tile][ks]: first of the two chunks (A) / the chunk (B)
+    int a_off[2], b_off[4][2];   // A: [ks] first of the two chunks; B: [column block][ks] the chunk
+    {
+        const int R = wm * 32 + l31, f = (R >> 1) & 7;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int R = (wm * 2 + i) * 32 + l31, f = (R >> 1) & 7;
-        const int Rn = (wn * 2 + i) * 32 + l31, g = (Rn >> 2) & 3;
+        for (int ks = 0; ks < 2; ++ks) a_off[ks] = R * 128 + (((2 * (lhi + 2 * ks)) ^ f) << 4);   // the partner chunk is this address ^ 16
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            a_off[i][ks] = R * 128 + (((2 * (lhi + 2 * ks)) ^ f) << 4);   // the partner chunk is this address ^ 16
-            b_off[i][ks] = D_A_BYTES + Rn * 64 + (((lhi + 2 * ks) ^ g) << 4);
+        for (int j = 0; j < 4; ++j) {
+            const int Rn = j * 32 + l31, g = (Rn >> 2) & 3;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b_off[j][ks] = D_A_BYTES + Rn * 64 + (((lhi + 2 * ks) ^ g) << 4);
         }
     }
 
@@ -163,13 +165,11 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
     issue_tile(0, 0);
     if (KT > 1) issue_tile(1, 1);
     for (;;) {
-        f32x16 acc1[2][2], acc2[2][2];
+        f32x16 acc1[4], acc2[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc1[i][j][r] = acc2[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc1[j][r] = acc2[j][r] = 0.f;
 
         int stage = 0;
         for (int kt = 0; kt < KT; ++kt) {
@@ -181,45 +181,45 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             if (kt + 2 < KT) issue_tile(kt + 2, stage >= 1 ? stage - 1 : 2);
             const unsigned char* st = smem + stage * D_STAGE;
-            // One wavefront pair per SIMD cannot hide a ds_read -> split -> MFMA chain per k-step: all 16 fragment reads
-            // of the K tile are issued up front and the split of k-step 1 is scheduled between the MFMAs of k-step 0.
-            f32x4 xa[2][2][2];
-            f16x8 bh[2][2], bl[2][2];
+            // both A fragments and the B fragments of k-step 0 are read up front, both splits done before the first MFMA; the B
+            // fragments of k-step 1 are read under the MFMAs of k-step 0 (all 16 up front do not fit 256 VGPRs next to 128 accumulators)
+            f32x4 xa[2][2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    xa[ks][i][0] = *reinterpret_cast<const f32x4*>(st + a_off[i][ks]);
-                    xa[ks][i][1] = *reinterpret_cast<const f32x4*>(st + (a_off[i][ks] ^ 16));
-                    bh[ks][i] = *reinterpret_cast<const f16x8*>(st + b_off[i][ks]);
-                    bl[ks][i] = *reinterpret_cast<const f16x8*>(st + b_off[i][ks] + D_B_BYTES);
-                }
-            f16x8 ah0[2], al0[2], ah1[2], al1[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) split8(xa[0][i][0], xa[0][i][1], ah0[i], al0[i]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) split8(xa[1][i][0], xa[1][i][1], ah1[i], al1[i]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[i], bh[0][j], acc1[i][j], 0, 0, 0);
-                    acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[i], bl[0][j], acc2[i][j], 0, 0, 0);
-                    acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0[i], bh[0][j], acc2[i][j], 0, 0, 0);
-                }
-#pragma unroll
-            for (int g = 0; g < 12; ++g) {   // split of k-step 1 (~56 VALU ops) under the 12 MFMAs of k-step 0
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            for (int ks = 0; ks < 2; ++ks) {
+                xa[ks][0] = *reinterpret_cast<const f32x4*>(st + a_off[ks]);
+                xa[ks][1] = *reinterpret_cast<const f32x4*>(st + (a_off[ks] ^ 16));
             }
+            f16x8 ah0, al0, ah1, al1;
+            {
+                f16x8 bh[4], bl[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[i], bh[1][j], acc1[i][j], 0, 0, 0);
-                    acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[i], bl[1][j], acc2[i][j], 0, 0, 0);
-                    acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1[i], bh[1][j], acc2[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    bh[j] = *reinterpret_cast<const f16x8*>(st + b_off[j][0]);
+                    bl[j] = *reinterpret_cast<const f16x8*>(st + b_off[j][0] + D_B_BYTES);
                 }
+                split8(xa[0][0], xa[0][1], ah0, al0);
+                split8(xa[1][0], xa[1][1], ah1, al1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[j], acc1[j], 0, 0, 0);
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[j], acc2[j], 0, 0, 0);
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[j], acc2[j], 0, 0, 0);
+                }
+            }
+            {
+                f16x8 bh[4], bl[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bh[j] = *reinterpret_cast<const f16x8*>(st + b_off[j][1]);
+                    bl[j] = *reinterpret_cast<const f16x8*>(st + b_off[j][1] + D_B_BYTES);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh[j], acc1[j], 0, 0, 0);
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl[j], acc2[j], 0, 0, 0);
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh[j], acc2[j], 0, 0, 0);
+                }
+            }
             stage = stage == 2 ? 0 : stage + 1;
         }
         // every wavefront must be past its last LDS read before the next output tile's DMAs land in stages 0 / 1
@@ -234,12 +234,11 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
         }
         // ---- epilogue (bias, activation, residual, range guard on the pre-activation value: kernels_conv_h3.hip)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = en0 + (wn * 2 + j) * 32 + l31;
+        for (int j = 0; j < 4; ++j) {
+            const int n = en0 + j * 32 + l31;
             if (n >= p.Ng) continue;
             const float bv = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) dma_finish_tile<false>(p, acc1[i][j], acc2[i][j], em0 + (wm * 2 + i) * 32 + 4 * lhi, n, bv, emax);
+            dma_finish_tile<false>(p, acc1[j], acc2[j], em0 + wm * 32 + 4 * lhi, n, bv, emax);
         }
         if (!has_next) break;
         v = vnext;
