@@ -108,13 +108,16 @@ __global__ void __launch_bounds__(1024) lc_mixer_res_kernel(MixerParams p, const
                 // bias, GELU, split: C/D rows 4 kg + r of block hb = hidden 16 hb + 4 kg + r -> B slot 4 b + r of k-step q
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(&B1s[16 * hb + 4 * kg]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = rd_gelu(fmaf(a2[r], 1.f / 2048.f, a1[r]) + bv[r]);
-                    _Float16 h, l;
-                    rd_split(v, h, l);
-                    hh[4 * b + r] = h;
-                    hl[4 * b + r] = l;
-                    amax = fmaxf(amax, fabsf(v));
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x2 v = rd_gelu2(f32x2{fmaf(a2[r], 1.f / 2048.f, a1[r]) + bv[r], fmaf(a2[r + 1], 1.f / 2048.f, a1[r + 1]) + bv[r + 1]});
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        _Float16 h, l;
+                        rd_split(v[u], h, l);
+                        hh[4 * b + r + u] = h;
+                        hl[4 * b + r + u] = l;
+                        amax = fmaxf(amax, fabsf(v[u]));
+                    }
                 }
             }
             // ---- GEMM2: every output block takes k-step q

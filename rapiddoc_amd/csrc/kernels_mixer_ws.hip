@@ -255,13 +255,16 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
         for (int b = 0; b < 2; ++b) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(&B1s[q * WS_HC + 16 * b + 4 * g]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = rd_gelu(fmaf(hc[b][r], hfac_cur, bv[r]));
-                _Float16 a, c;
-                ws_split(v, WS_SH, a, c);
-                amax = fmaxf(amax, fabsf(v));
-                hh[4 * b + r] = a;
-                hl[4 * b + r] = c;
+            for (int r = 0; r < 4; r += 2) {
+                const f32x2 v = rd_gelu2(f32x2{fmaf(hc[b][r], hfac_cur, bv[r]), fmaf(hc[b][r + 1], hfac_cur, bv[r + 1])});
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    _Float16 a, c;
+                    ws_split(v[u], WS_SH, a, c);
+                    amax = fmaxf(amax, fabsf(v[u]));
+                    hh[4 * b + r + u] = a;
+                    hl[4 * b + r + u] = c;
+                }
             }
         }
     };

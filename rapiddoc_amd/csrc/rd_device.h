@@ -27,6 +27,31 @@ __device__ __forceinline__ float rd_gelu(float v) {
     return 0.5f * v * (1.f + copysignf(erfz, v));
 }
 
+// Two GELUs at once for the fused mixers, arranged for the packed fp32 VALU (v_pk_mul / v_pk_fma: one issue slot for two lanes'
+// worth of work) - VALU time adds to MFMA time on gfx950, and GELU is most of a mixer's VALU time.  Same
+// Abramowitz-Stegun 7.1.26 erfc as rd_gelu, rewritten without the sign handling:
+//   GELU(v) = max(v, 0) - 0.5 |v| t p(t) exp(-z^2),  z = |v| / sqrt2,  t = 1 / (1 + 0.3275911 z)
+// (v >= 0: 0.5 v (2 - p t e) ; v < 0: 0.5 v (p t e)), with z' = z sqrt(log2 e) so that exp(-z^2) = exp2(-z'^2) is one v_exp_f32 with a
+// negated input, and the 0.5 folded into p's coefficients.  7.5 plain + 2 transcendental instructions per element (rd_gelu: ~12 + 2).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 rd_gelu2(f32x2 v) {
+    constexpr float SQ = 1.2011224087864498f;                       // sqrt(log2 e)
+    constexpr float S = 0.70710678118654752440f * SQ, D = 0.3275911f / SQ;
+    const f32x2 a = {fabsf(v[0]), fabsf(v[1])};
+    const f32x2 zp = a * S;
+    const f32x2 d = zp * D + 1.f;
+    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2 pl = t * (0.5f * 1.061405429f) + (0.5f * -1.453152027f);
+    pl = pl * t + (0.5f * 1.421413741f);
+    pl = pl * t + (0.5f * -0.284496736f);
+    pl = pl * t + (0.5f * 0.254829592f);
+    const f32x2 q = (a * t) * pl;
+    const f32x2 m = zp * zp;
+    const f32x2 e = {__builtin_amdgcn_exp2f(-m[0]), __builtin_amdgcn_exp2f(-m[1])};
+    const f32x2 r = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
+    return r - q * e;
+}
+
 __device__ __forceinline__ float rd_act(float v, int act) {
     switch (act) {
         case ACT_RELU: return fmaxf(v, 0.f);
