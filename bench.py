@@ -126,8 +126,11 @@ def bench_backbone(args, pool, pages, rank, world, dist, backend):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    # defaults: ~1.5 s of timed work.  One warm-up step is not enough on a box whose GPU has been idle: the first process measured
+    # 125 ms/step over 3 steps after 1 warm-up against 102 in every later run (clocks / first-use code loading), with normal
+    # per-kernel durations in the profiling pass that follows
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pages", type=int, default=PAGES_PER_GPU, help="pages per GPU and step (weak scaling)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: the global document has --pages x N pages; strong: it has --global-pages whatever N is.  Either way "
