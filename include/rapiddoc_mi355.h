@@ -56,8 +56,8 @@ int rd_query_workspace(rd_handle* h, int B, int H, int W, int flags, size_t* ws_
 int rd_det_forward(rd_handle* h, const float* x_nchw_dev, int B, int H, int W, float* prob_b1hw_dev, void* ws_dev,
                    size_t ws_bytes, void* stream);
 
-/* PP-OCRv6 rec: x [B,3,48,W] (W multiple of 8) -> per time step (T = W/8) argmax class and its softmax
- * probability; full_btc_dev is only written with RD_REC_WANT_SOFTMAX / RD_REC_WANT_LOGITS (else may be NULL). */
+/* PP-OCRv6 rec: x [B,3,48,W] (any W >= 16) -> per time step (T = rd_rec_seq_len(W): two stride-2 convs and the (3,2)
+ * average pool, W/8 when W is a multiple of 8) argmax class and its softmax probability; full_btc_dev is only written with RD_REC_WANT_SOFTMAX / RD_REC_WANT_LOGITS (else may be NULL). */
 int rd_rec_forward(rd_handle* h, const float* x_nchw_dev, int B, int W, int32_t* idx_bt_dev, float* prob_bt_dev,
                    float* full_btc_dev, int flags, void* ws_dev, size_t ws_bytes, void* stream);
 int rd_rec_num_classes(rd_handle* h);
@@ -108,6 +108,11 @@ int rd_formula_max_new_tokens(rd_handle* h);
 int rd_preproc_resize_norm(int device_id, const uint8_t* hwc_u8_dev, int H, int W, int OH, int OW, const float mean[3],
                            const float std[3], float scale, int interp, int swap_rb, float* out_chw_dev, void* stream);
 
+/* The same for P images of one size in ONE launch: pages_u8_dev [P][H][W][3] -> out [P][3][OH][OW] (the reference's per-page
+ * loop over PPPreProcess / DetPreProcess, rapid_layout_self/main.py:41-56, rapid_ocr.py:474-536). */
+int rd_preproc_resize_norm_batch(int device_id, const uint8_t* pages_u8_dev, int P, int H, int W, int OH, int OW, const float mean[3],
+                                 const float std[3], float scale, int interp, int swap_rb, float* out_nchw_dev, void* stream);
+
 /* Text-line crops for one rec batch (replaces per-line cv2.warpPerspective + rapidocr resize_norm_img:
  * rapid_doc/utils/ocr_utils.py:494-536, rapid_doc/model/ocr/rapid_ocr.py:436-440).  pages_u8_dev: [P][H][W][3];
  * descs_dev: n device-resident rd_crop_desc; out: [n][3][out_h][out_w_padded] float32, zero right-padded. */
@@ -140,6 +145,16 @@ typedef struct rd_line_crop_desc {
 int rd_line_crops_batch(int device_id, const uint8_t* pages_u8_dev, int P, int H, int W, const rd_line_crop_desc* descs_dev,
                         int n, int64_t max_crop_pixels, uint8_t* scratch_u8_dev, int out_h, int out_w_padded, int swap_rb,
                         float* out_nchw_dev, void* stream);
+
+/* The two stages of rd_line_crops_batch as separate calls, for callers whose text lines come from SEVERAL source images of
+ * different sizes but are recognised together (the reference pools every line of a page batch per language before it sorts
+ * and chunks them, rapid_doc/backend/pipeline/analyze_utils.py:216-252): rd_line_warp_batch once per source image array
+ * (stage 1: cubic warp of its lines into the shared scratch buffer), then rd_line_resize_norm_batch once per rec batch
+ * (stage 2: rot90 / linear resize to out_h / normalise / zero right-pad; reads the scratch buffer only). */
+int rd_line_warp_batch(int device_id, const uint8_t* pages_u8_dev, int P, int H, int W, const rd_line_crop_desc* descs_dev, int n,
+                       int64_t max_crop_pixels, uint8_t* scratch_u8_dev, void* stream);
+int rd_line_resize_norm_batch(int device_id, const rd_line_crop_desc* descs_dev, int n, const uint8_t* scratch_u8_dev, int out_h,
+                              int out_w_padded, int swap_rb, float* out_nchw_dev, void* stream);
 
 /* CTC greedy decode on the device (replaces rapidocr CTCLabelDecode's per-line loop, called from
  * rapid_doc/model/ocr/rapid_ocr.py:444-449): idx / prob [B][T] as rd_rec_forward wrote them -> per line, at out + b * row_bytes:
@@ -204,8 +219,10 @@ int rd_layout_postprocess(const float* boxes, int n, int ncol, int img_w, int im
 
 /* Arithmetic of the dense layers of a network handle; every mode returns fp32 tensors with fp32-level error
  * (the reference runs the same layers through onnxruntime / torch fp32: rapid_doc/model/ocr/.../torch.py:58-76).
- *   "auto" (default)  fp32 MFMA, except the fused PPLCNetV4 channel mixers: fp16 matrix cores with (hi, lo) operand
- *                     splitting, 3 MFMAs per product, fp32 accumulate (measured error vs fp64 below the fp32 MFMA path's).
+ *   "auto" (default)  split-fp16 matrix cores ((hi, lo) operand splitting, 3 fp16 MFMAs per product, fp32 accumulate,
+ *                     measured error vs fp64 at or below the fp32 MFMA path's) for the fused PPLCNetV4 channel mixers,
+ *                     the CTC head, 1x1 convs with K >= 96 and N >= 96, k x k convs with K >= 96 and N >= 24 and the
+ *                     small-K stem layers; fp32 MFMA for the rest (narrow / short layers, M < 2048).
  *   "fp32"            native fp32 MFMA only.
  *   "h3"              every dense layer split (experimental; needs RD_PRECISION=h3 in the environment at rd_load_weights).
  * Split operands must stay inside the fp16 range (|v| < 65504).  The kernels never return a silently wrong answer:

@@ -41,8 +41,9 @@ def _attn(state, p, x, kv, causal):
     return _lin(state, p + ".out_proj", o)
 
 
-def decoder_logits(state, enc_proj, ids):
-    """Logits of the LAST position for token prefix `ids` [B,L]."""
+def decoder_logits(state, enc_proj, ids, all_positions=False):
+    """Logits of the LAST position for token prefix `ids` [B,L] (all positions [B,L,V] with `all_positions`: the causal
+    mask makes position t's logits those of the prefix ids[:, :t+1] - teacher forcing, one pass instead of L)."""
     d = state[DEC + "embed_tokens.weight"].shape[1]
     L = ids.shape[1]
     x = state[DEC + "embed_tokens.weight"][ids] * math.sqrt(d) + state[DEC + "embed_positions.weight"][torch.arange(L) + 2]
@@ -59,7 +60,14 @@ def decoder_logits(state, enc_proj, ids):
         h = _ln(state, p + ".final_layer_norm", x)
         x = x + _lin(state, p + ".fc2", F.gelu(_lin(state, p + ".fc1", h)))
     x = _ln(state, DEC + "layer_norm", x)
-    return F.linear(x[:, -1], state["head.decoder.lm_head.weight"])
+    return F.linear(x if all_positions else x[:, -1], state["head.decoder.lm_head.weight"])
+
+
+def teacher_forced_logits(state, enc, ids):
+    """Logits [B, L-1, V] the decoder produces at every step when it is fed the prefix of `ids` [B,L] (start token included):
+    row t is the distribution the (t+1)-th token was chosen from.  Forced-EOS rule not applied (sequences shorter than 1536)."""
+    enc_proj = _lin(state, "head.enc_to_dec_proj", enc)
+    return decoder_logits(state, enc_proj, ids[:, :-1], all_positions=True)
 
 
 def formula_decode(state, enc, max_new_tokens, return_logits=False):

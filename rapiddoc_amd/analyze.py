@@ -13,8 +13,9 @@ the GPU:
   `_run_ocr_rec_postprocess` (analyze_utils.py:216-292)
      recognise every span's line crop, write text / score, demote low-confidence spans
 
-Deviations (both documented in DESIGN.md s4): the recogniser batches the lines of one size group at a time (the reference
-sorts all lines of a language globally before chunking), and `rec_batch_num` is GPU sized.
+The lines of ALL regions of the page batch are recognised together (`PagePipeline.rec_forward_sources`), pooled page by
+page like `_run_ocr_rec_postprocess` does per language; with a pipeline built with rec_mode="strict" the batching is the
+reference's (one global argsort, chunks of 6), otherwise `rec_batch_num` is GPU sized.
 """
 from __future__ import annotations
 
@@ -24,7 +25,7 @@ import numpy as np
 import torch
 
 from . import layout_host, ocr_host
-from .engine import preproc_resize_norm
+from .engine import preproc_resize_norm_batch
 
 OCR_TEXT, LOW_SCORE_TEXT = 15, 16                 # utils/enum_class.py:103-104
 MIN_CONFIDENCE, MIN_WIDTH = 0.5, 3                # utils/ocr_utils.py:9-11
@@ -93,9 +94,8 @@ class RegionOcr:
         benchmarks with random weights, whose maps carry no text); the det forward still runs."""
         b, H, W, _ = canvases.shape
         dh, dw = ocr_host.det_resize_shape(H, W, 960, "max")
-        x = torch.empty((b, 3, dh, dw), dtype=torch.float32, device=canvases.device)
-        for i in range(b):   # DetPreProcess: BGR, (x/255 - 0.5)/0.5 (rapid_ocr.py:474-536)
-            preproc_resize_norm(canvases[i], (dh, dw), mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), interp=1, swap_rb=True, out=x[i])
+        # DetPreProcess: BGR, (x/255 - 0.5)/0.5 (rapid_ocr.py:474-536), the whole group in one launch
+        x = preproc_resize_norm_batch(canvases, (dh, dw), mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), interp=1, swap_rb=True)
         maps = self.pipe.det.det_forward(x)
         if self.pipe.det.check_range_and_fallback():      # split-fp16 range guard (the pipeline's engines defer it)
             maps = self.pipe.det.det_forward(x)
@@ -134,6 +134,7 @@ class RegionOcr:
             return out
         groups = ocr_host.det_buckets([(u[7], u[6]) for _, _, u, _ in regions], [self.lang] * len(regions),
                                       det_batch_num=len(regions))
+        pending = []                                   # per size group: (unmasked canvases, quads, spans, page of each image)
         for _lang, (gh, gw), members, _bs in groups:
             canv = torch.full((len(members), gh, gw, 3), 255, dtype=torch.uint8, device=pages.device)
             # The reference whites the formula boxes out of a COPY that only the detector sees (`det_image`,
@@ -183,9 +184,13 @@ class RegionOcr:
                     quads.append(q)                    # the line crop is taken from the UNcorrected box (:381-383)
                 spans_per_img.append(spans)
                 quads_per_img.append(np.asarray(quads, dtype=np.float32).reshape(-1, 4, 2))
-            texts = self.pipe.rec_forward_lines(canv, quads_per_img)
-            for k, ridx in enumerate(members):
-                p = regions[ridx][0]
+            pending.append((canv, quads_per_img, spans_per_img, [regions[ridx][0] for ridx in members]))
+        if not pending:
+            return out
+        # rec: every line of the page batch in ONE pooled call (analyze_utils.py:216-252), ordered page by page
+        texts_all = self.pipe.rec_forward_sources([(c, q) for c, q, _s, _p in pending], image_keys=[pg for _c, _q, _s, pg in pending])
+        for (canv, _q, spans_per_img, pages_of), texts in zip(pending, texts_all):
+            for k, p in enumerate(pages_of):
                 for span, (text, score) in zip(spans_per_img[k], texts[k]):
                     span["text"] = text
                     span["score"] = float(f"{score:.3f}")
@@ -216,6 +221,7 @@ class RegionTextModel:
         shapes = [(int(im.shape[0]), int(im.shape[1])) for im in image_list]
         keep = [i for i, (h, w) in enumerate(shapes) if h > 0 and w > 0]
         groups = ocr_host.det_buckets([shapes[i] for i in keep], ["_"] * len(keep), det_batch_num=max(1, len(keep)))
+        pending = []
         for _lang, (gh, gw), members, _bs in groups:
             ids = [keep[m] for m in members]
             canv = torch.full((len(ids), gh, gw, 3), 255, dtype=torch.uint8, device=pipe.tdev)
@@ -225,9 +231,12 @@ class RegionTextModel:
             override = det_maps_fn(ids, (gh, gw), ocr_host.det_resize_shape(gh, gw, 960, "max")) if det_maps_fn else None
             boxes = self._ocr._detect_group(canv, override)
             quads = [np.asarray([q for q in b if q[2][0] - q[0][0] >= MIN_WIDTH], dtype=np.float32).reshape(-1, 4, 2) for b in boxes]
-            lines = pipe.rec_forward_lines(canv, quads)
-            for k, i in enumerate(ids):
-                texts[i] = "\n".join(t for t, s in lines[k] if s >= MIN_CONFIDENCE and t)
+            pending.append((canv, quads, ids))
+        if pending:
+            lines_all = pipe.rec_forward_sources([(c, q) for c, q, _i in pending], image_keys=[ids for _c, _q, ids in pending])
+            for (_c, _q, ids), lines in zip(pending, lines_all):
+                for k, i in enumerate(ids):
+                    texts[i] = "\n".join(t for t, s in lines[k] if s >= MIN_CONFIDENCE and t)
         return texts
 
 

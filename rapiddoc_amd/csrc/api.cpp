@@ -40,7 +40,7 @@ static int guarded(rd_handle* h, F&& f) {
 
 extern "C" {
 
-const char* rd_version(void) { return "rapiddoc_mi355 0.1 (gfx950, fp32 MFMA)"; }
+const char* rd_version(void) { return "rapiddoc_mi355 0.3 (gfx950; fp32 results, split-fp16 + fp32 MFMA kernels)"; }
 
 rd_handle* rd_create(int device_id, const char* model_kind) {
     try {
@@ -176,6 +176,19 @@ int rd_preproc_resize_norm(int device_id, const uint8_t* src, int H, int W, int 
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+int rd_preproc_resize_norm_batch(int device_id, const uint8_t* src, int P, int H, int W, int OH, int OW, const float mean[3],
+                                 const float std[3], float scale, int interp, int swap_rb, float* out, void* stream) {
+    if (!src || !out || P <= 0 || P > 65535 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || (interp != 1 && interp != 2)) return 1;
+    if (hipSetDevice(device_id) != hipSuccess) return 1;
+    rd::PreprocParams p{};
+    p.src = src; p.H = H; p.W = W; p.dst = out; p.OH = OH; p.OW = OW;
+    for (int i = 0; i < 3; ++i) { p.mean[i] = mean ? mean[i] : 0.f; p.inv_std[i] = 1.f / (std ? std[i] : 1.f); }
+    p.scale = scale; p.interp = interp; p.swap_rb = swap_rb;
+    p.batch = P; p.src_stride = (size_t)H * W * 3; p.dst_stride = (size_t)3 * OH * OW;
+    rd::launch_preproc_resize_norm(p, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 int rd_crop_resize_norm_batch(int device_id, const uint8_t* pages, int P, int H, int W, const rd_crop_desc* descs, int n,
                               int out_h, int out_w_padded, const float mean[3], const float std[3], float scale, int swap_rb,
                               float* out, void* stream) {
@@ -203,6 +216,29 @@ int rd_line_crops_batch(int device_id, const uint8_t* pages, int P, int H, int W
     p.scratch = scratch; p.max_crop_pixels = (long)max_crop_pixels;
     p.dst = out; p.OH = out_h; p.OWp = out_w_padded; p.swap_rb = swap_rb;
     if (rd::launch_line_crops(p, (hipStream_t)stream) != 0) return 1;
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int rd_line_warp_batch(int device_id, const uint8_t* pages, int P, int H, int W, const rd_line_crop_desc* descs, int n,
+                       int64_t max_crop_pixels, uint8_t* scratch, void* stream) {
+    if (!pages || !descs || !scratch || P <= 0 || n < 0 || max_crop_pixels <= 0) return 1;
+    if (hipSetDevice(device_id) != hipSuccess) return 1;
+    rd::LineCropParams p{};
+    p.pages = pages; p.H = H; p.W = W; p.page_stride = (size_t)H * W * 3;
+    p.descs = reinterpret_cast<const rd::LineCropDesc*>(descs); p.n = n;
+    p.scratch = scratch; p.max_crop_pixels = (long)max_crop_pixels;
+    if (rd::launch_line_warp(p, (hipStream_t)stream) != 0) return 1;
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+int rd_line_resize_norm_batch(int device_id, const rd_line_crop_desc* descs, int n, const uint8_t* scratch, int out_h, int out_w_padded,
+                              int swap_rb, float* out, void* stream) {
+    if (!descs || !scratch || !out || n < 0 || out_h <= 0 || out_w_padded <= 0) return 1;
+    if (hipSetDevice(device_id) != hipSuccess) return 1;
+    rd::LineCropParams p{};
+    p.descs = reinterpret_cast<const rd::LineCropDesc*>(descs); p.n = n;
+    p.scratch = const_cast<uint8_t*>(scratch);
+    p.dst = out; p.OH = out_h; p.OWp = out_w_padded; p.swap_rb = swap_rb;
+    if (rd::launch_line_resize_norm(p, (hipStream_t)stream) != 0) return 1;
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

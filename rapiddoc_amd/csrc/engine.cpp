@@ -844,7 +844,7 @@ TView Builder::layernorm(const std::string& prefix, const TView& x, float eps) {
 TView Builder::attention(const TView& qkv, int B, int T, int heads, int hd, const TView* seg) {
     RD_CHECK(qkv.c == 3 * heads * hd && qkv.coff == 0 && plan_->ld(qkv) == qkv.c, "attention: packed qkv expected");
     RD_CHECK(hd == 15 || hd == 16 || hd == 32, "attention: head_dim 15/16/32");
-    RD_CHECK((size_t)2 * T * hd * sizeof(float) <= 160 * 1024 - 1024, "attention: sequence too long for LDS");
+    // (any T: sequences longer than the LDS holds run over key tiles, kernels_misc.hip attention_kernel)
     TView o = alloc(qkv.n, qkv.h, qkv.w, heads * hd);
     if (!planning()) return o;
     const float sc = 1.0f / std::sqrt((float)hd);
@@ -1075,12 +1075,22 @@ const Plan& Engine::plan_for(int B, int H, int W, int flags) {
     RD_CHECK(loaded_, "weights not loaded");
     auto key = std::make_tuple(B, H, W, flags | (precision_ << 24));
     auto it = plans_.find(key);
-    if (it != plans_.end()) return *it->second;
-    if (plans_.size() >= 256) plans_.clear();
+    if (it != plans_.end()) {
+        it->second->last_use = ++plan_clock_;
+        return *it->second;
+    }
+    // LRU: one cold shape (a long line, an odd page size) must not throw away the hot plans of this handle
+    while (plans_.size() >= kMaxPlans) {
+        auto victim = plans_.begin();
+        for (auto j = plans_.begin(); j != plans_.end(); ++j)
+            if (j->second->last_use < victim->second->last_use) victim = j;
+        plans_.erase(victim);
+    }
     auto plan = std::make_unique<Plan>();
     Builder b(Mode::PLAN, &store_, &params_, plan.get(), precision_ == PREC_H3, precision_ == PREC_AUTO, range_flag_);
     build(b, B, H, W, flags);
     plan->arena_bytes = (plan->arena_bytes + 255) / 256 * 256;
+    plan->last_use = ++plan_clock_;
     auto& ref = *plan;
     plans_[key] = std::move(plan);
     return ref;

@@ -104,6 +104,7 @@ struct Plan {
     std::vector<Buf> bufs;
     std::vector<OpRecord> ops;
     size_t arena_bytes = 0;
+    mutable uint64_t last_use = 0;   // Engine::plan_for's LRU clock
     std::vector<TView> outputs;  // model specific
     float* vptr(const TView& v, const RunCtx& c) const {
         const Buf& b = bufs[v.buf];
@@ -246,6 +247,8 @@ class Engine {
     ParamBlock params_;
     WeightStore store_;
     std::map<std::tuple<int, int, int, int>, std::unique_ptr<Plan>> plans_;
+    uint64_t plan_clock_ = 0;
+    static constexpr size_t kMaxPlans = 512;   // least recently used plans are dropped beyond this
     uint8_t* arena_ = nullptr;
     size_t arena_bytes_ = 0;
     std::vector<ProfileEntry> profile_;

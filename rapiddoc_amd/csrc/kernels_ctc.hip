@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(512) ctc_head_h3_kernel(CtcParams p, int cls_p
                     rd_split(v[e], h, l);
                     xh[ks][4 * hq + e] = h;
                     xl[ks][4 * hq + e] = l;
-                    amax = fmaxf(amax, fabsf(v[e]));
+                    amax = (v[e] != v[e]) ? INFINITY : fmaxf(amax, fabsf(v[e]));   // fmaxf alone would drop a NaN token
                 }
             }
     }

@@ -47,6 +47,8 @@ __device__ __forceinline__ void cv_src_pos(int d, double scale, int& s, float& f
 // ---- whole-image resize + normalise.  interp 2: INTER_CUBIC, 1: INTER_LINEAR (both on uint8, result uint8, then normalised)
 __global__ void __launch_bounds__(256) resize_u8_norm_kernel(PreprocParams p, double scale_x, double scale_y) {
     const long total = (long)p.OH * p.OW;
+    p.src += (size_t)blockIdx.y * p.src_stride;      // image blockIdx.y of a batch (strides 0 / grid.y 1 for a single image)
+    p.dst += (size_t)blockIdx.y * p.dst_stride;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int ox = (int)(idx % p.OW), oy = (int)(idx / p.OW);
         int sx, sy;
@@ -110,7 +112,7 @@ __global__ void __launch_bounds__(256) resize_u8_norm_kernel(PreprocParams p, do
 
 void launch_preproc_resize_norm(const PreprocParams& p, hipStream_t s) {
     const double sx = 1.0 / ((double)p.OW / (double)p.W), sy = 1.0 / ((double)p.OH / (double)p.H);
-    hipLaunchKernelGGL(resize_u8_norm_kernel, dim3(img_grid((long)p.OH * p.OW)), dim3(256), 0, s, p, sx, sy);
+    hipLaunchKernelGGL(resize_u8_norm_kernel, dim3(img_grid((long)p.OH * p.OW), p.batch > 1 ? p.batch : 1), dim3(256), 0, s, p, sx, sy);
 }
 
 // ---- remap weight table of INTER_CUBIC: [32 * 32][16] int16, block (fy * 32 + fx), taps row-major (y, x)
@@ -242,13 +244,23 @@ __global__ void __launch_bounds__(256) line_resize_norm_kernel(LineCropParams p)
     }
 }
 
-int launch_line_crops(const LineCropParams& p, hipStream_t s) {
+// stage 1 alone: the rectified uint8 crops of p.n lines into the scratch buffer (p.dst unused)
+int launch_line_warp(const LineCropParams& p, hipStream_t s) {
     if (p.n <= 0) return 0;
     const int16_t* tab = cubic_remap_table_dev();
     if (!tab) return 1;
     hipLaunchKernelGGL(line_warp_kernel, dim3(img_grid(p.max_crop_pixels, 256), p.n), dim3(256), 0, s, p, tab);
+    return 0;
+}
+// stage 2 alone: scratch crops -> [n][3][OH][OWp] (p.pages unused)
+int launch_line_resize_norm(const LineCropParams& p, hipStream_t s) {
+    if (p.n <= 0) return 0;
     hipLaunchKernelGGL(line_resize_norm_kernel, dim3(img_grid((long)p.OH * p.OWp, 64), p.n), dim3(256), 0, s, p);
     return 0;
+}
+int launch_line_crops(const LineCropParams& p, hipStream_t s) {
+    if (launch_line_warp(p, s) != 0) return 1;
+    return launch_line_resize_norm(p, s);
 }
 
 }  // namespace rd

@@ -531,15 +531,19 @@ void launch_layernorm(const float* x, int xld, float* y, int yld, const float* g
 // (row max, then exp/sum/PV) exactly like a max-subtracted softmax.
 // --------------------------------------------------------------------------------------------------
 template <int HD>
-__global__ void __launch_bounds__(256) attention_kernel(const float* qkv, float* o, int T, int heads, float scale, const int32_t* seg) {
+__global__ void __launch_bounds__(256) attention_kernel(const float* qkv, float* o, int T, int heads, float scale, const int32_t* seg,
+                                                        int tk_cap) {
     // K / V rows are padded to HDP = 16 / 32 floats in LDS so that a key costs HDP / 4 ds_read_b128 (every lane reads the same
     // address: a broadcast) instead of HD ds_read_b32 - round 1's 15 scalar reads per dot product made this kernel LDS-issue
     // bound (51 us per launch for 0.4 GFLOP); same two-pass max-subtracted softmax, same operation order per element.
+    // Sequences longer than the LDS holds (tk_cap keys; > 1200 tokens = a text line wider than ~9600 px at height 48) run the
+    // same two passes over KEY TILES that are re-staged per pass: identical arithmetic in identical order, more LDS fills.
     constexpr int HDP = (HD + 3) / 4 * 4;
     constexpr int NV = HDP / 4;
     extern __shared__ float sm[];
-    f32x4* Ks = reinterpret_cast<f32x4*>(sm);               // [T][NV]
-    f32x4* Vs = Ks + (size_t)T * NV;
+    const int TL = min(T, tk_cap);                          // LDS rows (the launcher sized the allocation with the same rule)
+    f32x4* Ks = reinterpret_cast<f32x4*>(sm);               // [TL][NV]
+    f32x4* Vs = Ks + (size_t)TL * NV;
     const int b = blockIdx.x, h = blockIdx.y;
     const int C = heads * HD;
     size_t tok0 = (size_t)b * T;
@@ -548,18 +552,27 @@ __global__ void __launch_bounds__(256) attention_kernel(const float* qkv, float*
         T = seg[2 * b + 1];
     }
     const float* base = qkv + tok0 * 3 * C;
-    for (int i = threadIdx.x; i < T * HDP; i += 256) {
-        const int t = i / HDP, d = i - t * HDP;
-        reinterpret_cast<float*>(Ks)[i] = d < HD ? base[(size_t)t * 3 * C + C + h * HD + d] : 0.f;
-        reinterpret_cast<float*>(Vs)[i] = d < HD ? base[(size_t)t * 3 * C + 2 * C + h * HD + d] : 0.f;
+    auto stage = [&](int k0, int kn, bool with_v) {         // keys [k0, k0 + kn) -> LDS rows [0, kn)
+        for (int i = threadIdx.x; i < kn * HDP; i += 256) {
+            const int t = i / HDP, d = i - t * HDP;
+            reinterpret_cast<float*>(Ks)[i] = d < HD ? base[(size_t)(k0 + t) * 3 * C + C + h * HD + d] : 0.f;
+            if (with_v) reinterpret_cast<float*>(Vs)[i] = d < HD ? base[(size_t)(k0 + t) * 3 * C + 2 * C + h * HD + d] : 0.f;
+        }
+    };
+    const bool tiled = T > TL;
+    if (!tiled) {
+        stage(0, T, true);
+        __syncthreads();
     }
-    __syncthreads();
-    for (int t = threadIdx.x; t < T; t += 256) {
+    const int rounds = (T + 255) / 256;
+    for (int r = 0; r < rounds; ++r) {
+        const int t = r * 256 + threadIdx.x;
+        const bool live = t < T;
         f32x4 q[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) q[v][e] = (4 * v + e < HD) ? base[(size_t)t * 3 * C + h * HD + 4 * v + e] * scale : 0.f;
+            for (int e = 0; e < 4; ++e) q[v][e] = (live && 4 * v + e < HD) ? base[(size_t)t * 3 * C + h * HD + 4 * v + e] * scale : 0.f;
         auto dot = [&](int j) {
             float sdot = 0.f;
 #pragma unroll
@@ -572,38 +585,72 @@ __global__ void __launch_bounds__(256) attention_kernel(const float* qkv, float*
             return sdot;
         };
         float mx = -INFINITY;
-        for (int j = 0; j < T; ++j) mx = fmaxf(mx, dot(j));
+        if (!tiled) {
+            if (live)
+                for (int j = 0; j < T; ++j) mx = fmaxf(mx, dot(j));
+        } else {
+            for (int k0 = 0; k0 < T; k0 += TL) {
+                const int kn = min(TL, T - k0);
+                __syncthreads();
+                stage(k0, kn, false);
+                __syncthreads();
+                if (live)
+                    for (int j = 0; j < kn; ++j) mx = fmaxf(mx, dot(j));
+            }
+        }
         float l = 0.f;
         f32x4 acc[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < T; ++j) {
-            const float e = __expf(dot(j) - mx);
-            l += e;
+        auto accumulate = [&](int kn) {
+            for (int j = 0; j < kn; ++j) {
+                const float e = __expf(dot(j) - mx);
+                l += e;
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const f32x4 vv = Vs[(size_t)j * NV + v];
+                for (int v = 0; v < NV; ++v) {
+                    const f32x4 vv = Vs[(size_t)j * NV + v];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[v][c] = fmaf(e, vv[c], acc[v][c]);
+                    for (int c = 0; c < 4; ++c) acc[v][c] = fmaf(e, vv[c], acc[v][c]);
+                }
+            }
+        };
+        if (!tiled) {
+            if (live) accumulate(T);
+        } else {
+            for (int k0 = 0; k0 < T; k0 += TL) {
+                const int kn = min(TL, T - k0);
+                __syncthreads();
+                stage(k0, kn, true);
+                __syncthreads();
+                if (live) accumulate(kn);
             }
         }
-        const float inv = 1.f / l;
-        float* op = o + (tok0 + t) * C + h * HD;
+        if (live) {
+            const float inv = 1.f / l;
+            float* op = o + (tok0 + t) * C + h * HD;
 #pragma unroll
-        for (int v = 0; v < NV; ++v)
+            for (int v = 0; v < NV; ++v)
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (4 * v + c < HD) op[4 * v + c] = acc[v][c] * inv;
+                for (int c = 0; c < 4; ++c)
+                    if (4 * v + c < HD) op[4 * v + c] = acc[v][c] * inv;
+        }
     }
 }
+// keys whose padded K and V rows fit the dynamic LDS of one workgroup (144 KB of the CU's 160: the rest is left to the
+// kernels of other streams that share the CU)
+int attention_lds_keys(int hd) { return (144 * 1024) / (2 * ((hd + 3) / 4 * 4) * (int)sizeof(float)); }
+template <int HD>
+static void launch_attention_t(const float* qkv, float* o, int B, int T, int heads, float scale, hipStream_t s, const int32_t* seg) {
+    const int cap = attention_lds_keys(HD);
+    const size_t sh = (size_t)2 * std::min(T, cap) * ((HD + 3) / 4 * 4) * sizeof(float);
+    static unsigned long long lds_ok = 0;
+    if (sh > 64 * 1024) rd_allow_dynamic_lds((const void*)attention_kernel<HD>, (size_t)144 * 1024, lds_ok);
+    hipLaunchKernelGGL(attention_kernel<HD>, dim3(B, heads), dim3(256), sh, s, qkv, o, T, heads, scale, seg, cap);
+}
 void launch_attention(const float* qkv, float* o, int B, int T, int heads, int hd, float scale, hipStream_t s, const int32_t* seg) {
-    const size_t sh = (size_t)2 * T * ((hd + 3) / 4 * 4) * sizeof(float);
-    if (hd == 15)
-        hipLaunchKernelGGL(attention_kernel<15>, dim3(B, heads), dim3(256), sh, s, qkv, o, T, heads, scale, seg);
-    else if (hd == 16)
-        hipLaunchKernelGGL(attention_kernel<16>, dim3(B, heads), dim3(256), sh, s, qkv, o, T, heads, scale, seg);
-    else if (hd == 32)
-        hipLaunchKernelGGL(attention_kernel<32>, dim3(B, heads), dim3(256), sh, s, qkv, o, T, heads, scale, seg);
+    if (hd == 15) launch_attention_t<15>(qkv, o, B, T, heads, scale, s, seg);
+    else if (hd == 16) launch_attention_t<16>(qkv, o, B, T, heads, scale, s, seg);
+    else if (hd == 32) launch_attention_t<32>(qkv, o, B, T, heads, scale, s, seg);
 }
 
 // --------------------------------------------------------------------------------------------------

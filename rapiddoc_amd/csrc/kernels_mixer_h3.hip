@@ -275,7 +275,6 @@ __global__ void __launch_bounds__(256, C <= 96 ? 2 : 1) lc_mixer_h3_kernel(Mixer
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         if (more) issue_w2(j + 1);
     }
-    if (!(amax < 65504.f) && p.range_flag) atomicOr(p.range_flag, 1u);   // also catches NaN
     // ---- epilogue: + b2 + residual (re-read from global, so it stays exact fp32; unconditional clamped loads), strided store.
     // Two alternatives measured slower: rebuilding the residual from the (hi, lo) tile in LDS (2-byte LDS reads, +10 %)
     // and parking the result rows in LDS to stream them out as float4 rows (+8 %); seeding the accumulators with X . I
@@ -295,9 +294,12 @@ __global__ void __launch_bounds__(256, C <= 96 ? 2 : 1) lc_mixer_h3_kernel(Mixer
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            if (m < p.M) __builtin_nontemporal_store(fmaf(y2[n][r], 1.f / 2048.f, y1[n][r]) + bv + res[r], &p.y[(size_t)m * p.yld + co]);
+            const float o = fmaf(y2[n][r], 1.f / 2048.f, y1[n][r]) + bv + res[r];
+            if (!(fabsf(o) < INFINITY)) amax = INFINITY;   // NaN operands are invisible to the fmaxf chains but reach the output
+            if (m < p.M) __builtin_nontemporal_store(o, &p.y[(size_t)m * p.yld + co]);
         }
     }
+    if (!(amax < 65504.f) && p.range_flag) atomicOr(p.range_flag, 1u);
 }
 
 

@@ -144,11 +144,13 @@ __global__ void __launch_bounds__(1024) lc_mixer_res_kernel(MixerParams p, const
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = fmaf(y2[ob][e], 1.f / 2048.f, y1[ob][e]) + bv[e] + v[e];
+                // a NaN operand is invisible to the fmaxf chains (they return the non-NaN operand) but reaches the output
+                if (!(fabsf(o[0]) + fabsf(o[1]) + fabsf(o[2]) + fabsf(o[3]) < INFINITY)) amax = INFINITY;
                 __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(yp + 16 * ob));
             }
         }
     }
-    if (!(amax < 65504.f) && p.range_flag) atomicOr(p.range_flag, 1u);   // also catches NaN
+    if (!(amax < 65504.f) && p.range_flag) atomicOr(p.range_flag, 1u);   // (NaN: through the output check in the epilogue)
 }
 
 bool mixer_res_supported(int C) {

@@ -294,6 +294,9 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = fmaf(y[n][e], inv2, bv[e]) + v[n][e];
+            // NaN anywhere upstream (X, the gate, a hidden unit) reaches the output through the MFMAs / the residual: the running
+            // maxima above are blind to it (v_max_f32 returns the non-NaN operand), this sum is not
+            bad = bad || !(fabsf(o[0]) + fabsf(o[1]) + fabsf(o[2]) + fabsf(o[3]) < INFINITY);
             if (mm < p.M) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(yp + 16 * n));
             y[n] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -361,7 +364,7 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
         for (int b = 0; b < 2; ++b) hc[b] = hn[b];
         hfac_cur = hfac;
     }
-    if ((bad || !(amax * WS_SH < 65504.f)) && p.range_flag) atomicOr(p.range_flag, 1u);   // also catches NaN
+    if ((bad || !(amax * WS_SH < 65504.f)) && p.range_flag) atomicOr(p.range_flag, 1u);   // NaN: `bad` (epilogue), not amax
 }
 
 // C = 96 builds and passes the same tests, but measures level with the round-1 kernel (99 vs 97 us at M = 211 200): the

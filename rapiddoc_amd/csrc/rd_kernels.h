@@ -157,6 +157,8 @@ struct PreprocParams {
     float mean[3], inv_std[3]; float scale;
     int interp;                         // 1 = bilinear, 2 = bicubic (a=-0.75, OpenCV convention)
     int swap_rb;
+    int batch = 1;                      // images in this launch: image i reads src + i * src_stride, writes dst + i * dst_stride
+    size_t src_stride = 0, dst_stride = 0;
 };
 void launch_preproc_resize_norm(const PreprocParams& p, hipStream_t s);
 
@@ -199,6 +201,8 @@ struct LineCropParams {
     int swap_rb;
 };
 int launch_line_crops(const LineCropParams& p, hipStream_t s);
+int launch_line_warp(const LineCropParams& p, hipStream_t s);          // stage 1 only (pages -> uint8 crops in the scratch buffer)
+int launch_line_resize_norm(const LineCropParams& p, hipStream_t s);   // stage 2 only (scratch crops -> fp32 rec batch tensor)
 // CTC greedy decode on the device: idx / prob [B][T] -> per line (row stride row_bytes): int32 n_text_bytes, float32
 // confidence (numpy float32 mean of the kept probabilities), int32 n_kept, int32 0, UTF-8 text.  ctab: [n_classes][1 + max_len]
 // bytes (length, then the entry's UTF-8 bytes).

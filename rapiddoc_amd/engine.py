@@ -26,6 +26,30 @@ def ragged_tables(line_lengths: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     return seg, tokinfo
 
 
+TAIL_LINE_BUCKET, TAIL_T_BUCKET, TAIL_TOKEN_BUCKET = 32, 8, 256
+
+
+def pad_tail_lengths(line_lengths) -> Tuple[np.ndarray, int]:
+    """Line lengths of one `rec_tail_forward` call padded with DUMMY lines so that the plan key of the call - (lines, longest
+    line, tokens) - falls on a coarse grid (multiples of 32 lines / 8 tokens / 256 tokens).  On real documents almost every
+    group of rec batches has a new total token count; an exact key would build a new plan (and possibly grow the workspace,
+    with a stream sync) per call.  Returns (padded lengths = the real lines followed by the dummy ones, padded longest line).
+    The dummy tokens must be finite (zero) in the token buffer; their outputs sit behind the real ones and are ignored."""
+    lens = np.asarray(line_lengths, dtype=np.int64)
+    n, tok = len(lens), int(lens.sum())
+    T = -(-int(lens.max()) // TAIL_T_BUCKET) * TAIL_T_BUCKET
+    d = (n // TAIL_LINE_BUCKET + 1) * TAIL_LINE_BUCKET - n          # 1 .. 32 dummy lines
+    while True:
+        pad = -(-(tok + d) // TAIL_TOKEN_BUCKET) * TAIL_TOKEN_BUCKET - tok      # >= d: every dummy line gets >= 1 token
+        if pad <= d * T:                                                      # and none is longer than the longest line
+            break
+        d += TAIL_LINE_BUCKET
+    base, extra = divmod(pad, d)
+    dummy = np.full(d, base, dtype=np.int64)
+    dummy[:extra] += 1
+    return np.concatenate([lens, dummy]), T
+
+
 class EngineError(RuntimeError):
     pass
 
@@ -162,11 +186,16 @@ class RdEngine:
         host = torch.from_numpy(np.concatenate([seg_h.reshape(-1), tokinfo_h])).pin_memory()
         return host.to(device, non_blocking=True)
 
-    def rec_tail_forward(self, tokens: torch.Tensor, line_lengths, tables: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    def rec_tail_forward(self, tokens: torch.Tensor, line_lengths, tables: Optional[torch.Tensor] = None,
+                         max_tokens: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """tokens [n_tokens, dim] = the text lines back to back, `line_lengths` their token counts -> (idx, prob) [n_tokens].
-        `tables`: rec_tail_tables(line_lengths) uploaded earlier (e.g. before the backbones were enqueued)."""
+        `tables`: rec_tail_tables(line_lengths) uploaded earlier (e.g. before the backbones were enqueued).  `max_tokens`: an
+        upper bound of the longest line used as the plan key instead of the exact maximum (see `pad_tail_lengths`)."""
         lens = np.asarray(line_lengths, dtype=np.int64)
         n_tokens = int(lens.sum())
+        longest = int(lens.max()) if max_tokens is None else int(max_tokens)
+        if longest < int(lens.max()):
+            raise EngineError("rec tail: max_tokens below the longest line")
         if tokens.numel() != n_tokens * self.rec_token_dim or lens.min() < 1 or lens.max() >= 32768:
             raise EngineError("rec tail: token count / line lengths mismatch")
         dev = tokens.device
@@ -177,7 +206,7 @@ class RdEngine:
         prob = torch.empty((n_tokens,), dtype=torch.float32, device=dev)
 
         def launch():
-            self._chk(self._l.rd_rec_tail_forward(self._h, tokens.data_ptr(), n_tokens, len(lens), int(lens.max()), seg.data_ptr(),
+            self._chk(self._l.rd_rec_tail_forward(self._h, tokens.data_ptr(), n_tokens, len(lens), longest, seg.data_ptr(),
                                                   tokinfo.data_ptr(), idx.data_ptr(), prob.data_ptr(), None, 0, _stream_ptr()))
             self._log()
         self._guarded(launch)
@@ -286,4 +315,25 @@ def preproc_resize_norm(img_u8_hwc: torch.Tensor, out_hw: Tuple[int, int], mean=
                                     interp, 1 if swap_rb else 0, out.data_ptr(), _stream_ptr())
     if rc != 0:
         raise EngineError("rd_preproc_resize_norm failed")
+    return out
+
+
+def preproc_resize_norm_batch(imgs_u8_nhwc: torch.Tensor, out_hw: Tuple[int, int], mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0),
+                              scale: float = 1.0 / 255.0, interp: int = 2, swap_rb: bool = False,
+                              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`preproc_resize_norm` for a whole [P,H,W,3] u8 array in one launch -> [P,3,OH,OW] float32."""
+    lib = _lib.load()
+    assert imgs_u8_nhwc.is_cuda and imgs_u8_nhwc.dtype == torch.uint8 and imgs_u8_nhwc.is_contiguous() and imgs_u8_nhwc.dim() == 4
+    P, H, W_, ch = imgs_u8_nhwc.shape
+    assert ch == 3
+    OH, OW = out_hw
+    if out is None:
+        out = torch.empty((P, 3, OH, OW), dtype=torch.float32, device=imgs_u8_nhwc.device)
+    assert out.is_contiguous() and tuple(out.shape) == (P, 3, OH, OW)
+    m = (C.c_float * 3)(*mean)
+    s = (C.c_float * 3)(*std)
+    rc = lib.rd_preproc_resize_norm_batch(imgs_u8_nhwc.device.index or 0, imgs_u8_nhwc.data_ptr(), P, H, W_, OH, OW, m, s, scale,
+                                          interp, 1 if swap_rb else 0, out.data_ptr(), _stream_ptr())
+    if rc != 0:
+        raise EngineError("rd_preproc_resize_norm_batch failed")
     return out

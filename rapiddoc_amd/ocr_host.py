@@ -126,12 +126,20 @@ def format_score(score: float) -> float:
 
 
 def rec_batches(wh_ratios: Sequence[float], rec_batch_num: int = 6, img_h: int = REC_IMG_H, img_w: int = REC_IMG_W,
-                width_multiple: int = 1) -> List[Tuple[np.ndarray, int]]:
+                width_multiple: int = 1, strict: bool = False, merge_equal_width: bool = False) -> List[Tuple[np.ndarray, int]]:
     """Reference batching (rapid_ocr.py:411-440): argsort by w/h, chunks of rec_batch_num, every chunk padded to
     imgW = int(img_h * max(img_w/img_h, chunk max ratio)).  Returns [(indices into the input, padded width)].
-    `width_multiple` > 1 rounds the padded width up (bounds the number of distinct shapes on the GPU)."""
-    order = np.argsort(np.asarray(wh_ratios, dtype=np.float64), kind="stable")
-    out = []
+    `width_multiple` > 1 rounds the padded width up (bounds the number of distinct shapes on the GPU).
+
+    `strict`: the sort is the very call the reference makes, `np.argsort(np.array(width_list))` with numpy's DEFAULT kind
+    (rapid_ocr.py:414; introsort / the SIMD sort of the running numpy build - equal ratios at a chunk border may land in
+    either chunk, exactly as they would in the reference on the same machine); otherwise a stable sort.
+    `merge_equal_width`: chunks with the same padded width become one launch.  A line's logits depend on the line and on
+    its padded width only (every layer is per sample; LightSVTR attends over the line's own padded columns), so the merge
+    changes the launch count, not the result."""
+    ratios = np.array([float(r) for r in wh_ratios])
+    order = np.argsort(ratios) if strict else np.argsort(ratios, kind="stable")
+    out: List[Tuple[np.ndarray, int]] = []
     for beg in range(0, len(order), rec_batch_num):
         chunk = order[beg: beg + rec_batch_num]
         max_ratio = max(img_w / img_h, max(wh_ratios[i] for i in chunk))
@@ -139,6 +147,11 @@ def rec_batches(wh_ratios: Sequence[float], rec_batch_num: int = 6, img_h: int =
         if width_multiple > 1:
             wpad = (wpad + width_multiple - 1) // width_multiple * width_multiple
         out.append((chunk, wpad))
+    if merge_equal_width:
+        by_w: dict = {}
+        for chunk, wpad in out:          # first-appearance order of the widths, chunk order inside a width
+            by_w.setdefault(wpad, []).append(chunk)
+        out = [(np.concatenate(chunks), wpad) for wpad, chunks in by_w.items()]
     return out
 
 

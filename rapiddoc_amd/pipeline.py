@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib, ocr_host
-from .engine import RdEngine, preproc_resize_norm
+from .engine import RdEngine, pad_tail_lengths, preproc_resize_norm, preproc_resize_norm_batch
 
 LAYOUT_SIZE = 800          # PP-DocLayout-L/plus-L/V2/V3 input (pp_doclayout/main.py:17-29)
 DET_LIMIT = 960            # rapidocr Det.limit_side_len (rapid_ocr.py:517-518)
@@ -59,13 +59,25 @@ def quad_to_crop_matrix(quad: np.ndarray) -> Tuple[np.ndarray, float, float]:
     return np.append(h, 1.0).astype(np.float32), cw, ch
 
 
-def quads_to_crop_matrices(quads: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-    """Vectorised `quad_to_crop_matrix` for [n,4,2] quads -> ([n,9] float64, crop widths, crop heights)."""
-    q = np.asarray(quads, dtype=np.float64).reshape(-1, 4, 2)
+def quads_to_crop_matrices(quads: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
+    """Vectorised `quad_to_crop_matrix` for [n,4,2] quads -> ([n,9] float64, crop widths, crop heights, ok mask).
+    Crop size as `get_rotate_crop_image` computes it (utils/ocr_utils.py:508-519): `int(max(np.linalg.norm(p0 - p1),
+    np.linalg.norm(p2 - p3)))` on FLOAT32 points - float32 subtraction, float32 norm (sqrt of the float32 sum of the two
+    float32 squares), truncation - so an edge whose length is within float32 rounding of an integer gets the crop size
+    the reference gives it.  `ok` is False for quads no homography exists for (zero-size crop, collinear corners): the
+    reference's cv2.warpPerspective raises on them; callers here skip them."""
+    q32 = np.asarray(quads, dtype=np.float32).reshape(-1, 4, 2)
+    q = q32.astype(np.float64)
     n = len(q)
-    cw = np.maximum(np.linalg.norm(q[:, 0] - q[:, 1], axis=1), np.linalg.norm(q[:, 2] - q[:, 3], axis=1))
-    ch = np.maximum(np.linalg.norm(q[:, 0] - q[:, 3], axis=1), np.linalg.norm(q[:, 1] - q[:, 2], axis=1))
-    cw, ch = np.maximum(np.floor(cw), 1.0), np.maximum(np.floor(ch), 1.0)
+
+    def norm32(a, b):
+        d = a - b                                               # float32
+        return np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1])   # float32 throughout, like np.linalg.norm on a float32 vector
+    cw = np.maximum(norm32(q32[:, 0], q32[:, 1]), norm32(q32[:, 2], q32[:, 3])).astype(np.float64)
+    ch = np.maximum(norm32(q32[:, 0], q32[:, 3]), norm32(q32[:, 1], q32[:, 2])).astype(np.float64)
+    cw, ch = np.floor(cw), np.floor(ch)
+    ok = (cw >= 1.0) & (ch >= 1.0) & np.isfinite(cw) & np.isfinite(ch)
+    cw, ch = np.where(ok, cw, 1.0), np.where(ok, ch, 1.0)
     z = np.zeros(n)
     src = np.stack([np.stack([z, z], 1), np.stack([cw, z], 1), np.stack([cw, ch], 1), np.stack([z, ch], 1)], axis=1)  # [n,4,2]
     A = np.zeros((n, 8, 8))
@@ -76,8 +88,13 @@ def quads_to_crop_matrices(quads: np.ndarray) -> Tuple[np.ndarray, np.ndarray, n
     A[:, 1::2, 3], A[:, 1::2, 4], A[:, 1::2, 5] = x, y, 1.0
     A[:, 1::2, 6], A[:, 1::2, 7] = -v * x, -v * y
     b[:, 0::2], b[:, 1::2] = u, v
+    # a singular system (three collinear corners, repeated points) must not abort the whole page batch
+    with np.errstate(all="ignore"):
+        det = np.linalg.det(A)
+    ok &= np.isfinite(det) & (np.abs(det) > 1e-9)
+    A[~ok] = np.eye(8)
     h = np.linalg.solve(A, b[..., None])[..., 0]
-    return np.concatenate([h, np.ones((n, 1))], axis=1), cw, ch
+    return np.concatenate([h, np.ones((n, 1))], axis=1), cw, ch, ok
 
 
 def boxes_to_quads(boxes_xyxy: np.ndarray) -> np.ndarray:
@@ -93,9 +110,26 @@ class PageResult:
 
 class PagePipeline:
     def __init__(self, states: Dict[str, object], device: int = 0, characters: Optional[Sequence[str]] = None,
-                 rec_batch_num: int = 64, rec_width_multiple: int = 32, keep_feats: bool = False, n_rec_streams: int = 4):
+                 rec_batch_num: int = 64, rec_width_multiple: int = 32, keep_feats: bool = False, n_rec_streams: int = 4,
+                 rec_mode: str = "throughput"):
         """`states`: {'ppocrv6_det': ..., 'ppocrv6_rec': ..., 'pphgnetv2_b4': ...}, each a .safetensors path,
-        bytes, or name->ndarray dict."""
+        bytes, or name->ndarray dict.
+
+        `rec_mode`: how the text lines are batched for the recogniser.  A line's logits depend on its batch's padded width
+        (LightSVTR attends over the zero-padded columns), so the batching is part of the result:
+          "strict"      the reference's batching, result for result: every line of the call pooled, ONE
+                        `np.argsort(ratios)` with numpy's default sort, chunks of `rec_batch_num` = 6 (rapidocr's default),
+                        padded width int(48 * max ratio of the chunk) (rapid_ocr.py:404-449); chunks of equal padded width
+                        share a launch (same tensors per line, fewer launches).  `rec_batch_num` / `rec_width_multiple` are
+                        ignored.
+          "throughput"  GPU-sized chunks (`rec_batch_num` lines, default 64) of the same aspect-sorted list, padded width
+                        rounded up to `rec_width_multiple`: same per-tensor parity with the oracle, different padded
+                        widths than the reference would have used."""
+        if rec_mode not in ("strict", "throughput"):
+            raise ValueError("rec_mode must be 'strict' or 'throughput'")
+        self.rec_mode = rec_mode
+        if rec_mode == "strict":
+            rec_batch_num, rec_width_multiple = 6, 1
         self.device = device
         self.tdev = torch.device("cuda", device)
         # several forwards are in flight at once here, so the engines defer the split-fp16 range guard: run_batch (det,
@@ -132,36 +166,48 @@ class PagePipeline:
         self.stats: Dict[str, float] = {}
 
     # ---------------------------------------------------------------- stages
-    def layout_forward(self, pages: torch.Tensor) -> List[torch.Tensor]:
-        P = pages.shape[0]
-        x = torch.empty((P, 3, LAYOUT_SIZE, LAYOUT_SIZE), dtype=torch.float32, device=pages.device)
-        for i in range(P):  # PPPreProcess: INTER_CUBIC resize, /255, mean 0 / std 1 (pre_process.py:14-42)
-            preproc_resize_norm(pages[i], (LAYOUT_SIZE, LAYOUT_SIZE), interp=2, out=x[i])
-        return self.layout.backbone_forward(x)
+    def layout_preprocess(self, pages: torch.Tensor) -> torch.Tensor:
+        """PPPreProcess for the whole batch in one launch: INTER_CUBIC resize, /255, mean 0 / std 1 (pre_process.py:14-42)."""
+        return preproc_resize_norm_batch(pages, (LAYOUT_SIZE, LAYOUT_SIZE), interp=2)
 
-    def det_forward(self, pages: torch.Tensor) -> Tuple[torch.Tensor, Tuple[int, int]]:
+    def layout_forward(self, pages: torch.Tensor) -> List[torch.Tensor]:
+        return self.layout.backbone_forward(self.layout_preprocess(pages))
+
+    def det_preprocess(self, pages: torch.Tensor) -> Tuple[torch.Tensor, Tuple[int, int]]:
+        """64-px bucket of the page region with its 50-px white margin, then DetPreProcess (analyze_utils.py:129-188): BGR,
+        (x/255 - 0.5)/0.5, one launch for the batch."""
         P, H, W, _ = pages.shape
-        # 64-px bucket of the page region with its 50-px white margin, then DetPreProcess (analyze_utils.py:129-188)
         bh, bw = -(-(H + 100) // 64) * 64, -(-(W + 100) // 64) * 64
         dh, dw = ocr_host.det_resize_shape(bh, bw, DET_LIMIT, "max")
-        x = torch.empty((P, 3, dh, dw), dtype=torch.float32, device=pages.device)
-        for i in range(P):  # BGR, (x/255 - 0.5)/0.5
-            preproc_resize_norm(pages[i], (dh, dw), mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), interp=1, swap_rb=True, out=x[i])
-        return self.det.det_forward(x), (dh, dw)
+        x = preproc_resize_norm_batch(pages, (dh, dw), mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), interp=1, swap_rb=True)
+        return x, (dh, dw)
+
+    def det_forward(self, pages: torch.Tensor) -> Tuple[torch.Tensor, Tuple[int, int]]:
+        x, det_hw = self.det_preprocess(pages)
+        return self.det.det_forward(x), det_hw
 
     def rec_forward_lines(self, pages: torch.Tensor, quads_per_page: Sequence[np.ndarray]):
-        """All text lines of the page batch -> [(text, score)] per page, reference batching order
-        (rapid_ocr.py:404-472) with a GPU-sized rec_batch_num.  Carries the split-fp16 range guard of its rec engines
-        (every caller - run_batch, analyze.RegionOcr, RegionTextModel - gets it): a tripped engine is switched to native
-        fp32 and the lines are recognised again."""
-        out = self._rec_forward_lines_once(pages, quads_per_page)
+        """All text lines of ONE image array -> [(text, score)] per image: `rec_forward_sources` with a single source."""
+        return self.rec_forward_sources([(pages, quads_per_page)])[0]
+
+    def rec_forward_sources(self, sources: Sequence[Tuple[torch.Tensor, Sequence[np.ndarray]]],
+                            image_keys: Optional[Sequence[Sequence[int]]] = None):
+        """`sources`: [(images [P,H,W,3] u8 on the GPU, text-line quads per image)] - image arrays of DIFFERENT sizes whose
+        lines are recognised TOGETHER, the way the reference pools every line of a page batch per language before it sorts
+        and chunks them (analyze_utils.py:216-252 -> rapid_ocr.py:404-472).  Returns, per source, per image, [(text, score)]
+        in the order of the quads.  `image_keys[source][image]`: the pooled line list is ordered by this key first (stable;
+        e.g. the page a region crop came from - the reference pools page by page), which only matters to the strict mode's
+        sort when two lines have exactly the same aspect ratio.  Carries the split-fp16 range guard of its rec engines (every caller - run_batch,
+        analyze.RegionOcr, RegionTextModel - gets it): a tripped engine is switched to native fp32 and the lines are
+        recognised again."""
+        out = self._rec_forward_sources_once(sources, image_keys)
         # a pass can trip a LATER stage only once the earlier one runs in fp32 (an overflowed backbone feeds the tail NaNs or
         # finite-but-huge tokens), so check after every pass; a tripped engine stays in fp32, which bounds the loop
         for _ in range(3):
             if not any([e.check_range_and_fallback() for e in self.rec_engines + [self.rec_tail]]):     # list: check every engine
                 break
             self.stats["range_fallbacks"] = self.stats.get("range_fallbacks", 0) + 1
-            out = self._rec_forward_lines_once(pages, quads_per_page)
+            out = self._rec_forward_sources_once(sources, image_keys)
         return out
 
     def _collapse_rows(self, idx: torch.Tensor, prob: torch.Tensor, nb: int, st, record: bool = True):
@@ -186,26 +232,50 @@ class PagePipeline:
                 done.record(st)
         return rows, done
 
-    def _rec_forward_lines_once(self, pages: torch.Tensor, quads_per_page: Sequence[np.ndarray]):
-        P, H, W, _ = pages.shape
+    def _rec_forward_sources_once(self, sources, image_keys=None):
         t0 = time.perf_counter()
-        counts = [len(np.asarray(q).reshape(-1, 4, 2)) for q in quads_per_page]
-        n = int(sum(counts))
+        dev = sources[0][0].device
+        # flat line list in source-major, image-major order (the reference's pooled order: pages, then a page's spans)
+        src_of, page_of, quad_list, n_img = [], [], [], []
+        for si, (imgs, quads_per_img) in enumerate(sources):
+            assert imgs.is_cuda and imgs.dtype == torch.uint8 and imgs.dim() == 4 and imgs.is_contiguous()
+            n_img.append(imgs.shape[0])
+            for pi, q in enumerate(quads_per_img):
+                q = np.asarray(q, dtype=np.float64).reshape(-1, 4, 2)
+                if len(q):
+                    quad_list.append(q)
+                    src_of.append(np.full(len(q), si, np.int32))
+                    page_of.append(np.full(len(q), pi, np.int32))
+        empty = [[[] for _ in range(k)] for k in n_img]
+        if not quad_list:
+            return empty
+        quads = np.concatenate(quad_list, axis=0)
+        src_of, page_of = np.concatenate(src_of), np.concatenate(page_of)
+        if image_keys is not None:      # pooled order: by key (page), then source / image / line as collected
+            key = np.array([image_keys[si][pi] for si, pi in zip(src_of.tolist(), page_of.tolist())], dtype=np.int64)
+            perm = np.argsort(key, kind="stable")
+            quads, src_of, page_of = quads[perm], src_of[perm], page_of[perm]
+        else:
+            perm = None
+        mats, cws_a, chs_a, ok = quads_to_crop_matrices(quads)
+        n_all = len(quads)
+        keep = np.nonzero(ok)[0]                      # degenerate quads (zero-area / collinear corners) get ("", 0.0)
+        n = len(keep)
+        texts: List[Tuple[str, float]] = [("", 0.0)] * n_all
         if n == 0:
-            return [[] for _ in range(P)]
-        page_of = np.repeat(np.arange(P), counts)
-        quads = np.concatenate([np.asarray(q, dtype=np.float64).reshape(-1, 4, 2) for q in quads_per_page if len(q)], axis=0)
-        mats, cws_a, chs_a = quads_to_crop_matrices(quads)
+            return self._scatter_texts(texts, src_of, page_of, n_img, perm)
+        mats, cws_a, chs_a = mats[keep], cws_a[keep], chs_a[keep]
         rots_a = (chs_a / cws_a >= 2.0).astype(np.int32)  # ocr_utils.py:531-534 rotates crops with h/w >= 2
-        texts: List[Tuple[str, float]] = [("", 0.0)] * n
         eff_w = np.where(rots_a == 1, chs_a, cws_a)
         eff_h = np.where(rots_a == 1, cws_a, chs_a)
         ratios = (eff_w / eff_h).tolist()
-        batches = ocr_host.rec_batches(ratios, self.rec_batch_num, width_multiple=self.rec_width_multiple)
+        strict = self.rec_mode == "strict"
+        batches = ocr_host.rec_batches(ratios, self.rec_batch_num, width_multiple=self.rec_width_multiple, strict=strict,
+                                       merge_equal_width=strict)
         order_all = np.concatenate([c for c, _ in batches])
         wpad_all = np.concatenate([np.full(len(c), w) for c, w in batches])
         descs = np.zeros(n, dtype=LINE_DTYPE)
-        descs["page"] = page_of[order_all]
+        descs["page"] = page_of[keep][order_all]
         descs["out_w"] = np.minimum(wpad_all, np.ceil(ocr_host.REC_IMG_H * (eff_w / eff_h)[order_all])).astype(np.int32)
         descs["crop_w"] = cws_a[order_all].astype(np.int32)
         descs["crop_h"] = chs_a[order_all].astype(np.int32)
@@ -221,12 +291,38 @@ class PagePipeline:
             cb = crop_bytes[starts[b]:starts[b + 1]]
             offs[starts[b]:starts[b + 1]] = np.cumsum(cb) - cb
             batch_scratch.append(int(cb.sum()))
+        if max(batch_scratch) >= 2 ** 31:
+            raise RuntimeError("a rec batch needs >= 2 GB of crop scratch: lower rec_batch_num")
         descs["scratch_off"] = offs.astype(np.int32)
         batch_base = np.cumsum([0] + batch_scratch)
         if getattr(self, "_crop_scratch", None) is None or self._crop_scratch.numel() < int(batch_base[-1]):
-            self._crop_scratch = torch.empty(int(batch_base[-1] * 1.25) + 1024, dtype=torch.uint8, device=pages.device)
+            self._crop_scratch = torch.empty(int(batch_base[-1] * 1.25) + 1024, dtype=torch.uint8, device=dev)
+        # stage-1 (warp) launches: per rec batch, one per source image array present in it.  A single source (the page
+        # pipeline) needs no second descriptor array: the batch's own descriptors are the launch's.
+        multi = len(sources) > 1
+        src_sorted = src_of[keep][order_all]
+        crop_px = descs["crop_w"].astype(np.int64) * descs["crop_h"]
+        warp_jobs: List[List[Tuple[int, int, int, int]]] = []        # per batch: (source, first desc, count, max crop pixels)
+        if multi:
+            warp_order = np.concatenate([starts[b] + np.argsort(src_sorted[starts[b]:starts[b + 1]], kind="stable")
+                                         for b in range(len(batches))])
+            descs_warp = descs[warp_order]
+            ws_sorted = src_sorted[warp_order]
+            px_sorted = crop_px[warp_order]
+            for b in range(len(batches)):
+                jobs, lo = [], int(starts[b])
+                hi = int(starts[b + 1])
+                cuts = [lo] + [i for i in range(lo + 1, hi) if ws_sorted[i] != ws_sorted[i - 1]] + [hi]
+                for a, e in zip(cuts[:-1], cuts[1:]):
+                    jobs.append((int(ws_sorted[a]), a, e - a, int(px_sorted[a:e].max())))
+                warp_jobs.append(jobs)
+        else:
+            for b in range(len(batches)):
+                lo, hi = int(starts[b]), int(starts[b + 1])
+                warp_jobs.append([(0, lo, hi - lo, int(crop_px[lo:hi].max()))])
         self.stats["t_descs_ms"] = (time.perf_counter() - t0) * 1e3
-        descs_dev = torch.from_numpy(descs.view(np.uint8)).to(pages.device, non_blocking=True)
+        descs_dev = torch.from_numpy(descs.view(np.uint8)).to(dev, non_blocking=True)
+        descs_warp_dev = torch.from_numpy(descs_warp.view(np.uint8)).to(dev, non_blocking=True) if multi else descs_dev
         outs = []
         pos = 0
         main = torch.cuda.current_stream()
@@ -238,25 +334,38 @@ class PagePipeline:
             # the batches run the backbone only, each into its slice of one token buffer; the neck + CTC head then run once per
             # GROUP of S consecutive batches (one per stream) on the tail stream, under the backbones of the next group
             seq = [self._lib.rd_rec_seq_len(int(w)) for _c, w in batches]
-            tok_off = np.cumsum([0] + [len(c) * t for (c, _w), t in zip(batches, seq)])
-            tokens = torch.empty((int(tok_off[-1]), self.rec.rec_token_dim), dtype=torch.float32, device=pages.device)
             groups = [list(range(g, min(g + S, len(batches)))) for g in range(0, len(batches), S)]
             group_lens = [np.concatenate([np.full(len(batches[bi][0]), seq[bi], dtype=np.int64) for bi in grp]) for grp in groups]
-            group_tables = [self.rec_tail.rec_tail_tables(l, pages.device) for l in group_lens]   # uploaded now, used later
+            # every group's tail call is padded with dummy lines onto a coarse (lines, longest line, tokens) grid: the plan cache
+            # of the tail handle then sees a handful of keys instead of a new one per group (engine.pad_tail_lengths)
+            group_pad = [pad_tail_lengths(l) for l in group_lens]
+            group_base = np.cumsum([0] + [int(lp.sum()) for lp, _t in group_pad])
+            tok_lo = [0] * len(batches)
+            for gi, grp in enumerate(groups):
+                off = int(group_base[gi])
+                for bi in grp:
+                    tok_lo[bi] = off
+                    off += len(batches[bi][0]) * seq[bi]
+            tokens = torch.empty((int(group_base[-1]), self.rec.rec_token_dim), dtype=torch.float32, device=dev)
+            for gi in range(len(groups)):         # the dummy lines' tokens: finite values (their outputs are ignored)
+                tokens[int(group_base[gi]) + int(group_lens[gi].sum()): int(group_base[gi + 1])].zero_()
+            group_tables = [self.rec_tail.rec_tail_tables(lp, dev) for lp, _t in group_pad]   # uploaded now, used later
             ready.record(main)
             self.tail_stream.wait_event(ready)
 
         def run_tail(gi):
             grp = groups[gi]
-            t_lo, t_hi = int(tok_off[grp[0]]), int(tok_off[grp[-1] + 1])
+            t_lo, t_hi = int(group_base[gi]), int(group_base[gi + 1])
             for bi in grp:
                 self.tail_stream.wait_event(outs[bi][2])
             with torch.cuda.stream(self.tail_stream):
-                idx_all, prob_all = self.rec_tail.rec_tail_forward(tokens[t_lo:t_hi], group_lens[gi], group_tables[gi])
+                idx_all, prob_all = self.rec_tail.rec_tail_forward(tokens[t_lo:t_hi], group_pad[gi][0], group_tables[gi],
+                                                                   max_tokens=group_pad[gi][1])
             done = None
             for bi in grp:
                 nb, t = len(batches[bi][0]), seq[bi]
-                lo, hi = int(tok_off[bi]) - t_lo, int(tok_off[bi + 1]) - t_lo
+                lo = tok_lo[bi] - t_lo
+                hi = lo + nb * t
                 idx, prob = idx_all[lo:hi].view(nb, t), prob_all[lo:hi].view(nb, t)
                 rows, ev = self._collapse_rows(idx, prob, nb, self.tail_stream, record=bi == grp[-1])
                 done = ev or done
@@ -271,16 +380,21 @@ class PagePipeline:
             if bi < S:
                 st.wait_event(ready)          # descriptors (and the pages, the token buffer) are ready
             with torch.cuda.stream(st):
-                x = torch.empty((nb, 3, ocr_host.REC_IMG_H, wpad), dtype=torch.float32, device=pages.device)
-                d = descs[pos:pos + nb]
-                rc = self._lib.rd_line_crops_batch(
-                    self.device, pages.data_ptr(), P, H, W, descs_dev.data_ptr() + pos * LINE_DTYPE.itemsize, nb,
-                    int((d["crop_w"].astype(np.int64) * d["crop_h"]).max()), self._crop_scratch.data_ptr() + int(batch_base[bi]),
-                    ocr_host.REC_IMG_H, wpad, 1, x.data_ptr(), st.cuda_stream)
+                x = torch.empty((nb, 3, ocr_host.REC_IMG_H, wpad), dtype=torch.float32, device=dev)
+                scratch = self._crop_scratch.data_ptr() + int(batch_base[bi])
+                for si, first, cnt, max_px in warp_jobs[bi]:            # stage 1: page / canvas -> rectified uint8 crops
+                    imgs = sources[si][0]
+                    rc = self._lib.rd_line_warp_batch(self.device, imgs.data_ptr(), imgs.shape[0], imgs.shape[1], imgs.shape[2],
+                                                      descs_warp_dev.data_ptr() + first * LINE_DTYPE.itemsize, cnt, max_px, scratch,
+                                                      st.cuda_stream)
+                    if rc != 0:
+                        raise RuntimeError("rd_line_warp_batch failed")
+                rc = self._lib.rd_line_resize_norm_batch(self.device, descs_dev.data_ptr() + pos * LINE_DTYPE.itemsize, nb, scratch,
+                                                         ocr_host.REC_IMG_H, wpad, 1, x.data_ptr(), st.cuda_stream)   # stage 2
                 if rc != 0:
-                    raise RuntimeError("rd_line_crops_batch failed")
+                    raise RuntimeError("rd_line_resize_norm_batch failed")
                 if two_stage:
-                    self.rec_engines[k].rec_backbone_forward(x, tokens[int(tok_off[bi]): int(tok_off[bi + 1])])
+                    self.rec_engines[k].rec_backbone_forward(x, tokens[tok_lo[bi]: tok_lo[bi] + nb * seq[bi]])
                     ev = torch.cuda.Event()
                     ev.record(st)
                     outs.append((None, None, ev, x, None))
@@ -298,7 +412,8 @@ class PagePipeline:
         # overlaps the GPU work of the batches still in flight
         t_dec = 0.0
         if self.keep_rec_inputs:
-            self.last_rec_batches = [(np.asarray(chunk), x, idx, prob) for (chunk, _w), (idx, prob, _d, x, _r) in zip(batches, outs)]
+            self.last_rec_batches = [(keep[np.asarray(chunk)], x, idx, prob) for (chunk, _w), (idx, prob, _d, x, _r) in zip(batches, outs)]
+            self.last_rec_crop_sizes = (cws_a.astype(np.int64), chs_a.astype(np.int64), rots_a, keep)
         for (chunk, wpad), (idx, prob, done, _x, rows) in zip(batches, outs):
             done.synchronize()
             if rows is not None:
@@ -310,17 +425,27 @@ class PagePipeline:
                 dec = ocr_host.ctc_decode(idx_h, prob_h, self.characters)
             for j, i in enumerate(chunk):
                 t, s = dec[j]
-                texts[i] = (t, ocr_host.format_score(s))
+                texts[int(keep[i])] = (t, ocr_host.format_score(s))
             t_dec += time.perf_counter() - t1
         self.stats["t_decode_ms"] = t_dec * 1e3
         for st in self.rec_streams + [self.tail_stream]:
             main.wait_stream(st)
-        per_page: List[List[Tuple[str, float]]] = [[] for _ in range(P)]
-        for i, pi in enumerate(page_of.tolist()):
-            per_page[pi].append(texts[i])
         self.stats["rec_lines"] = n
         self.stats["rec_batches"] = len(batches)
-        return per_page
+        self.last_pool_order = perm
+        return self._scatter_texts(texts, src_of, page_of, n_img, perm)
+
+    @staticmethod
+    def _scatter_texts(texts, src_of, page_of, n_img, perm=None):
+        """pooled-order results -> [source][image][line], lines in the order their quads were given"""
+        if perm is not None:             # undo the key sort: collection order is (source, image, line)
+            inv = np.argsort(perm, kind="stable")
+            texts = [texts[i] for i in inv.tolist()]
+            src_of, page_of = src_of[inv], page_of[inv]
+        out = [[[] for _ in range(k)] for k in n_img]
+        for t, si, pi in zip(texts, src_of.tolist(), page_of.tolist()):
+            out[si][pi].append(t)
+        return out
 
     # ---------------------------------------------------------------- det maps -> text-line quads (host)
     def boxes_from_maps(self, maps_host: np.ndarray, page_hw: Tuple[int, int], box_thresh: float = 0.3,

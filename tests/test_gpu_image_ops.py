@@ -55,7 +55,7 @@ def test_line_crops_match_get_rotate_crop_image_and_resize_norm_img():
         [[100, 350], [595, 352], [596.5, 391], [100.5, 389]],            # long
     ], np.float64)
     page_of = np.array([0, 1, 0, 1, 0])
-    mats, cws, chs = quads_to_crop_matrices(quads)
+    mats, cws, chs, _ok = quads_to_crop_matrices(quads)
     rot = (chs / cws >= 2.0).astype(np.int32)
     eff_w, eff_h = np.where(rot == 1, chs, cws), np.where(rot == 1, cws, chs)
     wpad = 608

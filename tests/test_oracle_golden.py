@@ -78,3 +78,40 @@ def test_formula_decoder_oracle_matches_reference_golden(golden_dir, tag, max_ne
     st["head.decoder.lm_head.weight"][2] *= float(g["eos_gain"])
     ids = OF.formula_decode(O.as_torch_state(st), torch.from_numpy(g["enc"]), max_new)
     assert ids.shape == g["ids"].shape and (ids.numpy() == g["ids"]).all()
+
+
+def formula_long_case(golden_dir):
+    """(state dict, encoder states, golden npz) of the 300-token decode fixture (tests/golden/make_golden_r3.py): the encoder
+    states are regenerated from their seed (2.4 MB of noise is not worth committing) and checked against the stored crc."""
+    import zlib
+    g = np.load(golden_dir / "formula_seed0_dec_long.npz")
+    st = W.synth_state_dict(W.load_manifest(golden_dir / "manifest_ppformulanet_head_dec_long.json"), 0)
+    st["head.decoder.lm_head.weight"] = st["head.decoder.lm_head.weight"] * np.float32(g["logit_gain"])
+    st["head.decoder.lm_head.weight"][2] *= np.float32(g["eos_gain"])
+    enc = (np.random.default_rng(int(g["enc_seed"])).standard_normal(tuple(int(v) for v in g["enc_shape"])) * 3.0).astype(np.float32)
+    assert zlib.crc32(enc.tobytes()) == int(g["enc_crc32"]), "numpy's Generator stream changed: re-mint the fixture"
+    return st, enc, g
+
+
+def live_steps(ids):
+    """[B, L-1] bool: step t produced a real token (the sequence had not emitted EOS before it)."""
+    ended = np.cumsum(ids[:, 1:] == 2, axis=1) - (ids[:, 1:] == 2)      # EOS seen strictly before this step
+    return ended == 0
+
+
+def test_formula_oracle_long_decode_teacher_forced(golden_dir):
+    """The oracle fed the reference's own 300-token ids reproduces, step by step, the token the reference chose next
+    (one teacher-forced pass; the step-by-step greedy run of the oracle equalled the reference when the fixture was minted)."""
+    from oracle import formula as OF
+    st, enc, g = formula_long_case(golden_dir)
+    ids = g["ids"]
+    assert ids.shape == (2, 301)
+    with torch.no_grad():
+        lg = OF.teacher_forced_logits(O.as_torch_state(st), torch.from_numpy(enc), torch.from_numpy(ids))
+    live = live_steps(ids)
+    top2 = torch.topk(lg, 2, dim=-1).values
+    gaps = (top2[..., 0] - top2[..., 1]).numpy()
+    assert np.abs(gaps - g["top2gap"])[live].max() < 2e-3
+    assert (lg.argmax(-1).numpy() == ids[:, 1:])[live & (gaps > 1e-2)].all()
+    assert live[0].all() and live[1].sum() == 76          # sequence 0 runs to the limit, sequence 1 emits EOS as its 76th token
+    assert ids[1, 76] == 2 and (ids[1, 77:] == 1).all()    # and is padded afterwards
