@@ -63,11 +63,13 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 && BM * BN >= 128 *
     const int lrow = tid >> 3, lkq = tid & 7;
     const int K = p.K, Kp = (p.K + 31) & ~31;
 
-    const float* arow[AL];
+    // 32-bit element offsets from the uniform bases p.x / p.wh / p.wl instead of per-lane 64-bit pointers (the launcher
+    // checks that the tensors stay below 2^32 elements): the 256x128 tile runs at the 256-VGPR limit
+    unsigned arow[AL];
     bool avalid[AL];
-    int a_ih0[AL], a_iw0[AL];
-    const _Float16* bsrc[BL];
-    bool bvalid[BL];
+    int a_hw0[AL];           // k x k: (first input row << 16) | (first input column & 0xffff), both signed 16-bit
+    unsigned bsrc[BL];
+    bool bvalid[BL], bwhich[BL];
     int b_lds[BL], b_col[BL];
     auto setup_tile = [&](int v) {
     map_tile(v);
@@ -77,15 +79,15 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 && BM * BN >= 128 *
         avalid[i] = m < p.M;
         const int mm = avalid[i] ? m : 0;
         if (IS1X1) {
-            arow[i] = p.x + (size_t)mm * p.xld;
-            a_ih0[i] = a_iw0[i] = 0;
+            arow[i] = (unsigned)mm * (unsigned)p.xld;
+            a_hw0[i] = 0;
         } else {
             const int ohw = p.OH * p.OW;
             const int b = mm / ohw, rem = mm - b * ohw;
             const int oh = rem / p.OW, ow = rem - oh * p.OW;
-            a_ih0[i] = avalid[i] ? oh * p.SH - p.PT : -(1 << 28);
-            a_iw0[i] = ow * p.SW - p.PL;
-            arow[i] = p.x + (size_t)b * p.H * p.W * p.xld;
+            const int ih0 = avalid[i] ? oh * p.SH - p.PT : -16384;     // rows past M: every tap lands outside the image
+            a_hw0[i] = (ih0 << 16) | ((ow * p.SW - p.PL) & 0xffff);
+            arow[i] = (unsigned)b * (unsigned)(p.H * p.W) * (unsigned)p.xld;
         }
     }
     // B loader: BN*8 16-byte pieces (hi then lo), piece t -> (which, row, 8-half column)
@@ -96,7 +98,8 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 && BM * BN >= 128 *
         const int r = rem >> 2, c = rem & 3;
         const int n = n0 + r;
         bvalid[i] = n < p.Ng;
-        bsrc[i] = reinterpret_cast<const _Float16*>(which ? p.wl : p.wh) + (size_t)(bvalid[i] ? n : 0) * Kp;
+        bwhich[i] = which != 0;
+        bsrc[i] = (unsigned)(bvalid[i] ? n : 0) * (unsigned)Kp;
         b_col[i] = c * 8;
         b_lds[i] = (which ? BL0 : BH0) + r * HLD + c * 8;
     }
@@ -123,7 +126,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 && BM * BN >= 128 *
         if (IS1X1) {
 #pragma unroll
             for (int i = 0; i < AL; ++i) {
-                st.a[i] = *reinterpret_cast<const f32x4*>(arow[i] + kk);
+                st.a[i] = *reinterpret_cast<const f32x4*>(p.x + (arow[i] + (unsigned)kk));
                 st.am |= (unsigned)(kvalid && avalid[i]) << i;
             }
         } else {
@@ -131,10 +134,10 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 && BM * BN >= 128 *
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
 #pragma unroll
             for (int i = 0; i < AL; ++i) {
-                const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+                const int ih = (a_hw0[i] >> 16) + kh, iw = (int)(short)(a_hw0[i] & 0xffff) + kw;
                 const bool ok = kvalid && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                const size_t off = ok ? ((size_t)ih * p.W + iw) * p.xld + ci : 0;
-                st.a[i] = *reinterpret_cast<const f32x4*>(arow[i] + off);
+                const unsigned off = ok ? (unsigned)(ih * p.W + iw) * (unsigned)p.xld + (unsigned)ci : 0u;
+                st.a[i] = *reinterpret_cast<const f32x4*>(p.x + (arow[i] + off));
                 st.am |= (unsigned)ok << i;
             }
         }
@@ -142,7 +145,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 && BM * BN >= 128 *
         for (int i = 0; i < BL; ++i) {
             const int kb = k0 + b_col[i];
             const bool ok = kb < Kp && bvalid[i];
-            st.b[i] = *reinterpret_cast<const u32x4*>(bsrc[i] + (ok ? kb : 0));
+            st.b[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const _Float16*>(bwhich[i] ? p.wl : p.wh) + (bsrc[i] + (unsigned)(ok ? kb : 0)));
             st.bm |= (unsigned)ok << i;
         }
     };
@@ -377,13 +380,19 @@ void launch_conv_igemm_h3(const ConvParams& p, hipStream_t s) {
         launch_gemm_h3_dma(p, s);
         return;
     }
+    // the staged kernels address X and the split weights with 32-bit element offsets; a tensor beyond 2^32 elements (16 GB of
+    // fp32 activations in one layer) takes the fp32 MFMA kernel, which uses 64-bit addresses
+    if ((unsigned long long)p.N * p.H * p.W * (unsigned long long)p.xld >= (1ull << 32) ||
+        (unsigned long long)p.Ng * (unsigned long long)((p.K + 31) & ~31) >= (1ull << 32)) {
+        launch_conv_igemm(p, s);
+        return;
+    }
     switch (h3_pick_bn(p)) {
         case 32: h3_launch_cfg<128, 32, 4, 1>(p, s); break;
         case 64: h3_launch_cfg<128, 64, 4, 1>(p, s); break;
         case 96: h3_launch_cfg<128, 96, 4, 1>(p, s); break;
         case 258: h3_launch_cfg<256, 128, 4, 2>(p, s); break;
-        case 260: h3_launch_cfg<256, 64, 4, 2>(p, s); break;
-        default: h3_launch_cfg<128, 128, 2, 2>(p, s); break;
+        default: h3_launch_cfg<256, 64, 4, 2>(p, s); break;   // 260
     }
 }
 

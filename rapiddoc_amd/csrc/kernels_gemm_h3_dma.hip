@@ -53,46 +53,42 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, f16x8& hi, 
 // Epilogue of one 32x32 accumulator tile (16 rows of one output column per lane): combine the two accumulators, bias,
 // range guard, activation, residual, store.  The activation switch and the residual test sit OUTSIDE the 16-element loops
 // and the residual loads are unconditional (clamped row): per-element branches would serialise the loads and stores.
-template <bool LEAN>
 __device__ __forceinline__ void dma_finish_tile(const ConvParams& p, const f32x16& a1, const f32x16& a2, int mb, int n, float bv,
                                                 unsigned& emax) {
-    float o[16];
+    // eight values at a time: sixteen values + sixteen residuals + their 64-bit addresses next to 128 accumulator registers
+    // made the kernel spill (23 VGPRs at commit 27b771f); the halves keep the batched, unconditional residual loads
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        o[r] = fmaf(a2[r], 1.f / 2048.f, a1[r]) + bv;
-        emax = max(emax, __float_as_uint(o[r]) & 0x7fffffffu);
-    }
-    switch (p.act) {
-        case ACT_NONE: break;
-        case ACT_RELU:
+    for (int half = 0; half < 2; ++half) {
+        float o[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = fmaxf(o[r], 0.f);
-            break;
-        case ACT_GELU:
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = rd_gelu(o[r]);
-            break;
-        default:
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = rd_act(o[r], p.act);
-            break;
-    }
-    if (p.res) {
-        if (LEAN) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] += p.res[(size_t)min(mb + (r & 3) + 8 * (r >> 2), p.M - 1) * p.rld + n];
-        } else {
-            float res[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) res[r] = p.res[(size_t)min(mb + (r & 3) + 8 * (r >> 2), p.M - 1) * p.rld + n];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] += res[r];
+        for (int e = 0; e < 8; ++e) {
+            const int r = half * 8 + e;
+            o[e] = fmaf(a2[r], 1.f / 2048.f, a1[r]) + bv;
+            emax = max(emax, __float_as_uint(o[e]) & 0x7fffffffu);
         }
-    }
+        if (p.act == ACT_GELU) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = mb + (r & 3) + 8 * (r >> 2);
-        if (m < p.M) __builtin_nontemporal_store(o[r], &p.y[(size_t)m * p.yld + n]);
+            for (int e = 0; e < 8; ++e) o[e] = rd_gelu(o[e]);
+        } else if (p.act != ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rd_act(o[e], p.act);
+        }
+        if (p.res) {
+            float rs[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = half * 8 + e;
+                rs[e] = p.res[(size_t)min(mb + (r & 3) + 8 * (r >> 2), p.M - 1) * p.rld + n];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += rs[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int r = half * 8 + e;
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            if (m < p.M) __builtin_nontemporal_store(o[e], &p.y[(size_t)m * p.yld + n]);
+        }
     }
 }
 
@@ -109,11 +105,14 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
 
     // ---- DMA source addressing of this lane.  A: 4 instructions per wavefront and K tile, instruction j fills tile rows
     // 32*wave + 8*j .. +7 (lane -> row + lane/8, chunk position lane%8).  B: one instruction per plane, rows 16*wave + lane/4.
+    // Per-lane address state is kept small (the kernel runs at the 256-VGPR limit with its 128 accumulators): 32-bit element
+    // offsets from the uniform bases p.x / wh / wl (the launcher routes tensors of >= 2^31 elements to the 16-wavefront
+    // kernel), one chunk offset for the four A instructions (their swizzles differ by a constant: the row's swizzle bits
+    // are (4 jj + lane / 16) & 7, i.e. instruction jj flips bit 2 of the chunk index when jj is odd).
     int m0 = 0, n0 = 0;
-    const float* asrc[4];   // row base; the chunk's channel offset is kc[] (clamped per K tile, see issue_tile)
-    int kc[4];
-    const _Float16* bsrc_h;
-    const _Float16* bsrc_l;
+    unsigned aoff[4];       // row base (elements from p.x); the chunk's channel offset is kc0 ^ (16 * (jj & 1)), clamped per K tile
+    const int kc0 = 4 * ((lane & 7) ^ ((lane >> 4) & 7));
+    unsigned boff = 0;      // elements from wh / wl
     auto setup_tile = [&](int v) {
         const int xcd = v & 7, j = v >> 3, q = ntiles >> 3, r = ntiles & 7;
         const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
@@ -123,40 +122,32 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int row = 32 * wave + 8 * jj + (lane >> 3);
-            const int c = (lane & 7) ^ ((row >> 1) & 7);
             const int m = min(m0 + row, p.M - 1);               // rows past M re-read the last row; never stored
-            asrc[jj] = p.x + (size_t)m * p.xld;
-            kc[jj] = 4 * c;
+            aoff[jj] = (unsigned)m * (unsigned)p.xld;
         }
         const int brow = 16 * wave + (lane >> 2);
         const int bc = (lane & 3) ^ ((brow >> 2) & 3);
-        const size_t boff = (size_t)min(n0 + brow, p.Ng - 1) * Kp + 8 * bc;
-        bsrc_h = wh + boff;
-        bsrc_l = wl + boff;
+        boff = (unsigned)min(n0 + brow, p.Ng - 1) * (unsigned)Kp + 8u * bc;
     };
     auto issue_tile = [&](int kt, int stage) {
         const unsigned base = (unsigned)stage * D_STAGE;
         const int k0 = kt * DK;
 #pragma unroll
         // K need not be a multiple of 32: chunks past K re-read the row's last chunk (finite data) and meet zero weights
-        for (int jj = 0; jj < 4; ++jj) dma16(asrc[jj] + min(k0 + kc[jj], K - 4), base + (unsigned)(4 * wave + jj) * 1024u, smem);
-        dma16(bsrc_h + k0, base + D_A_BYTES + (unsigned)wave * 1024u, smem);
-        dma16(bsrc_l + k0, base + D_A_BYTES + D_B_BYTES + (unsigned)wave * 1024u, smem);
+        for (int jj = 0; jj < 4; ++jj)
+            dma16(p.x + (aoff[jj] + (unsigned)min(k0 + (kc0 ^ (16 * (jj & 1))), K - 4)), base + (unsigned)(4 * wave + jj) * 1024u, smem);
+        dma16(wh + (boff + (unsigned)k0), base + D_A_BYTES + (unsigned)wave * 1024u, smem);
+        dma16(wl + (boff + (unsigned)k0), base + D_A_BYTES + D_B_BYTES + (unsigned)wave * 1024u, smem);
     };
 
     // ---- fragment addressing (byte offsets inside a stage)
-    int a_off[2], b_off[4][2];   // A: [ks] first of the two chunks; B: [column block][ks] the chunk
-    {
-        const int R = wm * 32 + l31, f = (R >> 1) & 7;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) a_off[ks] = R * 128 + (((2 * (lhi + 2 * ks)) ^ f) << 4);   // the partner chunk is this address ^ 16
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int Rn = j * 32 + l31, g = (Rn >> 2) & 3;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) b_off[j][ks] = D_A_BYTES + Rn * 64 + (((lhi + 2 * ks) ^ g) << 4);
-        }
-    }
+    // A: [ks] first of the two chunks (k-step 1 = k-step 0 with bit 2 of the chunk index flipped, the partner chunk is the
+    // address ^ 16); B: column block j sits j * 2048 bytes further (its swizzle bits (Rn >> 2) & 3 do not depend on j) and
+    // k-step 1 flips bit 1 of the chunk index: two registers hold all ten fragment addresses, the rest are immediates
+    const int a_off0 = (wm * 32 + l31) * 128 + (((2 * lhi) ^ (((wm * 32 + l31) >> 1) & 7)) << 4);
+    const int b_off0 = D_A_BYTES + l31 * 64 + ((lhi ^ ((l31 >> 2) & 3)) << 4);
+    auto a_off = [&](int ks) { return a_off0 ^ (ks << 6); };
+    auto b_off = [&](int j, int ks) { return (b_off0 ^ (ks << 5)) + j * 2048; };
 
     unsigned emax = 0;
     bool fresh = true;
@@ -186,16 +177,16 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
             f32x4 xa[2][2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                xa[ks][0] = *reinterpret_cast<const f32x4*>(st + a_off[ks]);
-                xa[ks][1] = *reinterpret_cast<const f32x4*>(st + (a_off[ks] ^ 16));
+                xa[ks][0] = *reinterpret_cast<const f32x4*>(st + a_off(ks));
+                xa[ks][1] = *reinterpret_cast<const f32x4*>(st + (a_off(ks) ^ 16));
             }
             f16x8 ah0, al0, ah1, al1;
             {
                 f16x8 bh[4], bl[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    bh[j] = *reinterpret_cast<const f16x8*>(st + b_off[j][0]);
-                    bl[j] = *reinterpret_cast<const f16x8*>(st + b_off[j][0] + D_B_BYTES);
+                    bh[j] = *reinterpret_cast<const f16x8*>(st + b_off(j, 0));
+                    bl[j] = *reinterpret_cast<const f16x8*>(st + b_off(j, 0) + D_B_BYTES);
                 }
                 split8(xa[0][0], xa[0][1], ah0, al0);
                 split8(xa[1][0], xa[1][1], ah1, al1);
@@ -210,8 +201,8 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
                 f16x8 bh[4], bl[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    bh[j] = *reinterpret_cast<const f16x8*>(st + b_off[j][1]);
-                    bl[j] = *reinterpret_cast<const f16x8*>(st + b_off[j][1] + D_B_BYTES);
+                    bh[j] = *reinterpret_cast<const f16x8*>(st + b_off(j, 1));
+                    bl[j] = *reinterpret_cast<const f16x8*>(st + b_off(j, 1) + D_B_BYTES);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -238,7 +229,7 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
             const int n = en0 + j * 32 + l31;
             if (n >= p.Ng) continue;
             const float bv = p.bias ? p.bias[n] : 0.f;
-            dma_finish_tile<false>(p, acc1[j], acc2[j], em0 + wm * 32 + 4 * lhi, n, bv, emax);
+            dma_finish_tile(p, acc1[j], acc2[j], em0 + wm * 32 + 4 * lhi, n, bv, emax);
         }
         if (!has_next) break;
         v = vnext;
@@ -423,7 +414,10 @@ void launch_gemm_h3_dma(const ConvParams& p, hipStream_t s) {
     // the K loop itself runs at the same ~1.8 us per K tile with two or four wavefronts per SIMD (it is not latency hiding
     // inside a SIMD that is missing); the 16-wavefront tile only drains its prologue / epilogue faster, which shows for short K
     static const int force16 = [] { const char* e = getenv("RD_H3_DMA16"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-    const bool use16 = force16 >= 0 ? force16 == 1 : p.K <= 384;
+    // the 8-wavefront kernel addresses its operands with 32-bit element offsets from p.x / p.wh
+    const bool fits32 = (unsigned long long)p.M * (unsigned long long)p.xld + (unsigned long long)p.K < (1ull << 32) &&
+                        (unsigned long long)p.Ng * (unsigned long long)((p.K + DK - 1) / DK * DK) < (1ull << 32);
+    const bool use16 = !fits32 || (force16 >= 0 ? force16 == 1 : p.K <= 384);
     if (use16) {
         rd_allow_dynamic_lds((const void*)gemm_h3_dma16_kernel, sh, lds_ok16);
         hipLaunchKernelGGL(gemm_h3_dma16_kernel, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(1024), sh, s, p, ntn, ntiles);
