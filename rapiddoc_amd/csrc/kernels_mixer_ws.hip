@@ -88,7 +88,13 @@ __device__ __forceinline__ void ws_split(float v, float s, _Float16& hi, _Float1
 // inv1 = 1 / scale(W1), inv2 = 1 / (scale(W2) * WS_SH): exact powers of two
 // ABL: microbenchmark ablation bits (results are garbage): 1 no weight DMA after the first two stages, 2 no MFMAs,
 // 4 no fragment reads and no MFMAs, 8 no GELU, 16 no workgroup barrier
-template <int C, bool GATED, bool KEEPX, int ABL = 0>
+// P2 (round 3): GEMM2 runs ONE STEP BEHIND the GELU that feeds it.  In the round-2 order a step was [GELU(q): ~130 VALU, nothing
+// else can issue] then [GEMM1(q+1), GEMM2(q): 74 MFMAs]; the matrix pipe idled through every GELU (ablation: 32 of 168 us).  With
+// GEMM2(q-1) instead, all 74 MFMAs of a step are independent of the step's VALU work, and the instruction stream is pinned to
+// 1 MFMA : 2 VALU (a 16x16x32 MFMA keeps the pipe for 16 cycles: two or three single-issue instructions fit in its shadow,
+// MI355X_MICROARCH.md "two waves per SIMD").  Stage q of the weight image then holds [W1 chunk q+1 | W2 chunk q-1]; a tile
+// takes NC + 2 steps, consecutive tiles of a wavefront overlap by two.
+template <int C, bool GATED, bool KEEPX, int ABL = 0, bool P2 = false>
 __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, const unsigned char* __restrict__ wimg, int n_tiles,
                                                              int T_total, int ph_mul, int ph_unit, float inv1, float inv2) {
     using G = WsGeom<C>;
@@ -111,7 +117,8 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
     // switch stalls nobody else at the step barrier, while different workgroups - nothing couples them - switch at different
     // steps and the tile traffic of the chip is spread over the weight cycle instead of arriving in bursts)
     const int du = ((int)blockIdx.x * WS_WAVES + wave) / ph_unit, sub = ((int)blockIdx.x * WS_WAVES + wave) % ph_unit;
-    auto n_of = [&](int w) { return max(0, (T_total - 1 - (w * ph_mul) % NC) / NC); };
+    constexpr int TAIL = P2 ? 2 : 1;            // steps a tile needs beyond its NC chunk steps
+    auto n_of = [&](int w) { return max(0, (T_total - TAIL - (w * ph_mul) % NC) / NC); };
     const int ph = (du * ph_mul) % NC;
     int per_cycle = 0, before = 0;
     for (int j = 0; j < NC; ++j) {
@@ -303,6 +310,77 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
     };
 
     if (wave < WS_WAVES / 2) __builtin_amdgcn_s_setprio(1);   // static: the first wavefront of every SIMD wins arbitration
+    if constexpr (P2) {
+        f16x8 hh_old = {}, hl_old = {};                   // GELU(H) of the previous chunk: the B fragment of this step's GEMM2
+        for (int t = 0; t < T_total; ++t) {
+            ws_step_sync<G::PIECES>(t + 1 < T_total);
+            if (t + 2 < T_total) issue_stage(t + 2);
+            const int u = t - ph;
+            if (u < 0 || u > R * NC + 1) continue;           // (idle head / tail of this phase; barriers and DMA above still run)
+            const unsigned char* stage = lds + (t % WS_NSTAGE) * G::STAGE_BYTES;
+            const int q = (t + NC - 1) % NC;                  // chunk whose pre-activations were finished by the previous step
+            const int r = u / NC, uu = u - r * NC;
+            const bool do_g1 = u < R * NC, do_gelu = u >= 1 && u <= R * NC, do_g2 = u >= 2;
+            f16x8 hh_new = {}, hl_new = {};
+            if (do_g1 && do_gelu && do_g2 && uu >= 2) {
+                // common step: GELU(q) (VALU) beside GEMM1(q+1) and GEMM2(q-1) (74 independent MFMAs)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) hn[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+                unit_load(stage, 0, 0);
+                unit_load(stage, 1, 1);
+                gelu_split(q, hh_new, hl_new);
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    if (i + 2 < NU) unit_load(stage, i + 2, (i + 2) % 3);
+                    if (i < KS) unit_g1(i, i % 3);
+                    else unit_g2(2 * (i - KS), i % 3, hh_old, hl_old);
+                }
+                // issue order of the whole step: per unit its 4 fragment reads (two units ahead), then 6 x (1 MFMA, 2 VALU)
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    if (i + 2 < NU) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    }
+                }
+            } else {
+                // tile edges (first two / last two steps of a tile, head and tail of the wavefront's run): same operations,
+                // each under its own (wave-uniform) condition
+                if (do_gelu) gelu_split(q, hh_new, hl_new);      // before load_x: it belongs to the tile hfac_cur describes
+                if (do_g1 && uu == 0) load_x(r);
+                if (do_g1) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) hn[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    unit_load(stage, 0, 0);
+                    unit_load(stage, 1, 1);
+#pragma unroll
+                    for (int i = 0; i < KS; ++i) {
+                        if (i + 2 < KS) unit_load(stage, i + 2, (i + 2) % 3);
+                        unit_g1(i, i % 3);
+                        pin_unit(i + 2 < KS);
+                    }
+                }
+                if (do_g2) {
+                    unit_load(stage, KS, 0);
+                    unit_load(stage, KS + 1, 1);
+#pragma unroll
+                    for (int i = KS; i < NU; ++i) {
+                        if (i + 2 < NU) unit_load(stage, i + 2, (i + 2 - KS) % 3);
+                        unit_g2(2 * (i - KS), (i - KS) % 3, hh_old, hl_old);
+                        pin_unit(i + 2 < NU);
+                    }
+                    if (uu == 1) epilogue(r - 1);                 // that was the last chunk of tile r - 1
+                }
+            }
+            hh_old = hh_new;
+            hl_old = hl_new;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) hc[b] = hn[b];
+            hfac_cur = hfac;
+        }
+    } else
     for (int t = 0; t < T_total; ++t) {
         if constexpr (ABL & 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else ws_step_sync<G::PIECES>(t + 1 < T_total);
@@ -370,6 +448,10 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
 // C = 96 builds and passes the same tests, but measures level with the round-1 kernel (99 vs 97 us at M = 211 200): the
 // engine only routes C = 192 here
 bool mixer_ws_supported(int C) { return C == 96 || C == 192; }
+bool mixer_ws_pipelined() {
+    static const bool on = [] { const char* e = getenv("RD_WS_P2"); return e ? e[0] == '1' : false; }();
+    return on;
+}
 bool mixer_ws_preferred(int C) { return C == 192; }
 
 // largest power of two s with max|w| * s < 2^14 (1 for an all-zero matrix)
@@ -384,7 +466,7 @@ static float ws_weight_scale(const float* w, size_t n) {
 
 // host: the weight stream image.  w1 [2C][C], w2 [C][2C] fp32 (BN folded).  img: NC stages of STAGE_BYTES;
 // inv[0] = 1 / scale(W1), inv[1] = 1 / (scale(W2) * WS_SH) - what the kernel multiplies its accumulators by.
-void prepare_mixer_weights_ws(const float* w1, const float* w2, int C, std::vector<uint16_t>& img, float inv[2]) {
+void prepare_mixer_weights_ws(const float* w1, const float* w2, int C, std::vector<uint16_t>& img, float inv[2], bool p2) {
     const int KS = C / 32, NB = C / 16, NC = 2 * C / WS_HC, H2 = 2 * C;
     const int w1_frags = 2 * KS * 2, w2_frags = NB * 2, stage_halfs = (w1_frags + w2_frags) * 512;
     img.assign((size_t)NC * stage_halfs, 0);
@@ -411,11 +493,12 @@ void prepare_mixer_weights_ws(const float* w1, const float* w2, int C, std::vect
                         put(w1[(size_t)hid * C + ch], s1, st[f], st[f + 512]);
                     }
         uint16_t* st2 = st + (size_t)w1_frags * 512;
+        const int c2 = p2 ? (q + NC - 1) % NC : q;   // W2 chunk of this stage (P2: GEMM2 runs one step behind its GELU)
         for (int n = 0; n < NB; ++n)
             for (int l = 0; l < 64; ++l)
                 for (int e = 0; e < 8; ++e) {
                     const int m = l & 15, g = l >> 4;
-                    const int out = 16 * n + m, hid = 32 * q + 16 * (e / 4) + 4 * g + (e & 3);
+                    const int out = 16 * n + m, hid = 32 * c2 + 16 * (e / 4) + 4 * g + (e & 3);
                     const size_t f = (size_t)(2 * n) * 512 + l * 8 + e;
                     put(w2[(size_t)out * H2 + hid], s2, st2[f], st2[f + 512]);
                 }
@@ -423,11 +506,11 @@ void prepare_mixer_weights_ws(const float* w1, const float* w2, int C, std::vect
 }
 
 // smallest number of steps in which `waves` wavefronts with phases (w * ph_mul) mod NC cover n_tiles tiles
-static int ws_total_steps(int n_tiles, int waves, int NC, int ph_mul) {
-    for (int T = NC + 1;; ++T) {
+static int ws_total_steps(int n_tiles, int waves, int NC, int ph_mul, int tail = 1) {
+    for (int T = NC + tail;; ++T) {
         long cap = 0;
         for (int j = 0; j < NC; ++j) {
-            const long n = (T - 1 - (j * ph_mul) % NC) / NC;
+            const long n = (T - tail - (j * ph_mul) % NC) / NC;
             if (n <= 0) continue;
             cap += n * (waves / NC + (j < waves % NC ? 1 : 0));
         }
@@ -435,12 +518,12 @@ static int ws_total_steps(int n_tiles, int waves, int NC, int ph_mul) {
     }
 }
 
-template <int C, bool GATED, bool KEEPX, int ABL = 0>
+template <int C, bool GATED, bool KEEPX, int ABL = 0, bool P2 = false>
 static void launch_ws(const MixerParams& p, const unsigned char* wimg, int n_tiles, int grid, int ph_mul, int ph_unit, hipStream_t s) {
     static unsigned long long lds_ok = 0;
-    rd_allow_dynamic_lds((const void*)lc_mixer_ws_kernel<C, GATED, KEEPX, ABL>, WsGeom<C>::LDS_BYTES, lds_ok);
-    const int T = ws_total_steps((n_tiles + ph_unit - 1) / ph_unit, grid * WS_WAVES / ph_unit, WsGeom<C>::NC, ph_mul);
-    hipLaunchKernelGGL((lc_mixer_ws_kernel<C, GATED, KEEPX, ABL>), dim3(grid), dim3(512), WsGeom<C>::LDS_BYTES, s, p, wimg, n_tiles, T,
+    rd_allow_dynamic_lds((const void*)lc_mixer_ws_kernel<C, GATED, KEEPX, ABL, P2>, WsGeom<C>::LDS_BYTES, lds_ok);
+    const int T = ws_total_steps((n_tiles + ph_unit - 1) / ph_unit, grid * WS_WAVES / ph_unit, WsGeom<C>::NC, ph_mul, P2 ? 2 : 1);
+    hipLaunchKernelGGL((lc_mixer_ws_kernel<C, GATED, KEEPX, ABL, P2>), dim3(grid), dim3(512), WsGeom<C>::LDS_BYTES, s, p, wimg, n_tiles, T,
                        ph_mul, ph_unit, p.ws_inv1, p.ws_inv2);
 }
 
@@ -470,9 +553,11 @@ void launch_mixer_fused_ws(const MixerParams& p, hipStream_t s) {
     // traffic over the chip without that coupling.  Phases cost up to NC - 1 extra steps when the tiles divide evenly, so the
     // launcher takes them when the schedule grows by at most 1/8.
     const int NC = 2 * p.C / WS_HC;
-    const int t_lock = ws_total_steps(n_tiles, grid * WS_WAVES, NC, 0);
-    const int t_wg = ws_total_steps((n_tiles + WS_WAVES - 1) / WS_WAVES, grid, NC, 5);     // 5: coprime to NC = 6 and 12
-    const int t_wave = ws_total_steps(n_tiles, grid * WS_WAVES, NC, 5);
+    const bool p2 = p.ws_p2 && p.C == 192;
+    const int tail = p2 ? 2 : 1;
+    const int t_lock = ws_total_steps(n_tiles, grid * WS_WAVES, NC, 0, tail);
+    const int t_wg = ws_total_steps((n_tiles + WS_WAVES - 1) / WS_WAVES, grid, NC, 5, tail);     // 5: coprime to NC = 6 and 12
+    const int t_wave = ws_total_steps(n_tiles, grid * WS_WAVES, NC, 5, tail);
     int ph_mul = 0, ph_unit = 1;
     if (t_wave < t_lock) { ph_mul = 5; ph_unit = 1; }
     else if (t_wg * 8 <= t_lock * 9) { ph_mul = 5; ph_unit = WS_WAVES; }
@@ -491,6 +576,11 @@ void launch_mixer_fused_ws(const MixerParams& p, hipStream_t s) {
             case 29: launch_ws<192, false, false, 29>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
             default: break;
         }
+        return;
+    }
+    if (p2) {
+        if (gated) launch_ws<192, true, false, 0, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s);
+        else launch_ws<192, false, false, 0, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s);
         return;
     }
     const bool keepx = (p.C == 96) != ((p.dbg & 2) != 0);
