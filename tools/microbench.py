@@ -27,10 +27,11 @@ def mixer(C_, M, variant, iters=20, check=False):
     b1 += 0.05
     b2 -= 0.02
     ms = lib.rd_debug_time_mixer(C_, M, variant, iters, x.data_ptr(), y.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr())
-    if check:
-        xs = x[:2048].double()
+    if check:     # every 37th row plus the first and last 1024 (tile edges, the tail of the last workgroup)
+        sel = torch.unique(torch.cat([torch.arange(0, min(M, 1024)), torch.arange(0, M, 37), torch.arange(max(0, M - 1024), M)])).cuda()
+        xs = x[sel].double()
         ref = xs + torch.nn.functional.gelu(xs @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
-        return ms, 8.0 * M * C_ * C_ / ms / 1e9, float((y[:2048].double() - ref).abs().max())
+        return ms, 8.0 * M * C_ * C_ / ms / 1e9, float((y[sel].double() - ref).abs().max())
     return ms, 8.0 * M * C_ * C_ / ms / 1e9
 
 
