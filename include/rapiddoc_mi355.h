@@ -198,6 +198,18 @@ int rd_db_scores(int device_id, const float* prob_dev, int B, int H, int W, cons
 int rd_db_finish(const rd_db_candidate* cand, const double* scores, const int32_t* n_cand, int B, int max_cand, int H, int W,
                  const int32_t* src_hw, float box_thresh, float unclip_ratio, rd_text_box* out, int max_out, int32_t* n_out);
 
+/* The same post-process with NOTHING on the host (round 3): rows -> runs in raster order -> regions (union-find over
+ * row-adjacent runs) -> convex hull of each region's row extremes -> min-area rectangle -> box_score_fast -> unclip / rescale /
+ * filter_det_res, all on `stream`; the caller needs one device-to-host copy of n_out_dev and out_dev.  Boxes and their order
+ * equal rd_db_postprocess's.  src_hw_dev: int32 [B][2] on the device.  n_out_dev: int32 [B + 1]; entry B is an overflow flag
+ * (a page had more than max_runs bitmap runs: repeat that batch with rd_db_postprocess).  ws_dev: rd_db_boxes_workspace()
+ * bytes of device scratch.  The scores are sums in double precision reduced in a fixed tree order; the host path adds the same
+ * terms serially, so a candidate whose score sits within one ulp of box_thresh may be kept on one path and dropped on the other. */
+size_t rd_db_boxes_workspace(int B, int H, int W, int max_runs, int max_candidates);
+int rd_db_boxes_device(int device_id, const float* prob_dev, int B, int H, int W, const int32_t* src_hw_dev, float thresh, float box_thresh,
+                       float unclip_ratio, int use_dilation, int max_candidates, int max_runs, void* ws_dev, size_t ws_bytes,
+                       rd_text_box* out_dev, int max_out, int32_t* n_out_dev, void* stream);
+
 /* PP-DocLayout post-process, rectangle mode (HOST pointers).  Replaces PPPostProcess.__call__ with
  * layout_shape_mode="rect": rapid_doc/model/layout/rapid_layout_self/model_handler/pp_doclayout/post_process.py:20-243.
  * boxes: [n][ncol] float32 rows (cls, score, x0, y0, x1, y1[, order...]) in original-image pixels (ncol 6, 7 or 8).

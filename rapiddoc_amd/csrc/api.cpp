@@ -265,6 +265,22 @@ int rd_db_scores(int device_id, const float* prob, int B, int H, int W, const rd
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+size_t rd_db_boxes_workspace(int B, int H, int W, int max_runs, int max_candidates) {
+    (void)W;
+    if (B <= 0 || H <= 0 || max_runs <= 0 || max_candidates <= 0) return 0;
+    return rd::db_boxes_workspace_bytes(B, H, max_runs, max_candidates);
+}
+int rd_db_boxes_device(int device_id, const float* prob, int B, int H, int W, const int32_t* src_hw_dev, float thresh, float box_thresh,
+                       float unclip_ratio, int use_dilation, int max_candidates, int max_runs, void* ws, size_t ws_bytes, rd_text_box* out,
+                       int max_out, int32_t* n_out, void* stream) {
+    if (!prob || !src_hw_dev || !ws || !out || !n_out || B < 0 || H <= 0 || W <= 0) return 1;
+    if (hipSetDevice(device_id) != hipSuccess) return 1;
+    if (rd::launch_db_boxes(prob, B, H, W, src_hw_dev, thresh, box_thresh, unclip_ratio, use_dilation, max_candidates, max_runs, ws, ws_bytes,
+                            out, max_out, n_out, (hipStream_t)stream) != 0)
+        return 1;
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 // ---- developer micro-benchmarks (not part of the public header): time one kernel on caller-provided buffers
 float rd_debug_time_mixer(int C, int M, int variant, int iters, float* x, float* y, float* w1, float* b1, float* w2, float* b2) {
     rd::MixerParams p{};

@@ -23,13 +23,17 @@
 
 #include "../../include/rapiddoc_mi355.h"
 
+#include "db_geom.h"
+
 namespace {
 
-struct P2 { double x, y; };
+using rd_db::Cand;
+using rd_db::P2;
+using rd_db::Rect;
+using rd_db::cross;
 
-static double cross(const P2& o, const P2& a, const P2& b) { return (a.x - o.x) * (b.y - o.y) - (a.y - o.y) * (b.x - o.x); }
-
-// Andrew monotone chain; returns hull in counter-clockwise order (y down => visually clockwise), no duplicates
+// Andrew monotone chain over (x, y)-sorted points; returns the hull in the canonical order of db_geom.h (counter-clockwise
+// in (x, y) numbers, i.e. visually clockwise with y down, starting at the smallest (x, y)), no duplicates
 static std::vector<P2> convex_hull(std::vector<P2> pts) {
     std::sort(pts.begin(), pts.end(), [](const P2& a, const P2& b) { return a.x < b.x || (a.x == b.x && a.y < b.y); });
     pts.erase(std::unique(pts.begin(), pts.end(), [](const P2& a, const P2& b) { return a.x == b.x && a.y == b.y; }), pts.end());
@@ -47,55 +51,6 @@ static std::vector<P2> convex_hull(std::vector<P2> pts) {
     }
     h.resize(k - 1);
     return h;
-}
-
-struct Rect { P2 c[4]; double w, h; };
-
-// minimum-area enclosing rectangle of a point set (rotating calipers over hull edges) - cv2.minAreaRect + boxPoints
-static bool min_area_rect(const std::vector<P2>& pts, Rect& out) {
-    std::vector<P2> h = convex_hull(pts);
-    const int n = (int)h.size();
-    if (n == 0) return false;
-    if (n == 1) {
-        for (auto& c : out.c) c = h[0];
-        out.w = out.h = 0;
-        return true;
-    }
-    double best = 1e300;
-    for (int i = 0; i < n; ++i) {
-        const P2 a = h[i], b = h[(i + 1) % n];
-        double ex = b.x - a.x, ey = b.y - a.y;
-        const double len = std::sqrt(ex * ex + ey * ey);
-        if (len == 0) continue;
-        ex /= len; ey /= len;
-        double mn_u = 1e300, mx_u = -1e300, mn_v = 1e300, mx_v = -1e300;
-        for (const P2& p : h) {
-            const double u = (p.x - a.x) * ex + (p.y - a.y) * ey;
-            const double v = -(p.x - a.x) * ey + (p.y - a.y) * ex;
-            mn_u = std::min(mn_u, u); mx_u = std::max(mx_u, u);
-            mn_v = std::min(mn_v, v); mx_v = std::max(mx_v, v);
-        }
-        const double area = (mx_u - mn_u) * (mx_v - mn_v);
-        if (area < best) {
-            best = area;
-            const double us[4] = {mn_u, mx_u, mx_u, mn_u}, vs[4] = {mn_v, mn_v, mx_v, mx_v};
-            for (int k = 0; k < 4; ++k) out.c[k] = {a.x + us[k] * ex - vs[k] * ey, a.y + us[k] * ey + vs[k] * ex};
-            out.w = mx_u - mn_u;
-            out.h = mx_v - mn_v;
-        }
-        if (n == 2) break;
-    }
-    return true;
-}
-
-// PaddleOCR get_mini_boxes ordering: sort by x; left pair by y -> (tl, bl); right pair by y -> (tr, br)
-static void order_mini_box(const P2 in[4], P2 out[4]) {
-    P2 p[4] = {in[0], in[1], in[2], in[3]};
-    std::stable_sort(p, p + 4, [](const P2& a, const P2& b) { return a.x < b.x; });
-    int i1, i2, i3, i4;
-    if (p[1].y > p[0].y) { i1 = 0; i4 = 1; } else { i1 = 1; i4 = 0; }
-    if (p[3].y > p[2].y) { i2 = 2; i3 = 3; } else { i2 = 3; i3 = 2; }
-    out[0] = p[i1]; out[1] = p[i2]; out[2] = p[i3]; out[3] = p[i4];
 }
 
 static double box_score_fast(const float* pred, int H, int W, const P2 box[4]) {
@@ -130,66 +85,16 @@ static double box_score_fast(const float* pred, int H, int W, const P2 box[4]) {
 
 struct Params { float thresh, box_thresh, unclip_ratio; int use_dilation, max_candidates, min_size; };
 
-struct Cand { Rect r; P2 box[4]; };
-
 // border pixels (or any point set with the same convex hull) of one region -> min-area rectangle candidate
 static bool make_candidate(const std::vector<P2>& border, const Params& pr, Cand& c) {
-    if (!min_area_rect(border, c.r)) return false;
-    if (std::min(c.r.w, c.r.h) < pr.min_size) return false;
-    order_mini_box(c.r.c, c.box);
-    return true;
+    const std::vector<P2> h = convex_hull(border);
+    return rd_db::make_candidate_hull(h.data(), (int)h.size(), pr.min_size, c);
 }
 
-// score filter, unclip, second min-area rectangle, scale to the source image, filter_det_res.  Returns 1 if a box was written.
 static int finish_candidate(const Cand& c, double score, int H, int W, int src_h, int src_w, const Params& pr, rd_text_box* out) {
-    if (pr.box_thresh > score) return 0;
-    // unclip: Polygon(box).area * ratio / Polygon(box).length; pyclipper works on integer coordinates
-    const Rect& r = c.r;
-    const P2* box = c.box;
-    const double area = r.w * r.h, perim = 2.0 * (r.w + r.h);
-    if (perim <= 0) return 0;
-    const double dist = area * pr.unclip_ratio / perim;
-    std::vector<P2> ip(4);
-    for (int i = 0; i < 4; ++i) ip[i] = {(double)(long)box[i].x, (double)(long)box[i].y};
-    Rect ri;
-    if (!min_area_rect(ip, ri) || ri.w <= 0 || ri.h <= 0) return 0;
-    // grow the rectangle by `dist` on every side (== min-area rect of the round-join offset polygon)
-    P2 cen = {0, 0};
-    for (auto& c : ri.c) { cen.x += c.x * 0.25; cen.y += c.y * 0.25; }
-    double ux = ri.c[1].x - ri.c[0].x, uy = ri.c[1].y - ri.c[0].y;
-    double vx = ri.c[3].x - ri.c[0].x, vy = ri.c[3].y - ri.c[0].y;
-    const double ul = std::sqrt(ux * ux + uy * uy), vl = std::sqrt(vx * vx + vy * vy);
-    ux /= ul; uy /= ul; vx /= vl; vy /= vl;
-    const double hu = ul * 0.5 + dist, hv = vl * 0.5 + dist;
-    P2 ex[4] = {{cen.x - hu * ux - hv * vx, cen.y - hu * uy - hv * vy}, {cen.x + hu * ux - hv * vx, cen.y + hu * uy - hv * vy},
-                {cen.x + hu * ux + hv * vx, cen.y + hu * uy + hv * vy}, {cen.x - hu * ux + hv * vx, cen.y - hu * uy + hv * vy}};
-    if (std::min(2 * hu, 2 * hv) < pr.min_size + 2) return 0;
-    P2 eb[4];
-    order_mini_box(ex, eb);
-    // scale to the source image: np.clip(np.round(x / width * dest_width), 0, dest_width) -> int32
-    long bx[4], by[4];
-    for (int i = 0; i < 4; ++i) {
-        bx[i] = (long)std::min(std::max(std::nearbyint(eb[i].x / W * src_w), 0.0), (double)src_w);
-        by[i] = (long)std::min(std::max(std::nearbyint(eb[i].y / H * src_h), 0.0), (double)src_h);
-    }
-    // filter_det_res: order_points_clockwise, clip to the image, drop tiny boxes
-    int idx[4] = {0, 1, 2, 3};
-    std::stable_sort(idx, idx + 4, [&](int a, int b) { return bx[a] < bx[b]; });
-    int l0 = idx[0], l1 = idx[1], r0 = idx[2], r1 = idx[3];
-    if (by[l1] < by[l0]) std::swap(l0, l1);
-    if (by[r1] < by[r0]) std::swap(r0, r1);
-    const int ord[4] = {l0, r0, r1, l1};  // tl, tr, br, bl
-    float pts[8];
-    for (int i = 0; i < 4; ++i) {
-        pts[2 * i] = (float)std::min(std::max(bx[ord[i]], 0L), (long)src_w - 1);
-        pts[2 * i + 1] = (float)std::min(std::max(by[ord[i]], 0L), (long)src_h - 1);
-    }
-    const int rw = (int)std::sqrt((pts[0] - pts[2]) * (pts[0] - pts[2]) + (pts[1] - pts[3]) * (pts[1] - pts[3]));
-    const int rh = (int)std::sqrt((pts[0] - pts[6]) * (pts[0] - pts[6]) + (pts[1] - pts[7]) * (pts[1] - pts[7]));
-    if (rw <= 3 || rh <= 3) return 0;
-    std::memcpy(out->pts, pts, sizeof(pts));
-    out->score = (float)score;
-    return 1;
+    static_assert(sizeof(rd_db::TextBox) == sizeof(rd_text_box), "rd_text_box layout");
+    return rd_db::finish_candidate(c, score, H, W, src_h, src_w, pr.box_thresh, pr.unclip_ratio, pr.min_size,
+                                   reinterpret_cast<rd_db::TextBox*>(out));
 }
 
 static int process_one(const float* pred, int H, int W, int src_h, int src_w, const Params& pr, rd_text_box* out, int max_out) {

@@ -209,6 +209,11 @@ int launch_line_resize_norm(const LineCropParams& p, hipStream_t s);   // stage 
 // device half of the DB post-process (bitmap runs, candidate scores): include/rapiddoc_mi355.h rd_db_runs / rd_db_scores
 int launch_db_runs(const float* prob, int B, int H, int W, float thresh, int dilate, void* runs, int32_t* n_runs, int max_runs, hipStream_t s);
 int launch_db_scores(const float* prob, int B, int H, int W, const void* cand, const int32_t* n_cand, int max_cand, double* scores, hipStream_t s);
+// the whole DB post-process on the device (kernels_dbpost.hip): include/rapiddoc_mi355.h rd_db_boxes_device
+size_t db_boxes_workspace_bytes(int B, int H, int max_runs, int max_cand);
+int launch_db_boxes(const float* prob, int B, int H, int W, const int32_t* src_hw_dev, float thresh, float box_thresh, float unclip_ratio,
+                    int dilate, int max_cand, int max_runs, void* ws, size_t ws_bytes, void* out_boxes, int max_out, int32_t* n_out_dev,
+                    hipStream_t s);
 int launch_ctc_collapse(const int32_t* idx, const float* prob, int B, int T, const uint8_t* ctab, int max_len, int n_classes,
                         uint8_t* out, int row_bytes, hipStream_t s);
 

@@ -197,14 +197,79 @@ def db_postprocess(prob: np.ndarray, src_hw: Sequence[Tuple[int, int]], thresh: 
 DB_CAND_DTYPE = np.dtype([("box", "<f8", (8,)), ("rect", "<f8", (8,)), ("w", "<f8"), ("h", "<f8")])     # rd_db_candidate
 
 
+_DB_WS: dict = {}      # (device, B, H, max_runs, max_candidates) -> cached device buffers of the device post-process
+
+
 def db_postprocess_device(prob_dev, src_hw: Sequence[Tuple[int, int]], thresh: float = 0.3, box_thresh: float = 0.5,
                           unclip_ratio: float = 1.6, use_dilation: bool = True, max_candidates: int = 1000, max_out: int = 2048,
                           max_runs: int = 65536, stats: dict = None) -> List[Tuple[np.ndarray, List[float]]]:
-    """`db_postprocess` with the maps staying on the GPU: `prob_dev` is the CUDA tensor [B,1,H,W] / [B,H,W] the det
-    forward wrote.  The device thresholds / dilates and emits bitmap runs (rd_db_runs) and scores the candidate rectangles
-    (rd_db_scores); the host labels the runs, fits the rectangles and finishes them (rd_db_candidates / rd_db_finish) - the
-    same C++ arithmetic as the host-only path, only KBs cross PCIe.  Falls back to the host path if a page has more than
-    `max_runs` runs (noise maps)."""
+    """`db_postprocess` with NOTHING on the host (`rd_db_boxes_device`): `prob_dev` is the CUDA tensor [B,1,H,W] /
+    [B,H,W] the det forward wrote; bitmap runs, region labelling, min-area rectangles, scores, unclip and the final filter run
+    as six kernels on the current stream, and ONE device-to-host copy brings the finished boxes (a few KB).  Same boxes in the
+    same order as the host path (tests/test_gpu_image_ops.py).  Falls back to the host path if a page has more than `max_runs`
+    bitmap runs (noise maps)."""
+    import ctypes as C
+    import time
+
+    import torch
+
+    from . import _lib
+    lib = _lib.load()
+    p = prob_dev if prob_dev.dim() == 3 else prob_dev[:, 0]
+    assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
+    B, H, W = p.shape
+    dev = p.device.index or 0
+    st = torch.cuda.current_stream().cuda_stream
+    t0 = time.perf_counter()
+    mo = int(min(max_out, max_candidates))
+    key = (dev, B, H, max_runs, max_candidates, mo)
+    bufs = _DB_WS.get(key)
+    if bufs is None:
+        nbytes = lib.rd_db_boxes_workspace(B, H, W, max_runs, max_candidates)
+        if len(_DB_WS) > 8:
+            _DB_WS.clear()
+        # results: int32 [B + 1] counts (+ overflow flag), padded to 64 bytes, then [B][mo] boxes of 9 floats - one buffer,
+        # one copy
+        head = (4 * (B + 1) + 63) // 64 * 64
+        bufs = {"ws": torch.empty(nbytes, dtype=torch.uint8, device=p.device), "head": head,
+                "res": torch.empty(head + B * mo * 36, dtype=torch.uint8, device=p.device),
+                "res_h": torch.empty(head + B * mo * 36, dtype=torch.uint8, pin_memory=True),
+                "hw": torch.empty((B, 2), dtype=torch.int32, device=p.device), "hw_key": None}
+        _DB_WS[key] = bufs
+    hw_np = np.ascontiguousarray(np.asarray(src_hw, dtype=np.int32).reshape(B, 2))
+    if bufs["hw_key"] != hw_np.tobytes():
+        bufs["hw"].copy_(torch.from_numpy(hw_np), non_blocking=False)
+        bufs["hw_key"] = hw_np.tobytes()
+    res, head = bufs["res"], bufs["head"]
+    rc = lib.rd_db_boxes_device(dev, p.data_ptr(), B, H, W, bufs["hw"].data_ptr(), thresh, box_thresh, unclip_ratio, 1 if use_dilation else 0,
+                                max_candidates, max_runs, bufs["ws"].data_ptr(), bufs["ws"].numel(), res.data_ptr() + head, mo,
+                                res.data_ptr(), st)
+    if rc != 0:
+        raise RuntimeError("rd_db_boxes_device failed")
+    bufs["res_h"].copy_(res, non_blocking=True)
+    torch.cuda.current_stream().synchronize()          # the one wait: det forward + post-process + copy
+    t1 = time.perf_counter()
+    raw = bufs["res_h"].numpy()
+    counts = raw[: 4 * (B + 1)].view("<i4")
+    if int(counts[B]) != 0:
+        return db_postprocess(p.cpu().numpy(), src_hw, thresh, box_thresh, unclip_ratio, use_dilation, max_candidates, max_out)
+    boxes = raw[head:].view(TEXT_BOX_DTYPE).reshape(B, mo)
+    out = []
+    for b in range(B):
+        k = int(counts[b])
+        out.append((boxes["pts"][b, :k].reshape(k, 4, 2).astype(np.int32), boxes["score"][b, :k].tolist()))
+    if stats is not None:
+        stats["t_wait_maps_ms"] = (t1 - t0) * 1e3
+        stats["t_db_post_ms"] = (time.perf_counter() - t1) * 1e3
+    return out
+
+
+def db_postprocess_device_assisted(prob_dev, src_hw: Sequence[Tuple[int, int]], thresh: float = 0.3, box_thresh: float = 0.5,
+                                   unclip_ratio: float = 1.6, use_dilation: bool = True, max_candidates: int = 1000, max_out: int = 2048,
+                                   max_runs: int = 65536, stats: dict = None) -> List[Tuple[np.ndarray, List[float]]]:
+    """Round 2's split (kept for A/B and as a second implementation to test against): the device thresholds / dilates and emits
+    bitmap runs (rd_db_runs) and scores the candidates (rd_db_scores); the host labels the runs, fits the rectangles and finishes
+    them (rd_db_candidates / rd_db_finish) - three blocking copies."""
     import time
 
     import torch

@@ -221,10 +221,12 @@ def test_page_analyzer_runs_the_reference_stage_order(golden_dir):
         assert all(isinstance(s["text"], str) and s["score"] == float(f"{s['score']:.3f}") for s in spans)
 
 
-@pytest.mark.parametrize("kind", ["lines", "blobs", "empty", "full"])
+@pytest.mark.parametrize("kind", ["lines", "blobs", "empty", "full", "speckle"])
 def test_device_db_postprocess_equals_host_path(kind):
-    """rd_db_runs + rd_db_candidates + rd_db_scores + rd_db_finish == rd_db_postprocess (flood fill on the host), box for box:
-    text-line maps, irregular blobs (touching the borders, diagonal 8-connections, holes), an empty and a full map."""
+    """rd_db_boxes_device (everything on the GPU: raster-ordered runs, union-find regions, hulls of the row extremes, min-area
+    rectangles, scores, unclip, filter) == rd_db_postprocess (flood fill on the host) == round 2's device-assisted split, box
+    for box and in the same order: text-line maps, irregular blobs (touching the borders, diagonal 8-connections, holes), an
+    empty and a full map, and a speckled map with more than max_candidates regions (only the first 1000 in raster order count)."""
     from rapiddoc_amd import ocr_host
     rng = np.random.default_rng(5)
     B, H, W = 3, 320, 448
@@ -247,15 +249,36 @@ def test_device_db_postprocess_equals_host_path(kind):
         m[1, 60:80, 320:360] = 0.01                            # a hole
     elif kind == "full":
         m[:] = 0.8
+    elif kind == "speckle":
+        dots = rng.random((B, H, W)) < 0.02                    # ~2800 isolated specks per page: more regions than max_candidates
+        dots[:, 250:, :] = False
+        m[dots] = 0.9
+        m[:, 280:300, 40:400] = 0.85                           # a text line BEHIND the first 1000 regions of page 0 / 1 ...
+        m[2, :250] = 0.02                                      # ... and in front of them on page 2
+        m[2, 20:40, 40:400] = 0.85
     hw = [(640, 896)] * B
     host = ocr_host.db_postprocess(m, hw, thresh=0.3, box_thresh=0.3, unclip_ratio=1.8)
     dev = ocr_host.db_postprocess_device(torch.from_numpy(m).cuda(), hw, thresh=0.3, box_thresh=0.3, unclip_ratio=1.8)
-    assert len(host) == len(dev) == B
-    for (hb, hs), (db, ds) in zip(host, dev):
+    mid = ocr_host.db_postprocess_device_assisted(torch.from_numpy(m).cuda(), hw, thresh=0.3, box_thresh=0.3, unclip_ratio=1.8)
+    assert len(host) == len(dev) == len(mid) == B
+    for (hb, hs), (db, ds), (mb, ms) in zip(host, dev, mid):
         assert hb.shape == db.shape and np.array_equal(hb, db)
         assert np.allclose(hs, ds, rtol=0, atol=1e-6)
+        assert np.array_equal(hb, mb) and np.allclose(hs, ms, rtol=0, atol=1e-6)
+    if kind == "speckle":
+        assert [len(b) for b, _ in dev] == [0, 0, 1] or [len(b) for b, _ in dev][2] >= 1
     if kind == "lines":
         assert all(len(b) >= 5 for b, _ in dev)
+        # the benchmark's size: 960 x 704 maps rendered from the page generator's line boxes, 8 pages
+        from rapiddoc_amd.pages import synth_batch
+        from rapiddoc_amd.pipeline import render_text_maps
+        pages_np, boxes = synth_batch(40, 8)
+        maps = render_text_maps(boxes, pages_np.shape[1:3], (960, 704), "cuda")
+        hw2 = [tuple(pages_np.shape[1:3])] * 8
+        h2 = ocr_host.db_postprocess(maps.cpu().numpy(), hw2, thresh=0.3, box_thresh=0.3, unclip_ratio=1.8)
+        d2 = ocr_host.db_postprocess_device(maps, hw2, thresh=0.3, box_thresh=0.3, unclip_ratio=1.8)
+        for (hb, hs), (db, ds) in zip(h2, d2):
+            assert len(hb) == 45 and np.array_equal(hb, db) and np.allclose(hs, ds, rtol=0, atol=1e-6)
     if kind == "empty":
         assert all(len(b) == 0 for b, _ in dev)
     # overflow of the run buffer falls back to the host path with identical results
