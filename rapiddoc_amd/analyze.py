@@ -81,16 +81,25 @@ def recognise_formulas(pages: torch.Tensor, layout_dets_per_page: Sequence[Seque
 
 
 class RegionOcr:
-    def __init__(self, pipeline, box_thresh: float = 0.3, unclip_ratio: float = 1.8, lang: str = "ch"):
+    def __init__(self, pipeline, box_thresh: float = 0.3, unclip_ratio: float = 1.8, lang: str = "ch",
+                 det_batch_num: Optional[int] = None, det_raw_fn=None):
         """`pipeline`: a `rapiddoc_amd.pipeline.PagePipeline` (its det / rec engines and streams are reused).  box_thresh 0.3 /
-        unclip 1.8 are the page-OCR settings of backend/pipeline/model_init.py:73."""
+        unclip 1.8 are the page-OCR settings of backend/pipeline/model_init.py:73.
+
+        `det_batch_num`: the reference's `Det.rec_batch_num` (analyze_utils.py:118,186): the batch size handed to
+        `det_batch_predict` is min(group size, det_batch_num); the engine here takes a group as one batch tensor whatever it
+        is, the number only reaches `det_raw_fn`.
+        `det_raw_fn(canvases [b,H64,W64,3] u8 RGB, batch_size) -> [raw boxes [n,4,2] per image]` replaces the detector
+        (pre-process, network, DB post-process) of a size group - the seam `ocr_model.det_batch_predict` is in the reference
+        (analyze_utils.py:187).  Used by tests/test_analyze_trace.py to replay traces of the reference's own driver."""
         self.pipe = pipeline
         self.box_thresh, self.unclip_ratio, self.lang = box_thresh, unclip_ratio, lang
+        self.det_batch_num, self.det_raw_fn = det_batch_num, det_raw_fn
 
     # ------------------------------------------------------------------ det on one size group
     def _detect_group(self, canvases: torch.Tensor, maps_override: Optional[torch.Tensor] = None) -> List[np.ndarray]:
-        """canvases [b, H64, W64, 3] u8 RGB on the GPU -> per image the reading-order sorted, merged boxes [n,4,2] (group
-        image coordinates).  `maps_override` [b,1,dh,dw] replaces the network output as the post-process input (tests and
+        """canvases [b, H64, W64, 3] u8 RGB on the GPU -> per image the detector's raw boxes [n,4,2] (group image coordinates,
+        DB post-process order).  `maps_override` [b,1,dh,dw] replaces the network output as the post-process input (tests and
         benchmarks with random weights, whose maps carry no text); the det forward still runs."""
         b, H, W, _ = canvases.shape
         dh, dw = ocr_host.det_resize_shape(H, W, 960, "max")
@@ -102,24 +111,25 @@ class RegionOcr:
         if maps_override is not None:
             assert tuple(maps_override.shape) == tuple(maps.shape)
             maps = maps_override
-        # DB post-process with the maps staying in HBM (runs + scores on the device, labelling / rectangles on the host)
+        # DB post-process with the maps staying in HBM (ocr_host.db_postprocess_device: everything on the device, one copy back)
         res = ocr_host.db_postprocess_device(maps.contiguous(), [(H, W)] * b, thresh=0.3, box_thresh=self.box_thresh,
                                              unclip_ratio=self.unclip_ratio)
-        out = []
-        for boxes, _scores in res:
-            if len(boxes) == 0:
-                out.append(np.zeros((0, 4, 2), np.float32))
-                continue
-            q = ocr_host.merge_det_boxes(ocr_host.sorted_boxes(boxes.astype(np.float32)))
-            out.append(np.asarray(q, dtype=np.float32).reshape(-1, 4, 2))
-        return out
+        return [boxes.astype(np.float32) for boxes, _scores in res]
+
+    @staticmethod
+    def _sort_merge(raw_boxes) -> np.ndarray:
+        """analyze_utils.py:193-196: reading-order sort, then same-line merge (nothing for an empty result)."""
+        if raw_boxes is None or len(raw_boxes) == 0:
+            return np.zeros((0, 4, 2), np.float32)
+        q = ocr_host.merge_det_boxes(ocr_host.sorted_boxes(np.asarray(raw_boxes, dtype=np.float32)))
+        return np.asarray(q, dtype=np.float32).reshape(-1, 4, 2)
 
     # ------------------------------------------------------------------ whole batch
     def __call__(self, pages: torch.Tensor, layout_dets_per_page: Sequence[Sequence[dict]], det_maps_fn=None) -> List[List[dict]]:
         """pages [P,H,W,3] u8 RGB (GPU); returns, per page, the layout detections followed by their OcrText spans
         (`layout_res` of the reference after both OCR stages).  `det_maps_fn(regions, (gh, gw), (dh, dw))` may supply the
         det maps of a size group (see `_detect_group`); regions = [(page, region dict, useful_list)]."""
-        assert pages.is_cuda and pages.dtype == torch.uint8
+        assert pages.dtype == torch.uint8 and (pages.is_cuda or self.det_raw_fn is not None)
         P, H, W, _ = pages.shape
         out: List[List[dict]] = [list(d) for d in layout_dets_per_page]
         regions = []                                   # (page, region dict, useful_list, formula boxes in crop coords)
@@ -127,7 +137,7 @@ class RegionOcr:
             ocr_regions, _tables, formulas = layout_host.split_regions(dets)
             for r in ocr_regions:
                 useful = layout_host.crop_geometry(r, PASTE, PASTE)
-                if useful[6] <= 2 * PASTE or useful[7] <= 2 * PASTE:
+                if useful[6] < 2 * PASTE or useful[7] < 2 * PASTE:        # inverted box: the reference's np.ones would raise
                     continue
                 regions.append((p, r, useful, _formula_boxes_in_crop(formulas, useful)))
         if not regions:
@@ -156,7 +166,11 @@ class RegionOcr:
             override = None
             if det_maps_fn is not None:
                 override = det_maps_fn([regions[i][:3] for i in members], (gh, gw), ocr_host.det_resize_shape(gh, gw, 960, "max"))
-            boxes_per_img = self._detect_group(det_canv, override)
+            if self.det_raw_fn is not None:
+                raw = self.det_raw_fn(det_canv, min(len(members), self.det_batch_num or len(members)))
+            else:
+                raw = self._detect_group(det_canv, override)
+            boxes_per_img = [self._sort_merge(r) for r in raw]
             spans_per_img: List[List[dict]] = []
             quads_per_img: List[np.ndarray] = []
             for k, ridx in enumerate(members):
@@ -229,7 +243,7 @@ class RegionTextModel:
                 rgb = np.ascontiguousarray(np.asarray(image_list[i], dtype=np.uint8)[:, :, ::-1])     # BGR -> RGB
                 canv[k, : shapes[i][0], : shapes[i][1]] = torch.from_numpy(rgb).to(pipe.tdev)
             override = det_maps_fn(ids, (gh, gw), ocr_host.det_resize_shape(gh, gw, 960, "max")) if det_maps_fn else None
-            boxes = self._ocr._detect_group(canv, override)
+            boxes = [self._ocr._sort_merge(r) for r in self._ocr._detect_group(canv, override)]
             quads = [np.asarray([q for q in b if q[2][0] - q[0][0] >= MIN_WIDTH], dtype=np.float32).reshape(-1, 4, 2) for b in boxes]
             pending.append((canv, quads, ids))
         if pending:
@@ -260,14 +274,18 @@ class PageAnalyzer:
     OCR, the 'txt' det mode (PDF text layer)."""
 
     def __init__(self, layout_model, pipeline, formula_model=None, table_model=None, custom_ocr=None, layout_batch_size: int = 1,
-                 formula_level: int = 0, box_thresh: float = 0.3, unclip_ratio: float = 1.8):
+                 formula_level: int = 0, box_thresh: float = 0.3, unclip_ratio: float = 1.8, formula_batch_size: int = 1,
+                 formula_expand_px: int = 2, det_batch_num: Optional[int] = None, det_raw_fn=None, lang: str = "ch"):
+        """Batch sizes default to the reference's (layout_config['batch_num'] / formula_config['batch_num'] = 1,
+        batch_analyze.py:66-71); `det_batch_num` / `det_raw_fn`: see RegionOcr."""
         self.layout_model, self.pipe = layout_model, pipeline
         self.formula_model, self.table_model, self.custom_ocr = formula_model, table_model, custom_ocr
         self.layout_batch_size, self.formula_level = layout_batch_size, formula_level
-        self.ocr = RegionOcr(pipeline, box_thresh, unclip_ratio)
+        self.formula_batch_size, self.formula_expand_px = formula_batch_size, formula_expand_px
+        self.ocr = RegionOcr(pipeline, box_thresh, unclip_ratio, lang, det_batch_num, det_raw_fn)
 
     def __call__(self, pages: torch.Tensor, det_maps_fn=None) -> List[List[dict]]:
-        assert pages.is_cuda and pages.dtype == torch.uint8 and pages.dim() == 4
+        assert pages.dtype == torch.uint8 and pages.dim() == 4 and (pages.is_cuda or self.ocr.det_raw_fn is not None)
         P, H, W, _ = pages.shape
         use_custom = self.custom_ocr is not None
         # 1. layout (+ overlap filter, formula level)
@@ -278,7 +296,7 @@ class PageAnalyzer:
             dets = [[d for d in page if d["category_id"] != inline] for page in dets]
         # 3. formulas (region collection happens inside the helpers, per page)
         if self.formula_model is not None:
-            recognise_formulas(pages, dets, self.formula_model)
+            recognise_formulas(pages, dets, self.formula_model, self.formula_expand_px, self.formula_batch_size)
         # 4. OCR
         if use_custom:
             out = [list(d) for d in dets]

@@ -167,13 +167,13 @@ def filter_overlap_boxes(layout_dets: Sequence[dict], use_custom_ocr: bool = Fal
 
 
 def split_regions(layout_dets: Sequence[dict]) -> Tuple[List[dict], List[dict], List[dict]]:
-    """(ocr regions, table regions, formula regions with 'bbox') - get_res_list_from_layout_res without the
-    image-in-table bookkeeping."""
+    """(ocr regions, table regions, formula regions with 'bbox') - get_res_list_from_layout_res (utils/model_utils.py:
+    162-196) without the image-in-table bookkeeping.  Like the reference it writes the integer 'bbox' INTO the formula
+    detections (they are the caller's dicts: the field is part of the page's output)."""
     ocr, tables, formulas = [], [], []
     for d in layout_dets:
         cid = int(d["category_id"])
         if cid in FORMULA_CATEGORY_IDS:
-            d = dict(d)
             p = d["poly"]
             d["bbox"] = [int(p[0]), int(p[1]), int(p[4]), int(p[5])]
             formulas.append(d)

@@ -1,0 +1,123 @@
+"""CPU: `PageAnalyzer` / `RegionOcr` replay traces of the REFERENCE's own page-batch driver.
+
+tests/golden/analyze_trace_seed*.json were recorded by running rapid_doc's `BatchAnalyze.__call__`
+(backend/pipeline/batch_analyze.py:78-164 -> analyze_utils.py:105-292 -> utils/ocr_utils.py:361-431) with recording stand-ins
+for the three models (tests/golden/make_golden_analyze.py).  Here the same stand-ins are plugged into this repo's driver through
+its model seams and everything the reference did is demanded back:
+
+  * the call sequence: one layout call (batch size, image shapes), one formula call with every formula crop of the batch
+    (shapes = `_expand_formula_crop_res` + `crop_img`), one detector call per (language, 64-px size bucket) in first-appearance
+    order with the reference's batch size, ONE recogniser call with every text line of the page batch pooled page by page;
+  * the detector's input canvases BYTE FOR BYTE (crc32 of the BGR image: 50-px white margin, 255 padding to the bucket, formula
+    boxes whited out of the det copy only);
+  * the recogniser's crop SIZES in pooled order (`get_rotate_crop_image`'s float32 edge norms, truncation, the h/w >= 2 rotation);
+  * the output `layout_dets` of every page, dict for dict: pass-through layout boxes (+ the 'bbox' / 'latex' fields written
+    into formulas), overlap filter, inline-formula drop, spans sorted / merged / cut around formulas / tilt-corrected / mapped
+    to page coordinates, scores formatted to 3 decimals, LowScoreText demotion.
+No GPU: the networks are exactly what the stand-ins replace."""
+import copy
+import json
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from rapiddoc_amd import analyze, ocr_host
+from rapiddoc_amd.pages import synth_page
+from rapiddoc_amd.pipeline import quads_to_crop_matrices
+
+
+def rec_text_and_score(h, w, k):        # == make_golden_analyze.rec_text_and_score
+    score = ((h * 131 + w * 17 + k * 29) % 1000) / 1000.0
+    return f"T{k}:{h}x{w}", score
+
+
+class ReplayLayout:
+    def __init__(self, dets, log):
+        self.dets, self.log = dets, log
+
+    def batch_predict(self, images, batch_size):
+        self.log.append({"batch_size": int(batch_size), "shapes": [list(i.shape) for i in images]})
+        return copy.deepcopy(self.dets)
+
+
+class ReplayFormula:
+    def __init__(self, log):
+        self.log = log
+
+    def batch_predict(self, images, batch_size=1, **kw):
+        self.log.append({"batch_size": int(batch_size), "shapes": [list(np.asarray(i).shape[:2]) for i in images]})
+        return [f"\\\\frac{{{np.asarray(i).shape[0]}}}{{{np.asarray(i).shape[1]}}}" for i in images]
+
+
+class ReplayPipe:
+    """Stands where a PagePipeline stands: `rec_forward_sources` is the recogniser seam (`ocr_model.ocr(crops, det=False)` in
+    the reference, analyze_utils.py:252)."""
+
+    def __init__(self, log):
+        self.log = log
+
+    def rec_forward_sources(self, sources, image_keys=None):
+        # the pooled line list exactly as PagePipeline builds it: (source, image, line), then a stable sort by the image key
+        quads, owner = [], []
+        for si, (_imgs, per_img) in enumerate(sources):
+            for pi, q in enumerate(per_img):
+                q = np.asarray(q, dtype=np.float64).reshape(-1, 4, 2)
+                for j in range(len(q)):
+                    quads.append(q[j])
+                    owner.append((si, pi))
+        keys = np.array([image_keys[si][pi] for si, pi in owner], dtype=np.int64)
+        perm = np.argsort(keys, kind="stable")
+        _m, cw, ch, ok = quads_to_crop_matrices(np.asarray(quads)[perm])
+        assert ok.all()
+        shapes = []
+        for w_, h_ in zip(cw.astype(int).tolist(), ch.astype(int).tolist()):
+            shapes.append([w_, h_] if h_ / w_ >= 2 else [h_, w_])          # np.rot90 of tall crops (ocr_utils.py:531-535)
+        self.log.append({"shapes": shapes})
+        out = [[[] for _ in per_img] for _imgs, per_img in sources]
+        res = [None] * len(quads)
+        for k, src_index in enumerate(perm.tolist()):
+            t, s = rec_text_and_score(shapes[k][0], shapes[k][1], k)
+            res[src_index] = (t, ocr_host.format_score(s))
+        for (si, pi), r in zip(owner, res):
+            out[si][pi].append(r)
+        return out
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_page_analyzer_replays_the_reference_trace(golden_dir, seed):
+    fx = json.loads((golden_dir / f"analyze_trace_seed{seed}.json").read_text())
+    tr = fx["trace"]
+    pages = torch.from_numpy(np.stack([synth_page(i)[0] for i in fx["page_ids"]]))      # CPU tensor: the networks are stood in for
+    assert list(pages.shape[1:3]) == fx["page_hw"]
+    log = {"layout": [], "formula": [], "det": [], "rec": []}
+    det_calls = iter(tr["det_calls"])
+
+    def det_raw_fn(canvases, batch_size):
+        call = next(det_calls)
+        bgr = np.ascontiguousarray(canvases.numpy()[..., ::-1])
+        log["det"].append({"batch_size": batch_size, "shapes": [list(c.shape) for c in bgr],
+                           "crc32": [zlib.crc32(np.ascontiguousarray(c).tobytes()) for c in bgr]})
+        return [np.asarray(b, dtype=np.float32).reshape(-1, 4, 2) for b in call["boxes"]]
+
+    formula_model = ReplayFormula(log["formula"]) if fx["formula_enable"] else None
+    pa = analyze.PageAnalyzer(ReplayLayout(fx["layout_dets"], log["layout"]), ReplayPipe(log["rec"]), formula_model=formula_model,
+                              layout_batch_size=fx["layout_batch_num"], formula_level=fx["formula_level"],
+                              formula_batch_size=fx["formula_batch_num"], det_batch_num=fx["ocr_config"]["Det.rec_batch_num"],
+                              det_raw_fn=det_raw_fn)
+    out = pa(pages)
+
+    # ---- calls
+    assert log["layout"] == tr["layout_calls"]
+    assert log["formula"] == tr["formula_calls"]
+    assert [{k: c[k] for k in ("batch_size", "shapes", "crc32")} for c in tr["det_calls"]] == log["det"]
+    assert next(det_calls, None) is None
+    assert log["rec"] == tr["rec_calls"] and len(log["rec"]) == 1
+    # ---- output, dict for dict
+    ref = fx["output"]
+    assert len(out) == len(ref)
+    for p, (mine, theirs) in enumerate(zip(out, ref)):
+        assert len(mine) == len(theirs), (p, len(mine), len(theirs))
+        for a, b in zip(mine, theirs):
+            assert a == b, (p, a, b)

@@ -262,3 +262,58 @@ def test_region_ocr_pools_the_lines_of_all_size_groups(golden_dir):
     spans = [[d for d in page if d["category_id"] in (15, 16)] for page in out]
     assert all(len(s) > 5 for s in spans)
     assert all(isinstance(d["text"], str) and 0.0 <= d["score"] <= 1.0 for s in spans for d in s)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (d) the reference driver's traces on the GPU (rows a1 / a7): same replay as tests/test_analyze_trace.py, but the canvases are
+#     built on the device and the lines go through the real crop kernels and recogniser
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", [0, 2])
+def test_page_analyzer_replays_the_reference_trace_on_the_gpu(golden_dir, seed):
+    import copy
+    import json
+    import zlib
+    from rapiddoc_amd import analyze
+    from rapiddoc_amd.pages import synth_page
+    from rapiddoc_amd.pipeline import PagePipeline
+    from test_analyze_trace import ReplayFormula, ReplayLayout
+    fx = json.loads((golden_dir / f"analyze_trace_seed{seed}.json").read_text())
+    tr = fx["trace"]
+    pages = torch.from_numpy(np.stack([synth_page(i)[0] for i in fx["page_ids"]])).cuda()
+    pipe = PagePipeline(_states(golden_dir, ("ppocrv6_det", "ppocrv6_rec")), rec_mode="strict", n_rec_streams=2)
+    pipe.keep_rec_inputs = True
+    log = {"layout": [], "formula": [], "det": []}
+    det_calls = iter(tr["det_calls"])
+
+    def det_raw_fn(canvases, batch_size):
+        assert canvases.is_cuda
+        call = next(det_calls)
+        bgr = np.ascontiguousarray(canvases.cpu().numpy()[..., ::-1])
+        log["det"].append({"batch_size": batch_size, "shapes": [list(c.shape) for c in bgr],
+                           "crc32": [zlib.crc32(np.ascontiguousarray(c).tobytes()) for c in bgr]})
+        return [np.asarray(b, dtype=np.float32).reshape(-1, 4, 2) for b in call["boxes"]]
+    pa = analyze.PageAnalyzer(ReplayLayout(fx["layout_dets"], log["layout"]), pipe,
+                              formula_model=ReplayFormula(log["formula"]) if fx["formula_enable"] else None,
+                              layout_batch_size=fx["layout_batch_num"], formula_level=fx["formula_level"],
+                              formula_batch_size=fx["formula_batch_num"], det_batch_num=fx["ocr_config"]["Det.rec_batch_num"],
+                              det_raw_fn=det_raw_fn)
+    out = pa(pages)
+    assert log["formula"] == tr["formula_calls"]
+    assert [{k: c[k] for k in ("batch_size", "shapes", "crc32")} for c in tr["det_calls"]] == log["det"]
+    # the recogniser saw the reference's crops (sizes, pooled order) ...
+    cw, ch, rot, keep = pipe.last_rec_crop_sizes
+    shapes = [[int(cw[i]), int(ch[i])] if rot[i] else [int(ch[i]), int(cw[i])] for i in range(len(cw))]
+    assert shapes == tr["rec_calls"][0]["shapes"]
+    # ... in the reference's chunks of 6 (one global argsort over the pooled list)
+    expected = _reference_rec_chunks([tuple(s) for s in shapes])
+    want_w = {i: w for idxs, w in expected for i in idxs}
+    got_w = {int(i): int(x.shape[3]) for chunk, x, _i, _p in pipe.last_rec_batches for i in chunk.tolist()}
+    assert got_w == want_w
+    # ... and every page's output is the reference's, except what the (random-weight) recogniser read
+    for mine, theirs in zip(out, fx["output"]):
+        assert len(mine) == len(theirs)
+        for a, b in zip(mine, theirs):
+            skip = ("text", "score", "category_id") if b["category_id"] in (15, 16) else ()
+            assert {k: v for k, v in a.items() if k not in skip} == {k: v for k, v in b.items() if k not in skip}
+            if skip:
+                assert a["category_id"] == (16 if a["score"] < 0.5 else 15) and isinstance(a["text"], str)
