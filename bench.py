@@ -172,6 +172,10 @@ def main():
                     help="rec batching of the TIMED steps: throughput = chunks of --rec-batch lines, width rounded up to --rec-width-multiple; "
                          "strict = the reference's own batching (one global argsort, chunks of 6, width int(48 * max ratio), "
                          "rapid_ocr.py:404-449).  The other mode is measured in a short post-pass and reported next to it")
+    ap.add_argument("--vary-pages", type=int, default=1,
+                    help="K > 1: K different page sets, step i runs set i mod K (a real document stream never repeats a batch: every "
+                         "step then meets new line widths / token counts, i.e. the plan caches and the tail's bucketing are exercised; "
+                         "the default re-runs one set, like the reference's own benchmark loop would)")
     ap.add_argument("--no-extra-passes", action="store_true", help="skip the post-passes (other rec mode, fp32 precision, backbone alone)")
     args = ap.parse_args()
 
@@ -223,16 +227,26 @@ def main():
     P = len(my_pages)
     pages_np, boxes = synth_pages(my_pages)
     pages = torch.from_numpy(pages_np).cuda()
+    K_sets = max(1, args.vary_pages)
+    # further page sets (--vary-pages): the same shard positions of later "documents" (page ids offset by n_global * k)
+    page_sets = [(pages, boxes)]
+    for k in range(1, K_sets):
+        pk, bk = synth_pages([i + n_global * k for i in my_pages])
+        page_sets.append((torch.from_numpy(pk).cuda(), bk))
     if args.only == "backbone":
         return bench_backbone(args, pool, pages, rank, world, dist, backend)
     # random-weight det maps carry no text, so the DB post-process stage gets maps rendered from the generator's own
     # line boxes (the det network still runs every step); its boxes then drive cropping and recognition
     det_hw = pipe.det_forward(pages[:1])[1]
     text_maps = render_text_maps(boxes, pages_np.shape[1:3], det_hw, pages.device)
+    set_maps = [text_maps] + [render_text_maps(b, pages_np.shape[1:3], det_hw, pages.device) for _p, b in page_sets[1:]]
     quads = None
+    step_no = [0]
 
     def compute(k=0):
-        res = pools[k].run_batch(pages, quads, det_maps_override=text_maps)
+        si = step_no[0] % K_sets
+        step_no[0] += 1
+        res = pools[k].run_batch(page_sets[si][0], quads, det_maps_override=set_maps[si])
         return [(my_pages[i], [(t, s) for _, t, s in r.lines]) for i, r in enumerate(res)]
 
     def step():
@@ -437,6 +451,7 @@ def main():
                                        "throughput (chunks of %d aspect-sorted lines, width rounded up to x%d; the reference's own "
                                        "batching is timed in strict_rec_batching)" % (args.rec_batch, args.rec_width_multiple),
                        "pages_per_gpu": P, "global_pages": n_global, "pages_gathered": len(out), "result_crc32": result_crc,
+                       "page_sets_cycled": K_sets,
                        "lines_per_step": n_lines, "host_stage_ms": host_stats,
                        "host_ms_per_step_max_over_ranks": round(host_ms_max, 2), "cores_per_rank": cores_per_rank,
                        "range_fallbacks": int(sum(e.range_fallbacks for q in pools for e in q.engines)),   # engines that left the split-fp16 mode (0 = the dtype claim holds)

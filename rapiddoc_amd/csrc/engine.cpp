@@ -627,6 +627,71 @@ TView Builder::stem3x3s2(const std::string& wname, const std::string& bn, const 
     return y;
 }
 
+TView Builder::stem_front(const std::string& w1, const std::string& bn1, const std::string& w2a, const std::string& bn2a,
+                          const std::string& w2b, const std::string& bn2b, const TView& xin) {
+    const int c1 = weight_dim(w1, 0);
+    ConvGeom g2;            // padding='same' with an even kernel / F.pad(0,1,0,1): pad right + bottom only
+    g2.kh = g2.kw = 2;
+    g2.pb = g2.pr = 1;
+    const std::string fkey = w1 + "|" + bn1 + "|stemfront";
+    const bool off = std::getenv("RD_STEM_FUSED") && std::getenv("RD_STEM_FUSED")[0] == '0';   // A/B switch, read per plan
+    const bool fused = planning() && !off && (h3_ || mixer_h3_) && pb_->has(fkey + "#img");
+    if (!fused) {
+        // the four separate kernels (fp32 precision mode, unsupported widths, and - in PREPARE mode - the weight folding of both forms)
+        TView e = stem3x3s2(w1, bn1, xin, ACT_RELU);
+        TView a = conv(w2a, "", bn2a, e, g2, ACT_RELU);
+        TView cat = alloc(e.n, e.h, e.w, 2 * c1);
+        TView cat_pool = slice(cat, 0, c1), cat_b = slice(cat, c1, c1);
+        maxpool2x2s1(e, cat_pool);
+        conv(w2b, "", bn2b, a, g2, ACT_RELU, &cat_b);
+        release(e);
+        release(a);
+        if (!planning() && stem_fused_supported(c1) && !pb_->has(fkey + "#img")) {
+            const std::string k1 = w1 + "|" + bn1 + "|stem", k2a = w2a + "|" + bn2a, k2b = w2b + "|" + bn2b;
+            const float* f1 = pb_->host_ptr(k1 + "#w");
+            const float* f2a = pb_->host_ptr(k2a + "#w");
+            const float* f2b = pb_->host_ptr(k2b + "#w");
+            const int na = c1 / 2;
+            const bool fits = fits_fp16_range(std::vector<float>(f1, f1 + (size_t)27 * c1)) &&
+                              fits_fp16_range(std::vector<float>(f2a, f2a + (size_t)na * 4 * c1)) &&
+                              fits_fp16_range(std::vector<float>(f2b, f2b + (size_t)c1 * 4 * na));
+            if (fits && weight_dim(w2a, 0) == na && weight_dim(w2a, 1) == c1 && weight_dim(w2b, 0) == c1 && weight_dim(w2b, 1) == na) {
+                std::vector<uint16_t> img;
+                prepare_stem_fused_weights(c1, f1, f2a, f2b, img);
+                pb_->add_u16(fkey + "#img", img);
+                std::vector<float> bias;
+                const float* b1 = pb_->host_ptr(k1 + "#b");
+                bias.insert(bias.end(), b1, b1 + c1);
+                const float* b2a = pb_->host_ptr(k2a + "#b");
+                bias.insert(bias.end(), b2a, b2a + na);
+                const float* b2b = pb_->host_ptr(k2b + "#b");
+                bias.insert(bias.end(), b2b, b2b + c1);
+                pb_->add(fkey + "#bias", bias);
+            }
+        }
+        return cat;
+    }
+    const int oh = out_dim(xin.h, 3, 2, 1, 1), ow = out_dim(xin.w, 3, 2, 1, 1);
+    TView cat = alloc(xin.n, oh, ow, 2 * c1);
+    const uint16_t* img = reinterpret_cast<const uint16_t*>(pb_->ptr(fkey + "#img"));
+    const float* bias = pb_->ptr(fkey + "#bias");
+    OpRecord r;
+    r.name = w1 + ":front";
+    r.kind = "stem_fused";
+    r.cfg = "C" + std::to_string(c1);
+    r.shape = "N" + std::to_string(xin.n) + "_" + std::to_string(oh) + "x" + std::to_string(ow);
+    const int na = c1 / 2;
+    r.flops = 2.0 * xin.n * oh * ow * (27.0 * c1 + 4.0 * c1 * na + 4.0 * na * c1);
+    r.bytes = 4.0 * ((double)xin.n * xin.c * xin.h * xin.w + (double)xin.n * oh * ow * 2 * c1);
+    const TView xv = xin, yv = cat;
+    unsigned* flag = range_flag_;
+    r.run = [xv, yv, img, bias, c1, flag](const Plan& pl, const RunCtx& c) {
+        launch_stem_fused(c1, pl.vptr(xv, c), xv.n, xv.h, xv.w, xv.c, img, bias, pl.vptr(yv, c), pl.ld(yv), flag, c.stream);
+    };
+    emit(std::move(r));
+    return cat;
+}
+
 TView Builder::dwconv(const std::string& wname, const std::string& bname, const std::string& bn, const TView& x,
                       const ConvGeom& g, int act, const TView* out, const TView* res, GapOut* gap, const TView* tokinfo) {
     const HostTensor& w = ws_->get(wname);

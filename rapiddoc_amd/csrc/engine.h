@@ -157,6 +157,10 @@ class Builder {
     TView deconv2x2(const std::string& wname, const std::string& bname, const std::string& bn, const TView& x, int act,
                     const TView* out = nullptr);
     TView stem3x3s2(const std::string& wname, const std::string& bn, const TView& x_nchw, int act);
+    // stem1 -> [max-pool | stem2a -> stem2b] -> the 2 c1-channel concat buffer at half resolution (StemBlock front).  One fused
+    // kernel in the split-fp16 precision modes (kernels_stem_fused.hip), the four separate kernels otherwise.
+    TView stem_front(const std::string& w1, const std::string& bn1, const std::string& w2a, const std::string& bn2a,
+                     const std::string& w2b, const std::string& bn2b, const TView& x_nchw);
     struct GapOut { TView partial; int chunks = 0; };  // per-image partial sums of a layer's output (SE pooling)
     TView dwconv(const std::string& wname, const std::string& bname, const std::string& bn, const TView& x,
                  const ConvGeom& g, int act, const TView* out = nullptr, const TView* res = nullptr, GapOut* gap = nullptr,

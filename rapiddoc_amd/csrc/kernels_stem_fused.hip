@@ -1,0 +1,421 @@
+// Fused stem front of PPLCNetV4 / PPHGNetV2 (rec_lcnetv4.py:148-169, rec_pphgnetv2.py:979-1056 StemBlock):
+//
+//     x [N,3,H,W] --stem1: conv3x3 s2 +BN+ReLU--> e [H/2,W/2,C1] --stem2a: conv2x2 (pad r/b) +ReLU--> a [C1/2]
+//                                                    |                        --stem2b: conv2x2 (pad r/b) +ReLU--> b [C1]
+//                                                    +--maxpool 2x2 s1 (pad r/b)--> p [C1]          cat = [p | b]  (2 C1 channels)
+//
+// as ONE kernel.  Round 2 ran it as four (stem_conv3x3s2 at 1.9 TB/s, two conv_stream_h3 at 2.1-3.5 TB/s, maxpool at 4.4 TB/s):
+// 13 ms of a 101-ms step, all of it HBM round trips of half-resolution tensors with 12-48 channels - e alone (written once, read
+// twice) is 160 MB per 64-line recogniser batch against 10 MB of input image.  Here a workgroup owns an 8 x 32 tile of `cat`:
+// the image patch it needs (21 x 69 x 3) goes to LDS, e (10 x 34), a (9 x 33) live only in LDS as fp32 tiles, and the three
+// convolutions run on the split-fp16 matrix cores straight from those tiles (A fragments = 8 consecutive channels of one tap of
+// one pixel: two ds_read_b128, split in registers like the LDS-DMA GEMM does; pixel strides of 4 x odd floats make the
+// fragment reads conflict-free).  stem1's K = 27 is laid out as 3 k-steps of 16 slots (one kernel row each: 9 taps x channels
+// contiguous in the channel-interleaved patch, 7 zero-weight slots).  Halo recompute: 1.33x for stem1, 1.16x for stem2a.
+// HBM traffic per tile: the patch + the cat tile.  Persistent workgroups; the next tile's patch is prefetched into registers.
+// Arithmetic: the split-fp16 scheme of kernels_conv_h3.hip (x = hi + lo 2^-11, three MFMAs per product, fp32 accumulate); the
+// `fp32` precision mode keeps the four separate fp32 kernels.
+#include <cstdlib>
+#include <vector>
+
+#include "rd_device.h"
+
+namespace rd {
+
+static constexpr int SF_TH = 8, SF_TW = 32;                       // cat tile
+static constexpr int SF_EH = SF_TH + 2, SF_EW = SF_TW + 2;        // e tile (stem2a needs +1, stem2b another +1)
+static constexpr int SF_AH = SF_TH + 1, SF_AW = SF_TW + 1;        // a tile
+static constexpr int SF_PH = 2 * SF_EH + 1, SF_PW = 2 * SF_EW + 1;   // image patch of the e tile (3x3, stride 2)
+static constexpr int SF_PROW = 208;                               // floats per patch row (69 x 3 = 207, even for 8-byte reads)
+static constexpr int SF_PATCH_FLOATS = SF_PH * SF_PROW + 16;      // + overrun of the last row's zero-weight slots
+static constexpr int SF_NT = 512;
+
+template <int C1>
+struct SfGeom {
+    static constexpr int CA = C1, NA = C1 / 2, CB = (NA + 7) / 8 * 8;
+    static constexpr int K1 = 48, K2A = 4 * CA, K2B = 4 * CB;
+    static constexpr int SE = CA + 4, SA = CB + 4;                 // fp32 pixel strides: (stride / 4) odd
+    static_assert(((SE / 4) & 1) == 1 && ((SA / 4) & 1) == 1, "pixel strides must be 4 x odd floats");
+    static constexpr int pad8(int k) { return ((k / 8) & 1) ? k : k + 8; }   // row stride in halfs with (stride / 8) odd
+    static constexpr int R1 = pad8(K1), R2A = pad8(K2A), R2B = pad8(K2B);
+    // weight image (halfs): [w1 hi | w1 lo | w2a hi | w2a lo | w2b hi | w2b lo], rows = output channels
+    static constexpr int W1_H = C1 * R1, W2A_H = NA * R2A, W2B_H = C1 * R2B;
+    static constexpr int W_HALFS = 2 * (W1_H + W2A_H + W2B_H);
+    static constexpr int BIAS_FLOATS = C1 + NA + C1;
+    static constexpr int E_FLOATS = SF_EH * SF_EW * SE;
+    static constexpr int A_FLOATS_RAW = SF_AH * SF_AW * SA;
+    static constexpr int A_FLOATS = A_FLOATS_RAW > SF_PATCH_FLOATS ? A_FLOATS_RAW : SF_PATCH_FLOATS;   // the patch shares this region
+    static constexpr size_t LDS_BYTES = (size_t)W_HALFS * 2 + (size_t)(BIAS_FLOATS + E_FLOATS + A_FLOATS) * 4 + 64;
+    static constexpr int MB1 = (SF_EH * SF_EW + 31) / 32, NB1 = (C1 + 31) / 32;
+    static constexpr int MB2 = (SF_AH * SF_AW + 31) / 32;
+    static constexpr int MB3 = SF_TH * SF_TW / 32, NB3 = (C1 + 31) / 32;
+    static_assert(NA <= 32 && MB3 == 8, "one N block for stem2a, one M block per wavefront for stem2b");
+};
+
+struct StemFusedParams {
+    const float* x; int N, H, W, in_ch;       // NCHW image (in_ch 1: the grey plane is read three times)
+    const uint16_t* wimg;                       // prepare_stem_fused_weights
+    const float* bias;                          // [C1 | C1/2 | C1]
+    float* y; int yld;                          // cat NHWC [N][H2][W2][2 C1]: p at channel 0, b at channel C1
+    int H2, W2, tiles_x, tiles_y;
+    unsigned* range_flag;
+};
+
+__device__ __forceinline__ void sf_split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        _Float16 h0, l0, h1, l1;
+        rd_split(a[e], h0, l0);
+        rd_split(b[e], h1, l1);
+        hi[e] = h0; hi[4 + e] = h1;
+        lo[e] = l0; lo[4 + e] = l1;
+    }
+}
+
+template <int C1>
+__global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p) {
+    using G = SfGeom<C1>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    _Float16* Wl = reinterpret_cast<_Float16*>(lds);
+    float* Bs = reinterpret_cast<float*>(lds + (size_t)G::W_HALFS * 2);
+    float* Es = Bs + ((G::BIAS_FLOATS + 3) & ~3);
+    float* As = Es + G::E_FLOATS;                  // also the image patch (before stem2a overwrites it)
+    const _Float16* W1h = Wl;
+    const _Float16* W1l = Wl + G::W1_H;
+    const _Float16* W2Ah = Wl + 2 * G::W1_H;
+    const _Float16* W2Al = W2Ah + G::W2A_H;
+    const _Float16* W2Bh = W2Ah + 2 * G::W2A_H;
+    const _Float16* W2Bl = W2Bh + G::W2B_H;
+    const float* b1 = Bs;
+    const float* b2a = Bs + C1;
+    const float* b2b = Bs + C1 + G::NA;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    // weights + biases -> LDS, once per (persistent) workgroup
+    for (int i = tid; i < G::W_HALFS / 8; i += SF_NT)
+        reinterpret_cast<u32x4*>(Wl)[i] = reinterpret_cast<const u32x4*>(p.wimg)[i];
+    for (int i = tid; i < G::BIAS_FLOATS; i += SF_NT) Bs[i] = p.bias[i];
+
+    const int tiles_per_img = p.tiles_x * p.tiles_y, ntiles = p.N * tiles_per_img;
+    constexpr int PATCH_ELEMS = SF_PH * SF_PW * 3;
+    constexpr int PRE = (PATCH_ELEMS + SF_NT - 1) / SF_NT;
+    float pre[PRE];
+    auto tile_origin = [&](int t, int& n, int& ty0, int& tx0) {
+        n = t / tiles_per_img;
+        const int r = t - n * tiles_per_img;
+        const int tyi = r / p.tiles_x;
+        ty0 = tyi * SF_TH;
+        tx0 = (r - tyi * p.tiles_x) * SF_TW;
+    };
+    // which patch elements this thread moves never changes: (row, column, plane, LDS slot) once, per tile only the origin is added
+    int p_rc[PRE], p_lds[PRE], p_ci[PRE];
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+        const int i = tid + k * SF_NT;
+        const int row = i / (SF_PW * 3), rem = i - row * (SF_PW * 3);
+        const int col = rem / 3, ci = rem - col * 3;
+        p_rc[k] = i < PATCH_ELEMS ? (row << 16) | col : -1;
+        p_lds[k] = row * SF_PROW + rem;
+        p_ci[k] = (p.in_ch == 1 ? 0 : ci) * p.H * p.W;
+    }
+    auto load_patch = [&](int t) {               // global -> registers (zero outside the image: the conv's padding)
+        int n, ty0, tx0;
+        tile_origin(t, n, ty0, tx0);
+        const int iy0 = 2 * ty0 - 1, ix0 = 2 * tx0 - 1;
+        const float* img = p.x + (size_t)n * p.in_ch * p.H * p.W;
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) {
+            const int iy = iy0 + (p_rc[k] >> 16), ix = ix0 + (p_rc[k] & 0xffff);
+            const bool ok = p_rc[k] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const float v = img[p_ci[k] + (ok ? iy * p.W + ix : 0)];
+            pre[k] = ok ? v : 0.f;
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int k = 0; k < PRE; ++k)
+            if (p_rc[k] >= 0) As[p_lds[k]] = pre[k];
+        // the slots behind the last real column of every row and behind the last row are read with zero weights: keep them finite
+        if (tid < SF_PH) As[tid * SF_PROW + SF_PW * 3] = 0.f;
+        if (tid >= 64 && tid < 80) As[SF_PH * SF_PROW + tid - 64] = 0.f;
+    };
+
+    bool bad = false;
+    int t = blockIdx.x;
+    if (t < ntiles) load_patch(t);
+    __syncthreads();
+    for (; t < ntiles; t += gridDim.x) {
+        int n, ty0, tx0;
+        tile_origin(t, n, ty0, tx0);
+        store_patch();
+        __syncthreads();
+
+        // a tile whose whole e halo lies inside the map needs no per-element bounds tests (most tiles)
+        const bool inner = ty0 + SF_EH <= p.H2 && tx0 + SF_EW <= p.W2;
+
+        // ---------------- stem1: e = ReLU(conv3x3 s2 (patch)) on the matrix cores, K = 3 kernel rows x 16 slots
+        for (int u = wave; u < G::MB1 * G::NB1; u += 8) {
+            const int mb = u / G::NB1, nb = u - mb * G::NB1;
+            const int m = min(mb * 32 + l31, SF_EH * SF_EW - 1);
+            const int ey = m / SF_EW, ex = m - ey * SF_EW;
+            const int nrow = min(nb * 32 + l31, C1 - 1);
+            f32x16 acc1, acc2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[r] = acc2[r] = 0.f;
+            const float* src0 = As + 2 * ey * SF_PROW + 2 * ex * 3 + 8 * lhi;
+            const _Float16* wb = W1h + nrow * G::R1 + 8 * lhi;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const float* src = src0 + kh * SF_PROW;
+                f32x4 v0, v1;
+                {
+                    const f32x2 q0 = *reinterpret_cast<const f32x2*>(src), q1 = *reinterpret_cast<const f32x2*>(src + 2);
+                    const f32x2 q2 = *reinterpret_cast<const f32x2*>(src + 4), q3 = *reinterpret_cast<const f32x2*>(src + 6);
+                    v0 = f32x4{q0[0], q0[1], q1[0], q1[1]};
+                    v1 = f32x4{q2[0], q2[1], q3[0], q3[1]};
+                }
+                f16x8 ah, al;
+                sf_split8(v0, v1, ah, al);
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(wb + kh * 16);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(wb + G::W1_H + kh * 16);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
+            }
+            const int nn = nb * 32 + l31;
+            const float bv = b1[min(nn, C1 - 1)];
+            float* dst = Es + (mb * 32 + 4 * lhi) * G::SE + nn;
+            if (inner && mb + 1 < G::MB1 && (C1 % 32 == 0 || nb + 1 < G::NB1)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = fmaf(acc2[r], 1.f / 2048.f, acc1[r]) + bv;
+                    bad = bad || !(fabsf(v) < INFINITY);
+                    dst[((r & 3) + 8 * (r >> 2)) * G::SE] = fmaxf(v, 0.f);
+                }
+            } else {
+                const int mr0 = mb * 32 + 4 * lhi;
+                int ry = mr0 / SF_EW, rx = mr0 - ry * SF_EW;      // row / column of element r = 0; the others by carry
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int off = (r & 3) + 8 * (r >> 2);
+                    int cx = rx + off, cy = ry;
+                    if (cx >= SF_EW) { cx -= SF_EW; cy += 1; }
+                    float v = fmaf(acc2[r], 1.f / 2048.f, acc1[r]) + bv;
+                    bad = bad || !(fabsf(v) < INFINITY);
+                    v = fmaxf(v, 0.f);
+                    if (ty0 + cy >= p.H2 || tx0 + cx >= p.W2) v = 0.f;        // beyond the map: the zero padding of stem2a / the pool
+                    if (mr0 + off < SF_EH * SF_EW && nn < C1) dst[off * G::SE] = v;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---------------- stem2a: a = ReLU(conv2x2 (e)), K = 4 taps x C1 channels.  Ten 32-pixel blocks on eight wavefronts: the
+        // six wavefronts without a second block do the max-pool in the meantime (it only needs e)
+        for (int mb = wave; mb < G::MB2; mb += 8) {
+            const int m = min(mb * 32 + l31, SF_AH * SF_AW - 1);
+            const int ay = m / SF_AW, ax = m - ay * SF_AW;
+            const int nrow = min(l31, G::NA - 1);
+            f32x16 acc1, acc2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[r] = acc2[r] = 0.f;
+            const float* src0 = Es + (ay * SF_EW + ax) * G::SE;
+            const _Float16* wb = W2Ah + nrow * G::R2A + 8 * lhi;
+#pragma unroll
+            for (int j = 0; j < G::K2A / 16; ++j) {
+                // k0 = 16 j + 8 lhi -> (tap, channel): both halves resolved at compile time, one select per k-step
+                constexpr int CAc = G::CA;
+                const int t0 = (16 * j) / CAc, c0 = (16 * j) % CAc, t1 = (16 * j + 8) / CAc, c1 = (16 * j + 8) % CAc;
+                const int o0 = ((t0 >> 1) * SF_EW + (t0 & 1)) * G::SE + c0, o1 = ((t1 >> 1) * SF_EW + (t1 & 1)) * G::SE + c1;
+                const float* src = src0 + (lhi ? o1 : o0);
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+                f16x8 ah, al;
+                sf_split8(v0, v1, ah, al);
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(wb + 16 * j);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(wb + G::W2A_H + 16 * j);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
+            }
+            const float bv = b2a[min(l31, G::NA - 1)];
+            float* dst = As + (mb * 32 + 4 * lhi) * G::SA + l31;
+            const bool lane_on = l31 < G::CB;               // channels NA .. CB - 1 are the zero padding of the a tile
+            const bool real = l31 < G::NA;
+            if (inner && mb + 1 < G::MB2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = fmaf(acc2[r], 1.f / 2048.f, acc1[r]) + bv;
+                    bad = bad || !(fabsf(v) < INFINITY);
+                    if (lane_on) dst[((r & 3) + 8 * (r >> 2)) * G::SA] = real ? fmaxf(v, 0.f) : 0.f;
+                }
+            } else {
+                const int mr0 = mb * 32 + 4 * lhi;
+                int ry = mr0 / SF_AW, rx = mr0 - ry * SF_AW;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int off = (r & 3) + 8 * (r >> 2);
+                    int cx = rx + off, cy = ry;
+                    if (cx >= SF_AW) { cx -= SF_AW; cy += 1; }
+                    float v = fmaf(acc2[r], 1.f / 2048.f, acc1[r]) + bv;
+                    bad = bad || !(fabsf(v) < INFINITY);
+                    v = fmaxf(v, 0.f);
+                    if (ty0 + cy >= p.H2 || tx0 + cx >= p.W2 || !real) v = 0.f;   // padding of stem2b; zero pad channels
+                    if (mr0 + off < SF_AH * SF_AW && lane_on) dst[off * G::SA] = v;
+                }
+            }
+        }
+        // ---------------- pool: p = max over e[y..y+1][x..x+1] (e is zero beyond the map: F.pad(0,1,0,1)) -> cat[..., :C1];
+        // by the wavefronts that had one stem2a block only
+        {
+            constexpr int C4 = C1 / 4;
+            constexpr int FIRST = G::MB2 > 8 ? G::MB2 - 8 : 0, NTH = (8 - FIRST) * 64;
+            if (wave >= FIRST) {
+                for (int i = tid - FIRST * 64; i < SF_TH * SF_TW * C4; i += NTH) {
+                    const int pix = i / C4, cg = i - pix * C4;
+                    const int py = pix >> 5, px = pix & 31;
+                    const int gy = ty0 + py, gx = tx0 + px;
+                    if (gy >= p.H2 || gx >= p.W2) continue;
+                    const float* e0 = Es + (py * SF_EW + px) * G::SE + 4 * cg;
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(e0), b = *reinterpret_cast<const f32x4*>(e0 + G::SE);
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(e0 + SF_EW * G::SE), d = *reinterpret_cast<const f32x4*>(e0 + (SF_EW + 1) * G::SE);
+                    f32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = fmaxf(fmaxf(a[k], b[k]), fmaxf(c[k], d[k]));
+                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(p.y + (((size_t)n * p.H2 + gy) * p.W2 + gx) * p.yld + 4 * cg));
+                }
+            }
+        }
+        __syncthreads();
+
+        // the next tile's patch travels while stem2b runs
+        const int tn = t + (int)gridDim.x;
+        if (tn < ntiles) load_patch(tn);
+
+        // ---------------- stem2b: b = ReLU(conv2x2 (a)) -> cat[..., C1:], one tile row (32 pixels) per wavefront
+        {
+            const int by = wave, bx = l31;
+            f32x16 acc1[G::NB3], acc2[G::NB3];
+#pragma unroll
+            for (int nb = 0; nb < G::NB3; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[nb][r] = acc2[nb][r] = 0.f;
+            const float* src0 = As + (by * SF_AW + bx) * G::SA;
+#pragma unroll
+            for (int j = 0; j < G::K2B / 16; ++j) {
+                constexpr int CBc = G::CB;
+                const int t0 = (16 * j) / CBc, c0 = (16 * j) % CBc, t1 = (16 * j + 8) / CBc, c1 = (16 * j + 8) % CBc;
+                const int o0 = ((t0 >> 1) * SF_AW + (t0 & 1)) * G::SA + c0, o1 = ((t1 >> 1) * SF_AW + (t1 & 1)) * G::SA + c1;
+                const float* src = src0 + (lhi ? o1 : o0);
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+                f16x8 ah, al;
+                sf_split8(v0, v1, ah, al);
+#pragma unroll
+                for (int nb = 0; nb < G::NB3; ++nb) {
+                    const int nrow = min(nb * 32 + l31, C1 - 1);
+                    const f16x8 bh = *reinterpret_cast<const f16x8*>(W2Bh + nrow * G::R2B + 16 * j + 8 * lhi);
+                    const f16x8 bl = *reinterpret_cast<const f16x8*>(W2Bl + nrow * G::R2B + 16 * j + 8 * lhi);
+                    acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[nb], 0, 0, 0);
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[nb], 0, 0, 0);
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[nb], 0, 0, 0);
+                }
+            }
+            const int gy = ty0 + by;
+            float* yrow = p.y + (((size_t)n * p.H2 + min(gy, p.H2 - 1)) * p.W2 + tx0 + 4 * lhi) * p.yld + C1;
+#pragma unroll
+            for (int nb = 0; nb < G::NB3; ++nb) {
+                const int nn = nb * 32 + l31;
+                const float bv = b2b[min(nn, C1 - 1)];
+                if (inner && (C1 % 32 == 0 || nb + 1 < G::NB3)) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = fmaf(acc2[nb][r], 1.f / 2048.f, acc1[nb][r]) + bv;
+                        bad = bad || !(fabsf(v) < INFINITY);
+                        __builtin_nontemporal_store(fmaxf(v, 0.f), &yrow[(size_t)((r & 3) + 8 * (r >> 2)) * p.yld + nn]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int off = (r & 3) + 8 * (r >> 2);
+                        const float v = fmaf(acc2[nb][r], 1.f / 2048.f, acc1[nb][r]) + bv;
+                        bad = bad || !(fabsf(v) < INFINITY);
+                        if (gy < p.H2 && tx0 + 4 * lhi + off < p.W2 && nn < C1) yrow[(size_t)off * p.yld + nn] = fmaxf(v, 0.f);
+                    }
+                }
+            }
+        }
+        __syncthreads();        // e / a are free for the next tile
+    }
+    if (bad && p.range_flag) atomicOr(p.range_flag, 1u);
+}
+
+bool stem_fused_supported(int c1) { return c1 == 24 || c1 == 32 || c1 == 48; }
+
+template <int C1>
+static void sf_prepare(const float* w1, const float* w2a, const float* w2b, std::vector<uint16_t>& img) {
+    using G = SfGeom<C1>;
+    img.assign(G::W_HALFS, 0);
+    auto put = [&](size_t hi_at, size_t lo_at, float v) {
+        const _Float16 h = (_Float16)v;
+        const _Float16 l = (_Float16)((v - (float)h) * 2048.f);
+        __builtin_memcpy(&img[hi_at], &h, 2);
+        __builtin_memcpy(&img[lo_at], &l, 2);
+    };
+    // stem1: w1 [27][C1] with row (kh * 3 + kw) * 3 + ci  ->  [co][kh * 16 + kw * 3 + ci]
+    for (int co = 0; co < C1; ++co)
+        for (int kh = 0; kh < 3; ++kh)
+            for (int j = 0; j < 9; ++j)
+                put((size_t)co * G::R1 + kh * 16 + j, (size_t)G::W1_H + (size_t)co * G::R1 + kh * 16 + j, w1[(size_t)(kh * 9 + j) * C1 + co]);
+    // stem2a: folded [NA][4 * C1] with k = tap * C1 + c (tap = dy * 2 + dx): same order
+    const size_t o2a = 2 * (size_t)G::W1_H;
+    for (int n = 0; n < G::NA; ++n)
+        for (int k = 0; k < G::K2A; ++k)
+            put(o2a + (size_t)n * G::R2A + k, o2a + G::W2A_H + (size_t)n * G::R2A + k, w2a[(size_t)n * G::K2A + k]);
+    // stem2b: folded [C1][4 * NA] with k = tap * NA + c  ->  tap * CB + c (channels padded to a multiple of 8 per tap)
+    const size_t o2b = o2a + 2 * (size_t)G::W2A_H;
+    for (int n = 0; n < C1; ++n)
+        for (int tap = 0; tap < 4; ++tap)
+            for (int c = 0; c < G::NA; ++c)
+                put(o2b + (size_t)n * G::R2B + tap * G::CB + c, o2b + G::W2B_H + (size_t)n * G::R2B + tap * G::CB + c,
+                    w2b[(size_t)n * 4 * G::NA + tap * G::NA + c]);
+}
+// w1: the stem layout [27][C1] (kh, kw, ci major; co fastest), w2a / w2b: folded [Cout][kh * kw * Cin] (ci fastest), BN folded
+void prepare_stem_fused_weights(int c1, const float* w1, const float* w2a, const float* w2b, std::vector<uint16_t>& img) {
+    if (c1 == 24) sf_prepare<24>(w1, w2a, w2b, img);
+    else if (c1 == 32) sf_prepare<32>(w1, w2a, w2b, img);
+    else sf_prepare<48>(w1, w2a, w2b, img);
+}
+
+template <int C1>
+static void sf_launch(StemFusedParams& p, hipStream_t s, int n_cu) {
+    static unsigned long long lds_ok = 0;
+    rd_allow_dynamic_lds((const void*)stem_fused_kernel<C1>, SfGeom<C1>::LDS_BYTES, lds_ok);
+    const int ntiles = p.N * p.tiles_x * p.tiles_y;
+    hipLaunchKernelGGL(stem_fused_kernel<C1>, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(SF_NT), SfGeom<C1>::LDS_BYTES, s, p);
+}
+
+// x NCHW [N][in_ch][H][W] -> cat NHWC [N][H2][W2][2 c1] (row stride yld floats)
+void launch_stem_fused(int c1, const float* x, int N, int H, int W, int in_ch, const uint16_t* wimg, const float* bias, float* y, int yld,
+                       unsigned* range_flag, hipStream_t s) {
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    StemFusedParams p{};
+    p.x = x; p.N = N; p.H = H; p.W = W; p.in_ch = in_ch;
+    p.wimg = wimg; p.bias = bias; p.y = y; p.yld = yld;
+    p.H2 = (H + 2 - 3) / 2 + 1;
+    p.W2 = (W + 2 - 3) / 2 + 1;
+    p.tiles_y = (p.H2 + SF_TH - 1) / SF_TH;
+    p.tiles_x = (p.W2 + SF_TW - 1) / SF_TW;
+    p.range_flag = range_flag;
+    if (c1 == 24) sf_launch<24>(p, s, n_cu);
+    else if (c1 == 32) sf_launch<32>(p, s, n_cu);
+    else sf_launch<48>(p, s, n_cu);
+}
+
+}  // namespace rd

@@ -36,14 +36,9 @@ bool g_disable_fused_mixer = false;  // RD_DISABLE_FUSED_MIXER=1: A/B switch for
 static TView lc_stem(Builder& b, const std::string& p, const TView& x_nchw, int c1, int c2) {
     auto cw = [&](const char* n) { return p + "." + n + ".convolution.weight"; };
     auto bn = [&](const char* n) { return p + "." + n + ".normalization"; };
-    TView e = b.stem3x3s2(cw("stem1"), bn("stem1"), x_nchw, ACT_RELU);                 // H/2, c1
-    TView a = b.conv(cw("stem2a"), "", bn("stem2a"), e, geom_same_even(2), ACT_RELU);  // c1/2
-    TView cat = b.alloc(e.n, e.h, e.w, 2 * c1);
-    TView cat_pool = b.slice(cat, 0, c1), cat_b = b.slice(cat, c1, c1);
-    b.maxpool2x2s1(e, cat_pool);
-    b.conv(cw("stem2b"), "", bn("stem2b"), a, geom_same_even(2), ACT_RELU, &cat_b);
-    b.release(e);
-    b.release(a);
+    // stem1 (H/2, c1) -> [max-pool | stem2a (c1/2) -> stem2b (c1)] -> cat (2 c1): one fused kernel in the split-fp16 modes
+    (void)c1;
+    TView cat = b.stem_front(cw("stem1"), bn("stem1"), cw("stem2a"), bn("stem2a"), cw("stem2b"), bn("stem2b"), x_nchw);
     TView s3 = b.conv(cw("stem3"), "", bn("stem3"), cat, geom(3, 2), ACT_RELU);
     b.release(cat);
     TView s4 = b.conv(cw("stem4"), "", bn("stem4"), s3, geom(1), ACT_RELU);
@@ -307,14 +302,8 @@ static void build_pphgnetv2(Builder& b, const TView& x, const HgStageCfg (&cfg)[
     auto cw = [&](const std::string& p) { return pre + p + ".conv.weight"; };
     auto bn = [&](const std::string& p) { return pre + p + ".bn"; };
     // stem (StemBlock, rec_pphgnetv2.py:979-1056)
-    TView e = b.stem3x3s2(cw("stem.stem1"), bn("stem.stem1"), x, ACT_RELU);
-    TView a = b.conv(cw("stem.stem2a"), "", bn("stem.stem2a"), e, geom_same_even(2), ACT_RELU);
-    TView cat = b.alloc(B, e.h, e.w, 2 * e.c);
-    TView cat_pool = b.slice(cat, 0, e.c), cat_b = b.slice(cat, e.c, e.c);
-    b.maxpool2x2s1(e, cat_pool);
-    b.conv(cw("stem.stem2b"), "", bn("stem.stem2b"), a, geom_same_even(2), ACT_RELU, &cat_b);
-    b.release(e);
-    b.release(a);
+    TView cat = b.stem_front(cw("stem.stem1"), bn("stem.stem1"), cw("stem.stem2a"), bn("stem.stem2a"), cw("stem.stem2b"),
+                             bn("stem.stem2b"), x);
     TView s3 = b.conv(cw("stem.stem3"), "", bn("stem.stem3"), cat, geom(3, 2), ACT_RELU);
     b.release(cat);
 

@@ -75,6 +75,13 @@ struct StemParams {
 };
 void launch_stem_conv3x3s2(const StemParams& p, hipStream_t s);
 
+// Fused stem front (kernels_stem_fused.hip): stem1 (3x3 s2) + stem2a + stem2b (2x2, pad right / bottom) + the 2x2 / s1 max-pool in
+// one kernel, x NCHW -> cat NHWC [N][H2][W2][2 c1] = [pool | stem2b]; split-fp16 matrix cores; c1 in {24, 32, 48}
+bool stem_fused_supported(int c1);
+void prepare_stem_fused_weights(int c1, const float* w1_stem_layout, const float* w2a_folded, const float* w2b_folded, std::vector<uint16_t>& img);
+void launch_stem_fused(int c1, const float* x, int N, int H, int W, int in_ch, const uint16_t* wimg, const float* bias, float* y, int yld,
+                       unsigned* range_flag, hipStream_t s);
+
 struct DwParams {
     const float* x; int xld;
     int N, H, W, C;

@@ -317,3 +317,44 @@ def test_page_analyzer_replays_the_reference_trace_on_the_gpu(golden_dir, seed):
             assert {k: v for k, v in a.items() if k not in skip} == {k: v for k, v in b.items() if k not in skip}
             if skip:
                 assert a["category_id"] == (16 if a["score"] < 0.5 else 15) and isinstance(a["text"], str)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (e) fused stem front (stem1 + stem2a + stem2b + max-pool in one kernel) against the four separate kernels
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,shape", [("ppocrv6_rec", (3, 3, 48, 1000)), ("ppocrv6_rec", (2, 3, 48, 17)), ("ppocrv6_det", (2, 3, 96, 160)),
+                                        ("ppocrv6_det", (1, 3, 224, 352)), ("pphgnetv2_b4", (2, 3, 192, 320)),
+                                        ("pphgnetv2_b6_formula", (2, 1, 96, 160))])
+def test_fused_stem_equals_separate_kernels(golden_dir, kind, shape, monkeypatch):
+    """Same engine, same weights, same input: plans built with the fused stem kernel vs plans built with stem_conv3x3s2 +
+    conv_stream (2x2) x 2 + maxpool (RD_STEM_FUSED=0).  Ragged sizes: tiles cut by the right / bottom edge, odd widths, a map
+    narrower than one tile, the 1-channel formula input.  Both forms split their operands (22 significant bits): the outputs of
+    the whole network agree to fp32 round-off, and the per-op profile says which form ran."""
+    from rapiddoc_amd.engine import RdEngine
+    monkeypatch.setenv("RD_PRECISION", "auto")
+    st = W.synth_state_dict(W.load_manifest(golden_dir / f"manifest_{kind}.json"), 0)
+    x = torch.from_numpy(np.random.default_rng(sum(shape)).uniform(-1, 1, shape).astype(np.float32)).cuda()
+
+    def run(fused):
+        monkeypatch.setenv("RD_STEM_FUSED", "1" if fused else "0")
+        eng = RdEngine(kind, guard="off").load_weights(st)
+        eng.set_profiling(True)
+        if kind == "ppocrv6_rec":
+            from rapiddoc_amd.engine import REC_WANT_LOGITS
+            out = [eng.rec_forward(x, REC_WANT_LOGITS)[2]]
+        elif kind == "ppocrv6_det":
+            out = [eng.det_forward(x)]
+        elif kind == "pphgnetv2_b4":
+            out = eng.backbone_forward(x)
+        else:
+            out = [eng.formula_encoder_forward(x)]
+        kinds = [o["kind"] for o in eng.profile_log]
+        assert not eng.range_overflow()
+        return [o.clone() for o in out], kinds
+    a, ka = run(True)
+    b, kb = run(False)
+    assert "stem_fused" in ka and "stem3x3s2" not in ka
+    assert "stem_fused" not in kb and "stem3x3s2" in kb
+    for u, v in zip(a, b):
+        scale = max(1.0, float(v.abs().max()))
+        assert float((u - v).abs().max()) < 2e-5 * scale
