@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
         if (tid >= 64 && tid < 80) As[SF_PH * SF_PROW + tid - 64] = 0.f;
     };
 
-    bool bad = false;
+    unsigned emax = 0;      // largest |pre-activation| bit pattern of stem2b's outputs / the pool's: inf and NaN sort above every finite value
     int t = blockIdx.x;
     if (t < ntiles) load_patch(t);
     __syncthreads();
@@ -156,17 +156,19 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
         // a tile whose whole e halo lies inside the map needs no per-element bounds tests (most tiles)
         const bool inner = ty0 + SF_EH <= p.H2 && tx0 + SF_EW <= p.W2;
 
-        // ---------------- stem1: e = ReLU(conv3x3 s2 (patch)) on the matrix cores, K = 3 kernel rows x 16 slots
-        for (int u = wave; u < G::MB1 * G::NB1; u += 8) {
-            const int mb = u / G::NB1, nb = u - mb * G::NB1;
+        // ---------------- stem1: e = ReLU(conv3x3 s2 (patch)) on the matrix cores, K = 3 kernel rows x 16 slots.  The bias rides in
+        // the accumulator init; non-finite values are not tested here: they reach stem2b's outputs and the pool, which are
+        for (int mb = wave; mb < G::MB1; mb += 8) {
             const int m = min(mb * 32 + l31, SF_EH * SF_EW - 1);
             const int ey = m / SF_EW, ex = m - ey * SF_EW;
-            const int nrow = min(nb * 32 + l31, C1 - 1);
-            f32x16 acc1, acc2;
+            f32x16 acc1[G::NB1], acc2[G::NB1];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[r] = acc2[r] = 0.f;
+            for (int nb = 0; nb < G::NB1; ++nb) {
+                const float bv = b1[min(nb * 32 + l31, C1 - 1)];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc1[nb][r] = bv; acc2[nb][r] = 0.f; }
+            }
             const float* src0 = As + 2 * ey * SF_PROW + 2 * ex * 3 + 8 * lhi;
-            const _Float16* wb = W1h + nrow * G::R1 + 8 * lhi;
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
                 const float* src = src0 + kh * SF_PROW;
@@ -179,35 +181,36 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
                 }
                 f16x8 ah, al;
                 sf_split8(v0, v1, ah, al);
-                const f16x8 bh = *reinterpret_cast<const f16x8*>(wb + kh * 16);
-                const f16x8 bl = *reinterpret_cast<const f16x8*>(wb + G::W1_H + kh * 16);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
-            }
-            const int nn = nb * 32 + l31;
-            const float bv = b1[min(nn, C1 - 1)];
-            float* dst = Es + (mb * 32 + 4 * lhi) * G::SE + nn;
-            if (inner && mb + 1 < G::MB1 && (C1 % 32 == 0 || nb + 1 < G::NB1)) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = fmaf(acc2[r], 1.f / 2048.f, acc1[r]) + bv;
-                    bad = bad || !(fabsf(v) < INFINITY);
-                    dst[((r & 3) + 8 * (r >> 2)) * G::SE] = fmaxf(v, 0.f);
+                for (int nb = 0; nb < G::NB1; ++nb) {
+                    const _Float16* wb = W1h + min(nb * 32 + l31, C1 - 1) * G::R1 + 8 * lhi + kh * 16;
+                    const f16x8 bh = *reinterpret_cast<const f16x8*>(wb);
+                    const f16x8 bl = *reinterpret_cast<const f16x8*>(wb + G::W1_H);
+                    acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[nb], 0, 0, 0);
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[nb], 0, 0, 0);
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[nb], 0, 0, 0);
                 }
-            } else {
-                const int mr0 = mb * 32 + 4 * lhi;
-                int ry = mr0 / SF_EW, rx = mr0 - ry * SF_EW;      // row / column of element r = 0; the others by carry
+            }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int off = (r & 3) + 8 * (r >> 2);
-                    int cx = rx + off, cy = ry;
-                    if (cx >= SF_EW) { cx -= SF_EW; cy += 1; }
-                    float v = fmaf(acc2[r], 1.f / 2048.f, acc1[r]) + bv;
-                    bad = bad || !(fabsf(v) < INFINITY);
-                    v = fmaxf(v, 0.f);
-                    if (ty0 + cy >= p.H2 || tx0 + cx >= p.W2) v = 0.f;        // beyond the map: the zero padding of stem2a / the pool
-                    if (mr0 + off < SF_EH * SF_EW && nn < C1) dst[off * G::SE] = v;
+            for (int nb = 0; nb < G::NB1; ++nb) {
+                const int nn = nb * 32 + l31;
+                float* dst = Es + (mb * 32 + 4 * lhi) * G::SE + nn;
+                if (inner && mb + 1 < G::MB1 && (C1 % 32 == 0 || nb + 1 < G::NB1)) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        dst[((r & 3) + 8 * (r >> 2)) * G::SE] = fmaxf(fmaf(acc2[nb][r], 1.f / 2048.f, acc1[nb][r]), 0.f);
+                } else {
+                    const int mr0 = mb * 32 + 4 * lhi;
+                    const int ry = mr0 / SF_EW, rx = mr0 - ry * SF_EW;      // row / column of element r = 0; the others by carry
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int off = (r & 3) + 8 * (r >> 2);
+                        int cx = rx + off, cy = ry;
+                        if (cx >= SF_EW) { cx -= SF_EW; cy += 1; }
+                        float v = fmaxf(fmaf(acc2[nb][r], 1.f / 2048.f, acc1[nb][r]), 0.f);
+                        if (ty0 + cy >= p.H2 || tx0 + cx >= p.W2) v = 0.f;        // beyond the map: the zero padding of stem2a / the pool
+                        if (mr0 + off < SF_EH * SF_EW && nn < C1) dst[off * G::SE] = v;
+                    }
                 }
             }
         }
@@ -219,9 +222,10 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
             const int m = min(mb * 32 + l31, SF_AH * SF_AW - 1);
             const int ay = m / SF_AW, ax = m - ay * SF_AW;
             const int nrow = min(l31, G::NA - 1);
+            const float bv = b2a[nrow];
             f32x16 acc1, acc2;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[r] = acc2[r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc1[r] = bv; acc2[r] = 0.f; }
             const float* src0 = Es + (ay * SF_EW + ax) * G::SE;
             const _Float16* wb = W2Ah + nrow * G::R2A + 8 * lhi;
 #pragma unroll
@@ -240,15 +244,13 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
             }
-            const float bv = b2a[min(l31, G::NA - 1)];
             float* dst = As + (mb * 32 + 4 * lhi) * G::SA + l31;
             const bool lane_on = l31 < G::CB;               // channels NA .. CB - 1 are the zero padding of the a tile
             const bool real = l31 < G::NA;
             if (inner && mb + 1 < G::MB2) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = fmaf(acc2[r], 1.f / 2048.f, acc1[r]) + bv;
-                    bad = bad || !(fabsf(v) < INFINITY);
+                    const float v = fmaf(acc2[r], 1.f / 2048.f, acc1[r]);
                     if (lane_on) dst[((r & 3) + 8 * (r >> 2)) * G::SA] = real ? fmaxf(v, 0.f) : 0.f;
                 }
             } else {
@@ -259,9 +261,7 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
                     const int off = (r & 3) + 8 * (r >> 2);
                     int cx = rx + off, cy = ry;
                     if (cx >= SF_AW) { cx -= SF_AW; cy += 1; }
-                    float v = fmaf(acc2[r], 1.f / 2048.f, acc1[r]) + bv;
-                    bad = bad || !(fabsf(v) < INFINITY);
-                    v = fmaxf(v, 0.f);
+                    float v = fmaxf(fmaf(acc2[r], 1.f / 2048.f, acc1[r]), 0.f);
                     if (ty0 + cy >= p.H2 || tx0 + cx >= p.W2 || !real) v = 0.f;   // padding of stem2b; zero pad channels
                     if (mr0 + off < SF_AH * SF_AW && lane_on) dst[off * G::SA] = v;
                 }
@@ -284,6 +284,7 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
                     f32x4 o;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) o[k] = fmaxf(fmaxf(a[k], b[k]), fmaxf(c[k], d[k]));
+                    emax = max(emax, __float_as_uint(o[0] + o[1] + o[2] + o[3]) & 0x7fffffffu);      // (e >= 0: the sum is non-finite iff a term is)
                     __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(p.y + (((size_t)n * p.H2 + gy) * p.W2 + gx) * p.yld + 4 * cg));
                 }
             }
@@ -299,9 +300,11 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
             const int by = wave, bx = l31;
             f32x16 acc1[G::NB3], acc2[G::NB3];
 #pragma unroll
-            for (int nb = 0; nb < G::NB3; ++nb)
+            for (int nb = 0; nb < G::NB3; ++nb) {
+                const float bv = b2b[min(nb * 32 + l31, C1 - 1)];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc1[nb][r] = acc2[nb][r] = 0.f;
+                for (int r = 0; r < 16; ++r) { acc1[nb][r] = bv; acc2[nb][r] = 0.f; }
+            }
             const float* src0 = As + (by * SF_AW + bx) * G::SA;
 #pragma unroll
             for (int j = 0; j < G::K2B / 16; ++j) {
@@ -327,20 +330,19 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
 #pragma unroll
             for (int nb = 0; nb < G::NB3; ++nb) {
                 const int nn = nb * 32 + l31;
-                const float bv = b2b[min(nn, C1 - 1)];
                 if (inner && (C1 % 32 == 0 || nb + 1 < G::NB3)) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float v = fmaf(acc2[nb][r], 1.f / 2048.f, acc1[nb][r]) + bv;
-                        bad = bad || !(fabsf(v) < INFINITY);
+                        const float v = fmaf(acc2[nb][r], 1.f / 2048.f, acc1[nb][r]);
+                        emax = max(emax, __float_as_uint(v) & 0x7fffffffu);
                         __builtin_nontemporal_store(fmaxf(v, 0.f), &yrow[(size_t)((r & 3) + 8 * (r >> 2)) * p.yld + nn]);
                     }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int off = (r & 3) + 8 * (r >> 2);
-                        const float v = fmaf(acc2[nb][r], 1.f / 2048.f, acc1[nb][r]) + bv;
-                        bad = bad || !(fabsf(v) < INFINITY);
+                        const float v = fmaf(acc2[nb][r], 1.f / 2048.f, acc1[nb][r]);
+                        emax = max(emax, __float_as_uint(v) & 0x7fffffffu);
                         if (gy < p.H2 && tx0 + 4 * lhi + off < p.W2 && nn < C1) yrow[(size_t)off * p.yld + nn] = fmaxf(v, 0.f);
                     }
                 }
@@ -348,7 +350,7 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
         }
         __syncthreads();        // e / a are free for the next tile
     }
-    if (bad && p.range_flag) atomicOr(p.range_flag, 1u);
+    if (emax >= 0x7f800000u && p.range_flag) atomicOr(p.range_flag, 1u);
 }
 
 bool stem_fused_supported(int c1) { return c1 == 24 || c1 == 32 || c1 == 48; }
