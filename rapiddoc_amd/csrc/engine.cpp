@@ -1057,12 +1057,18 @@ void Builder::ctc_head(const std::string& prefix, const TView& x, const TView& i
     release(part);
 }
 
+Plan::~Plan() {
+    for (auto& g : graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+}
+
 // =================================================================================================
 // Engine
 // =================================================================================================
 extern bool g_disable_fused_mixer;
 Engine::Engine(int device, const std::string& kind) : device_(device), kind_(kind) {
     if (const char* e = getenv("RD_DISABLE_FUSED_MIXER")) g_disable_fused_mixer = e[0] == '1';
+    if (const char* e = getenv("RD_GRAPHS")) graphs_ = e[0] != '0';
     if (const char* e = getenv("RD_PRECISION")) {
         const std::string v(e);
         RD_CHECK(v == "auto" || v == "fp32" || v == "h3", "RD_PRECISION must be auto, fp32 or h3");
@@ -1217,9 +1223,54 @@ void Engine::run(int B, int H, int W, int flags, const std::vector<void*>& ext, 
         if (skip_kind) {
             for (const OpRecord& op : plan.ops)
                 if (op.kind != skip_kind) op.run(plan, ctx);
-        } else {
-            for (const OpRecord& op : plan.ops) op.run(plan, ctx);
+            RD_HIP(hipGetLastError());
+            return;
         }
+        // hipGraph replay.  A forward is 30-90 dependent launches whose arguments are fixed by (plan, external pointers, workspace):
+        // the second time the same triple shows up on a stream the launches are captured into a graph, from the third on the
+        // host issues ONE hipGraphLaunch (a page batch is ~900 launches: 6-10 ms of a single host thread per 95-ms step, and a
+        // slow host thread was measured to cost 10 % of the throughput).  Callers keep their buffers stable (PagePipeline).
+        if (graphs_ && !plan.graph_broken && plan.ops.size() >= 4) {
+            GraphSlot* slot = nullptr;
+            for (auto& g : plan.graphs)
+                if (g.arena == ctx.arena && g.stream == s && g.ext == ext) { slot = &g; break; }
+            if (slot && slot->exec) {
+                slot->last_use = ++plan_clock_;
+                RD_HIP(hipGraphLaunch(slot->exec, s));
+                return;
+            }
+            if (slot) {                       // seen once before: worth a capture
+                hipGraph_t graph = nullptr;
+                bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                if (ok) {
+                    for (const OpRecord& op : plan.ops) op.run(plan, ctx);
+                    ok = hipStreamEndCapture(s, &graph) == hipSuccess && graph != nullptr;
+                }
+                hipGraphExec_t exec = nullptr;
+                if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+                if (graph) (void)hipGraphDestroy(graph);
+                if (ok) {
+                    slot->exec = exec;
+                    slot->last_use = ++plan_clock_;
+                    RD_HIP(hipGraphLaunch(exec, s));
+                    return;
+                }
+                (void)hipGetLastError();
+                plan.graph_broken = true;     // this plan does not capture: direct launches from now on
+            } else {
+                if (plan.graphs.size() >= kMaxGraphSlots) {
+                    auto victim = plan.graphs.begin();
+                    for (auto j = plan.graphs.begin(); j != plan.graphs.end(); ++j)
+                        if (j->last_use < victim->last_use) victim = j;
+                    if (victim->exec) (void)hipGraphExecDestroy(victim->exec);
+                    plan.graphs.erase(victim);
+                }
+                GraphSlot g;
+                g.ext = ext; g.arena = ctx.arena; g.stream = s; g.last_use = ++plan_clock_;
+                plan.graphs.push_back(std::move(g));
+            }
+        }
+        for (const OpRecord& op : plan.ops) op.run(plan, ctx);
         RD_HIP(hipGetLastError());
         return;
     }

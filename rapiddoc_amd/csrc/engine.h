@@ -100,11 +100,24 @@ struct OpRecord {
     std::function<void(const struct Plan&, const RunCtx&)> run;
 };
 
+// One captured replay of a plan: valid for exactly these external pointers, this workspace and this stream (the kernel
+// arguments inside the graph are raw addresses).
+struct GraphSlot {
+    std::vector<void*> ext;
+    uint8_t* arena = nullptr;
+    hipStream_t stream = nullptr;
+    hipGraphExec_t exec = nullptr;
+    uint64_t last_use = 0;
+};
+
 struct Plan {
+    ~Plan();
     std::vector<Buf> bufs;
     std::vector<OpRecord> ops;
     size_t arena_bytes = 0;
     mutable uint64_t last_use = 0;   // Engine::plan_for's LRU clock
+    mutable std::vector<GraphSlot> graphs;   // Engine::run: hipGraph replays of this plan (at most kMaxGraphSlots)
+    mutable bool graph_broken = false;       // a capture of this plan failed once: launch directly from then on
     std::vector<TView> outputs;  // model specific
     float* vptr(const TView& v, const RunCtx& c) const {
         const Buf& b = bufs[v.buf];
@@ -253,6 +266,8 @@ class Engine {
     std::map<std::tuple<int, int, int, int>, std::unique_ptr<Plan>> plans_;
     uint64_t plan_clock_ = 0;
     static constexpr size_t kMaxPlans = 512;   // least recently used plans are dropped beyond this
+    static constexpr size_t kMaxGraphSlots = 4;
+    bool graphs_ = true;                       // RD_GRAPHS=0 switches the hipGraph replays off
     uint8_t* arena_ = nullptr;
     size_t arena_bytes_ = 0;
     std::vector<ProfileEntry> profile_;

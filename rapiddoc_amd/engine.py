@@ -67,7 +67,11 @@ class RdEngine:
     several forwards in flight (PagePipeline) and promise to call `check_range_and_fallback()` before they use the
     results; `guard="off"` leaves the flag to the caller (tests)."""
 
-    def __init__(self, kind: str, device: int = 0, guard: str = "sync"):
+    def __init__(self, kind: str, device: int = 0, guard: str = "sync", reuse_outputs: bool = False):
+        """`reuse_outputs`: the output tensors of a forward are cached per shape and handed out again by the next call with
+        that shape (a later call overwrites what an earlier one returned).  For callers that consume a result before they
+        issue the next forward of the same shape (PagePipeline): stable addresses are what lets the library replay a forward
+        as one hipGraph launch instead of 30-90 kernel launches (csrc/engine.cpp, Engine::run)."""
         if kind not in KINDS:
             raise ValueError(f"kind must be one of {KINDS}")
         if not torch.cuda.is_available():
@@ -83,6 +87,8 @@ class RdEngine:
             raise ValueError("guard must be 'sync', 'deferred' or 'off'")
         self.guard = guard
         self.range_fallbacks = 0
+        self.reuse_outputs = reuse_outputs
+        self._out_cache: Dict[tuple, torch.Tensor] = {}
         self.precision = os.environ.get("RD_PRECISION", "auto")   # the library reads the same variable in rd_create
         self.profile_log: List[dict] = []
 
@@ -120,6 +126,17 @@ class RdEngine:
         return n.value
 
     # ------------------------------------------------------------------ forwards
+    def _out(self, tag: str, shape: tuple, dtype, device) -> torch.Tensor:
+        if not self.reuse_outputs:
+            return torch.empty(shape, dtype=dtype, device=device)
+        key = (tag, tuple(shape), dtype)
+        t = self._out_cache.get(key)
+        if t is None:
+            if len(self._out_cache) > 64:
+                self._out_cache.clear()
+            t = self._out_cache[key] = torch.empty(shape, dtype=dtype, device=device)
+        return t
+
     def _prep(self, x: torch.Tensor) -> torch.Tensor:
         if x.device.type != "cuda":
             x = x.to(self._tdev, non_blocking=True)
@@ -130,7 +147,7 @@ class RdEngine:
     def det_forward(self, x: torch.Tensor) -> torch.Tensor:
         x = self._prep(x)
         B, Cc, H, W_ = x.shape
-        out = torch.empty((B, 1, H, W_), dtype=torch.float32, device=x.device)
+        out = self._out("det", (B, 1, H, W_), torch.float32, x.device)
 
         def launch():
             self._chk(self._l.rd_det_forward(self._h, x.data_ptr(), B, H, W_, out.data_ptr(), None, 0, _stream_ptr()))
@@ -180,17 +197,24 @@ class RdEngine:
         self._guarded(launch)
         return tokens_out
 
-    def rec_tail_tables(self, line_lengths, device) -> torch.Tensor:
-        """The two int32 tables rd_rec_tail_forward wants, as one device tensor [2 * n_lines + n_tokens] (seg, then tokinfo)."""
+    def rec_tail_tables(self, line_lengths, device, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The two int32 tables rd_rec_tail_forward wants, as one device tensor [2 * n_lines + n_tokens] (seg, then tokinfo).
+        `out`: a device int32 buffer at least that long to fill instead of a new tensor (a view of its head is returned)."""
         seg_h, tokinfo_h = ragged_tables(np.asarray(line_lengths, dtype=np.int64))
         host = torch.from_numpy(np.concatenate([seg_h.reshape(-1), tokinfo_h])).pin_memory()
-        return host.to(device, non_blocking=True)
+        if out is None:
+            return host.to(device, non_blocking=True)
+        view = out[: host.numel()]
+        view.copy_(host, non_blocking=True)
+        self._keep_host = getattr(self, "_keep_host", [])[-15:] + [host]      # the pinned source must outlive the asynchronous copy
+        return view
 
     def rec_tail_forward(self, tokens: torch.Tensor, line_lengths, tables: Optional[torch.Tensor] = None,
-                         max_tokens: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                         max_tokens: Optional[int] = None, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """tokens [n_tokens, dim] = the text lines back to back, `line_lengths` their token counts -> (idx, prob) [n_tokens].
         `tables`: rec_tail_tables(line_lengths) uploaded earlier (e.g. before the backbones were enqueued).  `max_tokens`: an
-        upper bound of the longest line used as the plan key instead of the exact maximum (see `pad_tail_lengths`)."""
+        upper bound of the longest line used as the plan key instead of the exact maximum (see `pad_tail_lengths`).  `out`:
+        (idx int32 [n_tokens], prob float32 [n_tokens]) to write into."""
         lens = np.asarray(line_lengths, dtype=np.int64)
         n_tokens = int(lens.sum())
         longest = int(lens.max()) if max_tokens is None else int(max_tokens)
@@ -202,8 +226,12 @@ class RdEngine:
         if tables is None:
             tables = self.rec_tail_tables(lens, dev)
         seg, tokinfo = tables[: 2 * len(lens)], tables[2 * len(lens):]
-        idx = torch.empty((n_tokens,), dtype=torch.int32, device=dev)
-        prob = torch.empty((n_tokens,), dtype=torch.float32, device=dev)
+        if out is not None:
+            idx, prob = out
+            assert idx.numel() == n_tokens and prob.numel() == n_tokens and idx.dtype == torch.int32 and prob.dtype == torch.float32
+        else:
+            idx = torch.empty((n_tokens,), dtype=torch.int32, device=dev)
+            prob = torch.empty((n_tokens,), dtype=torch.float32, device=dev)
 
         def launch():
             self._chk(self._l.rd_rec_tail_forward(self._h, tokens.data_ptr(), n_tokens, len(lens), longest, seg.data_ptr(),
@@ -217,7 +245,7 @@ class RdEngine:
         x = self._prep(x)
         B, Cc, H, W_ = x.shape
         chans = (128, 512, 1024, 2048)
-        feats = [torch.empty((B, c, H // s, W_ // s), dtype=torch.float32, device=x.device)
+        feats = [self._out("feat%d" % s, (B, c, H // s, W_ // s), torch.float32, x.device)
                  for c, s in zip(chans, (4, 8, 16, 32))]
         arr = (C.c_void_p * 4)(*[f.data_ptr() for f in feats])
 

@@ -134,7 +134,10 @@ class PagePipeline:
         self.tdev = torch.device("cuda", device)
         # several forwards are in flight at once here, so the engines defer the split-fp16 range guard: run_batch (det,
         # layout) and rec_forward_lines (rec) call check_range_and_fallback() before any result is used
-        self.det = RdEngine("ppocrv6_det", device, guard="deferred").load_weights(states["ppocrv6_det"])
+        # (reuse_outputs: the engines hand out the same output tensors for the same shape - every result is consumed inside the
+        #  step that produced it - so that buffer addresses repeat from step to step and the library replays a forward as ONE
+        #  hipGraph launch; the buffers this class owns are kept per role for the same reason, `_buf`)
+        self.det = RdEngine("ppocrv6_det", device, guard="deferred", reuse_outputs=True).load_weights(states["ppocrv6_det"])
         # rec batches are independent: they alternate between `n_rec_streams` HIP streams (one engine handle = one
         # workspace per stream) so that the launch gaps / tails of one batch are filled by kernels of the other
         self.rec_engines = [RdEngine("ppocrv6_rec", device, guard="deferred").load_weights(states["ppocrv6_rec"]) for _ in range(max(1, n_rec_streams))]
@@ -144,7 +147,8 @@ class PagePipeline:
         self.rec_tail = RdEngine("ppocrv6_rec", device, guard="deferred").load_weights(states["ppocrv6_rec"])
         self.tail_stream = torch.cuda.Stream(device=self.tdev)
         self.layout_stream = torch.cuda.Stream(device=self.tdev)
-        self.layout = RdEngine("pphgnetv2_b4", device, guard="deferred").load_weights(states["pphgnetv2_b4"]) if "pphgnetv2_b4" in states else None
+        self.layout = RdEngine("pphgnetv2_b4", device, guard="deferred", reuse_outputs=True).load_weights(states["pphgnetv2_b4"]) if "pphgnetv2_b4" in states else None
+        self._bufs: Dict[tuple, torch.Tensor] = {}
         ncls = self.rec.num_classes
         self.characters = list(characters) if characters is not None else ["blank"] + [chr(0x4E00 + i) for i in range(ncls - 2)] + [" "]
         assert len(self.characters) == ncls, (len(self.characters), ncls)
@@ -166,9 +170,20 @@ class PagePipeline:
         self.stats: Dict[str, float] = {}
 
     # ---------------------------------------------------------------- stages
+    def _buf(self, role, numel: int, dtype=torch.float32) -> torch.Tensor:
+        """A persistent 1-D device buffer per role, grown (x 1.25) when a call needs more: the same role gets the same address
+        step after step (hipGraph replays are keyed on the addresses)."""
+        key = (role, dtype)
+        t = self._bufs.get(key)
+        if t is None or t.numel() < numel:
+            t = self._bufs[key] = torch.empty(int(numel * 1.25) + 64, dtype=dtype, device=self.tdev)
+        return t[:numel]
+
     def layout_preprocess(self, pages: torch.Tensor) -> torch.Tensor:
         """PPPreProcess for the whole batch in one launch: INTER_CUBIC resize, /255, mean 0 / std 1 (pre_process.py:14-42)."""
-        return preproc_resize_norm_batch(pages, (LAYOUT_SIZE, LAYOUT_SIZE), interp=2)
+        P = pages.shape[0]
+        out = self._buf("layout_x", P * 3 * LAYOUT_SIZE * LAYOUT_SIZE).view(P, 3, LAYOUT_SIZE, LAYOUT_SIZE)
+        return preproc_resize_norm_batch(pages, (LAYOUT_SIZE, LAYOUT_SIZE), interp=2, out=out)
 
     def layout_forward(self, pages: torch.Tensor) -> List[torch.Tensor]:
         return self.layout.backbone_forward(self.layout_preprocess(pages))
@@ -179,7 +194,8 @@ class PagePipeline:
         P, H, W, _ = pages.shape
         bh, bw = -(-(H + 100) // 64) * 64, -(-(W + 100) // 64) * 64
         dh, dw = ocr_host.det_resize_shape(bh, bw, DET_LIMIT, "max")
-        x = preproc_resize_norm_batch(pages, (dh, dw), mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), interp=1, swap_rb=True)
+        out = self._buf("det_x", P * 3 * dh * dw).view(P, 3, dh, dw)
+        x = preproc_resize_norm_batch(pages, (dh, dw), mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), interp=1, swap_rb=True, out=out)
         return x, (dh, dw)
 
     def det_forward(self, pages: torch.Tensor) -> Tuple[torch.Tensor, Tuple[int, int]]:
@@ -346,10 +362,12 @@ class PagePipeline:
                 for bi in grp:
                     tok_lo[bi] = off
                     off += len(batches[bi][0]) * seq[bi]
-            tokens = torch.empty((int(group_base[-1]), self.rec.rec_token_dim), dtype=torch.float32, device=dev)
+            dim = self.rec.rec_token_dim
+            tokens = self._buf("rec_tokens", int(group_base[-1]) * dim).view(int(group_base[-1]), dim)
             for gi in range(len(groups)):         # the dummy lines' tokens: finite values (their outputs are ignored)
                 tokens[int(group_base[gi]) + int(group_lens[gi].sum()): int(group_base[gi + 1])].zero_()
-            group_tables = [self.rec_tail.rec_tail_tables(lp, dev) for lp, _t in group_pad]   # uploaded now, used later
+            group_tables = [self.rec_tail.rec_tail_tables(lp, dev, out=self._buf(("tail_tab", gi), 2 * len(lp) + int(lp.sum()), torch.int32))
+                            for gi, (lp, _t) in enumerate(group_pad)]   # uploaded now, used later
             ready.record(main)
             self.tail_stream.wait_event(ready)
 
@@ -359,8 +377,10 @@ class PagePipeline:
             for bi in grp:
                 self.tail_stream.wait_event(outs[bi][2])
             with torch.cuda.stream(self.tail_stream):
-                idx_all, prob_all = self.rec_tail.rec_tail_forward(tokens[t_lo:t_hi], group_pad[gi][0], group_tables[gi],
-                                                                   max_tokens=group_pad[gi][1])
+                n_tok = t_hi - t_lo
+                idx_all, prob_all = self.rec_tail.rec_tail_forward(
+                    tokens[t_lo:t_hi], group_pad[gi][0], group_tables[gi], max_tokens=group_pad[gi][1],
+                    out=(self._buf(("tail_idx", gi), n_tok, torch.int32), self._buf(("tail_prob", gi), n_tok)))
             done = None
             for bi in grp:
                 nb, t = len(batches[bi][0]), seq[bi]
@@ -380,7 +400,8 @@ class PagePipeline:
             if bi < S:
                 st.wait_event(ready)          # descriptors (and the pages, the token buffer) are ready
             with torch.cuda.stream(st):
-                x = torch.empty((nb, 3, ocr_host.REC_IMG_H, wpad), dtype=torch.float32, device=dev)
+                # one input buffer per stream (batches bi, bi + S, ... of a stream run one after the other)
+                x = self._buf(("rec_x", k), nb * 3 * ocr_host.REC_IMG_H * wpad).view(nb, 3, ocr_host.REC_IMG_H, wpad)
                 scratch = self._crop_scratch.data_ptr() + int(batch_base[bi])
                 for si, first, cnt, max_px in warp_jobs[bi]:            # stage 1: page / canvas -> rectified uint8 crops
                     imgs = sources[si][0]
@@ -397,11 +418,11 @@ class PagePipeline:
                     self.rec_engines[k].rec_backbone_forward(x, tokens[tok_lo[bi]: tok_lo[bi] + nb * seq[bi]])
                     ev = torch.cuda.Event()
                     ev.record(st)
-                    outs.append((None, None, ev, x, None))
+                    outs.append((None, None, ev, x.clone() if self.keep_rec_inputs else x, None))
                 else:
                     idx, prob, _ = self.rec_engines[k].rec_forward(x)
                     rows, done = self._collapse_rows(idx, prob, nb, st)
-                    outs.append((idx, prob, done, x, rows))
+                    outs.append((idx, prob, done, x.clone() if self.keep_rec_inputs else x, rows))
             pos += nb
             if two_stage and (bi + 1) % S == 0:
                 run_tail(bi // S)

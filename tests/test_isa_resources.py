@@ -18,6 +18,8 @@ ALLOWED = {
     r"lc_mixer_ws_kernel.*Lb1E": "KEEPX instantiations (fp32 X tile kept in registers): debug entry only, C = 192 spills by design",
     r"lc_mixer_ws_kernel.*Li(1|4|8|12|13|16|29)E": "ablation instantiations of the ws mixer (tools/microbench.py)",
     r"lc_mixer_h3_kernel.*Li192E": "round-1 C = 192 mixer: superseded by the ws kernel, kept for A/B (RD_MIXER_WS=0)",
+    r"db_(regions|finish)_kernel": "no spill: local arrays (4-corner boxes, hull scratch) of the geometry code shared with the host path "
+                                   "(csrc/db_geom.h), indexed at run time; one thread per text-line candidate, ~50 candidates per page",
     r"ctc_collapse_kernel": "no spill: 32 bytes of CALL STACK for the recursive numpy-pairwise-sum restatement (one thread per line)",
 }
 
@@ -59,7 +61,7 @@ def test_no_hot_kernel_spills(tables):
     bad = []
     for src, rows in tables.items():
         for name, vgprs, spills, private in rows:
-            if "ctc_collapse_kernel" in name:
+            if "ctc_collapse_kernel" in name or "db_regions_kernel" in name or "db_finish_kernel" in name:
                 assert spills == 0
             if any(re.search(pat, name) for pat in ALLOWED):
                 continue
