@@ -358,11 +358,13 @@ def main():
                     name = "ctc_head_h3_kernel"
                 elif op["kind"] == "ctc_head_fused":
                     name = "ctc_head_kernel"
+                elif op["kind"] == "stem_fused":
+                    name = "stem_fused_kernel<%s>" % op["cfg"][1:]
                 a = agg[name]
                 a[0] += op["flops"]; a[1] += op["bytes"]; a[2] += op["ms"]; a[3] += 1
                 tot_ms += op["ms"]
             e.set_profiling(False)
-        mfma = {k: v for k, v in agg.items() if k.startswith(("conv_igemm", "gemm_h3", "lc_mixer", "ctc_head"))}
+        mfma = {k: v for k, v in agg.items() if k.startswith(("conv_igemm", "gemm_h3", "lc_mixer", "ctc_head", "conv_direct", "conv_stream", "stem_fused"))}
         dom = max(mfma, key=lambda k: mfma[k][2])
         fl, by, ms, n = mfma[dom]
         ach = fl / (ms * 1e-3) / 1e12
@@ -378,7 +380,7 @@ def main():
                 traffic_source = "profiles/pmc_traffic.json (%s)" % tj.get("_collected", "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes")
         # a split-fp16 kernel issues 3 fp16 MFMAs per fp32 product: its ceiling in algorithmic (fp32) FLOPs is the dense
         # fp16 MFMA peak / 3
-        peak = F16_MFMA_PEAK_TFLOPS / 3.0 if ("_h3_" in dom or "_ws_" in dom) else FP32_MFMA_PEAK_TFLOPS   # split-fp16 kernels
+        peak = F16_MFMA_PEAK_TFLOPS / 3.0 if ("_h3" in dom or "_ws_" in dom or "_res_" in dom or "stem_fused" in dom) else FP32_MFMA_PEAK_TFLOPS   # split-fp16 kernels
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": round(by / n), "launches_per_step": n,

@@ -176,28 +176,6 @@ int rd_db_postprocess(const float* prob_host, int B, int H, int W, const int32_t
                       float unclip_ratio, int use_dilation, int max_candidates, rd_text_box* out, int max_out,
                       int32_t* n_out, int n_threads);
 
-/* Device-assisted DB post-process: the probability maps never leave the GPU.
- *   rd_db_runs        (device)  threshold (pred > thresh), optional 2x2 dilation, then the horizontal runs of the bitmap:
- *                               runs_dev [B][max_runs] of {int16 y, x0, x1, pad}, n_runs_dev [B] (may exceed max_runs: overflow)
- *   rd_db_candidates  (host)    runs -> 8-connected regions in raster order -> min-area rectangles with min side >= 3
- *                               (returns 2 if a page overflowed max_runs: use rd_db_postprocess on that batch instead)
- *   rd_db_scores      (device)  box_score_fast of every candidate: mean probability inside its rectangle
- *   rd_db_finish      (host)    score filter, unclip, scale to the source image, filter_det_res -> rd_text_box
- * Same arithmetic and results as rd_db_postprocess (tests/test_gpu_image_ops.py compares them box for box). */
-typedef struct rd_db_candidate {
-    double box[8];   /* ordered mini-box corners (x, y) x 4, map pixels */
-    double rect[8];  /* min-area rectangle corners */
-    double w, h;     /* its side lengths */
-} rd_db_candidate;
-int rd_db_runs(int device_id, const float* prob_dev, int B, int H, int W, float thresh, int use_dilation, void* runs_dev,
-               int32_t* n_runs_dev, int max_runs, void* stream);
-int rd_db_candidates(const void* runs_host, const int32_t* n_runs, int B, int max_runs, int max_candidates, rd_db_candidate* out,
-                     int max_out, int32_t* n_out);
-int rd_db_scores(int device_id, const float* prob_dev, int B, int H, int W, const rd_db_candidate* cand_dev, const int32_t* n_cand_dev,
-                 int max_cand, double* scores_dev, void* stream);
-int rd_db_finish(const rd_db_candidate* cand, const double* scores, const int32_t* n_cand, int B, int max_cand, int H, int W,
-                 const int32_t* src_hw, float box_thresh, float unclip_ratio, rd_text_box* out, int max_out, int32_t* n_out);
-
 /* The same post-process with NOTHING on the host (round 3): rows -> runs in raster order -> regions (union-find over
  * row-adjacent runs) -> convex hull of each region's row extremes -> min-area rectangle -> box_score_fast -> unclip / rescale /
  * filter_det_res, all on `stream`; the caller needs one device-to-host copy of n_out_dev and out_dev.  Boxes and their order

@@ -66,11 +66,30 @@ def db_postprocess(pred: np.ndarray, src_hw, thresh=0.3, box_thresh=0.5, unclip_
         d[1:, :] |= bm[:-1, :]
         d[1:, 1:] |= bm[:-1, :-1]
         bm = d
+    # contours (cv2.findContours RETR_LIST): one outer border per 8-connected region, one hole border per 4-connected
+    # background component that does not reach the image frame (= the region pixels 4-adjacent to that hole)
     lab, n = ndimage.label(bm, structure=np.ones((3, 3)))
-    out = []
+    point_sets = []
     for sl, k in zip(ndimage.find_objects(lab), range(1, n + 1)):
         ys, xs = np.nonzero(lab[sl] == k)
         pts = np.stack([xs + sl[1].start, ys + sl[0].start], 1)
+        first = pts[np.lexsort((pts[:, 0], pts[:, 1]))][0]
+        point_sets.append(((int(first[1]), int(first[0])), pts))
+    cross = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], bool)
+    blab, nb = ndimage.label(~bm, structure=cross)
+    frame = set(np.unique(np.concatenate([blab[0], blab[-1], blab[:, 0], blab[:, -1]]))) - {0}
+    for k in range(1, nb + 1):
+        if k in frame:
+            continue
+        hole = blab == k
+        ring = ndimage.binary_dilation(hole, structure=cross) & bm
+        ys, xs = np.nonzero(ring)
+        hy, hx = np.nonzero(hole)
+        o = np.lexsort((hx, hy))[0]
+        point_sets.append(((int(hy[o]), int(hx[o]) - 1), np.stack([xs, ys], 1)))
+    point_sets.sort(key=lambda t: t[0])            # raster order of the contours' start pixels
+    out = []
+    for start, pts in point_sets:
         r = _min_area_rect(pts)
         if r is None:
             continue
@@ -102,6 +121,5 @@ def db_postprocess(pred: np.ndarray, src_hw, thresh=0.3, box_thresh=0.5, unclip_
         box4[:, 0] = np.clip(box4[:, 0], 0, src_w - 1); box4[:, 1] = np.clip(box4[:, 1], 0, src_h - 1)
         if int(np.linalg.norm(box4[0] - box4[1])) <= 3 or int(np.linalg.norm(box4[0] - box4[3])) <= 3:
             continue
-        out.append((box4.astype(np.int32), score, (int(pts[np.lexsort((pts[:, 0], pts[:, 1]))][0][1]), int(pts[np.lexsort((pts[:, 0], pts[:, 1]))][0][0]))))
-    out.sort(key=lambda t: t[2])  # raster order of the first pixel, like the C++ scan
+        out.append((box4.astype(np.int32), score))
     return [o[0] for o in out], [o[1] for o in out]

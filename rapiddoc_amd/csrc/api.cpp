@@ -250,21 +250,6 @@ int rd_ctc_collapse(int device_id, const int32_t* idx, const float* prob, int B,
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-int rd_db_runs(int device_id, const float* prob, int B, int H, int W, float thresh, int use_dilation, void* runs, int32_t* n_runs,
-               int max_runs, void* stream) {
-    if (!prob || !runs || !n_runs || B < 0 || H <= 0 || W <= 0 || max_runs <= 0) return 1;
-    if (hipSetDevice(device_id) != hipSuccess) return 1;
-    if (rd::launch_db_runs(prob, B, H, W, thresh, use_dilation, runs, n_runs, max_runs, (hipStream_t)stream) != 0) return 1;
-    return hipGetLastError() == hipSuccess ? 0 : 1;
-}
-int rd_db_scores(int device_id, const float* prob, int B, int H, int W, const rd_db_candidate* cand, const int32_t* n_cand, int max_cand,
-                 double* scores, void* stream) {
-    if (!prob || !cand || !n_cand || !scores || B < 0 || max_cand <= 0) return 1;
-    if (hipSetDevice(device_id) != hipSuccess) return 1;
-    if (rd::launch_db_scores(prob, B, H, W, cand, n_cand, max_cand, scores, (hipStream_t)stream) != 0) return 1;
-    return hipGetLastError() == hipSuccess ? 0 : 1;
-}
-
 size_t rd_db_boxes_workspace(int B, int H, int W, int max_runs, int max_candidates) {
     (void)W;
     if (B <= 0 || H <= 0 || max_runs <= 0 || max_candidates <= 0) return 0;

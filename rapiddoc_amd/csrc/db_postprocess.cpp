@@ -10,10 +10,17 @@
 //   -> filter_det_res (clockwise order, clip, drop boxes with a side <= 3 px).
 // PARITY UNPINNED: the reference holds no vectors for this step and cv2/pyclipper are not available to mint any;
 // tests pin it against an independent restatement (oracle/dbpost.py) and analytic known answers.
-// Differences to OpenCV that are known and accepted (all sub-pixel): regions are 8-connected components whose OUTER
-// boundary is used (RETR_LIST would also return hole borders as extra candidates); the polygon fill of
-// box_score_fast uses an inclusive point-in-convex-quad test instead of cv2.fillPoly's line rasteriser; the
-// JT_ROUND offset of a rectangle is replaced by its exact min-area rectangle (the rectangle grown by `distance`).
+// Contours (cv2.findContours(RETR_LIST), Suzuki-Abe border following, 8-connected foreground / 4-connected background):
+//   * one OUTER border per 8-connected region of the bitmap;
+//   * one HOLE border per 4-connected background component that does not reach the image frame: the region pixels that have a
+//     pixel of that hole among their 4 neighbours.  RETR_LIST returns hole borders as contours like any other, so the reference
+//     scores them as candidates too (a 3 x 3 hole inside a text blob yields an extra ~9-px box there); round 2 dropped them.
+//   Candidates are taken in raster order of the contour's start pixel (outer border: the region's first pixel; hole border:
+//   the pixel left of the hole's first pixel), the first `max_candidates` count.  (OpenCV hands the list back in reverse
+//   discovery order; that only matters to which 1000 survive on a map with more than 1000 contours.)
+// Differences to OpenCV that are known and accepted (all sub-pixel): the polygon fill of box_score_fast uses an inclusive
+// point-in-convex-quad test instead of cv2.fillPoly's line rasteriser; the JT_ROUND offset of a rectangle is replaced by its
+// exact min-area rectangle (the rectangle grown by `distance`).
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -117,14 +124,14 @@ static int process_one(const float* pred, int H, int W, int src_h, int src_w, co
     }
     std::vector<int32_t> label(n, 0);
     std::vector<int32_t> stack;
-    int n_out = 0, n_cand = 0;
-    std::vector<P2> border;
-    for (int y = 0; y < H && n_out < max_out; ++y)
-        for (int x = 0; x < W && n_out < max_out; ++x) {
+    struct Contour { int key_y, key_x; std::vector<P2> pts; };
+    std::vector<Contour> contours;
+    // outer borders: flood fill every 8-connected region, collecting its border pixels
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
             const size_t s = (size_t)y * W + x;
             if (!bm[s] || label[s]) continue;
-            // flood fill the 8-connected region, collecting its border pixels
-            border.clear();
+            Contour c{y, x, {}};
             stack.clear();
             stack.push_back((int32_t)s);
             label[s] = 1;
@@ -145,108 +152,50 @@ static int process_one(const float* pred, int H, int W, int src_h, int src_w, co
                         }
                         if (!label[t]) { label[t] = 1; stack.push_back((int32_t)t); }
                     }
-                if (edge) border.push_back({(double)qx, (double)qy});
+                if (edge) c.pts.push_back({(double)qx, (double)qy});
             }
-            if (++n_cand > pr.max_candidates) return n_out;
-            Cand c;
-            if (!make_candidate(border, pr, c)) continue;
-            const double score = box_score_fast(pred, H, W, c.box);
-            n_out += finish_candidate(c, score, H, W, src_h, src_w, pr, out + n_out);
+            contours.push_back(std::move(c));
         }
+    // hole borders: 4-connected background components that do not reach the image frame
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const size_t s = (size_t)y * W + x;
+            if (bm[s] || label[s]) continue;
+            Contour c{y, x - 1, {}};
+            bool open = false;
+            stack.clear();
+            stack.push_back((int32_t)s);
+            label[s] = 1;
+            while (!stack.empty()) {
+                const int32_t q = stack.back();
+                stack.pop_back();
+                const int qy = q / W, qx = q - qy * W;
+                if (qx == 0 || qy == 0 || qx == W - 1 || qy == H - 1) open = true;
+                const int ny4[4] = {qy - 1, qy + 1, qy, qy}, nx4[4] = {qx, qx, qx - 1, qx + 1};
+                for (int k = 0; k < 4; ++k) {
+                    if (ny4[k] < 0 || nx4[k] < 0 || ny4[k] >= H || nx4[k] >= W) continue;
+                    const size_t t = (size_t)ny4[k] * W + nx4[k];
+                    if (bm[t]) c.pts.push_back({(double)nx4[k], (double)ny4[k]});        // a region pixel on this hole's border
+                    else if (!label[t]) { label[t] = 1; stack.push_back((int32_t)t); }
+                }
+            }
+            if (!open) contours.push_back(std::move(c));
+        }
+    std::stable_sort(contours.begin(), contours.end(), [](const Contour& a, const Contour& b) {
+        return a.key_y < b.key_y || (a.key_y == b.key_y && a.key_x < b.key_x);
+    });
+    int n_out = 0, n_cand = 0;
+    for (const Contour& ct : contours) {
+        if (n_out >= max_out || ++n_cand > pr.max_candidates) break;
+        Cand c;
+        if (!make_candidate(ct.pts, pr, c)) continue;
+        const double score = box_score_fast(pred, H, W, c.box);
+        n_out += finish_candidate(c, score, H, W, src_h, src_w, pr, out + n_out);
+    }
     return n_out;
 }
 
 }  // namespace
-
-// ---- device-assisted path: the GPU thresholds / dilates the maps and emits the horizontal RUNS of the bitmap
-// (rd_db_runs), scores the candidate rectangles (rd_db_scores); the host only sees a few thousand runs per page.
-struct Run { int16_t y, x0, x1, pad; };
-
-// runs of one page -> 8-connected regions in raster order of their first pixel -> candidates (same rectangles as the
-// flood fill above: a region's convex hull is the hull of its run end points)
-static int candidates_from_runs(std::vector<Run>& runs, int max_cand, const Params& pr, rd_db_candidate* out) {
-    std::sort(runs.begin(), runs.end(), [](const Run& a, const Run& b) { return a.y < b.y || (a.y == b.y && a.x0 < b.x0); });
-    const int n = (int)runs.size();
-    std::vector<int> parent(n);
-    for (int i = 0; i < n; ++i) parent[i] = i;
-    auto find = [&](int i) { while (parent[i] != i) { parent[i] = parent[parent[i]]; i = parent[i]; } return i; };
-    int prev_b = 0, prev_e = 0;   // [prev_b, prev_e): runs of the previous row
-    for (int i = 0; i < n;) {
-        int j = i;
-        while (j < n && runs[j].y == runs[i].y) ++j;
-        if (prev_e > prev_b && runs[prev_b].y == runs[i].y - 1) {
-            int q = prev_b;
-            for (int k = i; k < j; ++k) {
-                while (q < prev_e && runs[q].x1 + 1 < runs[k].x0) ++q;           // runs entirely to the left
-                for (int t = q; t < prev_e && runs[t].x0 <= runs[k].x1 + 1; ++t) {  // 8-connected: columns may differ by one
-                    const int a = find(t), b = find(k);
-                    if (a != b) parent[std::max(a, b)] = std::min(a, b);           // root = earliest run = first pixel in raster order
-                }
-            }
-        }
-        prev_b = i;
-        prev_e = j;
-        i = j;
-    }
-    // regions in order of their root run (runs are sorted in raster order, the root is the smallest index)
-    std::vector<std::vector<P2>> pts;
-    std::vector<int> slot(n, -1);
-    for (int i = 0; i < n; ++i) {
-        const int r = find(i);
-        if (slot[r] < 0) { slot[r] = (int)pts.size(); pts.emplace_back(); }
-        pts[slot[r]].push_back({(double)runs[i].x0, (double)runs[i].y});
-        if (runs[i].x1 != runs[i].x0) pts[slot[r]].push_back({(double)runs[i].x1, (double)runs[i].y});
-    }
-    int n_out = 0, n_cand = 0;
-    for (auto& border : pts) {
-        if (++n_cand > pr.max_candidates || n_out >= max_cand) break;
-        Cand c;
-        if (!make_candidate(border, pr, c)) continue;
-        for (int k = 0; k < 4; ++k) {
-            out[n_out].box[2 * k] = c.box[k].x; out[n_out].box[2 * k + 1] = c.box[k].y;
-            out[n_out].rect[2 * k] = c.r.c[k].x; out[n_out].rect[2 * k + 1] = c.r.c[k].y;
-        }
-        out[n_out].w = c.r.w;
-        out[n_out].h = c.r.h;
-        ++n_out;
-    }
-    return n_out;
-}
-
-extern "C" int rd_db_candidates(const void* runs_host, const int32_t* n_runs, int B, int max_runs, int max_candidates,
-                                rd_db_candidate* out, int max_out, int32_t* n_out) {
-    if (!runs_host || !n_runs || !out || !n_out || B < 0 || max_runs <= 0 || max_out <= 0) return 1;
-    Params pr{0.f, 0.f, 0.f, 0, max_candidates > 0 ? max_candidates : 1000, 3};
-    for (int b = 0; b < B; ++b) {
-        if (n_runs[b] < 0 || n_runs[b] > max_runs) return 2;      // the device buffer overflowed: caller falls back to the host path
-        const Run* r = reinterpret_cast<const Run*>(runs_host) + (size_t)b * max_runs;
-        std::vector<Run> runs(r, r + n_runs[b]);
-        n_out[b] = candidates_from_runs(runs, max_out, pr, out + (size_t)b * max_out);
-    }
-    return 0;
-}
-
-extern "C" int rd_db_finish(const rd_db_candidate* cand, const double* scores, const int32_t* n_cand, int B, int max_cand, int H, int W,
-                            const int32_t* src_hw, float box_thresh, float unclip_ratio, rd_text_box* out, int max_out, int32_t* n_out) {
-    if (!cand || !scores || !n_cand || !src_hw || !out || !n_out || B < 0) return 1;
-    Params pr{0.f, box_thresh, unclip_ratio, 0, 0, 3};
-    for (int b = 0; b < B; ++b) {
-        int n = 0;
-        for (int i = 0; i < n_cand[b] && n < max_out; ++i) {
-            const rd_db_candidate& q = cand[(size_t)b * max_cand + i];
-            Cand c;
-            for (int k = 0; k < 4; ++k) {
-                c.box[k] = {q.box[2 * k], q.box[2 * k + 1]};
-                c.r.c[k] = {q.rect[2 * k], q.rect[2 * k + 1]};
-            }
-            c.r.w = q.w;
-            c.r.h = q.h;
-            n += finish_candidate(c, scores[(size_t)b * max_cand + i], H, W, src_hw[2 * b], src_hw[2 * b + 1], pr, out + (size_t)b * max_out + n);
-        }
-        n_out[b] = n;
-    }
-    return 0;
-}
 
 extern "C" int rd_db_postprocess(const float* prob_host, int B, int H, int W, const int32_t* src_hw, float thresh, float box_thresh,
                                  float unclip_ratio, int use_dilation, int max_candidates, rd_text_box* out, int max_out,

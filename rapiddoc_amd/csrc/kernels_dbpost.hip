@@ -10,9 +10,12 @@
 //   db_row_runs_kernel<true>    per row: the runs, written at their raster position
 //   db_regions_kernel           per page, one workgroup: union-find over row-adjacent runs (8-connectivity: columns may differ
 //                               by one; lock-free min-root linking, so a region's root is its first run in raster order), regions
-//                               ranked by root, per (region, row) the extreme columns by integer atomicMin / atomicMax
-//                               (deterministic), then one thread per region: convex hull of the row extremes (the hull of a
-//                               region is the hull of its rows' end points), min-area rectangle, min-side filter -> candidates
+//                               a second union-find over the GAPS between the runs of a row (4-connectivity, node 0 = everything
+//                               that reaches the image frame) finds the holes: cv2.findContours(RETR_LIST) returns their borders
+//                               as contours too.  Contours (outer borders and hole borders) ranked by their start pixel, per
+//                               (contour, row) the extreme columns by integer atomicMin / atomicMax (deterministic), then one thread
+//                               per contour: convex hull of the row extremes (the hull of a point set is the hull of its rows' end
+//                               points), min-area rectangle, min-side filter -> candidates
 //   db_scores_kernel            (kernels_image.hip) box_score_fast of every candidate
 //   db_finish_kernel            per page: score filter, unclip, rescale, filter_det_res, order-preserving compaction
 // A page whose bitmap has more runs than the buffer holds raises an overflow flag: the caller repeats the batch on the host path.
@@ -30,7 +33,7 @@ using rd_db::Cand;
 using rd_db::P2;
 
 struct DbRun { int16_t y, x0, x1, pad; };
-struct DbCand { double box[8], rect[8], w, h; };     // == rd_db_candidate
+struct DbCand { double box[8], rect[8], w, h; };     // == DbCand of kernels_image.hip (db_scores_kernel)
 
 // block-wide exclusive scan of one int per thread (1024 threads max); returns the exclusive prefix, *total = block sum
 template <int NT>
@@ -115,13 +118,18 @@ __global__ void __launch_bounds__(1024) db_row_scan_kernel(const int32_t* __rest
 }
 
 // ---- runs -> regions -> candidates
+// (contour, row) slots per run: a region has at most one row per run; a hole of g gaps has at most g + 2 rows (its border reaches
+// one row above and below) and there are fewer gaps than runs
+constexpr int kExt = 4;
 struct RegionsWs {
     const DbRun* runs; const int32_t* row_off; const int32_t* n_runs;
     int32_t* parent;        // [B][max_runs]
-    int32_t* comp_of;       // [B][max_runs]  region index of a ROOT run, -1 otherwise
-    int32_t* ext_l; int32_t* ext_r;   // [B][max_runs]  per (region, row) extreme columns
+    int32_t* comp_of;       // [B][max_runs]  contour index of a ROOT run, -1 otherwise
+    int32_t* gparent;       // [B][max_runs + 1]  gaps: node i + 1 = the gap between runs i and i + 1 of one row; node 0 = outside
+    int32_t* gcomp_of;      // [B][max_runs + 1]  contour index of a hole's ROOT gap, -1 otherwise
+    int32_t* ext_l; int32_t* ext_r;   // [B][kExt * max_runs]  per (contour, row) extreme columns
     int32_t* comp_y0; int32_t* comp_y1; int32_t* comp_off;   // [B][max_cand + 1]
-    int2* pts; P2* hullbuf;           // [B][2 * max_runs], [B][2 * max_runs + max_cand]
+    int2* pts; P2* hullbuf;           // [B][2 * kExt * max_runs], [B][2 * kExt * max_runs + max_cand]
     DbCand* cand; int32_t* n_cand;    // [B][max_cand], [B]
     int max_runs, max_cand, H, min_size;
 };
@@ -151,6 +159,16 @@ __device__ __forceinline__ void uf_union(int32_t* parent, int a, int b) {
     }
 }
 
+// first run of [lo, hi) (one row: sorted, disjoint) whose x1 >= x
+__device__ __forceinline__ int first_run_reaching(const DbRun* runs, int lo, int hi, int x) {
+    while (lo < hi) {
+        const int m = (lo + hi) >> 1;
+        if (runs[m].x1 < x) lo = m + 1;
+        else hi = m;
+    }
+    return lo;
+}
+
 __global__ void __launch_bounds__(1024) db_regions_kernel(RegionsWs w) {
     __shared__ int smem[1024];
     __shared__ int s_ncomp;
@@ -160,8 +178,10 @@ __global__ void __launch_bounds__(1024) db_regions_kernel(RegionsWs w) {
     const int32_t* row_off = w.row_off + (size_t)b * (w.H + 1);
     int32_t* parent = w.parent + (size_t)b * w.max_runs;
     int32_t* comp_of = w.comp_of + (size_t)b * w.max_runs;
-    int32_t* ext_l = w.ext_l + (size_t)b * w.max_runs;
-    int32_t* ext_r = w.ext_r + (size_t)b * w.max_runs;
+    int32_t* gparent = w.gparent + (size_t)b * (w.max_runs + 1);
+    int32_t* gcomp_of = w.gcomp_of + (size_t)b * (w.max_runs + 1);
+    int32_t* ext_l = w.ext_l + (size_t)b * kExt * w.max_runs;
+    int32_t* ext_r = w.ext_r + (size_t)b * kExt * w.max_runs;
     int32_t* cy0 = w.comp_y0 + (size_t)b * (w.max_cand + 1);
     int32_t* cy1 = w.comp_y1 + (size_t)b * (w.max_cand + 1);
     int32_t* coff = w.comp_off + (size_t)b * (w.max_cand + 1);
@@ -169,28 +189,40 @@ __global__ void __launch_bounds__(1024) db_regions_kernel(RegionsWs w) {
         if (tid == 0) w.n_cand[b] = 0;
         return;
     }
+    // the gap behind run i (node i + 1) exists when run i + 1 lies in the same row
+    auto has_gap = [&](int i) { return i + 1 < n && runs[i + 1].y == runs[i].y; };
     for (int i = tid; i < n; i += 1024) { parent[i] = i; comp_of[i] = -1; }
+    for (int i = tid; i <= n; i += 1024) { gparent[i] = i; gcomp_of[i] = -1; }
     __syncthreads();
-    // 1. union every run with the runs of the previous row it touches (columns may differ by one: 8-connectivity)
+    // 1. union every run with the runs of the previous row it touches (columns may differ by one: 8-connectivity); union every
+    //    gap with the background of the rows above and below it (same columns only: the background is 4-connected)
     for (int i = tid; i < n; i += 1024) {
         const DbRun r = runs[i];
-        if (r.y == 0) continue;
-        int lo = row_off[r.y - 1];
-        const int hi = row_off[r.y];
-        // first run of the previous row with x1 + 1 >= r.x0 (binary search: runs of a row are sorted and disjoint)
-        int a = lo, e = hi;
-        while (a < e) {
-            const int m = (a + e) >> 1;
-            if (runs[m].x1 + 1 < r.x0) a = m + 1;
-            else e = m;
+        if (r.y > 0) {
+            const int lo = row_off[r.y - 1], hi = row_off[r.y];
+            for (int t = first_run_reaching(runs, lo, hi, r.x0 - 1); t < hi && runs[t].x0 <= r.x1 + 1; ++t) uf_union(parent, t, i);
         }
-        for (int t = a; t < hi && runs[t].x0 <= r.x1 + 1; ++t) uf_union(parent, t, i);
+        if (!has_gap(i)) continue;
+        const int g = i + 1, gx0 = r.x1 + 1, gx1 = runs[i + 1].x0 - 1;
+        if (r.y == 0 || r.y == w.H - 1) uf_union(gparent, 0, g);          // on the image frame
+        for (int yy = r.y - 1; yy <= r.y + 1; yy += 2) {
+            if (yy < 0 || yy >= w.H) continue;
+            const int lo = row_off[yy], hi = row_off[yy + 1];
+            if (lo == hi || gx0 < runs[lo].x0 || gx1 > runs[hi - 1].x1) uf_union(gparent, 0, g);    // empty row, or its leading / trailing background
+            if (yy > r.y) continue;
+            // gap t + 1 = (runs[t].x1, runs[t + 1].x0) meets [gx0, gx1] when runs[t + 1].x0 > gx0 and runs[t].x1 < gx1
+            for (int t = max(lo, first_run_reaching(runs, lo, hi, gx0) - 1); t + 1 < hi && runs[t].x1 < gx1; ++t)
+                if (runs[t + 1].x0 > gx0) uf_union(gparent, t + 1, g);
+        }
     }
     __syncthreads();
     // 2. flatten
     for (int i = tid; i < n; i += 1024) parent[i] = uf_find(parent, i);
+    for (int i = tid; i <= n; i += 1024) gparent[i] = uf_find(gparent, i);
     __syncthreads();
-    // 3. regions ranked by their root run (= raster order of their first pixel)
+    // 3. contours ranked by their start pixel: the region whose first run is i starts at (y, x0_i), the hole whose first gap lies
+    //    behind run i at (y, x1_i) (cv2 starts a hole border on the region pixel left of the hole's first pixel); a run cannot
+    //    start both, so raster order = (run index, region before hole)
     if (tid == 0) s_ncomp = 0;
     __syncthreads();
     {
@@ -198,12 +230,18 @@ __global__ void __launch_bounds__(1024) db_regions_kernel(RegionsWs w) {
         for (int i0 = 0; i0 < n; i0 += 1024) {
             const int i = i0 + tid;
             const int is_root = i < n && lda(&parent[i]) == i;
+            const int is_hole = i < n && has_gap(i) && lda(&gparent[i + 1]) == i + 1;     // (a root other than node 0)
             int total;
-            const int ex = block_exclusive_scan<1024>(is_root, smem, &total);
+            const int ex = block_exclusive_scan<1024>(is_root + is_hole, smem, &total);
             if (is_root) {
                 const int c = carry + ex;
                 comp_of[i] = c;
                 if (c < w.max_cand) { cy0[c] = runs[i].y; cy1[c] = runs[i].y; }
+            }
+            if (is_hole) {
+                const int c = carry + ex + is_root;
+                gcomp_of[i + 1] = c;
+                if (c < w.max_cand) { cy0[c] = runs[i].y - 1; cy1[c] = runs[i].y + 1; }
             }
             carry += total;
         }
@@ -211,13 +249,17 @@ __global__ void __launch_bounds__(1024) db_regions_kernel(RegionsWs w) {
     }
     __syncthreads();
     const int ncomp = min(s_ncomp, w.max_cand);      // the reference looks at the first max_candidates contours only
-    // 4. last row of every region
+    // 4. last row of every contour
     for (int i = tid; i < n; i += 1024) {
         const int c = comp_of[lda(&parent[i])];
         if (c < ncomp) atomicMax(&cy1[c], (int)runs[i].y);
+        if (has_gap(i)) {
+            const int hc = gcomp_of[lda(&gparent[i + 1])];
+            if (hc >= 0 && hc < ncomp) atomicMax(&cy1[hc], (int)runs[i].y + 1);
+        }
     }
     __syncthreads();
-    // 5. storage offsets of the per-(region, row) extremes: exclusive scan of the region heights
+    // 5. storage offsets of the per-(contour, row) extremes: exclusive scan of the contour heights
     {
         int carry = 0;
         for (int c0 = 0; c0 < ncomp; c0 += 1024) {
@@ -228,24 +270,44 @@ __global__ void __launch_bounds__(1024) db_regions_kernel(RegionsWs w) {
             if (c < ncomp) coff[c] = carry + ex;
             carry += total;
         }
-        if (tid == 0) coff[ncomp] = carry;       // <= n: every (region, row) holds at least one run
+        if (tid == 0) coff[ncomp] = carry;       // <= kExt * n
     }
     __syncthreads();
     const int n_ext = coff[ncomp];
     for (int i = tid; i < n_ext; i += 1024) { ext_l[i] = 0x7fffffff; ext_r[i] = -1; }
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
-        const int c = comp_of[lda(&parent[i])];
-        if (c >= ncomp) continue;
         const DbRun r = runs[i];
-        const int k = coff[c] + (r.y - cy0[c]);
-        atomicMin(&ext_l[k], (int)r.x0);
-        atomicMax(&ext_r[k], (int)r.x1);
+        const int c = comp_of[lda(&parent[i])];
+        if (c < ncomp) {
+            const int k = coff[c] + (r.y - cy0[c]);
+            atomicMin(&ext_l[k], (int)r.x0);
+            atomicMax(&ext_r[k], (int)r.x1);
+        }
+        if (!has_gap(i)) continue;
+        const int hc = gcomp_of[lda(&gparent[i + 1])];
+        if (hc < 0 || hc >= ncomp) continue;
+        // the hole's border = the region pixels 4-adjacent to it: the two pixels that close this gap, and the region pixels
+        // right above / below it
+        const int gx0 = r.x1 + 1, gx1 = runs[i + 1].x0 - 1;
+        const int k = coff[hc] + (r.y - cy0[hc]);
+        atomicMin(&ext_l[k], gx0 - 1);
+        atomicMax(&ext_r[k], gx1 + 1);
+        for (int yy = r.y - 1; yy <= r.y + 1; yy += 2) {
+            const int lo = row_off[yy], hi = row_off[yy + 1];
+            const int t = first_run_reaching(runs, lo, hi, gx0);
+            if (t >= hi || runs[t].x0 > gx1) continue;
+            int u = t;
+            while (u + 1 < hi && runs[u + 1].x0 <= gx1) ++u;
+            const int kk = coff[hc] + (yy - cy0[hc]);
+            atomicMin(&ext_l[kk], max(gx0, (int)runs[t].x0));
+            atomicMax(&ext_r[kk], min(gx1, (int)runs[u].x1));
+        }
     }
     __syncthreads();
-    // 6. one thread per region: points sorted by (y, x) -> hull -> min-area rectangle -> candidate (or not)
-    int2* pts_all = w.pts + (size_t)b * 2 * w.max_runs;
-    P2* hull_all = w.hullbuf + (size_t)b * (2 * (size_t)w.max_runs + w.max_cand);
+    // 6. one thread per contour: points sorted by (y, x) -> hull -> min-area rectangle -> candidate (or not)
+    int2* pts_all = w.pts + (size_t)b * 2 * kExt * w.max_runs;
+    P2* hull_all = w.hullbuf + (size_t)b * (2 * (size_t)kExt * w.max_runs + w.max_cand);
     int carry = 0;
     for (int c0 = 0; c0 < ncomp; c0 += 1024) {
         const int c = c0 + tid;
@@ -260,7 +322,7 @@ __global__ void __launch_bounds__(1024) db_regions_kernel(RegionsWs w) {
             int m = 0;
             for (int ry = 0; ry < hgt; ++ry) {           // row extremes in raster order = sorted by (y, x), no duplicates
                 const int l = lda(&ext_l[base + ry]), r = lda(&ext_r[base + ry]);
-                if (r < 0) continue;                      // (cannot happen: every row of a region holds a run)
+                if (r < 0) continue;                      // (cannot happen: every row of a contour holds a border pixel)
                 pl[m++] = make_int2(l, cy0[c] + ry);
                 if (r != l) pl[m++] = make_int2(r, cy0[c] + ry);
             }
@@ -342,7 +404,7 @@ namespace rd {
 
 // workspace layout (all offsets 256-byte aligned); see rd_db_boxes_workspace
 struct DbWsLayout {
-    size_t row_cnt, row_off, n_runs, runs, parent, comp_of, ext_l, ext_r, cy0, cy1, coff, pts, hull, cand, n_cand, scores, total;
+    size_t row_cnt, row_off, n_runs, runs, parent, comp_of, gparent, gcomp_of, ext_l, ext_r, cy0, cy1, coff, pts, hull, cand, n_cand, scores, total;
 };
 static DbWsLayout db_ws_layout(int B, int H, int max_runs, int max_cand) {
     DbWsLayout L{};
@@ -354,13 +416,15 @@ static DbWsLayout db_ws_layout(int B, int H, int max_runs, int max_cand) {
     L.runs = take((size_t)B * max_runs * sizeof(DbRun));
     L.parent = take((size_t)B * max_runs * 4);
     L.comp_of = take((size_t)B * max_runs * 4);
-    L.ext_l = take((size_t)B * max_runs * 4);
-    L.ext_r = take((size_t)B * max_runs * 4);
+    L.gparent = take((size_t)B * (max_runs + 1) * 4);
+    L.gcomp_of = take((size_t)B * (max_runs + 1) * 4);
+    L.ext_l = take((size_t)B * kExt * max_runs * 4);
+    L.ext_r = take((size_t)B * kExt * max_runs * 4);
     L.cy0 = take((size_t)B * (max_cand + 1) * 4);
     L.cy1 = take((size_t)B * (max_cand + 1) * 4);
     L.coff = take((size_t)B * (max_cand + 1) * 4);
-    L.pts = take((size_t)B * 2 * max_runs * sizeof(int2));
-    L.hull = take((size_t)B * (2 * (size_t)max_runs + max_cand) * sizeof(rd_db::P2));
+    L.pts = take((size_t)B * 2 * kExt * max_runs * sizeof(int2));
+    L.hull = take((size_t)B * (2 * (size_t)kExt * max_runs + max_cand) * sizeof(rd_db::P2));
     L.cand = take((size_t)B * max_cand * sizeof(DbCand));
     L.n_cand = take((size_t)B * 4);
     L.scores = take((size_t)B * max_cand * 8);
@@ -391,6 +455,8 @@ int launch_db_boxes(const float* prob, int B, int H, int W, const int32_t* src_h
     w.runs = runs; w.row_off = row_off; w.n_runs = n_runs;
     w.parent = reinterpret_cast<int32_t*>(base + L.parent);
     w.comp_of = reinterpret_cast<int32_t*>(base + L.comp_of);
+    w.gparent = reinterpret_cast<int32_t*>(base + L.gparent);
+    w.gcomp_of = reinterpret_cast<int32_t*>(base + L.gcomp_of);
     w.ext_l = reinterpret_cast<int32_t*>(base + L.ext_l);
     w.ext_r = reinterpret_cast<int32_t*>(base + L.ext_r);
     w.comp_y0 = reinterpret_cast<int32_t*>(base + L.cy0);

@@ -369,38 +369,8 @@ int launch_ctc_collapse(const int32_t* idx, const float* prob, int B, int T, con
 }  // namespace rd
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Device half of the DB post-process (ocr_patch.py:223-241): bitmap runs and box scores, see include/rapiddoc_mi355.h.
+// box_score_fast of the DB post-process's candidates (ocr_patch.py:223-241); the rest of the chain is kernels_dbpost.hip.
 // ---------------------------------------------------------------------------------------------------------------------
-struct DbRun { int16_t y, x0, x1, pad; };
-
-__global__ void __launch_bounds__(256) db_runs_kernel(const float* __restrict__ prob, int H, int W, float thresh, int dilate, DbRun* runs,
-                                                      int32_t* n_runs, int max_runs) {
-    extern __shared__ unsigned char rowm[];     // dilated bitmap of this row
-    const int y = blockIdx.x, b = blockIdx.y;
-    const float* p1 = prob + ((size_t)b * H + y) * W;
-    const float* p0 = p1 - W;
-    for (int x = threadIdx.x; x < W; x += 256) {
-        bool v = p1[x] > thresh;
-        if (dilate) {      // cv2.dilate 2x2, anchor (1,1): max over (y-1..y, x-1..x)
-            if (x > 0) v = v || p1[x - 1] > thresh;
-            if (y > 0) {
-                v = v || p0[x] > thresh;
-                if (x > 0) v = v || p0[x - 1] > thresh;
-            }
-        }
-        rowm[x] = v;
-    }
-    __syncthreads();
-    for (int x = threadIdx.x; x < W; x += 256) {
-        if (rowm[x] && (x == 0 || !rowm[x - 1])) {
-            int x1 = x;
-            while (x1 + 1 < W && rowm[x1 + 1]) ++x1;
-            const int slot = atomicAdd(&n_runs[b], 1);
-            if (slot < max_runs) runs[(size_t)b * max_runs + slot] = DbRun{(int16_t)y, (int16_t)x, (int16_t)x1, 0};
-        }
-    }
-}
-
 struct DbCand { double box[8], rect[8], w, h; };
 
 __global__ void __launch_bounds__(256) db_scores_kernel(const float* __restrict__ prob, int H, int W, const DbCand* cand, const int32_t* n_cand,
@@ -447,13 +417,6 @@ __global__ void __launch_bounds__(256) db_scores_kernel(const float* __restrict_
 }
 
 namespace rd {
-int launch_db_runs(const float* prob, int B, int H, int W, float thresh, int dilate, void* runs, int32_t* n_runs, int max_runs, hipStream_t s) {
-    if (B <= 0) return 0;
-    if (W > 32767 || H > 32767 || W > 60000) return 1;
-    (void)hipMemsetAsync(n_runs, 0, (size_t)B * sizeof(int32_t), s);
-    hipLaunchKernelGGL(db_runs_kernel, dim3(H, B), dim3(256), (size_t)W, s, prob, H, W, thresh, dilate, reinterpret_cast<DbRun*>(runs), n_runs, max_runs);
-    return 0;
-}
 int launch_db_scores(const float* prob, int B, int H, int W, const void* cand, const int32_t* n_cand, int max_cand, double* scores, hipStream_t s) {
     if (B <= 0 || max_cand <= 0) return 0;
     hipLaunchKernelGGL(db_scores_kernel, dim3(max_cand, B), dim3(256), 0, s, prob, H, W, reinterpret_cast<const DbCand*>(cand), n_cand, max_cand, scores);

@@ -213,8 +213,7 @@ int launch_line_resize_norm(const LineCropParams& p, hipStream_t s);   // stage 
 // CTC greedy decode on the device: idx / prob [B][T] -> per line (row stride row_bytes): int32 n_text_bytes, float32
 // confidence (numpy float32 mean of the kept probabilities), int32 n_kept, int32 0, UTF-8 text.  ctab: [n_classes][1 + max_len]
 // bytes (length, then the entry's UTF-8 bytes).
-// device half of the DB post-process (bitmap runs, candidate scores): include/rapiddoc_mi355.h rd_db_runs / rd_db_scores
-int launch_db_runs(const float* prob, int B, int H, int W, float thresh, int dilate, void* runs, int32_t* n_runs, int max_runs, hipStream_t s);
+// box_score_fast of the DB post-process candidates (kernels_image.hip), used by launch_db_boxes
 int launch_db_scores(const float* prob, int B, int H, int W, const void* cand, const int32_t* n_cand, int max_cand, double* scores, hipStream_t s);
 // the whole DB post-process on the device (kernels_dbpost.hip): include/rapiddoc_mi355.h rd_db_boxes_device
 size_t db_boxes_workspace_bytes(int B, int H, int max_runs, int max_cand);

@@ -194,9 +194,6 @@ def db_postprocess(prob: np.ndarray, src_hw: Sequence[Tuple[int, int]], thresh: 
     return res
 
 
-DB_CAND_DTYPE = np.dtype([("box", "<f8", (8,)), ("rect", "<f8", (8,)), ("w", "<f8"), ("h", "<f8")])     # rd_db_candidate
-
-
 _DB_WS: dict = {}      # (device, B, H, max_runs, max_candidates) -> cached device buffers of the device post-process
 
 
@@ -262,64 +259,6 @@ def db_postprocess_device(prob_dev, src_hw: Sequence[Tuple[int, int]], thresh: f
         stats["t_wait_maps_ms"] = (t1 - t0) * 1e3
         stats["t_db_post_ms"] = (time.perf_counter() - t1) * 1e3
     return out
-
-
-def db_postprocess_device_assisted(prob_dev, src_hw: Sequence[Tuple[int, int]], thresh: float = 0.3, box_thresh: float = 0.5,
-                                   unclip_ratio: float = 1.6, use_dilation: bool = True, max_candidates: int = 1000, max_out: int = 2048,
-                                   max_runs: int = 65536, stats: dict = None) -> List[Tuple[np.ndarray, List[float]]]:
-    """Round 2's split (kept for A/B and as a second implementation to test against): the device thresholds / dilates and emits
-    bitmap runs (rd_db_runs) and scores the candidates (rd_db_scores); the host labels the runs, fits the rectangles and finishes
-    them (rd_db_candidates / rd_db_finish) - three blocking copies."""
-    import time
-
-    import torch
-
-    from . import _lib
-    lib = _lib.load()
-    p = prob_dev if prob_dev.dim() == 3 else prob_dev[:, 0]
-    assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
-    B, H, W = p.shape
-    dev = p.device.index or 0
-    st = torch.cuda.current_stream().cuda_stream
-    t0 = time.perf_counter()
-    runs = torch.empty((B, max_runs, 4), dtype=torch.int16, device=p.device)
-    n_runs = torch.empty(B, dtype=torch.int32, device=p.device)
-    if lib.rd_db_runs(dev, p.data_ptr(), B, H, W, thresh, 1 if use_dilation else 0, runs.data_ptr(), n_runs.data_ptr(), max_runs, st) != 0:
-        raise RuntimeError("rd_db_runs failed")
-    n_runs_h = n_runs.cpu().numpy()                      # (synchronises: the det forward and the run kernel are done)
-    t1 = time.perf_counter()
-    if int(n_runs_h.max(initial=0)) > max_runs:
-        return db_postprocess(p.cpu().numpy(), src_hw, thresh, box_thresh, unclip_ratio, use_dilation, max_candidates, max_out)
-    nmax = max(1, int(n_runs_h.max(initial=0)))
-    runs_h = np.ascontiguousarray(runs[:, :nmax].contiguous().cpu().numpy())
-    cand = np.zeros((B, max_candidates), dtype=DB_CAND_DTYPE)
-    n_cand = np.zeros(B, dtype=np.int32)
-    rc = lib.rd_db_candidates(runs_h.ctypes.data, n_runs_h.ctypes.data, B, nmax, max_candidates, cand.ctypes.data, max_candidates, n_cand.ctypes.data)
-    if rc != 0:
-        raise RuntimeError("rd_db_candidates failed")
-    cmax = max(1, int(n_cand.max(initial=0)))
-    cand_c = np.ascontiguousarray(cand[:, :cmax])
-    cand_dev = torch.from_numpy(cand_c.view(np.uint8)).to(p.device)
-    n_cand_dev = torch.from_numpy(n_cand).to(p.device)
-    scores_dev = torch.zeros((B, cmax), dtype=torch.float64, device=p.device)
-    if lib.rd_db_scores(dev, p.data_ptr(), B, H, W, cand_dev.data_ptr(), n_cand_dev.data_ptr(), cmax, scores_dev.data_ptr(), st) != 0:
-        raise RuntimeError("rd_db_scores failed")
-    scores = np.ascontiguousarray(scores_dev.cpu().numpy())
-    hw = np.ascontiguousarray(np.asarray(src_hw, dtype=np.int32).reshape(B, 2))
-    out = np.zeros((B, max_out), dtype=TEXT_BOX_DTYPE)
-    n = np.zeros(B, dtype=np.int32)
-    rc = lib.rd_db_finish(cand_c.ctypes.data, scores.ctypes.data, n_cand.ctypes.data, B, cmax, H, W, hw.ctypes.data, box_thresh, unclip_ratio,
-                          out.ctypes.data, max_out, n.ctypes.data)
-    if rc != 0:
-        raise RuntimeError("rd_db_finish failed")
-    if stats is not None:
-        stats["t_wait_maps_ms"] = (t1 - t0) * 1e3
-        stats["t_db_post_ms"] = (time.perf_counter() - t1) * 1e3
-    res = []
-    for b in range(B):
-        k = int(n[b])
-        res.append((out["pts"][b, :k].reshape(k, 4, 2).astype(np.int32), out["score"][b, :k].tolist()))
-    return res
 
 
 def sorted_boxes(dt_boxes: Sequence[np.ndarray]) -> List[np.ndarray]:

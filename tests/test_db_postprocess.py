@@ -74,3 +74,29 @@ def test_sorted_boxes_reading_order():
     boxes = [mk(300, 12), mk(10, 100), mk(20, 8), mk(200, 104)]
     out = H.sorted_boxes(boxes)
     assert [int(b[0][0]) for b in out] == [20, 300, 10, 200]
+
+
+def test_hole_borders_are_contours_like_retr_list():
+    """cv2.findContours(RETR_LIST) hands the hole borders of a region back as contours of their own, so the
+    reference scores them as candidates.  A 60 x 200 text blob with a 9 x 9 hole gives TWO candidates: the blob's outer border,
+    and the ring of blob pixels around the hole - a 10 x 10 box whose mean PROBABILITY (81 pixels of the 9 x 9 probability hole at 0.05, 19 at
+    0.9) is 0.2115: kept at box_thresh 0.2, dropped at 0.3 / 0.5 - which is why real pages rarely show them.  A hole that reaches the
+    image frame is background, not a hole; a 2 x 2 hole's ring is too small (its min-area rectangle has a side < 3)."""
+    pred = np.full((200, 400), 0.05, np.float32)
+    pred[40:100, 100:300] = 0.9
+    pred[60:69, 150:159] = 0.05                       # 9 x 9 hole (the 2 x 2 dilation eats one row / column of it: 8 x 8 remain)
+    pred[80:82, 250:252] = 0.05                       # 2 x 2 hole: filled by the dilation
+    pred[120:180, 0:120] = 0.9
+    pred[140:160, 0:30] = 0.05                        # a notch that reaches the left image border: not a hole
+    for box_thresh, expect in ((0.2, 3), (0.3, 2), (0.5, 2)):
+        (boxes, scores), = H.db_postprocess(pred[None], [(200, 400)], box_thresh=box_thresh, unclip_ratio=1.8)
+        oboxes, oscores = OD.db_postprocess(pred, (200, 400), box_thresh=box_thresh, unclip_ratio=1.8)
+        assert len(boxes) == len(oboxes) == expect, (box_thresh, len(boxes), len(oboxes))
+        for b, ob, s, os_ in zip(boxes, oboxes, scores, oscores):
+            assert np.abs(b - ob).max() <= 1 and abs(s - os_) < 1e-6
+    (boxes, scores), = H.db_postprocess(pred[None], [(200, 400)], box_thresh=0.2, unclip_ratio=1.8)
+    # raster order of the contours' start pixels: blob (40, 100), hole ring (61, 150), second blob (120, 0)
+    hole = boxes[1]
+    assert 140 <= hole[:, 0].min() and hole[:, 0].max() <= 170 and 50 <= hole[:, 1].min() and hole[:, 1].max() <= 80
+    ring_mean = (0.9 * 19 + 0.05 * 81) / 100.0
+    assert abs(scores[1] - ring_mean) < 1e-6

@@ -221,16 +221,20 @@ def test_page_analyzer_runs_the_reference_stage_order(golden_dir):
         assert all(isinstance(s["text"], str) and s["score"] == float(f"{s['score']:.3f}") for s in spans)
 
 
-@pytest.mark.parametrize("kind", ["lines", "blobs", "empty", "full", "speckle"])
+@pytest.mark.parametrize("kind", ["lines", "blobs", "holes", "empty", "full", "speckle"])
 def test_device_db_postprocess_equals_host_path(kind):
     """rd_db_boxes_device (everything on the GPU: raster-ordered runs, union-find regions, hulls of the row extremes, min-area
-    rectangles, scores, unclip, filter) == rd_db_postprocess (flood fill on the host) == round 2's device-assisted split, box
-    for box and in the same order: text-line maps, irregular blobs (touching the borders, diagonal 8-connections, holes), an
-    empty and a full map, and a speckled map with more than max_candidates regions (only the first 1000 in raster order count)."""
+    rectangles, scores, unclip, filter) == rd_db_postprocess (flood fill on the host), box for box and in the same order:
+    text-line maps, irregular blobs (touching the borders, diagonal 8-connections, holes), a map built around hole borders
+    (cv2.findContours RETR_LIST returns them as contours: rings, a hole with an island with a hole, one-pixel holes, holes that
+    touch only diagonally = two holes, notches that reach the image frame = no hole; scored with a box_thresh low enough to keep
+    them), an empty and a full map, and a speckled map with more than max_candidates regions (only the first 1000 contours in
+    raster order count)."""
     from rapiddoc_amd import ocr_host
     rng = np.random.default_rng(5)
     B, H, W = 3, 320, 448
     m = np.full((B, H, W), 0.02, np.float32)
+    box_thresh = 0.3
     if kind == "lines":
         for b in range(B):
             y = 10
@@ -247,6 +251,31 @@ def test_device_db_postprocess_equals_host_path(kind):
             m[0, 100 + k, 200 + k] = 0.9
         m[1, 50:90, 300:380] = 0.9
         m[1, 60:80, 320:360] = 0.01                            # a hole
+    elif kind == "holes":
+        box_thresh = 0.02
+        m[0, 20:120, 30:300] = 0.9
+        m[0, 40:100, 60:260] = 0.01                            # a ring ...
+        m[0, 55:85, 100:220] = 0.9                             # ... an island in its hole ...
+        m[0, 65:75, 120:160] = 0.01                            # ... with two holes of its own
+        m[0, 62:70, 180:200] = 0.01
+        m[0, 150:250, 0:200] = 0.9
+        m[0, 170:200, 0:50] = 0.01                             # reaches the left frame: not a hole
+        m[0, 210:230, 80:120] = 0.01
+        m[0, 260:319, 250:447] = 0.9                           # region in the bottom right corner
+        m[0, 300:320, 300:330] = 0.01                          # reaches the bottom frame
+        m[0, 280:290, 400:448] = 0.01                          # reaches the right frame
+        m[0, 270:296, 260:290] = 0.01
+        m[1, 30:200, 30:400] = 0.9
+        for k in range(12):                                    # a diagonal chain of holes that touch at their corners (after the
+            m[1, 40 + 4 * k: 45 + 4 * k, 50 + 4 * k: 55 + 4 * k] = 0.01     # dilation too): each is its own 4-connected hole
+        m[1, 150:180, 100:103] = 0.01                          # thin holes: two columns / two rows survive the dilation's bite
+        m[1, 150:153, 200:300] = 0.01
+        m[1, 100:140, 300:340] = 0.01                          # an L-shaped hole
+        m[1, 120:140, 340:380] = 0.01
+        m[2, 10:310, 10:440] = 0.9                             # page 2: a region with hundreds of ragged holes
+        for _ in range(400):
+            y, x, h, w = int(rng.integers(12, 300)), int(rng.integers(12, 430)), int(rng.integers(3, 9)), int(rng.integers(3, 9))
+            m[2, y:y + h, x:x + w] = 0.01
     elif kind == "full":
         m[:] = 0.8
     elif kind == "speckle":
@@ -257,14 +286,20 @@ def test_device_db_postprocess_equals_host_path(kind):
         m[2, :250] = 0.02                                      # ... and in front of them on page 2
         m[2, 20:40, 40:400] = 0.85
     hw = [(640, 896)] * B
-    host = ocr_host.db_postprocess(m, hw, thresh=0.3, box_thresh=0.3, unclip_ratio=1.8)
-    dev = ocr_host.db_postprocess_device(torch.from_numpy(m).cuda(), hw, thresh=0.3, box_thresh=0.3, unclip_ratio=1.8)
-    mid = ocr_host.db_postprocess_device_assisted(torch.from_numpy(m).cuda(), hw, thresh=0.3, box_thresh=0.3, unclip_ratio=1.8)
-    assert len(host) == len(dev) == len(mid) == B
-    for (hb, hs), (db, ds), (mb, ms) in zip(host, dev, mid):
+    host = ocr_host.db_postprocess(m, hw, thresh=0.3, box_thresh=box_thresh, unclip_ratio=1.8)
+    dev = ocr_host.db_postprocess_device(torch.from_numpy(m).cuda(), hw, thresh=0.3, box_thresh=box_thresh, unclip_ratio=1.8)
+    assert len(host) == len(dev) == B
+    for (hb, hs), (db, ds) in zip(host, dev):
         assert hb.shape == db.shape and np.array_equal(hb, db)
         assert np.allclose(hs, ds, rtol=0, atol=1e-6)
-        assert np.array_equal(hb, mb) and np.allclose(hs, ms, rtol=0, atol=1e-6)
+    if kind == "holes":
+        from oracle import dbpost as OD
+        assert len(host[0][0]) == 9 and len(host[1][0]) == 1 + 12 + 3 and len(host[2][0]) > 100
+        for b in range(B):
+            ob, osc = OD.db_postprocess(m[b], hw[b], thresh=0.3, box_thresh=box_thresh, unclip_ratio=1.8)
+            assert len(ob) == len(dev[b][0])
+            for x, y in zip(ob, dev[b][0]):
+                assert np.abs(np.asarray(x) - y).max() <= 1
     if kind == "speckle":
         assert [len(b) for b, _ in dev] == [0, 0, 1] or [len(b) for b, _ in dev][2] >= 1
     if kind == "lines":
@@ -282,7 +317,7 @@ def test_device_db_postprocess_equals_host_path(kind):
     if kind == "empty":
         assert all(len(b) == 0 for b, _ in dev)
     # overflow of the run buffer falls back to the host path with identical results
-    small = ocr_host.db_postprocess_device(torch.from_numpy(m).cuda(), hw, thresh=0.3, box_thresh=0.3, unclip_ratio=1.8, max_runs=4)
+    small = ocr_host.db_postprocess_device(torch.from_numpy(m).cuda(), hw, thresh=0.3, box_thresh=box_thresh, unclip_ratio=1.8, max_runs=4)
     for (hb, _), (sb, _) in zip(host, small):
         assert np.array_equal(hb, sb)
 
