@@ -274,7 +274,9 @@ float rd_debug_time_mixer(int C, int M, int variant, int iters, float* x, float*
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     void* hbuf[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (variant >= 600) variant -= 300;   // (600+ = 300+: keeps the resident-weights variants clear of the 400..599 P2 range)
+    int ws_abl = 0;                       // 1000 + 256 * bits: ablations of the ws kernel (C = 192, results are garbage)
+    if (variant >= 1000) { ws_abl = (variant - 1000) & ~0xff; variant = 200 + ((variant - 1000) & 0xff); }
+    if (variant >= 600) variant -= 300;   // (600+ = 300+: keeps the resident-weights variants clear of the 400..599 PF range)
     if (variant >= 300 && variant < 400) {  // resident-weights split mixer (kernels_mixer_res.hip)
         std::vector<float> hw1((size_t)2 * C * C), hw2((size_t)2 * C * C);
         (void)hipMemcpy(hw1.data(), w1, hw1.size() * 4, hipMemcpyDeviceToHost);
@@ -284,17 +286,17 @@ float rd_debug_time_mixer(int C, int M, int variant, int iters, float* x, float*
         (void)hipMalloc(&hbuf[0], img.size() * 2);
         (void)hipMemcpy(hbuf[0], img.data(), img.size() * 2, hipMemcpyHostToDevice);
         p.w1h = (const uint16_t*)hbuf[0];
-    } else if (variant >= 200) {  // weight-streaming split mixer (kernels_mixer_ws.hip); 400+: the pipelined form (P2)
-        const bool p2 = variant >= 400 && variant < 600;
-        if (p2) variant -= 200;
-        p.ws_p2 = p2;
-        p.dbg = variant - 200;
+    } else if (variant >= 200) {  // weight-streaming split mixer (kernels_mixer_ws.hip); 400+: the prefetching form (PF)
+        const bool pf = variant >= 400 && variant < 600;
+        if (pf) variant -= 200;
+        p.ws_pf = pf;
+        p.dbg = (variant - 200) | ws_abl;
         std::vector<float> hw1((size_t)2 * C * C), hw2((size_t)2 * C * C);
         (void)hipMemcpy(hw1.data(), w1, hw1.size() * 4, hipMemcpyDeviceToHost);
         (void)hipMemcpy(hw2.data(), w2, hw2.size() * 4, hipMemcpyDeviceToHost);
         std::vector<uint16_t> img;
         float inv[2];
-        rd::prepare_mixer_weights_ws(hw1.data(), hw2.data(), C, img, inv, p2);
+        rd::prepare_mixer_weights_ws(hw1.data(), hw2.data(), C, img, inv);
         p.ws_inv1 = inv[0]; p.ws_inv2 = inv[1];
         (void)hipMalloc(&hbuf[0], img.size() * 2);
         (void)hipMemcpy(hbuf[0], img.data(), img.size() * 2, hipMemcpyHostToDevice);
@@ -314,7 +316,7 @@ float rd_debug_time_mixer(int C, int M, int variant, int iters, float* x, float*
         p.w2h = (const uint16_t*)hbuf[2]; p.w2l = (const uint16_t*)hbuf[3];
     }
     auto go = [&] {
-        if (variant >= 300 && !p.ws_p2) rd::launch_mixer_fused_res(p, nullptr);
+        if (variant >= 300 && !p.ws_pf) rd::launch_mixer_fused_res(p, nullptr);
         else if (variant >= 200) rd::launch_mixer_fused_ws(p, nullptr);
         else if (variant >= 100) rd::launch_mixer_fused_h3(p, nullptr);
         else rd::launch_mixer_debug(p, variant, nullptr);

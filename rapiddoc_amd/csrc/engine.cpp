@@ -447,7 +447,7 @@ TView Builder::mixer_fused(const std::string& prefix, const TView& x, const TVie
         if (!pb_->has(hkey + ".ws") && fits && mixer_ws_preferred(C)) {   // weight stream image of the ws kernel
             std::vector<uint16_t> img;
             float inv[2];
-            prepare_mixer_weights_ws(f1, f2, C, img, inv, mixer_ws_pipelined() && C == 192);
+            prepare_mixer_weights_ws(f1, f2, C, img, inv);
             pb_->add_u16(hkey + ".ws", img);
             pb_->add(hkey + ".wsinv", std::vector<float>{inv[0], inv[1]});
         }
@@ -465,7 +465,7 @@ TView Builder::mixer_fused(const std::string& prefix, const TView& x, const TVie
         p.w1h = reinterpret_cast<const uint16_t*>(pb_->ptr(hkey + ".ws"));
         p.ws_inv1 = pb_->host_ptr(hkey + ".wsinv")[0];
         p.ws_inv2 = pb_->host_ptr(hkey + ".wsinv")[1];
-        p.ws_p2 = mixer_ws_pipelined() && C == 192;
+        p.ws_pf = mixer_ws_prefetch() && C == 192;
         p.range_flag = range_flag_;
     } else if (split) {
         p.w1h = reinterpret_cast<const uint16_t*>(pb_->ptr(hkey + ".w1h")); p.w1l = reinterpret_cast<const uint16_t*>(pb_->ptr(hkey + ".w1l"));

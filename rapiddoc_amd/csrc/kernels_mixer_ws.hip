@@ -39,6 +39,7 @@
 // channel); GELU outputs by a fixed 2^4 (guarded: |h| >= 4094 raises the range flag -> fp32 re-run, as in round 1).
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "rd_device.h"
@@ -76,6 +77,18 @@ __device__ __forceinline__ void ws_step_sync(bool next_in_flight) {
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// the same with an allowance of `extra` (0 / 12 / 24) younger operations: loads or stores the previous step issued BEHIND its DMA
+// pieces (C = 192, PIECES = 6)
+// (in the PF kernel every step issues its six DMA pieces, also the last two whose stages nobody reads: the count never has a
+// special case, and the code between a register load and its wait stays free of branches)
+template <int EXTRA>
+__device__ __forceinline__ void ws_step_sync_pf() {
+    static_assert(EXTRA == 0 || EXTRA == 12 || EXTRA == 24, "");
+    if constexpr (EXTRA == 0) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    else if constexpr (EXTRA == 12) asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(30)\n\ts_barrier" ::: "memory");
+}
+
 static constexpr float WS_SH = 16.f;   // fixed scale of the hidden activations (GELU outputs)
 
 // v -> (hi, lo) of v * s
@@ -88,13 +101,17 @@ __device__ __forceinline__ void ws_split(float v, float s, _Float16& hi, _Float1
 // inv1 = 1 / scale(W1), inv2 = 1 / (scale(W2) * WS_SH): exact powers of two
 // ABL: microbenchmark ablation bits (results are garbage): 1 no weight DMA after the first two stages, 2 no MFMAs,
 // 4 no fragment reads and no MFMAs, 8 no GELU, 16 no workgroup barrier
-// P2 (round 3): GEMM2 runs ONE STEP BEHIND the GELU that feeds it.  In the round-2 order a step was [GELU(q): ~130 VALU, nothing
-// else can issue] then [GEMM1(q+1), GEMM2(q): 74 MFMAs]; the matrix pipe idled through every GELU (ablation: 32 of 168 us).  With
-// GEMM2(q-1) instead, all 74 MFMAs of a step are independent of the step's VALU work, and the instruction stream is pinned to
-// 1 MFMA : 2 VALU (a 16x16x32 MFMA keeps the pipe for 16 cycles: two or three single-issue instructions fit in its shadow,
-// MI355X_MICROARCH.md "two waves per SIMD").  Stage q of the weight image then holds [W1 chunk q+1 | W2 chunk q-1]; a tile
-// takes NC + 2 steps, consecutive tiles of a wavefront overlap by two.
-template <int C, bool GATED, bool KEEPX, int ABL = 0, bool P2 = false>
+// PF (round 3): no synchronous memory round trip at a tile switch.  Ablations of the round-2 kernel at M = 105 600 ADD UP (tile IO
+// alone 38 us, + MFMAs and fragment reads 60, + GELU 27, + barriers 33, + weight DMA 14 = 172): all eight wavefronts of a CU switch
+// tiles in the same step and sit through two HBM round trips (residual re-read, next X tile) plus the in-order retirement of the
+// stores in between.  Here the X registers themselves are the landing buffer: GEMM1 of a tile's last chunk is the last reader of
+// the split X fragments, so from the middle of step NC-1 to the switch those 48 VGPRs are free.  They first receive the raw fp32 tile
+// again (issued behind the last GEMM1, landing under GEMM2 of that step) which is FOLDED INTO THE ACCUMULATORS at the start of the
+// switch step (Y^T += x' * scale(W2) * WS_SH, exact power of two; only the last chunk's three products are accumulated on top of the
+// large term, so the rounding stays at the fp32 level), then the NEXT tile (issued right after the fold, landing under the last
+// chunk's GELU + GEMM2), which is split in place after the epilogue's stores have been issued.  No load is ever waited for behind a
+// store: the step barrier's vmcnt allows for what the previous step issued behind its DMA pieces.
+template <int C, bool GATED, bool KEEPX, int ABL = 0, bool PF = false>
 __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, const unsigned char* __restrict__ wimg, int n_tiles,
                                                              int T_total, int ph_mul, int ph_unit, float inv1, float inv2) {
     using G = WsGeom<C>;
@@ -117,7 +134,7 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
     // switch stalls nobody else at the step barrier, while different workgroups - nothing couples them - switch at different
     // steps and the tile traffic of the chip is spread over the weight cycle instead of arriving in bursts)
     const int du = ((int)blockIdx.x * WS_WAVES + wave) / ph_unit, sub = ((int)blockIdx.x * WS_WAVES + wave) % ph_unit;
-    constexpr int TAIL = P2 ? 2 : 1;            // steps a tile needs beyond its NC chunk steps
+    constexpr int TAIL = 1;                     // steps a tile needs beyond its NC chunk steps
     auto n_of = [&](int w) { return max(0, (T_total - TAIL - (w * ph_mul) % NC) / NC); };
     const int ph = (du * ph_mul) % NC;
     int per_cycle = 0, before = 0;
@@ -310,76 +327,252 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
     };
 
     if (wave < WS_WAVES / 2) __builtin_amdgcn_s_setprio(1);   // static: the first wavefront of every SIMD wins arbitration
-    if constexpr (P2) {
-        f16x8 hh_old = {}, hl_old = {};                   // GELU(H) of the previous chunk: the B fragment of this step's GEMM2
-        for (int t = 0; t < T_total; ++t) {
-            ws_step_sync<G::PIECES>(t + 1 < T_total);
-            if (t + 2 < T_total) issue_stage(t + 2);
-            const int u = t - ph;
-            if (u < 0 || u > R * NC + 1) continue;           // (idle head / tail of this phase; barriers and DMA above still run)
-            const unsigned char* stage = lds + (t % WS_NSTAGE) * G::STAGE_BYTES;
-            const int q = (t + NC - 1) % NC;                  // chunk whose pre-activations were finished by the previous step
-            const int r = u / NC, uu = u - r * NC;
-            const bool do_g1 = u < R * NC, do_gelu = u >= 1 && u <= R * NC, do_g2 = u >= 2;
-            f16x8 hh_new = {}, hl_new = {};
-            if (do_g1 && do_gelu && do_g2 && uu >= 2) {
-                // common step: GELU(q) (VALU) beside GEMM1(q+1) and GEMM2(q-1) (74 independent MFMAs)
+    if constexpr (PF) {
+        static_assert(!KEEPX && G::PIECES == 6, "PF: C = 192, residual folded");
+        const float s2h = 1.f / inv2;                         // scale(W2) * WS_SH: an exact power of two
+        // raw tile -> the X registers (bit patterns): block n = channels 16n + 4g .. + 4 lands in xh[n / 2] (n even) / xl[n / 2] (n odd).
+        // The loads, the stores and the waits between them are inline assembly: the compiler's own wait insertion cannot express
+        // "the loads have landed, the younger stores need not have" once a store sits under an exec mask (it falls back to
+        // vmcnt(0)), and a wait it places for anything drains the weight DMA queue as well.  What is hidden from it only makes the
+        // waits it does place (gate loads) more conservative; the counts used here are stated where they are used.
+        auto issue_raw = [&](int r) {
+            const int m = min(tile_m(r), p.M - 1);
+            const float* xp = p.x + (size_t)m * p.xld + 4 * g;
 #pragma unroll
-                for (int b = 0; b < 2; ++b) hn[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-                unit_load(stage, 0, 0);
-                unit_load(stage, 1, 1);
-                gelu_split(q, hh_new, hl_new);
+            for (int sblk = 0; sblk < KS; ++sblk) {
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(xh[sblk]) : "v"(xp), "n"(64 * (2 * sblk)));
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(xl[sblk]) : "v"(xp), "n"(64 * (2 * sblk + 1)));
+            }
+        };
+        // the raw tile has landed: at most `newer` younger vector-memory operations are still outstanding (operations complete
+        // in issue order).  Ties the twelve registers to the wait so that no reader can be scheduled above it.
+        static_assert(KS == 6, "raw_landed lists twelve registers");
+        auto raw_landed = [&](auto newer) {
+            constexpr int N = decltype(newer)::value;
+            if constexpr (N == 6)
+                asm volatile("s_waitcnt vmcnt(6)" : "+v"(xh[0]), "+v"(xl[0]), "+v"(xh[1]), "+v"(xl[1]), "+v"(xh[2]), "+v"(xl[2]), "+v"(xh[3]),
+                             "+v"(xl[3]), "+v"(xh[4]), "+v"(xl[4]), "+v"(xh[5]), "+v"(xl[5]));
+            else if constexpr (N == 12)
+                asm volatile("s_waitcnt vmcnt(12)" : "+v"(xh[0]), "+v"(xl[0]), "+v"(xh[1]), "+v"(xl[1]), "+v"(xh[2]), "+v"(xl[2]), "+v"(xh[3]),
+                             "+v"(xl[3]), "+v"(xh[4]), "+v"(xl[4]), "+v"(xh[5]), "+v"(xl[5]));
+            else
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(xh[0]), "+v"(xl[0]), "+v"(xh[1]), "+v"(xl[1]), "+v"(xh[2]), "+v"(xl[2]), "+v"(xh[3]),
+                             "+v"(xl[3]), "+v"(xh[4]), "+v"(xl[4]), "+v"(xh[5]), "+v"(xl[5]));
+        };
+        auto raw_block = [&](int n) { return __builtin_bit_cast(f32x4, (n & 1) ? xl[n >> 1] : xh[n >> 1]); };
+        auto gate_block = [&](int r, int n) {
+            const int m = min(tile_m(r), p.M - 1);
+            return *reinterpret_cast<const f32x4*>(p.gate + (size_t)(m / p.HW) * C + 4 * g + 16 * n);
+        };
+        // the residual of tile r: Y^T += x' * s2h
+        auto fold_raw = [&](int r) {
 #pragma unroll
-                for (int i = 0; i < NU; ++i) {
-                    if (i + 2 < NU) unit_load(stage, i + 2, (i + 2) % 3);
-                    if (i < KS) unit_g1(i, i % 3);
-                    else unit_g2(2 * (i - KS), i % 3, hh_old, hl_old);
-                }
-                // issue order of the whole step: per unit its 4 fragment reads (two units ahead), then 6 x (1 MFMA, 2 VALU)
+            for (int n = 0; n < NB; ++n) {
+                f32x4 v = raw_block(n);
+                if (GATED) v *= gate_block(r, n);
 #pragma unroll
-                for (int i = 0; i < NU; ++i) {
-                    if (i + 2 < NU) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                for (int e = 0; e < 4; ++e) y[n][e] = fmaf(v[e], s2h, y[n][e]);
+            }
+        };
+        // raw tile r in the X registers -> (gate) -> per-pixel scale -> split, in place (load_x without the loads)
+        auto split_raw = [&](int r) {
+            if (GATED) {
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                    }
-                }
-            } else {
-                // tile edges (first two / last two steps of a tile, head and tail of the wavefront's run): same operations,
-                // each under its own (wave-uniform) condition
-                if (do_gelu) gelu_split(q, hh_new, hl_new);      // before load_x: it belongs to the tile hfac_cur describes
-                if (do_g1 && uu == 0) load_x(r);
-                if (do_g1) {
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) hn[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    unit_load(stage, 0, 0);
-                    unit_load(stage, 1, 1);
-#pragma unroll
-                    for (int i = 0; i < KS; ++i) {
-                        if (i + 2 < KS) unit_load(stage, i + 2, (i + 2) % 3);
-                        unit_g1(i, i % 3);
-                        pin_unit(i + 2 < KS);
-                    }
-                }
-                if (do_g2) {
-                    unit_load(stage, KS, 0);
-                    unit_load(stage, KS + 1, 1);
-#pragma unroll
-                    for (int i = KS; i < NU; ++i) {
-                        if (i + 2 < NU) unit_load(stage, i + 2, (i + 2 - KS) % 3);
-                        unit_g2(2 * (i - KS), (i - KS) % 3, hh_old, hl_old);
-                        pin_unit(i + 2 < NU);
-                    }
-                    if (uu == 1) epilogue(r - 1);                 // that was the last chunk of tile r - 1
+                for (int n = 0; n < NB; ++n) {
+                    const f32x4 v = raw_block(n) * gate_block(r, n);
+                    if (n & 1) xl[n >> 1] = __builtin_bit_cast(f16x8, v);
+                    else xh[n >> 1] = __builtin_bit_cast(f16x8, v);
                 }
             }
-            hh_old = hh_new;
-            hl_old = hl_new;
+            float mx = 0.f;
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                const f32x4 v = raw_block(n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(v[e]));
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            // rows past M (the clamped "next" tile behind the last one; a tile whose masked stores did not count in vmcnt may even
+            // be split before it has landed) never reach memory and must not raise the flag either
+            bad = bad || (!(mx < INFINITY) && tile_m(r) < p.M);
+            const int ex = max((int)((__float_as_uint(mx) >> 23) & 0xffu), 40);
+            const float sx = __uint_as_float((unsigned)(267 - ex) << 23);
+            hfac = __uint_as_float((unsigned)(ex - 13) << 23) * inv1;
+#pragma unroll
+            for (int sblk = 0; sblk < KS; ++sblk) {           // 8 raw registers -> the same 8 registers as (hi, lo) fragments
+                const f32x4 v0 = raw_block(2 * sblk), v1 = raw_block(2 * sblk + 1);
+                f16x8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 a, b;
+                    ws_split(v0[e], sx, a, b);
+                    hi[e] = a; lo[e] = b;
+                    ws_split(v1[e], sx, a, b);
+                    hi[4 + e] = a; lo[4 + e] = b;
+                }
+                xh[sblk] = hi;
+                xl[sblk] = lo;
+            }
+        };
+        bool stores_counted = false;      // the last epilogue's stores were issued with lanes enabled (they count in vmcnt for sure)
+        // un-scale + b2 (the residual is in the accumulator), store, clear
+        auto epilogue_pf = [&](int r) {
+            const int mm = tile_m(r);
+            float* yp = p.y + (size_t)min(mm, p.M - 1) * p.yld + 4 * g;
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(&B2s[16 * n + 4 * g]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[n][e] = fmaf(y[n][e], inv2, bv[e]);
+                bad = bad || !(fabsf(y[n][0]) + fabsf(y[n][1]) + fabsf(y[n][2]) + fabsf(y[n][3]) < INFINITY);
+            }
+            // twelve 16-byte stores, rows past M masked off by EXEC - always ISSUED, so that the counts of the waits that follow hold
+            // (a wavefront whose whole tile lies past M does not count on them: see `stores_counted`)
+            static_assert(NB == 12, "twelve stores");
+            const unsigned long long ok = __ballot(mm < p.M);
+            unsigned long long saved;
+            asm volatile(
+                "s_and_saveexec_b64 %[sv], %[ok]\n\t"
+                "global_store_dwordx4 %[p], %[d0], off nt\n\t"
+                "global_store_dwordx4 %[p], %[d1], off offset:64 nt\n\t"
+                "global_store_dwordx4 %[p], %[d2], off offset:128 nt\n\t"
+                "global_store_dwordx4 %[p], %[d3], off offset:192 nt\n\t"
+                "global_store_dwordx4 %[p], %[d4], off offset:256 nt\n\t"
+                "global_store_dwordx4 %[p], %[d5], off offset:320 nt\n\t"
+                "global_store_dwordx4 %[p], %[d6], off offset:384 nt\n\t"
+                "global_store_dwordx4 %[p], %[d7], off offset:448 nt\n\t"
+                "global_store_dwordx4 %[p], %[d8], off offset:512 nt\n\t"
+                "global_store_dwordx4 %[p], %[d9], off offset:576 nt\n\t"
+                "global_store_dwordx4 %[p], %[d10], off offset:640 nt\n\t"
+                "global_store_dwordx4 %[p], %[d11], off offset:704 nt\n\t"
+                "s_mov_b64 exec, %[sv]"
+                : [sv] "=&s"(saved)
+                : [ok] "s"(ok), [p] "v"(yp), [d0] "v"(y[0]), [d1] "v"(y[1]), [d2] "v"(y[2]), [d3] "v"(y[3]), [d4] "v"(y[4]), [d5] "v"(y[5]),
+                  [d6] "v"(y[6]), [d7] "v"(y[7]), [d8] "v"(y[8]), [d9] "v"(y[9]), [d10] "v"(y[10]), [d11] "v"(y[11])
+                : "memory");
+            stores_counted = ok != 0ull;
+#pragma unroll
+            for (int n = 0; n < NB; ++n) y[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        // ---- the schedule of this wavefront, written out tile by tile: ph idle steps, [first X tile], R x (NC - 1 common steps +
+        // switch step), idle steps to T_total.  Every step begins with the workgroup's wait + barrier + DMA of the stage two steps
+        // ahead.  BETWEEN A REGISTER LOAD AND ITS WAIT THE CODE IS STRAIGHT-LINE (no branch, so no block boundary at which the
+        // compiler could place copies of registers whose loads are still in flight; tests/test_isa_resources.py checks the ISA for
+        // exactly that): the step that follows a re-fetch knows its allowance at compile time, the switch step requests, splits and
+        // starts the "next" tile also behind the last one (clamped rows, results never used).
+        int t = 0;
+        auto step_begin = [&](auto extra) {
+            ws_step_sync_pf<decltype(extra)::value>();
+            issue_stage(t + 2);
+        };
+        using E0 = std::integral_constant<int, 0>;
+        using E12 = std::integral_constant<int, 12>;
+        auto stage_of = [&]() { return lds + (t % WS_NSTAGE) * G::STAGE_BYTES; };
+        auto gemm1_only = [&](const unsigned char* stage) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) hn[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            unit_load(stage, 0, 0);
+            unit_load(stage, 1, 1);
+#pragma unroll
+            for (int i = 0; i < KS; ++i) {
+                if (i + 2 < KS) unit_load(stage, i + 2, (i + 2) % 3);
+                unit_g1(i, i % 3);
+                pin_unit(i + 2 < KS);
+            }
+        };
+        auto roll = [&]() {
 #pragma unroll
             for (int b = 0; b < 2; ++b) hc[b] = hn[b];
             hfac_cur = hfac;
+        };
+        // common step: GELU of the finished chunk, GEMM1 of the next one, GEMM2 of the finished one; REFETCH: behind the last
+        // reader of the X fragments (GEMM1) the raw tile is requested again into the same registers
+        auto common_step = [&](int r, auto refetch) {
+            const unsigned char* stage = stage_of();
+            const int q = (t + NC - 1) % NC;
+            f16x8 hh, hl;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) hn[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            unit_load(stage, 0, 0);
+            unit_load(stage, 1, 1);
+            gelu_split(q, hh, hl);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                if (i + 2 < NU) unit_load(stage, i + 2, (i + 2) % 3);
+                if (i < KS) unit_g1(i, i % 3);
+                else unit_g2(2 * (i - KS), i % 3, hh, hl);
+                pin_unit(i + 2 < NU);
+                if constexpr (decltype(refetch)::value) {
+                    if (i == KS - 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_raw(r);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            roll();
+        };
+        bool after_switch = false;
+        auto step_begin_rt = [&]() {                                           // allowance known at run time only (no load in flight)
+            if (!after_switch) step_begin(E0{});
+            else step_begin(E12{});
+            after_switch = false;
+        };
+        for (; t < T_total && (R == 0 || t < ph); ++t) step_begin(E0{});       // idle head (all of it for a wavefront without tiles)
+        if (R > 0) {
+            step_begin(E0{});                                                  // first tile: nothing to hide its load under
+            issue_raw(0);
+            raw_landed(E0{});
+            split_raw(0);
+            gemm1_only(stage_of());
+            roll();
+            ++t;
+            for (int r = 0; r < R; ++r) {
+                for (int j = 1; j < NC - 1; ++j) {
+                    step_begin_rt();
+                    common_step(r, std::false_type{});
+                    ++t;
+                }
+                step_begin(E0{});
+                common_step(r, std::true_type{});
+                ++t;
+                // switch step: residual into the accumulator, next tile requested, last chunk finished, epilogue, next tile split
+                step_begin(E12{});                    // the twelve re-fetch loads sit behind the previous step's DMA pieces
+                {
+                    const unsigned char* stage = stage_of();
+                    const int q = (t + NC - 1) % NC;
+                    raw_landed(std::integral_constant<int, 6>{});             // younger: this step's six DMA pieces
+                    fold_raw(r);
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_raw(r + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    f16x8 hh, hl;
+                    unit_load(stage, KS, 0);
+                    unit_load(stage, KS + 1, 1);
+                    gelu_split(q, hh, hl);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = KS; i < NU; ++i) {
+                        if (i + 2 < NU) unit_load(stage, i + 2, (i + 2 - KS) % 3);
+                        unit_g2(2 * (i - KS), (i - KS) % 3, hh, hl);
+                        pin_unit(i + 2 < NU);
+                    }
+                    epilogue_pf(r);
+                    __builtin_amdgcn_sched_barrier(0);
+                    raw_landed(E12{});                // younger: the twelve stores (a tile wholly past M: see split_raw)
+                    split_raw(r + 1);
+                    gemm1_only(stage);
+                    roll();
+                    after_switch = stores_counted;    // the stores are young (the next tile's loads have been waited for); stores that
+                                                      // may not have counted get no allowance
+                }
+                ++t;
+            }
         }
+        for (; t < T_total; ++t) step_begin_rt();                              // idle tail
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the DMA pieces of the two stages nobody reads
     } else
     for (int t = 0; t < T_total; ++t) {
         if constexpr (ABL & 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -448,8 +641,8 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
 // C = 96 builds and passes the same tests, but measures level with the round-1 kernel (99 vs 97 us at M = 211 200): the
 // engine only routes C = 192 here
 bool mixer_ws_supported(int C) { return C == 96 || C == 192; }
-bool mixer_ws_pipelined() {
-    static const bool on = [] { const char* e = getenv("RD_WS_P2"); return e ? e[0] == '1' : false; }();
+bool mixer_ws_prefetch() {
+    static const bool on = [] { const char* e = getenv("RD_WS_PF"); return e ? e[0] == '1' : true; }();
     return on;
 }
 bool mixer_ws_preferred(int C) { return C == 192; }
@@ -466,7 +659,7 @@ static float ws_weight_scale(const float* w, size_t n) {
 
 // host: the weight stream image.  w1 [2C][C], w2 [C][2C] fp32 (BN folded).  img: NC stages of STAGE_BYTES;
 // inv[0] = 1 / scale(W1), inv[1] = 1 / (scale(W2) * WS_SH) - what the kernel multiplies its accumulators by.
-void prepare_mixer_weights_ws(const float* w1, const float* w2, int C, std::vector<uint16_t>& img, float inv[2], bool p2) {
+void prepare_mixer_weights_ws(const float* w1, const float* w2, int C, std::vector<uint16_t>& img, float inv[2]) {
     const int KS = C / 32, NB = C / 16, NC = 2 * C / WS_HC, H2 = 2 * C;
     const int w1_frags = 2 * KS * 2, w2_frags = NB * 2, stage_halfs = (w1_frags + w2_frags) * 512;
     img.assign((size_t)NC * stage_halfs, 0);
@@ -493,7 +686,7 @@ void prepare_mixer_weights_ws(const float* w1, const float* w2, int C, std::vect
                         put(w1[(size_t)hid * C + ch], s1, st[f], st[f + 512]);
                     }
         uint16_t* st2 = st + (size_t)w1_frags * 512;
-        const int c2 = p2 ? (q + NC - 1) % NC : q;   // W2 chunk of this stage (P2: GEMM2 runs one step behind its GELU)
+        const int c2 = q;              // W2 chunk of this stage
         for (int n = 0; n < NB; ++n)
             for (int l = 0; l < 64; ++l)
                 for (int e = 0; e < 8; ++e) {
@@ -518,12 +711,12 @@ static int ws_total_steps(int n_tiles, int waves, int NC, int ph_mul, int tail =
     }
 }
 
-template <int C, bool GATED, bool KEEPX, int ABL = 0, bool P2 = false>
+template <int C, bool GATED, bool KEEPX, int ABL = 0, bool PF = false>
 static void launch_ws(const MixerParams& p, const unsigned char* wimg, int n_tiles, int grid, int ph_mul, int ph_unit, hipStream_t s) {
     static unsigned long long lds_ok = 0;
-    rd_allow_dynamic_lds((const void*)lc_mixer_ws_kernel<C, GATED, KEEPX, ABL, P2>, WsGeom<C>::LDS_BYTES, lds_ok);
-    const int T = ws_total_steps((n_tiles + ph_unit - 1) / ph_unit, grid * WS_WAVES / ph_unit, WsGeom<C>::NC, ph_mul, P2 ? 2 : 1);
-    hipLaunchKernelGGL((lc_mixer_ws_kernel<C, GATED, KEEPX, ABL, P2>), dim3(grid), dim3(512), WsGeom<C>::LDS_BYTES, s, p, wimg, n_tiles, T,
+    rd_allow_dynamic_lds((const void*)lc_mixer_ws_kernel<C, GATED, KEEPX, ABL, PF>, WsGeom<C>::LDS_BYTES, lds_ok);
+    const int T = ws_total_steps((n_tiles + ph_unit - 1) / ph_unit, grid * WS_WAVES / ph_unit, WsGeom<C>::NC, ph_mul, 1);
+    hipLaunchKernelGGL((lc_mixer_ws_kernel<C, GATED, KEEPX, ABL, PF>), dim3(grid), dim3(512), WsGeom<C>::LDS_BYTES, s, p, wimg, n_tiles, T,
                        ph_mul, ph_unit, p.ws_inv1, p.ws_inv2);
 }
 
@@ -553,8 +746,8 @@ void launch_mixer_fused_ws(const MixerParams& p, hipStream_t s) {
     // traffic over the chip without that coupling.  Phases cost up to NC - 1 extra steps when the tiles divide evenly, so the
     // launcher takes them when the schedule grows by at most 1/8.
     const int NC = 2 * p.C / WS_HC;
-    const bool p2 = p.ws_p2 && p.C == 192;
-    const int tail = p2 ? 2 : 1;
+    const bool pf = p.ws_pf && p.C == 192;
+    const int tail = 1;
     const int t_lock = ws_total_steps(n_tiles, grid * WS_WAVES, NC, 0, tail);
     const int t_wg = ws_total_steps((n_tiles + WS_WAVES - 1) / WS_WAVES, grid, NC, 5, tail);     // 5: coprime to NC = 6 and 12
     const int t_wave = ws_total_steps(n_tiles, grid * WS_WAVES, NC, 5, tail);
@@ -574,11 +767,15 @@ void launch_mixer_fused_ws(const MixerParams& p, hipStream_t s) {
             case 13: launch_ws<192, false, false, 13>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
             case 16: launch_ws<192, false, false, 16>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
             case 29: launch_ws<192, false, false, 29>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
+            case 2: launch_ws<192, false, false, 2>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
+            case 17: launch_ws<192, false, false, 17>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
+            case 25: launch_ws<192, false, false, 25>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
+            case 27: launch_ws<192, false, false, 27>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
             default: break;
         }
         return;
     }
-    if (p2) {
+    if (pf) {
         if (gated) launch_ws<192, true, false, 0, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s);
         else launch_ws<192, false, false, 0, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s);
         return;

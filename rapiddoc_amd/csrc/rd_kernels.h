@@ -242,7 +242,7 @@ struct MixerParams {
     unsigned* range_flag = nullptr;   // raised when a split operand leaves the fp16 range (|v| >= 65504)
     int dbg = 0;   // microbenchmark ablation bits (h3 kernel): 1 no GELU, 2 no weight streaming, 4 skip GEMM1, 8 skip GEMM2
     float ws_inv1 = 1.f, ws_inv2 = 1.f;   // ws kernel: inverse power-of-two scales of its weight stream image
-    bool ws_p2 = false;                   // ws kernel: the image was built for the pipelined form (GEMM2 one step behind its GELU)
+    bool ws_pf = false;                   // ws kernel (C = 192): tile prefetch into the X registers, residual folded into the accumulator
 };
 bool mixer_fused_supported(int C);
 void launch_mixer_fused_h3(const MixerParams& p, hipStream_t s);
@@ -253,8 +253,8 @@ void launch_mixer_fused(const MixerParams& p, hipStream_t s);
 // persistent 8-wavefront workgroups.  p.w1h carries the stream image built by prepare_mixer_weights_ws.
 bool mixer_ws_supported(int C);
 bool mixer_ws_preferred(int C);   // where it measures faster than the round-1 kernel
-void prepare_mixer_weights_ws(const float* w1, const float* w2, int C, std::vector<uint16_t>& img, float inv[2], bool p2 = false);
-bool mixer_ws_pipelined();            // RD_WS_P2 (default in kernels_mixer_ws.hip): which form the engine prepares and launches
+void prepare_mixer_weights_ws(const float* w1, const float* w2, int C, std::vector<uint16_t>& img, float inv[2]);
+bool mixer_ws_prefetch();             // RD_WS_PF (default 1): the engine launches the prefetching form of the ws kernel
 void launch_mixer_fused_ws(const MixerParams& p, hipStream_t s);
 void launch_mixer_debug(const MixerParams& p, int variant, hipStream_t s);
 // resident-weights variant for the narrow blocks (kernels_mixer_res.hip; C = 96): all split weights in LDS, 16 independent

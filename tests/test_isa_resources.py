@@ -15,8 +15,9 @@ CSRC = ROOT / "rapiddoc_amd" / "csrc"
 
 # kernels allowed to spill: not dispatched by the engine (microbenchmark ablations, opt-in experiments), with the reason
 ALLOWED = {
-    r"lc_mixer_ws_kernel.*Lb1E": "KEEPX instantiations (fp32 X tile kept in registers): debug entry only, C = 192 spills by design",
-    r"lc_mixer_ws_kernel.*Li(1|4|8|12|13|16|29)E": "ablation instantiations of the ws mixer (tools/microbench.py)",
+    # template arguments <C, GATED, KEEPX, ABL, PF>
+    r"lc_mixer_ws_kernelILi192ELb[01]ELb1E": "KEEPX instantiations (fp32 X tile kept in registers): debug entry only, C = 192 spills by design",
+    r"lc_mixer_ws_kernelILi192ELb[01]ELb[01]ELi(1|2|4|8|12|13|16|17|25|27|29)E": "ablation instantiations of the ws mixer (tools/microbench.py)",
     r"lc_mixer_h3_kernel.*Li192E": "round-1 C = 192 mixer: superseded by the ws kernel, kept for A/B (RD_MIXER_WS=0)",
     r"db_(regions|finish)_kernel": "no spill: local arrays (4-corner boxes, hull scratch) of the geometry code shared with the host path "
                                    "(csrc/db_geom.h), indexed at run time; one thread per text-line candidate, ~50 candidates per page",
@@ -78,3 +79,20 @@ def test_known_register_budgets(tables):
     k16 = next(v for n, v in rows.items() if "gemm_h3_dma16_kernel" in n)
     assert k8[0] <= 256 and k8[1:] == (0, 0)
     assert k16[0] <= 128 and k16[1:] == (0, 0)
+
+
+def test_inline_asm_register_loads_are_not_touched_in_flight():
+    """The prefetching ws mixer loads its X registers with inline assembly (the compiler's own wait insertion cannot express "loads
+    landed, younger stores still in flight").  The compiler therefore does not know those registers are in flight: between such a
+    load and the `s_waitcnt vmcnt` that ends its window no instruction may name one of them (a register copy at a block boundary
+    would silently move garbage), and no block boundary may fall into a window.  Checked on the ISA of every instantiation."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_inflight", ROOT / "tools" / "check_inflight.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "-S", "--cuda-device-only",
+                          f"-I{CSRC}", str(CSRC / "kernels_mixer_ws.hip"), "-o", "-"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.count("global_load_dwordx4") >= 48          # the PF instantiations are there
+    hazards = mod.check(out.stdout, ["ELb1EEEvNS_11MixerParams"])      # <..., PF = true>: the instantiations with inline-asm loads
+    assert not hazards, hazards[:10]

@@ -85,7 +85,7 @@ if __name__ == "__main__" and "--mixer-ws" in sys.argv:
     names = {1: "no DMA", 4: "no frag reads, no MFMA", 8: "no GELU", 12: "no GELU / reads / MFMA (DMA + barriers only)",
              13: "barriers only", 16: "no barrier", 29: "empty loop"}
     for bits in (1, 4, 8, 12, 13, 16, 29):
-        ms, tf = mixer(192, 105600, 200 + 256 * bits)
+        ms, tf = mixer(192, 105600, 1000 + 256 * bits)
         print(f"ws ablation M=105600 {names[bits]:45s}: {ms*1e3:8.1f} us", flush=True)
     sys.exit(0)
 
