@@ -81,10 +81,14 @@ __device__ __forceinline__ void ws_step_sync(bool next_in_flight) {
 // pieces (C = 192, PIECES = 6)
 // (in the PF kernel every step issues its six DMA pieces, also the last two whose stages nobody reads: the count never has a
 // special case, and the code between a register load and its wait stays free of branches)
-template <int EXTRA>
+template <int EXTRA, bool BARRIER = true>
 __device__ __forceinline__ void ws_step_sync_pf() {
     static_assert(EXTRA == 0 || EXTRA == 12 || EXTRA == 24, "");
-    if constexpr (EXTRA == 0) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    if constexpr (!BARRIER) {      // (ablation)
+        if constexpr (EXTRA == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (EXTRA == 12) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+    } else if constexpr (EXTRA == 0) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
     else if constexpr (EXTRA == 12) asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(30)\n\ts_barrier" ::: "memory");
 }
@@ -111,6 +115,9 @@ __device__ __forceinline__ void ws_split(float v, float s, _Float16& hi, _Float1
 // large term, so the rounding stays at the fp32 level), then the NEXT tile (issued right after the fold, landing under the last
 // chunk's GELU + GEMM2), which is split in place after the epilogue's stores have been issued.  No load is ever waited for behind a
 // store: the step barrier's vmcnt allows for what the previous step issued behind its DMA pieces.
+// Measured and dropped on top of this form: GELU(q) issued instruction by instruction in the shadow of GEMM1(q + 1) (one MFMA, then
+// 1 - 3 VALU instructions of the four value pairs' GELU pipelines, fenced with sched_barrier so the order holds in the ISA):
+// 151 - 154 us against 149 - the VALU time of a SIMD adds to its MFMA time however it is arranged (probe_mfma_valu).
 template <int C, bool GATED, bool KEEPX, int ABL = 0, bool PF = false>
 __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, const unsigned char* __restrict__ wimg, int n_tiles,
                                                              int T_total, int ph_mul, int ph_unit, float inv1, float inv2) {
@@ -237,8 +244,12 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
     // MFMA-source hazard nops).
     constexpr int NU = KS + NB / 2;
     f16x8 fr[3][4] = {};
+    int frag_once = 0;
     auto unit_load = [&](const unsigned char* stage, int i, int slot) {
         if constexpr (ABL & 4) return;
+        if constexpr (ABL & 64) {      // MFMAs on fragments that are read once: what the fragment reads cost
+            if (frag_once) return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) fr[slot][j] = frag(stage, 4 * i + j);
     };
@@ -463,8 +474,8 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
         // starts the "next" tile also behind the last one (clamped rows, results never used).
         int t = 0;
         auto step_begin = [&](auto extra) {
-            ws_step_sync_pf<decltype(extra)::value>();
-            issue_stage(t + 2);
+            ws_step_sync_pf<decltype(extra)::value, !(ABL & 16)>();
+            issue_stage(t + 2);        // (no "no DMA" ablation here: the wait counts below rely on the pieces)
         };
         using E0 = std::integral_constant<int, 0>;
         using E12 = std::integral_constant<int, 12>;
@@ -527,6 +538,7 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
             raw_landed(E0{});
             split_raw(0);
             gemm1_only(stage_of());
+            frag_once = 1;
             roll();
             ++t;
             for (int r = 0; r < R; ++r) {
@@ -771,6 +783,15 @@ void launch_mixer_fused_ws(const MixerParams& p, hipStream_t s) {
             case 17: launch_ws<192, false, false, 17>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
             case 25: launch_ws<192, false, false, 25>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
             case 27: launch_ws<192, false, false, 27>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
+            case 32 + 0: launch_ws<192, false, false, 0, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;      // 32 +: the PF form
+            case 32 + 4: launch_ws<192, false, false, 4, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
+            case 32 + 8: launch_ws<192, false, false, 8, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
+            case 32 + 12: launch_ws<192, false, false, 12, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
+            case 32 + 28: launch_ws<192, false, false, 28, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
+            case 32 + 64: launch_ws<192, false, false, 64, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
+            case 32 + 72: launch_ws<192, false, false, 72, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
+            case 32 + 88: launch_ws<192, false, false, 88, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
+            case 32 + 16: launch_ws<192, false, false, 16, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s); break;
             default: break;
         }
         return;

@@ -17,7 +17,7 @@ CSRC = ROOT / "rapiddoc_amd" / "csrc"
 ALLOWED = {
     # template arguments <C, GATED, KEEPX, ABL, PF>
     r"lc_mixer_ws_kernelILi192ELb[01]ELb1E": "KEEPX instantiations (fp32 X tile kept in registers): debug entry only, C = 192 spills by design",
-    r"lc_mixer_ws_kernelILi192ELb[01]ELb[01]ELi(1|2|4|8|12|13|16|17|25|27|29)E": "ablation instantiations of the ws mixer (tools/microbench.py)",
+    r"lc_mixer_ws_kernelILi192ELb[01]ELb[01]ELi(1|2|4|8|12|13|16|17|25|27|28|29|64|72|88)ELb[01]E": "ablation instantiations of the ws mixer (tools/microbench.py)",
     r"lc_mixer_h3_kernel.*Li192E": "round-1 C = 192 mixer: superseded by the ws kernel, kept for A/B (RD_MIXER_WS=0)",
     r"db_(regions|finish)_kernel": "no spill: local arrays (4-corner boxes, hull scratch) of the geometry code shared with the host path "
                                    "(csrc/db_geom.h), indexed at run time; one thread per text-line candidate, ~50 candidates per page",
