@@ -340,7 +340,139 @@ __global__ void __launch_bounds__(256) skinny_gemm_kernel(ConvParams p, int cols
     }
 }
 
+// Round 3: the decode step of the formula head is ~50 DEPENDENT launches of this kernel on 1 - 4 MB of weights each, i.e. every
+// launch is a latency chain (X staging -> LayerNorm -> weight loads -> FMAs -> reduction -> store), not a bandwidth problem
+// (profiles/r3_formula_decode.txt: 11.6 us average, 6.3 us for 1 MB of weights).  skinny2 shortens the chain:
+//   * a wavefront issues ALL weight loads of its first K pass (CW columns x KPL float4 per lane) BEFORE it touches X, so the
+//     HBM round trip runs under the staging + LayerNorm of X instead of behind it;
+//   * X (all of K) is staged and normalised ONCE per workgroup (the old kernel re-staged it for every column pair);
+//   * CW x MT accumulators are reduced over the 64 lanes by a halving butterfly (each exchange step halves the values a lane
+//     carries: NV + 6 shuffles instead of 6 NV), fixed order, deterministic;
+//   * wider column groups per wavefront (CW = 32 / MT): 8 - 16 independent 16-byte loads in flight per lane.
+template <int MT, int CW, int KPL>
+__global__ void __launch_bounds__(256) skinny2_gemm_kernel(ConvParams p, int kpad) {
+    constexpr int NV = MT * CW, KP = 256 * KPL;
+    extern __shared__ __attribute__((aligned(16))) float xs2[];          // [MT][kpad]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_base = (blockIdx.x * 4 + wave) * CW;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int passes = kpad / KP;
+    f32x4 wr[CW][KPL];
+    auto load_w = [&](int pass) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            const int n = min(n_base + c, p.Ng - 1);
+#pragma unroll
+            for (int h = 0; h < KPL; ++h) {
+                const int k = pass * KP + h * 256 + 4 * lane;
+                wr[c][h] = k < p.K ? *reinterpret_cast<const f32x4*>(p.w + (size_t)n * p.K + k) : zero4;
+            }
+        }
+    };
+    load_w(0);
+    // X -> LDS (zero padded to kpad), then the fused pre-LayerNorm: wave w normalises rows w, w + 4, ...
+    for (int i = tid; i < MT * (kpad / 4); i += 256) {
+        const int m = i / (kpad / 4), k = 4 * (i - m * (kpad / 4));
+        *reinterpret_cast<f32x4*>(&xs2[m * kpad + k]) =
+            (m < p.M && k < p.K) ? *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.xld + k) : zero4;
+    }
+    __syncthreads();
+    if (p.ln_g) {          // (K <= 512 here: launch_skinny)
+        for (int m = wave; m < MT; m += 4) {
+            float v[8], s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = lane + 64 * i;
+                v[i] = k < p.K ? xs2[m * kpad + k] : 0.f;
+                s1 += v[i];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+            const float mean = s1 / p.K;
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = lane + 64 * i;
+                const float d = k < p.K ? v[i] - mean : 0.f;
+                s2 += d * d;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+            const float rstd = rsqrtf(s2 / p.K + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = lane + 64 * i;
+                if (k < p.K) xs2[m * kpad + k] = (v[i] - mean) * rstd * p.ln_g[k] + p.ln_b[k];
+            }
+        }
+        __syncthreads();
+    }
+    float acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+    for (int pass = 0; pass < passes; ++pass) {
+        if (pass) load_w(pass);
+#pragma unroll
+        for (int h = 0; h < KPL; ++h) {
+            const int kq = pass * KP + h * 256 + 4 * lane;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(&xs2[m * kpad + kq]);
+#pragma unroll
+                for (int c = 0; c < CW; ++c)
+                    acc[c * MT + m] += xv[0] * wr[c][h][0] + xv[1] * wr[c][h][1] + xv[2] * wr[c][h][2] + xv[3] * wr[c][h][3];
+            }
+        }
+    }
+    // halving butterfly: after the step with offset o a lane carries half as many values; a lane whose bit o is set keeps the
+    // upper half.  When one value is left the remaining steps are plain sums (those lanes end up with copies).
+    int cnt = NV, idx = 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        if (cnt > 1) {
+            cnt >>= 1;
+            const bool up = (lane & o) != 0;
+#pragma unroll
+            for (int j = 0; j < NV / 2; ++j) {
+                if (j < cnt) {
+                    const float lo = acc[j], hi = acc[j + cnt];
+                    const float send = up ? lo : hi, keep = up ? hi : lo;
+                    acc[j] = keep + __shfl_xor(send, o, 64);
+                }
+            }
+            if (up) idx += cnt;
+        } else {
+            acc[0] += __shfl_xor(acc[0], o, 64);
+        }
+    }
+    // value idx = c * MT + m; with NV < 64 the lanes that differ only in the low (plain-sum) bits hold copies: the lowest writes
+    constexpr int LOW = NV >= 64 ? 0 : (64 / NV - 1);
+    const int c = idx / MT, m = idx - c * MT, n = n_base + c;
+    if ((lane & LOW) == 0 && m < p.M && n < p.Ng) {
+        float v = rd_act(acc[0] + (p.bias ? p.bias[n] : 0.f), p.act);
+        if (p.res) v += p.res[(size_t)m * p.rld + n];
+        p.y[(size_t)m * p.yld + n] = v;
+    }
+}
+
+template <int MT, int CW, int KPL>
+static void launch_skinny2(const ConvParams& p, hipStream_t s) {
+    const int kpad = (p.K + 256 * KPL - 1) / (256 * KPL) * (256 * KPL);
+    const size_t lds = (size_t)MT * kpad * sizeof(float);
+    static unsigned long long lds_ok = 0;
+    rd_allow_dynamic_lds((const void*)skinny2_gemm_kernel<MT, CW, KPL>, lds, lds_ok);
+    const int blocks = (p.Ng + 4 * CW - 1) / (4 * CW);
+    hipLaunchKernelGGL((skinny2_gemm_kernel<MT, CW, KPL>), dim3(blocks), dim3(256), lds, s, p, kpad);
+}
+
 static void launch_skinny(const ConvParams& p, hipStream_t s) {
+    static const bool v2 = [] { const char* e = getenv("RD_SKINNY2"); return !(e && e[0] == '0'); }();
+    if (v2 && p.K <= 2048 && (!p.ln_g || p.K <= 512)) {
+        const bool wide = p.K > 512;        // K passes of 1024 (fc2: K = 2048) instead of 512
+        if (p.M <= 8) { if (wide) launch_skinny2<8, 4, 4>(p, s); else launch_skinny2<8, 4, 2>(p, s); return; }
+        if (p.M <= 16) { if (wide) launch_skinny2<16, 2, 4>(p, s); else launch_skinny2<16, 2, 2>(p, s); return; }
+        if (!wide) { launch_skinny2<32, 2, 2>(p, s); return; }       // (M = 32, K = 2048: 256 KB of X - the chunked kernel below)
+    }
     // columns per wavefront: enough workgroups to fill the chip, not so many that X is re-staged excessively
     int cpw = 2;
     while ((p.Ng + 4 * cpw - 1) / (4 * cpw) > 2048 && cpw < 16) cpw *= 2;

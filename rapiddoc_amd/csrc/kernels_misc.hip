@@ -389,33 +389,101 @@ void launch_gap_partial(const float* x, int xld, int N, int HW, int C, float* pa
     hipLaunchKernelGGL(gap_partial_kernel, dim3(chunks, N), dim3(256), 0, s, x, xld, HW, C, partial, chunks);
 }
 
+// One workgroup per image; three short phases, each spread over all 256 threads (round 2's version walked the pooling partials
+// and the rows of W1 serially per thread: 128 launches of 16 - 44 us of pure load latency).  Every sum has a fixed order.
 __global__ void __launch_bounds__(256) se_fc_kernel(SeFcParams p) {
-    extern __shared__ float sm[];  // mean[C] + hid[Cr]
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // mean[C] + hid[Cr] + part[KS][C]
     float* mean = sm;
     float* hid = sm + p.C;
-    const int n = blockIdx.x;
-    for (int c = threadIdx.x; c < p.C; c += 256) {
+    float* part = hid + ((p.Cr + 3) & ~3);
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // 1. pooled mean: thread (slice, channel quad) adds every KS-th partial row, then the KS slices are added in order
+    const int c4n = p.C >> 2;
+    const int KS = max(1, min(8, 256 / c4n));
+    if (tid < KS * c4n) {
+        const int sl = tid / c4n, cg = tid - sl * c4n;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = sl; k < p.chunks; k += KS) s += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)n * p.chunks + k) * p.C + 4 * cg);
+        *reinterpret_cast<f32x4*>(part + (size_t)sl * p.C + 4 * cg) = s;
+    }
+    __syncthreads();
+    for (int c = tid; c < p.C; c += 256) {
         float s = 0.f;
-        for (int k = 0; k < p.chunks; ++k) s += p.partial[((size_t)n * p.chunks + k) * p.C + c];
+        for (int sl = 0; sl < KS; ++sl) s += part[sl * p.C + c];
         mean[c] = s * p.inv_hw;
     }
     __syncthreads();
-    for (int r = threadIdx.x; r < p.Cr; r += 256) {
-        float s = p.b1[r];
-        const float* w = p.w1 + (size_t)r * p.C;
-        for (int c = 0; c < p.C; ++c) s = fmaf(w[c], mean[c], s);
-        hid[r] = fmaxf(s, 0.f);
+    // 2. hidden units: a wavefront takes Cr / 4 consecutive units, eight at a time: lanes across the channels (16-byte coalesced
+    //    loads of the eight rows of W1, all issued before the first is used), halving butterfly over the eight sums
+    {
+        const int per = (p.Cr + 3) >> 2, r_lo = wave * per, r_hi = min(p.Cr, r_lo + per);
+        const int steps = (p.C + 255) >> 8;                 // channel quads per lane (C <= 512)
+        for (int g0 = r_lo; g0 < r_hi; g0 += 8) {
+            f32x4 wv[8][2];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = min(g0 + j, p.Cr - 1);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int c = 4 * lane + 256 * i;
+                    wv[j][i] = (i < steps && c < p.C) ? *reinterpret_cast<const f32x4*>(p.w1 + (size_t)r * p.C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = 4 * lane + 256 * i;
+                if (i < steps && c < p.C) {
+                    const f32x4 mv = *reinterpret_cast<const f32x4*>(mean + c);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        acc[j] += wv[j][i][0] * mv[0] + wv[j][i][1] * mv[1] + wv[j][i][2] * mv[2] + wv[j][i][3] * mv[3];
+                }
+            }
+            int cnt = 8, idx = 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                if (cnt > 1) {
+                    cnt >>= 1;
+                    const bool up = (lane & o) != 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (j < cnt) {
+                            const float lo = acc[j], hi = acc[j + cnt];
+                            acc[j] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, o, 64);
+                        }
+                    }
+                    if (up) idx += cnt;
+                } else {
+                    acc[0] += __shfl_xor(acc[0], o, 64);
+                }
+            }
+            const int r = g0 + idx;
+            if ((lane & 7) == 0 && r < r_hi) hid[r] = fmaxf(acc[0] + p.b1[r], 0.f);
+        }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < p.C; c += 256) {
+    // 3. gates: one thread per channel, its row of W2 (Cr floats, 16-byte loads)
+    for (int c = tid; c < p.C; c += 256) {
         float s = p.b2[c];
         const float* w = p.w2 + (size_t)c * p.Cr;
-        for (int r = 0; r < p.Cr; ++r) s = fmaf(w[r], hid[r], s);
+        if ((p.Cr & 3) == 0) {
+            for (int r = 0; r < p.Cr; r += 4) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + r);
+                s = fmaf(wv[0], hid[r], s); s = fmaf(wv[1], hid[r + 1], s); s = fmaf(wv[2], hid[r + 2], s); s = fmaf(wv[3], hid[r + 3], s);
+            }
+        } else {
+            for (int r = 0; r < p.Cr; ++r) s = fmaf(w[r], hid[r], s);
+        }
         p.scale[(size_t)n * p.C + c] = rd_act(s, p.gate);
     }
 }
 void launch_se_fc(const SeFcParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(se_fc_kernel, dim3(p.N), dim3(256), (p.C + p.Cr) * sizeof(float), s, p);
+    const int ks = std::max(1, std::min(8, 256 / (p.C >> 2)));
+    const size_t sh = ((size_t)p.C + ((p.Cr + 3) & ~3) + (size_t)ks * p.C) * sizeof(float);
+    hipLaunchKernelGGL(se_fc_kernel, dim3(p.N), dim3(256), sh, s, p);
 }
 
 __global__ void __launch_bounds__(256) scale_channels_kernel(const float* x, int xld, float* y, int yld,

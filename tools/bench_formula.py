@@ -17,7 +17,8 @@ man = [(n, (2562, 512) if n.endswith("embed_positions.weight") else s, d) for n,
 st = W.synth_state_dict(man, 0)
 enc_eng = RdEngine("pphgnetv2_b6_formula").load_weights({k: v for k, v in st.items() if k.startswith("backbone.")})
 dec_eng = RdEngine("ppformulanet_head").load_weights({k: v for k, v in st.items() if k.startswith("head.")})
-for B in (1, 8, 32):
+BATCHES = [int(a) for a in sys.argv[1:]] or [1, 8, 32]
+for B in BATCHES:
     x = torch.rand((B, 1, 384, 384), device="cuda") * 2 - 1
     enc = enc_eng.formula_encoder_forward(x)
     torch.cuda.synchronize()
