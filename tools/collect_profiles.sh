@@ -27,3 +27,20 @@ timeout 200 python $R/bench.py --only backbone 2>/dev/null | tail -1 > $O/${TAG}
 timeout 200 python $R/bench.py --rec-mode strict --no-cpu-baseline --no-extra-passes 2>/dev/null | tail -1 > $O/${TAG}_bench_strict.json
 cat $O/${TAG}_bench.json | cut -c1-900
 head -8 $O/${TAG}_rocprofv3_kernel_stats.csv | cut -c1-140
+# microbenchmarks behind DESIGN.md s3c: the ws mixer (round-2 form 200 vs prefetching form 400) and its ablations, each in its own process
+{
+  echo "# tools/mb_ws.py 200 400  (lc_mixer_ws_kernel<192>: round-2 form vs prefetching form, isolated, 20 iterations, error vs fp64)"
+  timeout 200 python $R/tools/mb_ws.py 200 400 2>/dev/null | grep mixer
+  echo "# tools/mb_ws_abl.py <bits>  (ablations, results are garbage, timing only; 32+ = prefetching form)"
+  for a in 0 1 4 8 12 13 16 17 25 29 32 36 40 44 48 60 96 104 120; do timeout 100 python $R/tools/mb_ws_abl.py $a 2>/dev/null | grep "ws M="; done
+} > $O/${TAG}_microbench_mixer_ws.txt
+# formula head: decode tokens/s at B = 8 / 32 and the per-kernel statistics of the B = 8 loop
+{
+  echo "# tools/bench_formula.py 8 32"
+  timeout 200 python $R/tools/bench_formula.py 8 32 2>/dev/null | grep -E "encoder|decoder"
+  echo "# RD_SKINNY2=0 (round-2 skinny GEMM)"
+  RD_SKINNY2=0 timeout 200 python $R/tools/bench_formula.py 8 32 2>/dev/null | grep -E "decoder"
+  echo "# rocprofv3 --kernel-trace --stats, B = 8, graphs off (tools/prof_formula.sh): decode-loop kernels"
+  bash $R/tools/prof_formula.sh 8 2>/dev/null | grep -E "skinny|dec_|layernorm"
+} > $O/${TAG}_formula_decode.txt
+cat $O/${TAG}_formula_decode.txt | cut -c1-160
