@@ -32,6 +32,13 @@ F16_MFMA_PEAK_TFLOPS = 2516.6   # same guide: v_mfma_f32_32x32x16_f16 dense
 HBM_PEAK_GBS = 8000.0
 
 
+def _throughput_rule(args):
+    if args.rec_chunking == "adaptive":
+        return ("chunks of the aspect-sorted lines whose size follows their width so that the persistent kernels' tile counts fill whole "
+                "rounds of the chip (ocr_host.rec_batches_adaptive, 16-160 lines), width rounded up to x%d" % args.rec_width_multiple)
+    return "chunks of %d aspect-sorted lines, width rounded up to x%d" % (args.rec_batch, args.rec_width_multiple)
+
+
 def load_states():
     from rapiddoc_amd import weights as W
     g = ROOT / "tests" / "golden"
@@ -163,6 +170,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-profile", type=str, default="")
     ap.add_argument("--rec-batch", type=int, default=64)
+    ap.add_argument("--rec-chunking", choices=("fixed", "adaptive"), default="adaptive",
+                    help="throughput mode: chunks of --rec-batch lines, or chunk sizes chosen per width so that the persistent kernels' "
+                         "tile counts fill whole rounds of the chip (ocr_host.rec_batches_adaptive)")
     ap.add_argument("--rec-streams", type=int, default=8)
     ap.add_argument("--rec-width-multiple", type=int, default=32, help="padded rec batch width is rounded up to this (plan-cache granularity)")
     ap.add_argument("--inflight", type=int, default=1, help="page batches (steps) in flight per GPU: each runs a whole batch on its own "
@@ -215,7 +225,7 @@ def main():
 
     states = load_states()
     pool_kw = dict(device=dev_index, workers=args.workers, rec_batch_num=args.rec_batch, rec_width_multiple=args.rec_width_multiple,
-                   n_rec_streams=max(1, args.rec_streams // max(1, args.workers)))
+                   n_rec_streams=max(1, args.rec_streams // max(1, args.workers)), rec_chunking=args.rec_chunking)
     pool = PagePipelinePool(states, rec_mode=args.rec_mode, **pool_kw)
     pipe = pool.pipes[0]
     extra_pools = [PagePipelinePool(states, rec_mode=args.rec_mode, **pool_kw) for _ in range(max(1, args.inflight) - 1)]
@@ -421,7 +431,7 @@ def main():
                       "rec_launch_batches": int(pool2.stats.get("rec_batches", 0)),
                       "rule": "one global np.argsort of all %d lines, chunks of 6, padded width int(48 * max ratio of the chunk) "
                               "(rapid_ocr.py:404-449); chunks of equal width share a launch" % n_lines if other == "strict"
-                              else "chunks of %d lines, width rounded up to x%d" % (args.rec_batch, args.rec_width_multiple)}
+                              else _throughput_rule(args)}
         del pool2
         if pipe.det.precision == "auto":
             for e in pool.engines:
@@ -450,8 +460,7 @@ def main():
                                     "fp32 MFMA for the rest; range-guarded with fp32 fallback (DESIGN.md s3)"
                                     if pipe.det.precision == "auto" else pipe.det.precision,
                        "rec_batching": args.rec_mode if args.rec_mode == "strict" else
-                                       "throughput (chunks of %d aspect-sorted lines, width rounded up to x%d; the reference's own "
-                                       "batching is timed in strict_rec_batching)" % (args.rec_batch, args.rec_width_multiple),
+                                       "throughput (%s; the reference's own batching is timed in strict_rec_batching)" % _throughput_rule(args),
                        "pages_per_gpu": P, "global_pages": n_global, "pages_gathered": len(out), "result_crc32": result_crc,
                        "page_sets_cycled": K_sets,
                        "lines_per_step": n_lines, "host_stage_ms": host_stats,

@@ -155,6 +155,58 @@ def rec_batches(wh_ratios: Sequence[float], rec_batch_num: int = 6, img_h: int =
     return out
 
 
+# Round-quantisation model of one recogniser chunk on a 256-CU MI355X (microseconds): the persistent kernels of the
+# backbone run whole ROUNDS of workgroup tiles - a chunk whose tile count is 3.09 x 256 costs four rounds.  Per layer family:
+# (rounds per unit of work, microseconds per round), measured at 64 x 48 x 1056 (tools/op_profile.py).
+_CHUNK_FIXED_US = 150.0           # ~59 launches of a backbone forward
+_CHUNK_LINEAR_US = 0.14           # per line and token column: depthwise convs, stem, pools (no tile quantisation to speak of)
+
+
+def rec_chunk_cost(n, wpad, n_cu: int = 256):
+    """Estimated GPU time (us) of a recogniser backbone forward on `n` lines padded to width `wpad` (numpy arrays broadcast)."""
+    n = np.asarray(n, dtype=np.float64)
+    t = np.asarray(wpad, dtype=np.float64) // 8                        # token columns per line row
+    px96, px192, px384 = n * 24 * t, n * 12 * t, n * 6 * t            # pixels at the C = 96 / 192 / 384 stages
+    rnd = lambda x: np.ceil(x / n_cu - 1e-9)
+    mt384, mt192 = np.ceil(px384 / 256), np.ceil(px192 / 256)          # 256-row GEMM tiles
+    c = 6 * 37.0 * rnd(px192 / 128)                                    # six C = 192 weight-streaming mixers, 128-pixel tiles
+    c = c + 3 * 21.0 * np.ceil(px96 / 16 / (16 * n_cu) - 1e-9)         # three C = 96 resident mixers, 16-pixel wavefront tiles
+    c = c + (2 * 51.0 + 28.0 + 19.0) * rnd(mt384 * 3)                  # N = 384 GEMMs of the C = 384 blocks (256 x 128 tiles)
+    c = c + 2 * 27.0 * rnd(mt384 * 6)                                  # N = 768
+    c = c + (17.0 + 13.0) * rnd(mt192 * 2)                             # N = 192 at the C = 192 stage
+    return c + _CHUNK_LINEAR_US * n * t + _CHUNK_FIXED_US
+
+
+def rec_batches_adaptive(wh_ratios: Sequence[float], img_h: int = REC_IMG_H, img_w: int = REC_IMG_W, width_multiple: int = 32,
+                         n_min: int = 16, n_max: int = 160, n_step: int = 2, n_cu: int = 256) -> List[Tuple[np.ndarray, int]]:
+    """Throughput-mode chunking of the aspect-sorted line list with chunk SIZES chosen so that the persistent kernels' tile counts
+    fill whole rounds of the chip (`rec_chunk_cost`): greedily, the chunk with the most lines per estimated microsecond.
+    Same return format as `rec_batches`; every line is in exactly one chunk, chunks are runs of the sorted order, the padded width
+    is the reference's `int(img_h * max_ratio)` of the chunk rounded up to `width_multiple`."""
+    ratios = np.array([float(r) for r in wh_ratios])
+    order = np.argsort(ratios, kind="stable")
+    rs = ratios[order]
+    wp = (img_h * np.maximum(img_w / img_h, rs)).astype(np.int64)
+    if width_multiple > 1:
+        wp = (wp + width_multiple - 1) // width_multiple * width_multiple
+    out: List[Tuple[np.ndarray, int]] = []
+    i, total = 0, len(rs)
+    cand = np.arange(n_min, n_max + 1, n_step)
+    while i < total:
+        left = total - i
+        if left <= n_min:
+            n = left
+        else:
+            ns = np.minimum(cand, left)
+            cost = rec_chunk_cost(ns, wp[i + ns - 1], n_cu)
+            n = int(ns[int(np.argmax(ns / cost))])
+            if 0 < left - n < n_min:          # do not leave a sliver behind
+                n = left if left <= n_max else left - n_min
+        out.append((order[i: i + n], int(wp[i + n - 1])))
+        i += n
+    return out
+
+
 def rec_resized_width(w: float, h: float, wpad: int, img_h: int = REC_IMG_H) -> int:
     """resize_norm_img: resized_w = min(imgW, ceil(imgH * w/h))."""
     return int(min(wpad, math.ceil(img_h * (w / h))))

@@ -111,7 +111,7 @@ class PageResult:
 class PagePipeline:
     def __init__(self, states: Dict[str, object], device: int = 0, characters: Optional[Sequence[str]] = None,
                  rec_batch_num: int = 64, rec_width_multiple: int = 32, keep_feats: bool = False, n_rec_streams: int = 4,
-                 rec_mode: str = "throughput"):
+                 rec_mode: str = "throughput", rec_chunking: str = "fixed"):
         """`states`: {'ppocrv6_det': ..., 'ppocrv6_rec': ..., 'pphgnetv2_b4': ...}, each a .safetensors path,
         bytes, or name->ndarray dict.
 
@@ -124,10 +124,16 @@ class PagePipeline:
                         ignored.
           "throughput"  GPU-sized chunks (`rec_batch_num` lines, default 64) of the same aspect-sorted list, padded width
                         rounded up to `rec_width_multiple`: same per-tensor parity with the oracle, different padded
-                        widths than the reference would have used."""
+                        widths than the reference would have used.  `rec_chunking="adaptive"` lets the chunk SIZE follow the
+                        width: `ocr_host.rec_batches_adaptive` picks, chunk by chunk, the size with the most lines per estimated
+                        microsecond, i.e. tile counts of the persistent kernels that fill whole rounds of the 256 CUs (64 lines of
+                        width 1056 are 3.09 rounds of mixer tiles and cost four)."""
         if rec_mode not in ("strict", "throughput"):
             raise ValueError("rec_mode must be 'strict' or 'throughput'")
+        if rec_chunking not in ("fixed", "adaptive"):
+            raise ValueError("rec_chunking must be 'fixed' or 'adaptive'")
         self.rec_mode = rec_mode
+        self.rec_chunking = rec_chunking
         if rec_mode == "strict":
             rec_batch_num, rec_width_multiple = 6, 1
         self.device = device
@@ -286,8 +292,11 @@ class PagePipeline:
         eff_h = np.where(rots_a == 1, cws_a, chs_a)
         ratios = (eff_w / eff_h).tolist()
         strict = self.rec_mode == "strict"
-        batches = ocr_host.rec_batches(ratios, self.rec_batch_num, width_multiple=self.rec_width_multiple, strict=strict,
-                                       merge_equal_width=strict)
+        if not strict and self.rec_chunking == "adaptive":
+            batches = ocr_host.rec_batches_adaptive(ratios, width_multiple=self.rec_width_multiple)
+        else:
+            batches = ocr_host.rec_batches(ratios, self.rec_batch_num, width_multiple=self.rec_width_multiple, strict=strict,
+                                           merge_equal_width=strict)
         order_all = np.concatenate([c for c, _ in batches])
         wpad_all = np.concatenate([np.full(len(c), w) for c, w in batches])
         descs = np.zeros(n, dtype=LINE_DTYPE)

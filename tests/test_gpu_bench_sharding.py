@@ -12,8 +12,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parents[1]
-COMMON = ["--scaling", "strong", "--global-pages", "4", "--rec-batch", "1", "--rec-streams", "2", "--steps", "1", "--warmup", "0",
-          "--no-cpu-baseline"]
+COMMON = ["--scaling", "strong", "--global-pages", "4", "--rec-chunking", "fixed", "--rec-batch", "1", "--rec-streams", "2", "--steps", "1",
+          "--warmup", "0", "--no-cpu-baseline"]
 
 
 def _last_json(out: str) -> dict:
@@ -37,4 +37,23 @@ def test_two_ranks_on_one_gpu_equal_one_rank():
     assert a["config"]["pages_gathered"] == b["config"]["pages_gathered"] == 4
     assert b["config"]["pages_per_gpu"] == 2
     assert a["config"]["lines_per_step"] == b["config"]["lines_per_step"] == 180
+    assert a["config"]["result_crc32"] == b["config"]["result_crc32"]
+
+
+def test_two_ranks_weak_scaling_cover_the_same_global_list():
+    """--scaling weak: 2 pages per rank x 2 ranks = the same 4-page global list (rank r takes pages r, r + 2): same crc as the
+    single-process run over 4 pages."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    base = ["--rec-chunking", "fixed", "--rec-batch", "1", "--rec-streams", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--scaling", "weak", "--pages", "4", *base], capture_output=True, text=True,
+                         timeout=900, env=env, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a = _last_json(one.stdout)
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29743", str(ROOT / "bench.py"), "--gpus", "2", "--scaling", "weak", "--pages", "2", *base],
+                         capture_output=True, text=True, timeout=900, env=dict(env, RD_BENCH_BACKEND="gloo"), cwd=ROOT)
+    assert two.returncode == 0, two.stderr[-2000:]
+    b = _last_json(two.stdout)
+    assert b["n_gpus"] == 2 and b["scaling"] == "weak" and b["config"]["pages_per_gpu"] == 2
+    assert a["config"]["pages_gathered"] == b["config"]["pages_gathered"] == 4
     assert a["config"]["result_crc32"] == b["config"]["result_crc32"]

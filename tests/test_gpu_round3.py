@@ -85,11 +85,11 @@ def test_formula_decoder_300_tokens_equals_reference(golden_dir):
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def bench_pipe(golden_dir):
-    """The pipeline exactly as bench.py builds it (rec batches of 64, width multiple 32, 8 rec streams) + its 32 pages."""
+    """The pipeline exactly as bench.py builds it (adaptive rec chunking, width multiple 32, 8 rec streams) + its 32 pages."""
     from rapiddoc_amd.pages import synth_pages
     from rapiddoc_amd.pipeline import PagePipeline
     states = _states(golden_dir, ("ppocrv6_det", "ppocrv6_rec", "pphgnetv2_b4"))
-    pipe = PagePipeline(states, rec_batch_num=64, rec_width_multiple=32, n_rec_streams=8)
+    pipe = PagePipeline(states, rec_batch_num=64, rec_width_multiple=32, n_rec_streams=8, rec_chunking="adaptive")
     pages_np, boxes = synth_pages(list(range(32)))
     return pipe, states, torch.from_numpy(pages_np).cuda(), pages_np, boxes
 
@@ -144,20 +144,25 @@ def _check_rec_batches_against_oracle(pipe, st_rec, batch_ids, flat_lines):
             assert flat_lines[i][2] == ocr_host.format_score(dec[j][1])
 
 
-def test_bench_step_rec_batches_match_oracle(bench_pipe):
-    """One whole benchmark step (32 pages, 1440 lines, 23 rec batches of 64 on 8 streams, two-stage recogniser): the first,
-    a middle and the last rec batch against the oracle on the tensors the crop kernels produced, and the strings the step
-    returned are the decode of those (idx, prob).  Two steps give the same result (what bench.py's result_crc32 hashes)."""
+@pytest.mark.parametrize("chunking", ["adaptive", "fixed"])
+def test_bench_step_rec_batches_match_oracle(bench_pipe, chunking):
+    """One whole benchmark step (32 pages, 1440 lines on 8 streams, two-stage recogniser) in the chunking bench.py runs ("adaptive":
+    chunk sizes chosen per width so that the persistent kernels fill whole rounds of the chip) and in fixed chunks of 64 (23
+    batches): the first, a middle and the last rec batch against the oracle on the tensors the crop kernels produced, and the
+    strings the step returned are the decode of those (idx, prob).  Two steps give the same result (what bench.py's result_crc32
+    hashes)."""
     from rapiddoc_amd.pipeline import render_text_maps
     pipe, states, pages, pages_np, boxes = bench_pipe
     det_hw = pipe.det_preprocess(pages[:1])[1]
     maps = render_text_maps(boxes, pages_np.shape[1:3], det_hw, pages.device)
     pipe.keep_rec_inputs = True
+    pipe.rec_chunking = chunking
     try:
         res = pipe.run_batch(pages, None, det_maps_override=maps)
         assert [len(r.lines) for r in res] == [45] * 32
         nb = len(pipe.last_rec_batches)
-        assert nb == 23 and sum(len(c) for c, *_ in pipe.last_rec_batches) == 1440
+        sizes = [len(c) for c, *_ in pipe.last_rec_batches]
+        assert sum(sizes) == 1440 and (nb == 23 if chunking == "fixed" else (all(16 <= n <= 160 for n in sizes) and nb < 23))
         flat = [ln for r in res for ln in r.lines]
         _check_rec_batches_against_oracle(pipe, O.as_torch_state(states["ppocrv6_rec"]), (0, nb // 2, nb - 1), flat)
         again = pipe.run_batch(pages, None, det_maps_override=maps)
@@ -165,6 +170,7 @@ def test_bench_step_rec_batches_match_oracle(bench_pipe):
     finally:
         pipe.keep_rec_inputs = False
         pipe.last_rec_batches = []
+        pipe.rec_chunking = "adaptive"
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -148,3 +148,27 @@ def test_char_table_and_row_parser_roundtrip():
     rows[0, 4:8] = np.frombuffer(np.float32(0.875).tobytes(), np.uint8)
     rows[0, 16:16 + len(t)] = np.frombuffer(t, np.uint8)
     assert ocr_host.parse_ctc_rows(rows) == [("a\u6587 ", 0.875), ("", 0.0)]
+
+
+def test_rec_batches_adaptive_partitions_the_sorted_list():
+    """Throughput-mode chunking with width-dependent chunk sizes: every line in exactly one chunk, chunks are runs of the aspect-sorted
+    order, the padded width is the reference's int(48 * max ratio) of the chunk rounded up to the multiple, sizes stay inside the
+    bounds, and the cost model it optimises prefers a chunk that fills whole rounds of the chip (62 lines of width 1056 = 3 rounds of
+    C = 192 mixer tiles) over one that spills into a fourth (64 lines)."""
+    from rapiddoc_amd import ocr_host as H
+    rng = np.random.default_rng(3)
+    ratios = rng.uniform(2.0, 44.0, 1440).tolist()
+    bat = H.rec_batches_adaptive(ratios, width_multiple=32)
+    order = np.concatenate([c for c, _ in bat])
+    assert sorted(order.tolist()) == list(range(1440))
+    assert np.all(np.diff(np.asarray(ratios)[order]) >= 0)
+    for chunk, wpad in bat:
+        assert 16 <= len(chunk) <= 160 or chunk is bat[-1][0]
+        need = int(48 * max(320 / 48, max(ratios[i] for i in chunk)))
+        assert wpad % 32 == 0 and need <= wpad < need + 32
+    assert len(bat) < len(H.rec_batches(ratios, 64, width_multiple=32)) + 8
+    c62, c64 = float(H.rec_chunk_cost(62, 1056)), float(H.rec_chunk_cost(64, 1056))
+    assert c62 / 62 < c64 / 64
+    # few lines: one chunk
+    assert [len(c) for c, _ in H.rec_batches_adaptive([5.0] * 9)] == [9]
+    assert H.rec_batches_adaptive([]) == []
