@@ -247,11 +247,24 @@ static inline void dw_tiled_geom(const DwParams& p, int TW, int& c4n, int& threa
     while ((long)((groups + gpb - 1) / gpb) * p.N > 8192) gpb += lanes_p;
     chunks = (groups + gpb - 1) / gpb;
 }
+static inline int dw_env_tw(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    const int v = e ? atoi(e) : 0;
+    return (v == 4 || v == 8) ? v : dflt;
+}
+static inline int dw3_tw() { static const int v = dw_env_tw("RD_DW3_TW", 8); return v; }
+static inline int dw5_tw() { static const int v = dw_env_tw("RD_DW5_TW", 8); return v; }
+static inline int dw7_tw() {
+    static const int v = [] { const char* e = std::getenv("RD_DW7_TW"); return e && atoi(e) == 8 ? 8 : 4; }();
+    return v;
+}
 static inline int dw_tiled_tw(const DwParams& p) {
     if (p.C % 4 != 0 || (p.C >> 2) > 256) return 0;
-    if (p.KH == 3 && p.KW == 3 && (p.SW == 1 || p.SW == 2)) return p.SW == 1 ? 8 : 4;
-    if (p.KH == 5 && p.KW == 5 && p.SW == 1) return 8;
-    if (p.KH == 7 && p.KW == 7 && p.SW == 1) return 8;
+    if (p.KH == 3 && p.KW == 3 && (p.SW == 1 || p.SW == 2)) return p.SW == 1 ? dw3_tw() : 4;
+    if (p.KH == 5 && p.KW == 5 && p.SW == 1) return dw5_tw();
+    // 7x7: TW = 8 needs 260 VGPRs (14-column row window + 8 accumulators of float4): one wavefront per SIMD, 271 us on the det
+    // neck's 96-channel map; TW = 4 fits three
+    if (p.KH == 7 && p.KW == 7 && p.SW == 1) return dw7_tw();
     return 0;
 }
 int dwconv_gap_chunks(const DwParams& p) {
@@ -284,14 +297,20 @@ void launch_dwconv(const DwParams& p, hipStream_t s) {
         int c4n, threads, gw, g, gpb, chunks;
         dw_tiled_geom(p, tw, c4n, threads, gw, g, gpb, chunks);
         dim3 grid(chunks, p.N), block(threads);
-        if (p.KH == 3 && p.SW == 1)
+        if (p.KH == 3 && p.SW == 1 && tw == 8)
             hipLaunchKernelGGL((dwconv_tiled_kernel<3, 3, 1, 8>), grid, block, 0, s, p, c4n, gw, g, gpb);
+        else if (p.KH == 3 && p.SW == 1)
+            hipLaunchKernelGGL((dwconv_tiled_kernel<3, 3, 1, 4>), grid, block, 0, s, p, c4n, gw, g, gpb);
         else if (p.KH == 3)
             hipLaunchKernelGGL((dwconv_tiled_kernel<3, 3, 2, 4>), grid, block, 0, s, p, c4n, gw, g, gpb);
-        else if (p.KH == 5)
+        else if (p.KH == 5 && tw == 8)
             hipLaunchKernelGGL((dwconv_tiled_kernel<5, 5, 1, 8>), grid, block, 0, s, p, c4n, gw, g, gpb);
-        else
+        else if (p.KH == 5)
+            hipLaunchKernelGGL((dwconv_tiled_kernel<5, 5, 1, 4>), grid, block, 0, s, p, c4n, gw, g, gpb);
+        else if (tw == 8)
             hipLaunchKernelGGL((dwconv_tiled_kernel<7, 7, 1, 8>), grid, block, 0, s, p, c4n, gw, g, gpb);
+        else
+            hipLaunchKernelGGL((dwconv_tiled_kernel<7, 7, 1, 4>), grid, block, 0, s, p, c4n, gw, g, gpb);
         return;
     }
     const long total = (long)p.N * p.OH * p.OW * (p.C >> 2);
