@@ -505,6 +505,62 @@ TView Builder::linear(const std::string& prefix, const TView& x, int act, const 
     return conv(prefix + ".weight", has_weight(prefix + ".bias") ? prefix + ".bias" : "", "", x, ConvGeom{}, act, out, res);
 }
 
+bool Builder::deconv_pair_to_prob(const std::string& w1n, const std::string& b1n, const std::string& bn1, const std::string& w2n,
+                                  const std::string& b2n, const TView& x, const TView& out) {
+    static const bool off = [] { const char* e = getenv("RD_DET_HEAD_FUSED"); return e && e[0] == '0'; }();
+    const HostTensor& w1 = ws_->get(w1n);
+    const HostTensor& w2 = ws_->get(w2n);
+    if (off || w1.shape.size() != 4 || w2.shape.size() != 4 || w1.shape[2] != 2 || w1.shape[3] != 2 || w2.shape[2] != 2 || w2.shape[3] != 2)
+        return false;
+    const int cin = (int)w1.shape[0], cmid = (int)w1.shape[1], cout = (int)w2.shape[1];
+    if (!det_head_tail_supported(cin, cmid, cout) || (int)w2.shape[0] != cmid || cin != x.c) return false;
+    RD_CHECK(out.h == 4 * x.h && out.w == 4 * x.w && out.c == 1 && out.n == x.n, "det head tail: output view mismatch");
+    const std::string key = w1n + "|" + bn1 + "|" + w2n + "|pair";
+    if (!planning()) {
+        if (!pb_->has(key + "#w1")) {
+            std::vector<float> shift;
+            std::vector<float> scale = bn_scale_shift(bn1, cmid, shift);
+            std::vector<float> wa((size_t)4 * cmid * cin), ba(cmid, 0.f), wb((size_t)4 * cmid), bb(1, 0.f);
+            const float* s1 = w1.f32();          // [cin][cmid][2][2]
+            for (int ci = 0; ci < cin; ++ci)
+                for (int co = 0; co < cmid; ++co)
+                    for (int tap = 0; tap < 4; ++tap)
+                        wa[((size_t)tap * cmid + co) * cin + ci] = s1[((size_t)ci * cmid + co) * 4 + tap] * scale[co];
+            if (!b1n.empty()) {
+                const float* bs = ws_->get(b1n).f32();
+                for (int co = 0; co < cmid; ++co) ba[co] = bs[co] * scale[co];
+            }
+            for (int co = 0; co < cmid; ++co) ba[co] += shift[co];
+            const float* s2 = w2.f32();          // [cmid][1][2][2]
+            for (int co = 0; co < cmid; ++co)
+                for (int tap = 0; tap < 4; ++tap) wb[(size_t)tap * cmid + co] = s2[(size_t)co * 4 + tap];
+            if (!b2n.empty()) bb[0] = ws_->get(b2n).f32()[0];
+            pb_->add(key + "#w1", wa);
+            pb_->add(key + "#b1", ba);
+            pb_->add(key + "#w2", wb);
+            pb_->add(key + "#b2", bb);
+        }
+        return true;
+    }
+    const float* pw1 = pb_->ptr(key + "#w1");
+    const float* pb1 = pb_->ptr(key + "#b1");
+    const float* pw2 = pb_->ptr(key + "#w2");
+    const float* pb2 = pb_->ptr(key + "#b2");
+    OpRecord r;
+    r.name = w1n + "+" + w2n;
+    r.kind = "det_head_tail";
+    r.cfg = "fused";
+    const double m = (double)x.n * x.h * x.w;
+    r.flops = 2.0 * m * (4.0 * cmid * cin + 16.0 * cmid);
+    r.bytes = 4.0 * (m * cin + m * 16);
+    const TView xv = x, yv = out;
+    r.run = [xv, yv, pw1, pb1, pw2, pb2](const Plan& pl, const RunCtx& c) {
+        launch_det_head_tail(pl.vptr(xv, c), pl.ld(xv), xv.n, xv.h, xv.w, pw1, pb1, pw2, pb2, pl.vptr(yv, c), c.stream);
+    };
+    emit(std::move(r));
+    return true;
+}
+
 TView Builder::deconv2x2(const std::string& wname, const std::string& bname, const std::string& bn, const TView& x,
                          int act, const TView* out) {
     // nn.ConvTranspose2d(k=2, stride=2): weight [Cin, Cout, 2, 2]  (det_db_head.py:66-72,124-129)

@@ -167,6 +167,9 @@ class Builder {
     void fold_conv(const std::string& wname, const std::string& bname, const std::string& bn);
     TView linear(const std::string& prefix, const TView& x, int act, const TView* out = nullptr,
                  const TView* res = nullptr);
+    // ConvTranspose2d(2, 2) + BN + ReLU -> ConvTranspose2d(2, 2) to ONE channel -> sigmoid, fused when the widths allow (DB head tail)
+    bool deconv_pair_to_prob(const std::string& w1n, const std::string& b1n, const std::string& bn1, const std::string& w2n,
+                             const std::string& b2n, const TView& x, const TView& out);
     TView deconv2x2(const std::string& wname, const std::string& bname, const std::string& bn, const TView& x, int act,
                     const TView* out = nullptr);
     TView stem3x3s2(const std::string& wname, const std::string& bn, const TView& x_nchw, int act);

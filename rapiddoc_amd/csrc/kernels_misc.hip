@@ -527,6 +527,69 @@ void launch_scale_channels(const float* x, int xld, float* y, int yld, const flo
 }
 
 // --------------------------------------------------------------------------------------------------
+// DB head tail: ConvTranspose2d(C, C, 2, 2) + BN + ReLU -> ConvTranspose2d(C, 1, 2, 2) -> sigmoid (det_db_head.py:66-72,124-144) as ONE
+// kernel.  As two transposed-conv GEMMs (N = 96 and N = 4 on 128-wide fp32 MFMA tiles, scatter epilogues) they took 232 us per
+// 8 pages at 1.2 - 1.5 TB/s and passed a 130-MB 24-channel map of the doubled resolution through HBM.  A stride-2 2x2 transposed
+// conv has no overlap between taps: one input pixel owns a 2 x 2 block of the middle map and through it a 4 x 4 block of the
+// probability map.  One thread = one input pixel: 24 inputs in registers, per tap 24 x 24 FMAs (weights are wave-uniform: scalar
+// loads), ReLU, 4 x 24 FMAs of the final layer, sigmoid; four 16-byte stores per thread, consecutive lanes = consecutive columns.
+// Plain fp32 FMAs in every precision mode.
+// --------------------------------------------------------------------------------------------------
+// (Two pixels per thread, so that a scalar weight load feeds two FMAs, measured 126 us against 69: the wider loop body made the
+//  compiler hoist the scalar loads until it ran out of SGPRs - 2400 v_readlane / v_writelane spills - and half the wavefronts hide
+//  the scalar-load latency worse.)
+template <int CIN, int CMID>
+__global__ void __launch_bounds__(256) det_head_tail_kernel(const float* __restrict__ x, int xld, int N, int H, int W,
+                                                            const float* __restrict__ w1, const float* __restrict__ b1,
+                                                            const float* __restrict__ w2, const float* __restrict__ b2p, float* __restrict__ y) {
+    const long total = (long)N * H * W;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int iw = (int)(idx % W);
+    const long t = idx / W;
+    const int ih = (int)(t % H), n = (int)(t / H);
+    float xin[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; c += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)idx * xld + c);
+        xin[c] = v[0]; xin[c + 1] = v[1]; xin[c + 2] = v[2]; xin[c + 3] = v[3];
+    }
+    float o[4][4];          // [output row 2 dy + dy2][output column 2 dx + dx2]
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) {
+        const int dy = tap >> 1, dx = tap & 1;
+        float u[CMID];
+#pragma unroll
+        for (int co = 0; co < CMID; ++co) {
+            float a = b1[co];
+            const float* wr = w1 + ((size_t)tap * CMID + co) * CIN;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) a = fmaf(wr[ci], xin[ci], a);
+            u[co] = fmaxf(a, 0.f);
+        }
+#pragma unroll
+        for (int tap2 = 0; tap2 < 4; ++tap2) {
+            float a = b2p[0];
+            const float* wr = w2 + (size_t)tap2 * CMID;
+#pragma unroll
+            for (int co = 0; co < CMID; ++co) a = fmaf(wr[co], u[co], a);
+            o[2 * dy + (tap2 >> 1)][2 * dx + (tap2 & 1)] = rd_act(a, ACT_SIGMOID);
+        }
+    }
+    float* yb = y + ((size_t)n * 4 * H + 4 * ih) * (size_t)(4 * W) + 4 * iw;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        __builtin_nontemporal_store(f32x4{o[r][0], o[r][1], o[r][2], o[r][3]}, reinterpret_cast<f32x4*>(yb + (size_t)r * 4 * W));
+}
+bool det_head_tail_supported(int cin, int cmid, int cout) { return cin == 24 && cmid == 24 && cout == 1; }
+void launch_det_head_tail(const float* x, int xld, int N, int H, int W, const float* w1, const float* b1, const float* w2, const float* b2,
+                          float* y, hipStream_t s) {
+    const long total = (long)N * H * W;
+    hipLaunchKernelGGL((det_head_tail_kernel<24, 24>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, xld, N, H, W, w1, b1, w2,
+                       b2, y);
+}
+
+// --------------------------------------------------------------------------------------------------
 // nearest upsample (+ accumulate) - RepLKFPN top-down path and concat (db_fpn.py:395-415)
 // --------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) upsample_kernel(const float* x, int xld, float* y, int yld, int H, int W, int C,

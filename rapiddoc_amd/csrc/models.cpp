@@ -160,10 +160,15 @@ void build_ppocrv6_det(Builder& b, int B, int H, int W) {
     // DBHead v6
     TView c = b.conv("head.conv_down.convolution.weight", "", "head.conv_down.norm", cat, geom(3), ACT_RELU);
     b.release(cat);
-    TView u = b.deconv2x2("head.conv_up.convolution.weight", "head.conv_up.convolution.bias", "head.conv_up.norm", c, ACT_RELU);
-    b.release(c);
-    b.deconv2x2("head.conv_final.weight", "head.conv_final.bias", "", u, ACT_SIGMOID, &out);
-    b.release(u);
+    if (b.deconv_pair_to_prob("head.conv_up.convolution.weight", "head.conv_up.convolution.bias", "head.conv_up.norm", "head.conv_final.weight",
+                              "head.conv_final.bias", c, out)) {
+        b.release(c);
+    } else {
+        TView u = b.deconv2x2("head.conv_up.convolution.weight", "head.conv_up.convolution.bias", "head.conv_up.norm", c, ACT_RELU);
+        b.release(c);
+        b.deconv2x2("head.conv_final.weight", "head.conv_final.bias", "", u, ACT_SIGMOID, &out);
+        b.release(u);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -117,6 +117,9 @@ struct SeFcParams {
     float* scale;                      // [N][C]
 };
 void launch_se_fc(const SeFcParams& p, hipStream_t s);
+bool det_head_tail_supported(int cin, int cmid, int cout);
+void launch_det_head_tail(const float* x, int xld, int N, int H, int W, const float* w1, const float* b1, const float* w2, const float* b2,
+                          float* y, hipStream_t s);
 void launch_scale_channels(const float* x, int xld, float* y, int yld, const float* scale, float alpha,
                            int N, int HW, int C, hipStream_t s);
 
