@@ -59,6 +59,7 @@ struct StemFusedParams {
     float* y; int yld;                          // cat NHWC [N][H2][W2][2 C1]: p at channel 0, b at channel C1
     int H2, W2, tiles_x, tiles_y;
     unsigned* range_flag;
+    int dbg;                                    // developer: RD_STEM_DBG ablation bits (results garbage): 1 no stem1, 2 no stem2a, 4 no pool, 8 no stem2b, 16 no patch traffic
 };
 
 __device__ __forceinline__ void sf_split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
@@ -121,23 +122,29 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
         p_lds[k] = row * SF_PROW + rem;
         p_ci[k] = (p.in_ch == 1 ? 0 : ci) * p.H * p.W;
     }
-    auto load_patch = [&](int t) {               // global -> registers (zero outside the image: the conv's padding)
+    // global -> registers.  The loads are UNCONDITIONAL from clamped addresses and the zero padding is applied when the values go to
+    // LDS (store_patch): a select on the loaded value right here makes the compiler wait for every load before it issues the next
+    // (ISA of the first version: nine `global_load_dword ; s_waitcnt vmcnt(0)` pairs = nine serial memory round trips per tile with
+    // all eight wavefronts of the CU behind them; ablation: 50 of 262 us on the recogniser's stem)
+    auto load_patch = [&](int t) {
         int n, ty0, tx0;
         tile_origin(t, n, ty0, tx0);
         const int iy0 = 2 * ty0 - 1, ix0 = 2 * tx0 - 1;
         const float* img = p.x + (size_t)n * p.in_ch * p.H * p.W;
 #pragma unroll
         for (int k = 0; k < PRE; ++k) {
-            const int iy = iy0 + (p_rc[k] >> 16), ix = ix0 + (p_rc[k] & 0xffff);
-            const bool ok = p_rc[k] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const float v = img[p_ci[k] + (ok ? iy * p.W + ix : 0)];
-            pre[k] = ok ? v : 0.f;
+            const int iy = min(max(iy0 + (p_rc[k] >> 16), 0), p.H - 1), ix = min(max(ix0 + (p_rc[k] & 0xffff), 0), p.W - 1);
+            pre[k] = img[p_ci[k] + iy * p.W + ix];
         }
     };
-    auto store_patch = [&]() {
+    auto store_patch = [&](int ty0, int tx0) {    // (zero outside the image: the conv's padding)
+        const int iy0 = 2 * ty0 - 1, ix0 = 2 * tx0 - 1;
 #pragma unroll
-        for (int k = 0; k < PRE; ++k)
-            if (p_rc[k] >= 0) As[p_lds[k]] = pre[k];
+        for (int k = 0; k < PRE; ++k) {
+            const int iy = iy0 + (p_rc[k] >> 16), ix = ix0 + (p_rc[k] & 0xffff);
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            if (p_rc[k] >= 0) As[p_lds[k]] = ok ? pre[k] : 0.f;
+        }
         // the slots behind the last real column of every row and behind the last row are read with zero weights: keep them finite
         if (tid < SF_PH) As[tid * SF_PROW + SF_PW * 3] = 0.f;
         if (tid >= 64 && tid < 80) As[SF_PH * SF_PROW + tid - 64] = 0.f;
@@ -150,7 +157,7 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
     for (; t < ntiles; t += gridDim.x) {
         int n, ty0, tx0;
         tile_origin(t, n, ty0, tx0);
-        store_patch();
+        if (!(p.dbg & 16)) store_patch(ty0, tx0);
         __syncthreads();
 
         // a tile whose whole e halo lies inside the map needs no per-element bounds tests (most tiles)
@@ -158,7 +165,7 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
 
         // ---------------- stem1: e = ReLU(conv3x3 s2 (patch)) on the matrix cores, K = 3 kernel rows x 16 slots.  The bias rides in
         // the accumulator init; non-finite values are not tested here: they reach stem2b's outputs and the pool, which are
-        for (int mb = wave; mb < G::MB1; mb += 8) {
+        for (int mb = wave; mb < G::MB1 && !(p.dbg & 1); mb += 8) {
             const int m = min(mb * 32 + l31, SF_EH * SF_EW - 1);
             const int ey = m / SF_EW, ex = m - ey * SF_EW;
             f32x16 acc1[G::NB1], acc2[G::NB1];
@@ -218,7 +225,7 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
 
         // ---------------- stem2a: a = ReLU(conv2x2 (e)), K = 4 taps x C1 channels.  Ten 32-pixel blocks on eight wavefronts: the
         // six wavefronts without a second block do the max-pool in the meantime (it only needs e)
-        for (int mb = wave; mb < G::MB2; mb += 8) {
+        for (int mb = wave; mb < G::MB2 && !(p.dbg & 2); mb += 8) {
             const int m = min(mb * 32 + l31, SF_AH * SF_AW - 1);
             const int ay = m / SF_AW, ax = m - ay * SF_AW;
             const int nrow = min(l31, G::NA - 1);
@@ -272,7 +279,7 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
         {
             constexpr int C4 = C1 / 4;
             constexpr int FIRST = G::MB2 > 8 ? G::MB2 - 8 : 0, NTH = (8 - FIRST) * 64;
-            if (wave >= FIRST) {
+            if (wave >= FIRST && !(p.dbg & 4)) {
                 for (int i = tid - FIRST * 64; i < SF_TH * SF_TW * C4; i += NTH) {
                     const int pix = i / C4, cg = i - pix * C4;
                     const int py = pix >> 5, px = pix & 31;
@@ -293,10 +300,10 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
 
         // the next tile's patch travels while stem2b runs
         const int tn = t + (int)gridDim.x;
-        if (tn < ntiles) load_patch(tn);
+        if (tn < ntiles && !(p.dbg & 16)) load_patch(tn);
 
         // ---------------- stem2b: b = ReLU(conv2x2 (a)) -> cat[..., C1:], one tile row (32 pixels) per wavefront
-        {
+        if (!(p.dbg & 8)) {
             const int by = wave, bx = l31;
             f32x16 acc1[G::NB3], acc2[G::NB3];
 #pragma unroll
@@ -325,6 +332,11 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
                     acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[nb], 0, 0, 0);
                 }
             }
+            // The next tile's patch (requested above, before these MFMAs) must have landed BEFORE the stores below are issued: loads
+            // and stores retire in issue order, and the compiler's wait for `pre` at the top of the next tile would otherwise be a
+            // vmcnt(0) behind 32 stores per wavefront - an HBM write round trip per tile with all eight wavefronts of the CU waiting
+            // (ablation: 50 of 262 us on the recogniser's stem).  Here the loads have had the whole MFMA phase.
+            __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
             const int gy = ty0 + by;
             float* yrow = p.y + (((size_t)n * p.H2 + min(gy, p.H2 - 1)) * p.W2 + tx0 + 4 * lhi) * p.yld + C1;
 #pragma unroll
@@ -415,6 +427,8 @@ void launch_stem_fused(int c1, const float* x, int N, int H, int W, int in_ch, c
     p.tiles_y = (p.H2 + SF_TH - 1) / SF_TH;
     p.tiles_x = (p.W2 + SF_TW - 1) / SF_TW;
     p.range_flag = range_flag;
+    static const int dbg = [] { const char* e = getenv("RD_STEM_DBG"); return e ? atoi(e) : 0; }();
+    p.dbg = dbg;
     if (c1 == 24) sf_launch<24>(p, s, n_cu);
     else if (c1 == 32) sf_launch<32>(p, s, n_cu);
     else sf_launch<48>(p, s, n_cu);
