@@ -362,11 +362,16 @@ __global__ void __launch_bounds__(256) skinny2_gemm_kernel(ConvParams p, int kpa
 #pragma unroll
         for (int c = 0; c < CW; ++c) {
             const int n = min(n_base + c, p.Ng - 1);
+            // unconditional loads from clamped addresses, masked afterwards: a select on a conditional load makes the compiler wait for
+            // each load before it issues the next (the ISA of the first version had CW * KPL `global_load ; s_waitcnt vmcnt(0)` pairs)
 #pragma unroll
             for (int h = 0; h < KPL; ++h) {
                 const int k = pass * KP + h * 256 + 4 * lane;
-                wr[c][h] = k < p.K ? *reinterpret_cast<const f32x4*>(p.w + (size_t)n * p.K + k) : zero4;
+                wr[c][h] = *reinterpret_cast<const f32x4*>(p.w + (size_t)n * p.K + min(k, p.K - 4));
             }
+#pragma unroll
+            for (int h = 0; h < KPL; ++h)
+                if (pass * KP + h * 256 + 4 * lane >= p.K) wr[c][h] = zero4;
         }
     };
     load_w(0);

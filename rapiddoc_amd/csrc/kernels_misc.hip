@@ -719,10 +719,15 @@ __global__ void __launch_bounds__(256) attention_kernel(const float* qkv, float*
         const int t = r * 256 + threadIdx.x;
         const bool live = t < T;
         f32x4 q[NV];
+        const float* qrow = base + (size_t)min(t, T - 1) * 3 * C + h * HD;      // (clamped: unconditional loads are issued back to back)
 #pragma unroll
         for (int v = 0; v < NV; ++v)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) q[v][e] = (live && 4 * v + e < HD) ? base[(size_t)t * 3 * C + h * HD + 4 * v + e] * scale : 0.f;
+            for (int e = 0; e < 4; ++e) q[v][e] = qrow[min(4 * v + e, HD - 1)];
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[v][e] = (live && 4 * v + e < HD) ? q[v][e] * scale : 0.f;
         auto dot = [&](int j) {
             float sdot = 0.f;
 #pragma unroll
