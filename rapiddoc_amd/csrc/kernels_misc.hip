@@ -67,9 +67,10 @@ __global__ void __launch_bounds__(256) dwconv_kernel(DwParams p) {
 // at TW = 8 instead of 9, which moves the kernel from L1-request-bound towards the HBM roofline.  Optionally emits
 // deterministic per-block partial sums of its OUTPUT for the squeeze-excite global average pool that follows
 // (rec_lcnetv4.py:228-229): partial[n][chunk][c].
-template <int KH, int KW, int SW, int TW>
+template <int KH, int KW, int SW, int TW, int DBG = 0>
 __global__ void __launch_bounds__(256) dwconv_tiled_kernel(DwParams p, int c4n, int groups_w, int groups, int gpb) {
     constexpr int NCOL = (TW - 1) * SW + KW;
+    constexpr int dbg = DBG;           // developer (RD_DW_DBG, 3x3 only): 1 no stores, 2 no loads, 4 no boundary masks - timing only
     __shared__ f32x4 red[256];
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int lanes_p = blockDim.x / c4n;           // pixel-group lanes per block
@@ -89,6 +90,9 @@ __global__ void __launch_bounds__(256) dwconv_tiled_kernel(DwParams p, int c4n, 
 #pragma unroll
         for (int t = 0; t < TW; ++t) acc[t] = bias;
         const int ih0 = oh * p.SH - p.PT, iw0 = ow0 * SW - p.PL;
+        // Ablation at 101 376 x 192 (RD_DW_DBG): arithmetic alone 19 us, + loads 15, + stores 9 = the kernel's 43 - the phases add at three
+        // wavefronts per SIMD.  Requesting all three rows before the first is used (120 VGPRs of rows: two wavefronts per SIMD)
+        // measured 54-61 us, four outputs per thread with all rows up front 54, forcing 128 VGPRs spills: the row-by-row form stays.
 #pragma unroll
         for (int kh = 0; kh < KH; ++kh) {
             const int ih = ih0 + kh;
@@ -99,9 +103,14 @@ __global__ void __launch_bounds__(256) dwconv_tiled_kernel(DwParams p, int c4n, 
             // s_waitcnt per load); whole out-of-range ROWS are still skipped - with the short feature maps of the
             // recogniser a third of the rows are padding, and loading them measured slower
 #pragma unroll
-            for (int j = 0; j < NCOL; ++j) row[j] = *reinterpret_cast<const f32x4*>(xr + (size_t)min(max(iw0 + j, 0), p.W - 1) * p.xld);
+            for (int j = 0; j < NCOL; ++j) {
+                if constexpr ((dbg & 2) != 0) row[j] = bias;
+                else row[j] = *reinterpret_cast<const f32x4*>(xr + (size_t)min(max(iw0 + j, 0), p.W - 1) * p.xld);
+            }
+            if constexpr (!(dbg & 4)) {
 #pragma unroll
-            for (int j = 0; j < NCOL; ++j) row[j] = ((unsigned)(iw0 + j) < (unsigned)p.W) ? row[j] : zero4;
+                for (int j = 0; j < NCOL; ++j) row[j] = ((unsigned)(iw0 + j) < (unsigned)p.W) ? row[j] : zero4;
+            }
 #pragma unroll
             for (int kw = 0; kw < KW; ++kw) {
                 const f32x4 wv = *reinterpret_cast<const f32x4*>(p.w + (size_t)(kh * KW + kw) * p.C + c);
@@ -115,7 +124,7 @@ __global__ void __launch_bounds__(256) dwconv_tiled_kernel(DwParams p, int c4n, 
             if (ow0 + t < p.OW) {
                 f32x4 v = act4(acc[t], p.act);
                 if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (pix0 + t) * p.rld + c);
-                *reinterpret_cast<f32x4*>(p.y + (pix0 + t) * p.yld + c) = v;
+                if (!(dbg & 1)) *reinterpret_cast<f32x4*>(p.y + (pix0 + t) * p.yld + c) = v;
                 gsum += v;
             }
         }
@@ -280,7 +289,10 @@ int dwconv_gap_chunks(const DwParams& p) {
     return chunks;
 }
 
-void launch_dwconv(const DwParams& p, hipStream_t s) {
+void launch_dwconv(const DwParams& p_in, hipStream_t s) {
+    static const int dbg_env = [] { const char* e = std::getenv("RD_DW_DBG"); return e ? atoi(e) : 0; }();
+    DwParams p = p_in;
+    p.dbg = dbg_env;
     if (p.tokinfo) {      // ragged rows: only the per-pixel kernel knows about line ends
         const long total = (long)p.N * p.OH * p.OW * (p.C >> 2);
         hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for(total)), dim3(256), 0, s, p);
@@ -297,7 +309,15 @@ void launch_dwconv(const DwParams& p, hipStream_t s) {
         int c4n, threads, gw, g, gpb, chunks;
         dw_tiled_geom(p, tw, c4n, threads, gw, g, gpb, chunks);
         dim3 grid(chunks, p.N), block(threads);
-        if (p.KH == 3 && p.SW == 1 && tw == 8)
+        if (p.KH == 3 && p.SW == 1 && tw == 8 && p.dbg) {
+            switch (p.dbg) {
+                case 1: hipLaunchKernelGGL((dwconv_tiled_kernel<3, 3, 1, 8, 1>), grid, block, 0, s, p, c4n, gw, g, gpb); break;
+                case 2: hipLaunchKernelGGL((dwconv_tiled_kernel<3, 3, 1, 8, 2>), grid, block, 0, s, p, c4n, gw, g, gpb); break;
+                case 3: hipLaunchKernelGGL((dwconv_tiled_kernel<3, 3, 1, 8, 3>), grid, block, 0, s, p, c4n, gw, g, gpb); break;
+                case 4: hipLaunchKernelGGL((dwconv_tiled_kernel<3, 3, 1, 8, 4>), grid, block, 0, s, p, c4n, gw, g, gpb); break;
+                default: hipLaunchKernelGGL((dwconv_tiled_kernel<3, 3, 1, 8, 7>), grid, block, 0, s, p, c4n, gw, g, gpb); break;
+            }
+        } else if (p.KH == 3 && p.SW == 1 && tw == 8)
             hipLaunchKernelGGL((dwconv_tiled_kernel<3, 3, 1, 8>), grid, block, 0, s, p, c4n, gw, g, gpb);
         else if (p.KH == 3 && p.SW == 1)
             hipLaunchKernelGGL((dwconv_tiled_kernel<3, 3, 1, 4>), grid, block, 0, s, p, c4n, gw, g, gpb);

@@ -96,6 +96,7 @@ struct DwParams {
     // ragged rows (the recogniser's batched tail): the tensor is [1][1][W = all tokens][C], token i sits at position
     // tokinfo[i] & 0xffff of a text line of tokinfo[i] >> 16 tokens and the kernel's horizontal taps stop at the line's ends
     const int32_t* tokinfo = nullptr;
+    int dbg = 0;                // developer (RD_DW_DBG): 1 no stores, 2 no loads - timing only
 };
 void launch_dwconv(const DwParams& p, hipStream_t s);
 // number of per-image partial-sum chunks launch_dwconv writes to p.gap_partial for this geometry (0 = the fused
