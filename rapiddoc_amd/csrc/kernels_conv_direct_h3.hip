@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(512) conv_direct_h3_kernel(ConvParams p, Direc
         const int row = rem / CH8, ch = rem - row * CH8;
         w_ok[i] = q < wtotal && row < p.Ng && 8 * ch < g.CC;
         w_lo[i] = plane != 0;
-        w_src[i] = row * Kp + 8 * ch;
+        w_src[i] = w_ok[i] ? row * Kp + 8 * ch : 0;
         w_dst[i] = q < wtotal ? (unsigned)plane * wplane + (unsigned)row * S + (unsigned)ch * 16 : 0xffffffffu;
     }
     u32x4 wreg[3];
@@ -69,11 +69,13 @@ __global__ void __launch_bounds__(512) conv_direct_h3_kernel(ConvParams p, Direc
     auto load_w = [&](int gstep) {                    // slab of global step gstep -> registers
         const int st = gstep % nsteps;
         const int koff = (st % NT) * p.Cin + (st / NT) * g.CC;
+        // unconditional loads (w_src is 0 for the slots this thread does not own: a valid address) and a mask afterwards: a load
+        // under a condition is waited for before the next one is issued (ISA of the first version: load ; s_waitcnt vmcnt(0) pairs)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            wreg[i] = u32x4{0u, 0u, 0u, 0u};
-            if (w_ok[i]) wreg[i] = *reinterpret_cast<const u32x4*>((w_lo[i] ? wl : wh) + w_src[i] + koff);
-        }
+        for (int i = 0; i < 3; ++i) wreg[i] = *reinterpret_cast<const u32x4*>((w_lo[i] ? wl : wh) + w_src[i] + (w_ok[i] ? koff : 0));
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (!w_ok[i]) wreg[i] = u32x4{0u, 0u, 0u, 0u};
     };
     auto write_w = [&](int gstep) {
 #pragma unroll
@@ -104,19 +106,28 @@ __global__ void __launch_bounds__(512) conv_direct_h3_kernel(ConvParams p, Direc
         for (int j = 0; j < 2; ++j)
             s_ok[j] = tid + 512 * j < row_slots && 4 * s_g[j] < g.CC && c0 + 4 * s_g[j] < p.Cin &&
                       (unsigned)(ow0 - p.PL + s_col[j]) < (unsigned)p.W;
-        const float* xb = p.x + ((size_t)img * p.H * p.W + (size_t)(ow0 - p.PL)) * p.xld + c0;
+        const float* xb = p.x + (size_t)img * p.H * p.W * p.xld;
+        size_t s_off[2];           // element offset of the slot inside an image row (a slot that is masked reads the row's first pixel)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) s_off[j] = s_ok[j] ? (size_t)(ow0 - p.PL + s_col[j]) * p.xld + c0 + 4 * s_g[j] : 0;
         for (int r0 = 0; r0 < PH; r0 += RGRP) {
             f32x4 v[RGRP][2];
+            // every load of the row group is issued before the first is used: unconditional, from clamped rows / the slot's own (or a
+            // valid substitute) column, masked afterwards
+#pragma unroll
+            for (int rr = 0; rr < RGRP; ++rr) {
+                const int ih = oh0 - p.PT + r0 + rr;
+                const float* xr = xb + (size_t)min(max(ih, 0), p.H - 1) * p.W * p.xld;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) v[rr][j] = *reinterpret_cast<const f32x4*>(xr + s_off[j]);
+            }
 #pragma unroll
             for (int rr = 0; rr < RGRP; ++rr) {
                 const int ih = oh0 - p.PT + r0 + rr;
                 const bool row_ok = r0 + rr < PH && (unsigned)ih < (unsigned)p.H;
-                const float* xr = xb + (size_t)ih * p.W * p.xld;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    v[rr][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (row_ok && s_ok[j]) v[rr][j] = *reinterpret_cast<const f32x4*>(xr + (size_t)s_col[j] * p.xld + 4 * s_g[j]);
-                }
+                for (int j = 0; j < 2; ++j)
+                    if (!(row_ok && s_ok[j])) v[rr][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int rr = 0; rr < RGRP; ++rr) {

@@ -77,37 +77,55 @@ __global__ void __launch_bounds__(256) conv_stream_h3_kernel(ConvParams p, Strea
     float amax = 0.f;
     const int KS = g.C16 / 16;
     const unsigned b_lane = (unsigned)l31 * (unsigned)SB + (unsigned)lhi * 16u;
-    for (int tap = 0; tap < NT; ++tap) {
+    // One step = (tap, k-step): two 16-byte loads per lane.  The loads are UNCONDITIONAL (padding taps read pixel 0, channels past
+    // Cin re-read the last group) and masked afterwards - a load under a condition is waited for before the next one is issued,
+    // which made every step two serial round trips - and the loads of step s + 1 are requested before the MFMAs of step s.
+    const int nsteps = NT * KS;
+    auto step_src = [&](int st, bool& ok0, bool& ok1, int& o1) -> const float* {
+        const int tap = st / KS, ks = st - tap * KS;
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
         const int ih = ih0 + kh, iw = iw0 + kw;
         const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        const float* xp = ximg + ((size_t)(ok ? ih : 0) * p.W + (ok ? iw : 0)) * p.xld + 8 * lhi;
-        // (loading all k-steps of a tap before the first split - eight loads in flight per lane - measured slower: 59 vs 52 us on
-        //  rec stem2a; the extra registers cost more occupancy than the deeper per-wavefront queue wins)
-        for (int ks = 0; ks < KS; ++ks) {
-            const int c = ks * 16 + 8 * lhi;
-            f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
-            if (ok && c < p.Cin) x0 = *reinterpret_cast<const f32x4*>(xp + ks * 16);
-            if (ok && c + 4 < p.Cin) x1 = *reinterpret_cast<const f32x4*>(xp + ks * 16 + 4);
-            f16x8 ah, al;
+        const int c = ks * 16 + 8 * lhi;
+        ok0 = ok && c < p.Cin;
+        ok1 = ok && c + 4 < p.Cin;
+        o1 = min(c + 4, p.Cin - 4) - min(c, p.Cin - 4);      // (4, or 0 when the second group lies past Cin: masked)
+        return ximg + ((size_t)(ok ? ih : 0) * p.W + (ok ? iw : 0)) * p.xld + min(c, p.Cin - 4);
+    };
+    f32x4 x0, x1;
+    bool ok0, ok1;
+    int o1;
+    {
+        const float* xp = step_src(0, ok0, ok1, o1);
+        x0 = *reinterpret_cast<const f32x4*>(xp);
+        x1 = *reinterpret_cast<const f32x4*>(xp + o1);
+    }
+    for (int st = 0; st < nsteps; ++st) {
+        const int tap = st / KS, ks = st - tap * KS;
+        f32x4 c0 = ok0 ? x0 : f32x4{0.f, 0.f, 0.f, 0.f}, c1 = ok1 ? x1 : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (st + 1 < nsteps) {
+            const float* xp = step_src(st + 1, ok0, ok1, o1);
+            x0 = *reinterpret_cast<const f32x4*>(xp);
+            x1 = *reinterpret_cast<const f32x4*>(xp + o1);
+        }
+        f16x8 ah, al;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                _Float16 h0, l0, h1, l1;
-                rd_split(x0[e], h0, l0);
-                rd_split(x1[e], h1, l1);
-                ah[e] = h0; ah[4 + e] = h1;
-                al[e] = l0; al[4 + e] = l1;
-                amax = fmaxf(amax, fmaxf(fabsf(x0[e]), fabsf(x1[e])));
-            }
-            const unsigned bo = b_lane + (unsigned)(tap * g.C16 + ks * 16) * 2u;
+        for (int e = 0; e < 4; ++e) {
+            _Float16 h0, l0, h1, l1;
+            rd_split(c0[e], h0, l0);
+            rd_split(c1[e], h1, l1);
+            ah[e] = h0; ah[4 + e] = h1;
+            al[e] = l0; al[4 + e] = l1;
+            amax = fmaxf(amax, fmaxf(fabsf(c0[e]), fabsf(c1[e])));
+        }
+        const unsigned bo = b_lane + (unsigned)(tap * g.C16 + ks * 16) * 2u;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const f16x8 bh = *reinterpret_cast<const f16x8*>(Wh + bo + (unsigned)nb * 32u * (unsigned)SB);
-                const f16x8 bl = *reinterpret_cast<const f16x8*>(Wl + bo + (unsigned)nb * 32u * (unsigned)SB);
-                acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[nb], 0, 0, 0);
-                acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[nb], 0, 0, 0);
-                acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[nb], 0, 0, 0);
-            }
+        for (int nb = 0; nb < NB; ++nb) {
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(Wh + bo + (unsigned)nb * 32u * (unsigned)SB);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(Wl + bo + (unsigned)nb * 32u * (unsigned)SB);
+            acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[nb], 0, 0, 0);
+            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[nb], 0, 0, 0);
+            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[nb], 0, 0, 0);
         }
     }
 
