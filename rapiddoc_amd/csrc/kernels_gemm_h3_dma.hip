@@ -245,6 +245,8 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
 // (tools/probe_mfma_valu.hip), so the redundant splits were 2/3 of the MFMA time.  32x64 halves them at the same LDS traffic.)  The 8-wavefront kernel spends its time in phases that
 // do not overlap inside one wavefront (fragment read -> split -> MFMA); with twice the wavefronts the SIMD has another
 // wavefront's MFMAs to issue while one splits.  Costs: every A row tile is read and split by 4 wavefronts instead of 2.
+// ABL (developer, RD_GEMM_DBG; results garbage): 1 no stores, 2 no MFMAs, 4 no activation / residual in the epilogue, 8 no epilogue
+template <int ABL>
 __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int ntn, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -328,9 +330,13 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
                 for (int j = 0; j < 2; ++j) {
                     const f16x8 bh = *reinterpret_cast<const f16x8*>(st + b_off[j][ks]);
                     const f16x8 bl = *reinterpret_cast<const f16x8*>(st + b_off[j][ks] + D_B_BYTES);
-                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[j], 0, 0, 0);
-                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[j], 0, 0, 0);
-                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[j], 0, 0, 0);
+                    if constexpr (!(ABL & 2)) {
+                        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[j], 0, 0, 0);
+                        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[j], 0, 0, 0);
+                        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[j], 0, 0, 0);
+                    } else {
+                        acc1[j][0] += (float)ah[0] + (float)bh[0] + (float)bl[0] + (float)al[0];
+                    }
                 }
             }
             stage = stage == 2 ? 0 : stage + 1;
@@ -347,6 +353,7 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
 #pragma unroll
         for (int i = 0; i < 2; ++i) {           // the wavefront's two 32-column blocks
             const int n = en0 + wn * 64 + i * 32 + l31;
+            if constexpr ((ABL & 8) != 0) { emax = max(emax, __float_as_uint(acc1[i][0] + acc2[i][0]) & 0x7fffffffu); continue; }
             if (n >= p.Ng) continue;
             const float bv = p.bias ? p.bias[n] : 0.f;
             const int mb = em0 + wm * 32 + 4 * lhi;
@@ -361,14 +368,15 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
                     o[e] = fmaf(acc2[i][r], 1.f / 2048.f, acc1[i][r]) + bv;
                     emax = max(emax, __float_as_uint(o[e]) & 0x7fffffffu);
                 }
-                if (p.act == ACT_GELU) {
+                if constexpr ((ABL & 4) != 0) {
+                } else if (p.act == ACT_GELU) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = rd_gelu(o[e]);
+                    for (int e = 0; e < 8; ++e) o[e] = rd_gelu(o[e]);      // (the packed rd_gelu2 measured 173 vs 155 us here: 128 VGPRs)
                 } else if (p.act != ACT_NONE) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = rd_act(o[e], p.act);
                 }
-                if (p.res) {
+                if (p.res && !(ABL & 4)) {
                     float rs[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -382,7 +390,7 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
                 for (int e = 0; e < 8; ++e) {
                     const int r = half * 8 + e;
                     const int m = mb + (r & 3) + 8 * (r >> 2);
-                    if (m < p.M) __builtin_nontemporal_store(o[e], &p.y[(size_t)m * p.yld + n]);
+                    if (m < p.M && !((ABL & 1) && o[e] != 12345.678f)) __builtin_nontemporal_store(o[e], &p.y[(size_t)m * p.yld + n]);
                 }
             }
         }
@@ -419,8 +427,23 @@ void launch_gemm_h3_dma(const ConvParams& p, hipStream_t s) {
                         (unsigned long long)p.Ng * (unsigned long long)((p.K + DK - 1) / DK * DK) < (1ull << 32);
     const bool use16 = !fits32 || (force16 >= 0 ? force16 == 1 : p.K <= 384);
     if (use16) {
-        rd_allow_dynamic_lds((const void*)gemm_h3_dma16_kernel, sh, lds_ok16);
-        hipLaunchKernelGGL(gemm_h3_dma16_kernel, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(1024), sh, s, p, ntn, ntiles);
+        static const int dbg = [] { const char* e = getenv("RD_GEMM_DBG"); return e ? atoi(e) : 0; }();
+#define RD_DMA16(A)                                                                                                  \
+    do {                                                                                                             \
+        static unsigned long long ok_ = 0;                                                                           \
+        rd_allow_dynamic_lds((const void*)gemm_h3_dma16_kernel<A>, sh, ok_);                                         \
+        hipLaunchKernelGGL(gemm_h3_dma16_kernel<A>, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(1024), sh, s, p, ntn, ntiles); \
+    } while (0)
+        switch (dbg) {
+            case 1: RD_DMA16(1); break;
+            case 2: RD_DMA16(2); break;
+            case 4: RD_DMA16(4); break;
+            case 8: RD_DMA16(8); break;
+            case 10: RD_DMA16(10); break;
+            default: RD_DMA16(0); break;
+        }
+#undef RD_DMA16
+        (void)lds_ok16;
         return;
     }
     hipLaunchKernelGGL(gemm_h3_dma_kernel, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), sh, s, p, ntn, ntiles);

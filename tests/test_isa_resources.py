@@ -18,6 +18,8 @@ ALLOWED = {
     # template arguments <C, GATED, KEEPX, ABL, PF>
     r"lc_mixer_ws_kernelILi192ELb[01]ELb1E": "KEEPX instantiations (fp32 X tile kept in registers): debug entry only, C = 192 spills by design",
     r"lc_mixer_ws_kernelILi192ELb[01]ELb[01]ELi(1|2|4|8|12|13|16|17|25|27|28|29|64|72|88)ELb[01]E": "ablation instantiations of the ws mixer (tools/microbench.py)",
+    r"gemm_h3_dma16_kernelILi(1|2|4|8|10)E": "ablation instantiations of the 16-wavefront GEMM (tools/mb_gemm_abl.py, RD_GEMM_DBG)",
+    r"dwconv_tiled_kernelILi3ELi3ELi1ELi8ELi[1-7]E": "ablation instantiations of the depthwise 3x3 (RD_DW_DBG)",
     r"lc_mixer_h3_kernel.*Li192E": "round-1 C = 192 mixer: superseded by the ws kernel, kept for A/B (RD_MIXER_WS=0)",
     r"db_(regions|finish)_kernel": "no spill: local arrays (4-corner boxes, hull scratch) of the geometry code shared with the host path "
                                    "(csrc/db_geom.h), indexed at run time; one thread per text-line candidate, ~50 candidates per page",
@@ -76,7 +78,7 @@ def test_known_register_budgets(tables):
     the 128 of four."""
     rows = {n: (v, s, p) for n, v, s, p in tables["kernels_gemm_h3_dma.hip"]}
     k8 = next(v for n, v in rows.items() if "gemm_h3_dma_kernel" in n)
-    k16 = next(v for n, v in rows.items() if "gemm_h3_dma16_kernel" in n)
+    k16 = next(v for n, v in rows.items() if "gemm_h3_dma16_kernelILi0E" in n)
     assert k8[0] <= 256 and k8[1:] == (0, 0)
     assert k16[0] <= 128 and k16[1:] == (0, 0)
 
