@@ -355,6 +355,8 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
             const int n = en0 + wn * 64 + i * 32 + l31;
             if constexpr ((ABL & 8) != 0) { emax = max(emax, __float_as_uint(acc1[i][0] + acc2[i][0]) & 0x7fffffffu); continue; }
             if (n >= p.Ng) continue;
+            // (requesting the bias before the next tile's DMA pieces, so that its wait does not drain them, measured level in a same-box
+            //  A/B; so did nothing for the packed rd_gelu2 below, which measured 6 % slower: 128 VGPRs)
             const float bv = p.bias ? p.bias[n] : 0.f;
             const int mb = em0 + wm * 32 + 4 * lhi;
             // eight values at a time (128 VGPRs leave no room for sixteen): activation switch and residual test outside
@@ -371,7 +373,7 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
                 if constexpr ((ABL & 4) != 0) {
                 } else if (p.act == ACT_GELU) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = rd_gelu(o[e]);      // (the packed rd_gelu2 measured 173 vs 155 us here: 128 VGPRs)
+                    for (int e = 0; e < 8; ++e) o[e] = rd_gelu(o[e]);
                 } else if (p.act != ACT_NONE) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = rd_act(o[e], p.act);
