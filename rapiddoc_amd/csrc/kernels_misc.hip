@@ -823,6 +823,10 @@ static void launch_attention_t(const float* qkv, float* o, int B, int T, int hea
     hipLaunchKernelGGL(attention_kernel<HD>, dim3(B, heads), dim3(256), sh, s, qkv, o, T, heads, scale, seg, cap);
 }
 void launch_attention(const float* qkv, float* o, int B, int T, int heads, int hd, float scale, hipStream_t s, const int32_t* seg) {
+    if (attention_h3_applies(T, hd)) {
+        launch_attention_h3(qkv, o, B, T, heads, hd, scale, s, seg);
+        return;
+    }
     if (hd == 15) launch_attention_t<15>(qkv, o, B, T, heads, scale, s, seg);
     else if (hd == 16) launch_attention_t<16>(qkv, o, B, T, heads, scale, s, seg);
     else if (hd == 32) launch_attention_t<32>(qkv, o, B, T, heads, scale, s, seg);

@@ -132,6 +132,8 @@ void launch_layernorm(const float* x, int xld, float* y, int yld, const float* g
                       float eps, hipStream_t s);
 // qkv: [B*T][3*heads*hd] (q|k|v, head-major) -> o: [B*T][heads*hd]
 // seg != nullptr: ragged batch - sequence b is seg[2b+1] tokens starting at token seg[2b]; T is then the longest one
+bool attention_h3_applies(int T, int hd);     // kernels_attention_h3.hip: the same attention on the split-fp16 matrix cores
+void launch_attention_h3(const float* qkv, float* o, int B, int T, int heads, int hd, float scale, hipStream_t s, const int32_t* seg);
 void launch_attention(const float* qkv, float* o, int B, int T, int heads, int hd, float scale, hipStream_t s, const int32_t* seg = nullptr);
 
 // y = a + b (same geometry, views)
