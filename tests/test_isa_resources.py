@@ -98,3 +98,39 @@ def test_inline_asm_register_loads_are_not_touched_in_flight():
     assert out.stdout.count("global_load_dwordx4") >= 48          # the PF instantiations are there
     hazards = mod.check(out.stdout, ["ELb1EEEvNS_11MixerParams"])      # <..., PF = true>: the instantiations with inline-asm loads
     assert not hazards, hazards[:10]
+
+
+def test_no_serialised_load_runs_in_the_kernels_fixed_for_it():
+    """`x = ok ? p[i] : 0` compiles to `global_load ; s_waitcnt vmcnt(0) ; v_cndmask` per element: a run of conditional loads is a run
+    of serial memory round trips.  Round 3 found and removed such runs in the fused stem (image-patch prefetch), the
+    skinny GEMM of the formula decode steps, the streaming small-K conv and the MFMA attention's staging; this keeps them out: in
+    those kernels no four loads in a row may each be followed by a full vmcnt(0) wait before the next load is issued."""
+    bad = []
+    for fname, kernels in (("kernels_stem_fused.hip", ("stem_fused_kernel",)), ("kernels_conv.hip", ("skinny2_gemm_kernel",)),
+                           ("kernels_conv_stream_h3.hip", ("conv_stream_h3_kernel",)), ("kernels_attention_h3.hip", ("attention_h3_kernel",))):
+        out = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "-S", "--cuda-device-only",
+                              f"-I{CSRC}", str(CSRC / fname), "-o", "-"], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-2000:]
+        seen = 0
+        for m in re.finditer(r"^(\S+):\s*; @\1\n(.*?)\n\s*\.end_amdhsa_kernel", out.stdout, re.S | re.M):
+            name, body = m.group(1), m.group(2)
+            if not any(k in name for k in kernels):
+                continue
+            seen += 1
+            ev = []
+            for line in body.split("\n"):
+                ls = line.strip()
+                if ls.startswith(("global_load_dword", "buffer_load_dword")) and "lds" not in ls:
+                    ev.append("L")
+                elif ls.startswith("s_waitcnt") and "vmcnt(0)" in ls:
+                    ev.append("w")
+                elif ls.startswith(("v_mfma", "s_barrier", "global_store", "ds_write", "ds_read")):
+                    ev.append("x")
+            runs = re.findall(r"(?:Lw){4,}", "".join(ev))
+            if runs:
+                bad.append((name, [len(r) // 2 for r in runs]))
+        assert seen, fname
+    # (the 8-row / 4-column / 4-load instantiation of the skinny GEMM keeps one run of five: its 64 weight registers plus 32
+    #  accumulators leave the compiler no room to keep all sixteen loads in flight)
+    bad = [b for b in bad if not ("skinny2_gemm_kernelILi8ELi4ELi4E" in b[0] and max(b[1]) <= 5)]
+    assert not bad, bad
