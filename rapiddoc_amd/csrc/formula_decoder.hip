@@ -135,6 +135,25 @@ __global__ void __launch_bounds__(1024) dec_select_kernel(const float* logits, i
     const float* z = logits + (size_t)b * V;
     float mx = -INFINITY;
     int mi = 0x7fffffff;
+    if ((V & 3) == 0) {
+        // 16-byte loads, every load of the thread requested before the first compare (the scalar loop below ran its 49 loads per
+        // thread through a compare-and-select chain: 18 us for 200 KB); indices still visited in increasing order per thread
+        constexpr int MAXQ = 16;                     // V <= 65536
+        const int nq = V >> 2;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 q[MAXQ];
+#pragma unroll
+        for (int it = 0; it < MAXQ; ++it) q[it] = *reinterpret_cast<const f4*>(z + 4 * (size_t)min(tid + 1024 * it, nq - 1));
+#pragma unroll
+        for (int it = 0; it < MAXQ; ++it) {
+            const int c0 = 4 * (tid + 1024 * it);
+            if (tid + 1024 * it < nq) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (q[it][e] > mx) { mx = q[it][e]; mi = c0 + e; }
+            }
+        }
+    } else
     for (int c = tid; c < V; c += 1024) {
         const float v = z[c];
         if (v > mx) { mx = v; mi = c; }
