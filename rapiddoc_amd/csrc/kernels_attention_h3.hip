@@ -42,6 +42,7 @@ __global__ void __launch_bounds__(256) attention_h3_kernel(const float* __restri
         tok0 = (size_t)seg[2 * b];
         T = seg[2 * b + 1];
     }
+    if (T <= 0) return;                                     // (an empty line of a ragged batch: nothing to attend over, nothing to write)
     const int tpad = (T + 31) & ~31, nkt = tpad >> 5;
     const int vrow = att_vrow_halfs(tpad_max);              // (the launcher sized the allocation with tpad_max)
     _Float16* Kh = reinterpret_cast<_Float16*>(sm);
