@@ -110,8 +110,8 @@ class PageResult:
 
 class PagePipeline:
     def __init__(self, states: Dict[str, object], device: int = 0, characters: Optional[Sequence[str]] = None,
-                 rec_batch_num: int = 64, rec_width_multiple: int = 32, keep_feats: bool = False, n_rec_streams: int = 4,
-                 rec_mode: str = "throughput", rec_chunking: str = "fixed"):
+                 rec_batch_num: Optional[int] = None, rec_width_multiple: int = 32, keep_feats: bool = False, n_rec_streams: int = 4,
+                 rec_mode: str = "throughput", rec_chunking: Optional[str] = None):
         """`states`: {'ppocrv6_det': ..., 'ppocrv6_rec': ..., 'pphgnetv2_b4': ...}, each a .safetensors path,
         bytes, or name->ndarray dict.
 
@@ -124,12 +124,17 @@ class PagePipeline:
                         ignored.
           "throughput"  GPU-sized chunks (`rec_batch_num` lines, default 64) of the same aspect-sorted list, padded width
                         rounded up to `rec_width_multiple`: same per-tensor parity with the oracle, different padded
-                        widths than the reference would have used.  `rec_chunking="adaptive"` lets the chunk SIZE follow the
-                        width: `ocr_host.rec_batches_adaptive` picks, chunk by chunk, the size with the most lines per estimated
-                        microsecond, i.e. tile counts of the persistent kernels that fill whole rounds of the 256 CUs (64 lines of
-                        width 1056 are 3.09 rounds of mixer tiles and cost four)."""
+                        widths than the reference would have used.  `rec_chunking="adaptive"` (the default when no
+                        `rec_batch_num` is given - what bench.py measures) lets the chunk SIZE follow the width:
+                        `ocr_host.rec_batches_adaptive` picks, chunk by chunk, the size with the most lines per estimated
+                        microsecond, i.e. tile counts of the persistent kernels that fill whole rounds of the 256 CUs (64 lines
+                        of width 1056 are 3.09 rounds of mixer tiles and cost four)."""
         if rec_mode not in ("strict", "throughput"):
             raise ValueError("rec_mode must be 'strict' or 'throughput'")
+        if rec_chunking is None:
+            rec_chunking = "adaptive" if rec_batch_num is None else "fixed"
+        if rec_batch_num is None:
+            rec_batch_num = 64
         if rec_chunking not in ("fixed", "adaptive"):
             raise ValueError("rec_chunking must be 'fixed' or 'adaptive'")
         self.rec_mode = rec_mode
