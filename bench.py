@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0
 def _throughput_rule(args):
     if args.rec_chunking == "adaptive":
         return ("chunks of the aspect-sorted lines whose size follows their width so that the persistent kernels' tile counts fill whole "
-                "rounds of the chip (ocr_host.rec_batches_adaptive, 16-160 lines), width rounded up to x%d" % args.rec_width_multiple)
+                "rounds of the chip (ocr_host.rec_batches_adaptive / rd_rec_plan_chunks, 16-160 lines), width rounded up to x%d" % args.rec_width_multiple)
     return "chunks of %d aspect-sorted lines, width rounded up to x%d" % (args.rec_batch, args.rec_width_multiple)
 
 

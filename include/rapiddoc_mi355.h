@@ -207,6 +207,16 @@ typedef struct rd_layout_post_cfg {
 int rd_layout_postprocess(const float* boxes, int n, int ncol, int img_w, int img_h, const rd_layout_post_cfg* cfg,
                           float* out, int32_t* out_order, int32_t* n_out);
 
+/* Host: chunk sizes of the recogniser's THROUGHPUT mode (the engine's own scheduling; rapidocr's fixed rec_batch_num chunks,
+ * rapid_doc/model/ocr/rapid_ocr.py:430-440, are the `strict` mode of rapiddoc_amd.pipeline.PagePipeline).  wpad_sorted[i] = padded
+ * width of the i-th line of the aspect-sorted list (int(48 * max(320/48, w/h)) rounded up to the width multiple); a chunk is a run of
+ * that list padded to its last line.  rd_rec_plan_chunks cuts the list so that the summed rd_rec_chunk_cost (estimated microseconds
+ * of a backbone forward: whole rounds of workgroup tiles on n_cu compute units per persistent kernel + a linear term + a per-forward
+ * constant) is minimal; candidate sizes n_min, n_min + n_step, ... <= n_max, the last chunk any size.  Returns 0 on success. */
+double rd_rec_chunk_cost(int n_lines, int wpad, int n_cu);
+int rd_rec_plan_chunks(const int32_t* wpad_sorted, int n, int n_min, int n_max, int n_step, int n_cu, int32_t* sizes_out, int max_out,
+                       int32_t* n_out);
+
 /* Arithmetic of the dense layers of a network handle; every mode returns fp32 tensors with fp32-level error
  * (the reference runs the same layers through onnxruntime / torch fp32: rapid_doc/model/ocr/.../torch.py:58-76).
  *   "auto" (default)  split-fp16 matrix cores ((hi, lo) operand splitting, 3 fp16 MFMAs per product, fp32 accumulate,

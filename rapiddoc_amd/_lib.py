@@ -40,6 +40,8 @@ SYMBOLS = {
     "rd_db_boxes_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rd_db_boxes_device": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
                                      C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "rd_rec_chunk_cost": (C.c_double, [C.c_int, C.c_int, C.c_int]),
+    "rd_rec_plan_chunks": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "rd_layout_postprocess": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rd_set_precision": (C.c_int, [C.c_void_p, C.c_char_p]),
     "rd_range_status": (C.c_int, [C.c_void_p, C.c_void_p]),

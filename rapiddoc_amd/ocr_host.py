@@ -178,19 +178,41 @@ def rec_chunk_cost(n, wpad, n_cu: int = 256):
 
 
 def rec_batches_adaptive(wh_ratios: Sequence[float], img_h: int = REC_IMG_H, img_w: int = REC_IMG_W, width_multiple: int = 32,
-                         n_min: int = 16, n_max: int = 160, n_step: int = 2, n_cu: int = 256) -> List[Tuple[np.ndarray, int]]:
+                         n_min: int = 16, n_max: int = 160, n_step: int = 2, n_cu: int = 256, planner: str = "dp") -> List[Tuple[np.ndarray, int]]:
     """Throughput-mode chunking of the aspect-sorted line list with chunk SIZES chosen so that the persistent kernels' tile counts
-    fill whole rounds of the chip (`rec_chunk_cost`): greedily, the chunk with the most lines per estimated microsecond.
-    Same return format as `rec_batches`; every line is in exactly one chunk, chunks are runs of the sorted order, the padded width
-    is the reference's `int(img_h * max_ratio)` of the chunk rounded up to `width_multiple`."""
+    fill whole rounds of the chip (`rec_chunk_cost`).  `planner="dp"`: the cut positions that minimise the summed cost, a dynamic
+    programme in the library (`rd_rec_plan_chunks`, ~1 ms for 1440 lines); `"greedy"`: chunk by chunk the size with the most lines per
+    estimated microsecond (pure numpy).  Same return format as `rec_batches`; every line is in exactly one chunk, chunks are runs
+    of the sorted order, the padded width is the reference's `int(img_h * max_ratio)` of the chunk rounded up to `width_multiple`."""
+    import os
+    planner = os.environ.get("RD_REC_PLANNER", planner)       # (developer A/B switch)
     ratios = np.array([float(r) for r in wh_ratios])
     order = np.argsort(ratios, kind="stable")
     rs = ratios[order]
     wp = (img_h * np.maximum(img_w / img_h, rs)).astype(np.int64)
     if width_multiple > 1:
         wp = (wp + width_multiple - 1) // width_multiple * width_multiple
+    total = len(rs)
+    if total == 0:
+        return []
+    if planner == "dp":
+        import ctypes as C
+
+        from . import _lib
+        lib = _lib.load()
+        w32 = np.ascontiguousarray(wp, dtype=np.int32)
+        sizes = np.zeros(total, dtype=np.int32)
+        n_out = C.c_int32(0)
+        rc = lib.rd_rec_plan_chunks(w32.ctypes.data, total, n_min, n_max, n_step, n_cu, sizes.ctypes.data, total, C.byref(n_out))
+        if rc != 0:
+            raise RuntimeError("rd_rec_plan_chunks failed")
+        out, i = [], 0
+        for n in sizes[: n_out.value].tolist():
+            out.append((order[i: i + n], int(wp[i + n - 1])))
+            i += n
+        return out
     out: List[Tuple[np.ndarray, int]] = []
-    i, total = 0, len(rs)
+    i = 0
     cand = np.arange(n_min, n_max + 1, n_step)
     while i < total:
         left = total - i

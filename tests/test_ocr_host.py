@@ -150,7 +150,8 @@ def test_char_table_and_row_parser_roundtrip():
     assert ocr_host.parse_ctc_rows(rows) == [("a\u6587 ", 0.875), ("", 0.0)]
 
 
-def test_rec_batches_adaptive_partitions_the_sorted_list():
+@pytest.mark.parametrize("planner", ["dp", "greedy"])
+def test_rec_batches_adaptive_partitions_the_sorted_list(planner):
     """Throughput-mode chunking with width-dependent chunk sizes: every line in exactly one chunk, chunks are runs of the aspect-sorted
     order, the padded width is the reference's int(48 * max ratio) of the chunk rounded up to the multiple, sizes stay inside the
     bounds, and the cost model it optimises prefers a chunk that fills whole rounds of the chip (62 lines of width 1056 = 3 rounds of
@@ -158,7 +159,7 @@ def test_rec_batches_adaptive_partitions_the_sorted_list():
     from rapiddoc_amd import ocr_host as H
     rng = np.random.default_rng(3)
     ratios = rng.uniform(2.0, 44.0, 1440).tolist()
-    bat = H.rec_batches_adaptive(ratios, width_multiple=32)
+    bat = H.rec_batches_adaptive(ratios, width_multiple=32, planner=planner)
     order = np.concatenate([c for c, _ in bat])
     assert sorted(order.tolist()) == list(range(1440))
     assert np.all(np.diff(np.asarray(ratios)[order]) >= 0)
@@ -170,5 +171,40 @@ def test_rec_batches_adaptive_partitions_the_sorted_list():
     c62, c64 = float(H.rec_chunk_cost(62, 1056)), float(H.rec_chunk_cost(64, 1056))
     assert c62 / 62 < c64 / 64
     # few lines: one chunk
-    assert [len(c) for c, _ in H.rec_batches_adaptive([5.0] * 9)] == [9]
-    assert H.rec_batches_adaptive([]) == []
+    assert [len(c) for c, _ in H.rec_batches_adaptive([5.0] * 9, planner=planner)] == [9]
+    assert H.rec_batches_adaptive([], planner=planner) == []
+
+
+def test_rec_chunk_planner_is_optimal_and_matches_the_python_cost_model():
+    """rd_rec_plan_chunks (C++ dynamic programme, the default planner): its cost model equals ocr_host.rec_chunk_cost, its plan costs
+    no more than the greedy plan or fixed chunks of 64, and on a short list it equals a brute-force search over all compositions."""
+    import ctypes as C
+    import itertools
+
+    from rapiddoc_amd import _lib
+    from rapiddoc_amd import ocr_host as H
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    for n, w in zip(rng.integers(1, 200, 200).tolist(), (rng.integers(10, 110, 200) * 32).tolist()):
+        assert abs(lib.rd_rec_chunk_cost(n, w, 256) - float(H.rec_chunk_cost(n, w))) < 1e-6
+    ratios = rng.uniform(2.0, 44.0, 1440).tolist()
+    total = lambda bat: sum(float(H.rec_chunk_cost(len(c), w)) for c, w in bat)
+    dp, gr, fx = (H.rec_batches_adaptive(ratios, planner="dp"), H.rec_batches_adaptive(ratios, planner="greedy"), H.rec_batches(ratios, 64, width_multiple=32))
+    assert total(dp) <= total(gr) + 1e-6 and total(dp) < total(fx)
+    # brute force on 12 lines with sizes {2, 4, 6} (+ a free last chunk)
+    wp = np.sort(rng.integers(10, 60, 12) * 32).astype(np.int32)
+    sizes = np.zeros(12, np.int32)
+    n_out = C.c_int32(0)
+    assert lib.rd_rec_plan_chunks(wp.ctypes.data, 12, 2, 6, 2, 256, sizes.ctypes.data, 12, C.byref(n_out)) == 0
+    got = sizes[: n_out.value].tolist()
+    assert sum(got) == 12
+
+    def cost_of(comp):
+        j, c = 0, 0.0
+        for s_ in comp:
+            j += s_
+            c += lib.rd_rec_chunk_cost(s_, int(wp[j - 1]), 256)
+        return c
+    best = min(cost_of(comp) for k in range(1, 7) for comp in itertools.product(range(1, 7), repeat=k)
+               if sum(comp) == 12 and all(s_ in (2, 4, 6) for s_ in comp[:-1]))
+    assert abs(cost_of(got) - best) < 1e-6
