@@ -134,3 +134,19 @@ def test_no_serialised_load_runs_in_the_kernels_fixed_for_it():
     #  accumulators leave the compiler no room to keep all sixteen loads in flight)
     bad = [b for b in bad if not ("skinny2_gemm_kernelILi8ELi4ELi4E" in b[0] and max(b[1]) <= 5)]
     assert not bad, bad
+
+
+def test_inflight_checker_flags_a_hazard():
+    """The checker itself: a register copy of an in-flight register and a block boundary inside a load window must be reported, a clean
+    window must not (so that the test above cannot pass vacuously)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_inflight", ROOT / "tools" / "check_inflight.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    kernel = lambda body: "k1:                                     ; @k1\n" + body + "\n\t.end_amdhsa_kernel\n"
+    clean = kernel("\tglobal_load_dwordx4 v[8:11], v[2:3], off\n\tv_add_u32_e32 v1, v0, v0\n\ts_waitcnt vmcnt(0)\n\tv_mov_b32_e32 v20, v8")
+    assert mod.check(clean, ["k1"]) == []
+    copied = kernel("\tglobal_load_dwordx4 v[8:11], v[2:3], off\n\tv_mov_b32_e32 v20, v9\n\ts_waitcnt vmcnt(0)")
+    assert len(mod.check(copied, ["k1"])) == 1
+    split = kernel("\tglobal_load_dwordx4 v[8:11], v[2:3], off\n.LBB0_3:\n\ts_waitcnt vmcnt(0)")
+    assert any("block boundary" in h[2] for h in mod.check(split, ["k1"]))
