@@ -857,6 +857,7 @@ TView Builder::se_gate(const std::string& w1n, const std::string& b1n, const std
     const HostTensor& w1 = ws_->get(w1n);
     const int cr = (int)w1.shape[0], c = (int)w1.shape[1];
     RD_CHECK(c == x.c && c % 4 == 0, "SE channel mismatch: " + w1n);
+    RD_CHECK(c <= 512, "SE width above 512 channels (se_fc_kernel reads a row of W1 with two 16-byte loads per lane): " + w1n);
     const int hw = x.h * x.w;
     const bool fused_gap = pre && pre->chunks > 0;  // the producing depthwise conv already wrote the partial sums
     const int chunks = fused_gap ? pre->chunks : std::max(1, std::min(64, hw / 256));
