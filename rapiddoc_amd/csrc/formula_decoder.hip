@@ -70,61 +70,84 @@ struct AttnDecParams {
     const DecState* st; int fixed_T;  // T = fixed_T (cross) or st->step (self, then + current)
     float* out; int ldo;
 };
+// Round 3: the loop runs ~50 dependent launches of a few microseconds each, so this kernel is a latency chain.  Every row of K is
+// read with eight 16-byte loads requested before the first is used (it was 32 scalar loads per key), V by (16 key groups x 8 dim
+// quads) with four rows in flight per thread, the block reductions are wavefront shuffles + one LDS exchange (they were 7-step LDS
+// trees with a barrier per step).  11 -> ~7 us per launch (12 launches per token).
 __global__ void __launch_bounds__(128) dec_attention_kernel(AttnDecParams p) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
     extern __shared__ float sm[];  // scores[Tmax] + red[128]
-    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Tc = p.kcur ? p.st->step : p.fixed_T;   // cached keys
     const int T = Tc + (p.kcur ? 1 : 0);
     float* sc = sm;
     float* red = sm + ((T + 3) & ~3);
-    float q[HD];
+    static_assert(HD == 32, "eight float4 per head row");
+    f4 q[8];
+    const f4* qp = reinterpret_cast<const f4*>(p.q + (size_t)b * p.ldq + h * HD);
 #pragma unroll
-    for (int d = 0; d < HD; ++d) q[d] = p.q[(size_t)b * p.ldq + h * HD + d];
+    for (int d = 0; d < 8; ++d) q[d] = qp[d];
     if (p.kcur && tid < HD) {  // append this step's k, v for head h
         p.kw[(size_t)b * p.seq_stride + (size_t)Tc * p.ldkv + h * HD + tid] = p.kcur[(size_t)b * p.ldcur + h * HD + tid];
         p.vw[(size_t)b * p.seq_stride + (size_t)Tc * p.ldkv + h * HD + tid] = p.vcur[(size_t)b * p.ldcur + h * HD + tid];
     }
+    auto krow = [&](int j) { return (j < Tc) ? p.kc + (size_t)b * p.seq_stride + (size_t)j * p.ldkv + h * HD : p.kcur + (size_t)b * p.ldcur + h * HD; };
+    auto vrow = [&](int j) { return (j < Tc) ? p.vc + (size_t)b * p.seq_stride + (size_t)j * p.ldkv + h * HD : p.vcur + (size_t)b * p.ldcur + h * HD; };
     float mx = -INFINITY;
     for (int j = tid; j < T; j += 128) {
-        const float* kr = (j < Tc) ? p.kc + (size_t)b * p.seq_stride + (size_t)j * p.ldkv + h * HD : p.kcur + (size_t)b * p.ldcur + h * HD;
+        const f4* kr = reinterpret_cast<const f4*>(krow(j));
+        f4 k[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) k[d] = kr[d];
         float s = 0.f;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) s = fmaf(q[d], kr[d], s);
+        for (int d = 0; d < 8; ++d)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = fmaf(q[d][e], k[d][e], s);       // (same order as the scalar loop: d * 4 + e ascending)
         sc[j] = s;
         mx = fmaxf(mx, s);
     }
-    red[tid] = mx;
+    // block max: butterfly inside the wavefront, one exchange between the two
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wave] = mx;
     __syncthreads();
-    for (int o = 64; o > 0; o >>= 1) {
-        if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
-        __syncthreads();
-    }
-    mx = red[0];
-    __syncthreads();
+    mx = fmaxf(red[0], red[1]);
     float sum = 0.f;
     for (int j = tid; j < T; j += 128) {
         const float e = __expf(sc[j] - mx);
         sc[j] = e;
         sum += e;
     }
-    red[tid] = sum;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    __syncthreads();                       // (red[0 / 1] read by everybody; sc[] complete)
+    if (lane == 0) red[2 + wave] = sum;
     __syncthreads();
-    for (int o = 64; o > 0; o >>= 1) {
-        if (tid < o) red[tid] += red[tid + o];
-        __syncthreads();
+    const float inv = 1.f / (red[2] + red[3]);
+    // output: thread (g = tid / 8: one of 16 key groups, dq = tid % 8: dims 4 dq .. + 3) sums its keys, four rows in flight
+    const int dq = tid & 7, g = tid >> 3;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    int j = g;
+    for (; j + 48 < T; j += 64) {
+        const f4 v0 = reinterpret_cast<const f4*>(vrow(j))[dq], v1 = reinterpret_cast<const f4*>(vrow(j + 16))[dq];
+        const f4 v2 = reinterpret_cast<const f4*>(vrow(j + 32))[dq], v3 = reinterpret_cast<const f4*>(vrow(j + 48))[dq];
+        acc += v0 * sc[j];
+        acc += v1 * sc[j + 16];
+        acc += v2 * sc[j + 32];
+        acc += v3 * sc[j + 48];
     }
-    const float inv = 1.f / red[0];
-    __syncthreads();
-    // output: thread (g = tid / 32, d = tid % 32) sums its quarter of the keys for dimension d
-    const int d = tid & 31, g = tid >> 5;
-    float acc = 0.f;
-    for (int j = g; j < T; j += 4) {
-        const float* vr = (j < Tc) ? p.vc + (size_t)b * p.seq_stride + (size_t)j * p.ldkv + h * HD : p.vcur + (size_t)b * p.ldcur + h * HD;
-        acc = fmaf(sc[j], vr[d], acc);
+    for (; j < T; j += 16) acc += reinterpret_cast<const f4*>(vrow(j))[dq] * sc[j];
+    __syncthreads();                       // red[] is reused below
+    // sum over the 16 key groups: groups g and g ^ 1 .. sit 8 lanes apart inside a wavefront (8 groups per wavefront)
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
     }
-    red[tid] = acc;
+    if (lane < 8) *reinterpret_cast<f4*>(&red[wave * 32 + 4 * lane]) = acc;
     __syncthreads();
-    if (tid < 32) p.out[(size_t)b * p.ldo + h * HD + tid] = (red[tid] + red[tid + 32] + red[tid + 64] + red[tid + 96]) * inv;
+    if (tid < 32) p.out[(size_t)b * p.ldo + h * HD + tid] = (red[tid] + red[32 + tid]) * inv;
 }
 
 // next token: argmax of the logits row (forced EOS at the length limit), pad for finished sequences, append.  The last
