@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(1024) dec_select_kernel(const float* logits, i
     const float* z = logits + (size_t)b * V;
     float mx = -INFINITY;
     int mi = 0x7fffffff;
-    if ((V & 3) == 0) {
+    if ((V & 3) == 0 && V <= 65536) {
         // 16-byte loads, every load of the thread requested before the first compare (the scalar loop below ran its 49 loads per
         // thread through a compare-and-select chain: 18 us for 200 KB); indices still visited in increasing order per thread
         constexpr int MAXQ = 16;                     // V <= 65536
