@@ -84,7 +84,11 @@ extern "C" int rd_layout_postprocess(const float* boxes_in, int n, int ncol, int
             }
         }
     }
-    // 2. greedy NMS: IoU >= 0.6 suppresses within a class, >= 0.98 across classes (post_process.py:76,948-979)
+    // 2. greedy NMS: IoU >= 0.6 suppresses within a class, >= 0.98 across classes (post_process.py:76,948-979).
+    //    Boxes with EQUAL scores: the reference orders them with np.argsort's default kind reversed (:954), which is not a stable sort
+    //    (introsort, or x86-simd-sort where numpy dispatches to it), so their relative order there depends on the numpy build and the
+    //    CPU; here they keep their input order.  Seen with a stand-in detector emitting exact ties (tests/golden/make_golden_layout_trace.py
+    //    keeps its scores distinct for that reason); float32 scores of a real detector tie only by accident.
     if (cfg->layout_nms && !bx.empty()) {
         std::vector<int> idx(bx.size());
         std::iota(idx.begin(), idx.end(), 0);

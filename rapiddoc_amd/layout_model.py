@@ -162,9 +162,12 @@ class SyntheticBoxSession:
     call and of the scale factors (so the post-process sees page-pixel boxes like the real graph's, which rescales by
     1 / scale_factor in-graph, onnxruntime/main.py:61-78).  Plumbing tests / BASELINE `configs[0]` only."""
 
-    def __init__(self, labels: Sequence[str], boxes_per_page: int = 40, ncol: int = 6, seed: int = 0, size: int = 800):
+    def __init__(self, labels: Sequence[str], boxes_per_page: int = 40, ncol: int = 6, seed: int = 0, size: int = 800,
+                 twins: Optional[Tuple[str, str, int]] = None):
+        """`twins` = (label_a, label_b, k): the first k boxes of a page carry label_a and each gets a near-coincident copy
+        (2 px smaller all round, IoU > 0.9) labelled label_b - the situation `check_inline_formula` exists for."""
         self.characters = list(labels)
-        self.n, self.ncol, self.seed, self.size = boxes_per_page, ncol, seed, size
+        self.n, self.ncol, self.seed, self.size, self.twins = boxes_per_page, ncol, seed, size, twins
         self.calls: List[Tuple[Tuple[int, ...], np.ndarray]] = []
 
     def have_key(self, key: str = "character") -> bool:
@@ -190,5 +193,14 @@ class SyntheticBoxSession:
                 cols.append(rng.permutation(self.n).astype(np.float32))      # reading order column of V2 / V3
             if self.ncol == 8:
                 cols.append(np.zeros(self.n))
-            rows.append(np.stack(cols, axis=1).astype(np.float32))
-        return [np.concatenate(rows, axis=0), np.full(B, self.n, np.int32)]
+            page = np.stack(cols, axis=1).astype(np.float32)
+            if self.twins:
+                la, lb, k = self.twins
+                page[:k, 0], page[:k, 1] = self.characters.index(la), 0.9 - 0.01 * np.arange(k)     # (distinct: see layout_postprocess.cpp on ties)
+                page[:k, 4], page[:k, 5] = np.maximum(page[:k, 4], page[:k, 2] + 200), np.maximum(page[:k, 5], page[:k, 3] + 100)
+                twin = page[:k].copy()
+                twin[:, 0], twin[:, 1] = self.characters.index(lb), 0.8 - 0.01 * np.arange(k)
+                twin[:, 2:6] += np.float32([2, 2, -2, -2])
+                page = np.concatenate([page, twin], axis=0)
+            rows.append(page)
+        return [np.concatenate(rows, axis=0), np.asarray([len(r) for r in rows], np.int32)]

@@ -1,0 +1,59 @@
+"""Row a2 pinned to the reference's own wrapper stack: LayoutModel.batch_predict (rapiddoc_amd/layout_model.py) replayed against
+traces of RapidLayoutModel.batch_predict -> RapidLayout.__call__ -> PPDocLayoutModelHandler.__call__ -> PPPostProcess recorded by
+tests/golden/make_golden_layout_trace.py (reference code imported unmodified, detector session stood in by SyntheticBoxSession).
+Compared: how pages are chunked into session calls (input shape per model, scale factors), and the output dicts - category ids,
+labels, reading order, polys, rounded scores, the inline-formula re-labelling - value for value.
+The pre-process pixels are NOT what this test is about (the stand-in ignores them; GPU parity of the resize lives in
+test_gpu_image_ops.py), so `preprocess` is replaced by its shape / scale-factor half and the test runs without a GPU."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from rapiddoc_amd import _lib
+from rapiddoc_amd.layout_model import LayoutModel, SyntheticBoxSession
+
+TRACE = json.loads((Path(__file__).parent / "golden" / "layout_trace.json").read_text())
+pytestmark = pytest.mark.skipif(not _lib.LIB_PATH.exists(), reason="librapiddoc_mi355.so not built (rd_layout_postprocess is host C++)")
+
+
+def _shape_only_preprocess(self, pages):
+    S = self.m["S"]
+    sf = np.asarray([(S / p.shape[0], S / p.shape[1]) for p in pages], np.float32)
+    return torch.zeros((len(pages), 3, S, S), dtype=torch.float32), sf
+
+
+@pytest.mark.parametrize("case", TRACE["cases"], ids=[f"{i}-{c['model_type']}" for i, c in enumerate(TRACE["cases"])])
+def test_layout_wrapper_replays_the_reference_trace(case, monkeypatch):
+    monkeypatch.setattr(LayoutModel, "preprocess", _shape_only_preprocess)
+    size = {"pp_doclayout_s": 480, "pp_doclayout_l": 640}.get(case["model_type"], 800)
+    session = SyntheticBoxSession(case["labels"], case["boxes_per_page"], case["ncol"], seed=case["seed"], size=size, twins=case["twins"])
+    model = LayoutModel(session, case["model_type"], conf_thresh=case["conf_thresh"])
+    pages = [np.zeros((h, w, 3), np.uint8) for h, w in case["page_hw"]]
+    out = model.batch_predict(pages, case["batch_size"])
+
+    assert len(session.calls) == len(case["session_calls"])
+    for (shape, sf), ref in zip(session.calls, case["session_calls"]):
+        assert list(shape) == ref["shape"]
+        assert np.array_equal(sf, np.asarray(ref["scale_factor"], np.float32))
+
+    assert len(out) == len(case["layout_dets"])
+    for pi, (mine, ref) in enumerate(zip(out, case["layout_dets"])):
+        assert len(mine) == len(ref), f"page {pi}"
+        for bi, (a, b) in enumerate(zip(mine, ref)):
+            where = f"page {pi} box {bi}"
+            assert set(a) == set(b), where
+            assert a["category_id"] == b["category_id"] and a["original_label"] == b["original_label"], where
+            assert a["original_order"] == b["original_order"] and a["polygon_points"] == b["polygon_points"], where
+            assert [float(v) for v in a["poly"]] == b["poly"], where
+            assert float(a["score"]) == b["score"], where
+
+
+def test_traces_cover_the_inline_formula_relabelling_and_reading_order():
+    cats = [{d["category_id"] for p in c["layout_dets"] for d in p} for c in TRACE["cases"]]
+    assert any(13 in s for s in cats[1:4]), "no InlineEquation produced by check_inline_formula in the pp_doclayout families"
+    for page in TRACE["cases"][0]["layout_dets"]:                          # V3: a reading order per box, 0 .. n-1 after the sort
+        assert [d["original_order"] for d in page] == list(range(len(page)))
+    assert all(d["original_order"] == -1 for p in TRACE["cases"][3]["layout_dets"] for d in p)
