@@ -206,6 +206,33 @@ typedef struct rd_layout_post_cfg {
 } rd_layout_post_cfg;
 int rd_layout_postprocess(const float* boxes, int n, int ncol, int img_w, int img_h, const rd_layout_post_cfg* cfg,
                           float* out, int32_t* out_order, int32_t* n_out);
+/* The rows of `boxes` that reach the polygon stage of PPPostProcess.__call__ (post_process.py:213-218: after threshold / NMS /
+ * big-image filter / containment merge / reading-order sort, before unclip and clip): sel_boxes [n][6], sel_src[i] = row index in
+ * `boxes` (the detector's masks follow the boxes through those steps, :46-211).  Position i is out_order[k] - 1 of the row
+ * rd_layout_postprocess writes for the same box. */
+int rd_layout_postprocess_select(const float* boxes, int n, int ncol, int img_w, int img_h, const rd_layout_post_cfg* cfg,
+                                 float* sel_boxes, int32_t* sel_src, int32_t* n_sel);
+
+/* Raster / polygon primitives of the polygon branch (HOST pointers; rapiddoc_amd/csrc/polygon_ops.cpp).  Each replaces one
+ * OpenCV / shapely call of the reference (PARITY UNPINNED: neither library is available offline; restated from their published
+ * algorithms):
+ *   rd_find_external_contours  cv2.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)        post_process.py:409
+ *   rd_contour_area            cv2.contourArea                                                     :414
+ *   rd_arc_length              cv2.arcLength(cnt, closed)                                          :415
+ *   rd_approx_poly_dp          cv2.approxPolyDP(cnt, epsilon, closed)                              :416
+ *   rd_min_area_rect_points    cv2.boxPoints(cv2.minAreaRect(points))  (corner order unspecified)  :553-554
+ *   rd_polygon_area / rd_polygon_intersection_area   shapely Polygon.area / intersection(...).area :704-711
+ *   rd_fill_poly               cv2.fillPoly(mask, [polygon], value), u8 single channel    rapid_doc/utils/model_utils.py:114
+ * Points are [n][2] (x, y).  Return 0 = ok, 1 = bad arguments, 2 = output capacity (the needed counts are written). */
+int rd_find_external_contours(const uint8_t* mask, int h, int w, int32_t* pts_out, int max_pts, int32_t* counts_out, int max_contours,
+                              int32_t* n_contours, int32_t* n_pts);
+double rd_contour_area(const int32_t* pts, int n);
+double rd_arc_length(const int32_t* pts, int n, int closed);
+int rd_approx_poly_dp(const int32_t* pts, int n, double epsilon, int closed, int32_t* out, int32_t* n_out);
+int rd_min_area_rect_points(const float* pts, int n, float* out8);
+double rd_polygon_area(const double* a, int na);
+double rd_polygon_intersection_area(const double* a, int na, const double* b, int nb);
+int rd_fill_poly(uint8_t* img, int h, int w, const int32_t* pts, int n, int value);
 
 /* Host: chunk sizes of the recogniser's THROUGHPUT mode (the engine's own scheduling; rapidocr's fixed rec_batch_num chunks,
  * rapid_doc/model/ocr/rapid_ocr.py:430-440, are the `strict` mode of rapiddoc_amd.pipeline.PagePipeline).  wpad_sorted[i] = padded

@@ -43,6 +43,15 @@ SYMBOLS = {
     "rd_rec_chunk_cost": (C.c_double, [C.c_int, C.c_int, C.c_int]),
     "rd_rec_plan_chunks": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "rd_layout_postprocess": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rd_layout_postprocess_select": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rd_find_external_contours": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "rd_contour_area": (C.c_double, [C.c_void_p, C.c_int]),
+    "rd_arc_length": (C.c_double, [C.c_void_p, C.c_int, C.c_int]),
+    "rd_approx_poly_dp": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
+    "rd_min_area_rect_points": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "rd_polygon_area": (C.c_double, [C.c_void_p, C.c_int]),
+    "rd_polygon_intersection_area": (C.c_double, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "rd_fill_poly": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     "rd_set_precision": (C.c_int, [C.c_void_p, C.c_char_p]),
     "rd_range_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rd_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),

@@ -24,7 +24,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
-from . import layout_host, ocr_host
+from . import layout_host, layout_polygon, ocr_host
 from .engine import preproc_resize_norm_batch
 
 OCR_TEXT, LOW_SCORE_TEXT = 15, 16                 # utils/enum_class.py:103-104
@@ -72,7 +72,11 @@ def recognise_formulas(pages: torch.Tensor, layout_dets_per_page: Sequence[Seque
             if x1 <= x0 or y1 <= y0:
                 continue
             targets.append(d)
-            crops.append(pages[p, y0:y1, x0:x1].cpu().numpy())          # RGB crop, no margin (crop_img with paste 0)
+            crop = pages[p, y0:y1, x0:x1].cpu().numpy()                  # RGB crop, no margin (crop_img with paste 0)
+            if c.get("polygon_points"):                                  # crop_img whites out what lies outside the polygon
+                crop = crop.copy()
+                crop[~layout_polygon.polygon_keep_mask(crop.shape[:2], c["polygon_points"], int(c["poly"][0]), int(c["poly"][1]))] = 255
+            crops.append(crop)
     if crops:
         for d, res in zip(targets, formula_model.batch_predict(crops, batch_size=batch_size)):
             if res:
@@ -154,8 +158,11 @@ class RegionOcr:
                 p, _r, (px, py, x0, y0, x1, y1, _nw, _nh), fboxes = regions[ridx]
                 x0c, y0c, x1c, y1c = max(0, x0), max(0, y0), min(W, x1), min(H, y1)      # numpy slicing clips the same way
                 if x1c > x0c and y1c > y0c:
-                    canv[k, py + (y0c - y0): py + (y0c - y0) + (y1c - y0c), px + (x0c - x0): px + (x0c - x0) + (x1c - x0c)] = \
-                        pages[p, y0c:y1c, x0c:x1c]
+                    dst = canv[k, py + (y0c - y0): py + (y0c - y0) + (y1c - y0c), px + (x0c - x0): px + (x0c - x0) + (x1c - x0c)]
+                    dst[:] = pages[p, y0c:y1c, x0c:x1c]
+                    if _r.get("polygon_points"):       # crop_img (model_utils.py:109-118): outside the region's polygon -> white,
+                        keep = layout_polygon.polygon_keep_mask((y1c - y0c, x1c - x0c), _r["polygon_points"], x0, y0)   # for det AND rec
+                        dst[~torch.from_numpy(keep).to(dst.device)] = 255
             det_canv = canv.clone() if any(regions[ridx][3] for ridx in members) else canv
             for k, ridx in enumerate(members):
                 nh, nw = regions[ridx][2][7], regions[ridx][2][6]

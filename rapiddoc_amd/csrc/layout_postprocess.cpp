@@ -5,7 +5,8 @@
 // :611-662 `unclip_boxes`, :566-608 `restructured_boxes`), which becomes the bottleneck once the network takes ~ms.
 // Arithmetic is done in float32 exactly where numpy does it in float32 so that kept boxes / coordinates are
 // bit-identical to the reference (pinned by tests/golden/layout_post_seed*.json, minted from the reference class).
-// The polygon branch (masks -> cv2.findContours / approxPolyDP, shapely) is not built (cv2 absent; SURVEY 8a').
+// The polygon branch (masks -> polygon_points, post_process.py:213-218,425-535) runs between steps 5 and 6 on the Python side
+// (rapiddoc_amd/layout_polygon.py over polygon_ops.cpp); rd_layout_postprocess_select hands it the rows that reach that point.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -16,7 +17,7 @@
 
 namespace {
 
-struct Box { float v[8]; };
+struct Box { float v[8]; int32_t src; };
 
 static inline float iou_plus1(const float* a, const float* b) {  // post_process.py:921-946 (+1 pixel convention)
     const float x1 = std::max(a[0], b[0]), y1 = std::max(a[1], b[1]);
@@ -56,14 +57,11 @@ static void check_containment(const std::vector<Box>& b, int formula_index, int 
         }
 }
 
-}  // namespace
 
-extern "C" int rd_layout_postprocess(const float* boxes_in, int n, int ncol, int img_w, int img_h, const rd_layout_post_cfg* cfg,
-                                     float* out, int32_t* out_order, int32_t* n_out) {
-    if (!cfg || !out || !out_order || !n_out || n < 0 || (ncol != 6 && ncol != 7 && ncol != 8) || (n > 0 && !boxes_in)) return 1;
-    *n_out = 0;
+// steps 1 - 5: the rows that survive threshold / NMS / big-image filter / containment merge, in reading order
+static std::vector<Box> select_rows(const float* boxes_in, int n, int ncol, int img_w, int img_h, const rd_layout_post_cfg* cfg) {
     std::vector<Box> bx;
-    auto get = [&](int i) { Box b{}; for (int c = 0; c < ncol; ++c) b.v[c] = boxes_in[(size_t)i * ncol + c]; return b; };
+    auto get = [&](int i) { Box b{}; for (int c = 0; c < ncol; ++c) b.v[c] = boxes_in[(size_t)i * ncol + c]; b.src = i; return b; };
     // 1. score threshold (float: original order; dict: grouped by ascending class id, np.unique + vstack)
     if (!cfg->thresh_is_dict) {
         for (int i = 0; i < n; ++i) {
@@ -149,7 +147,7 @@ extern "C" int rd_layout_postprocess(const float* boxes_in, int n, int ncol, int
             if (keep[i]) f.push_back(bx[i]);
         bx.swap(f);
     }
-    if (bx.empty()) return 0;
+    if (bx.empty()) return bx;
     // 5. reading-order sort for the 7 / 8 column outputs (post_process.py:195-211)
     if (ncol == 8)
         std::stable_sort(bx.begin(), bx.end(), [](const Box& a, const Box& b) {
@@ -157,6 +155,31 @@ extern "C" int rd_layout_postprocess(const float* boxes_in, int n, int ncol, int
         });
     else if (ncol == 7)
         std::stable_sort(bx.begin(), bx.end(), [](const Box& a, const Box& b) { return a.v[6] < b.v[6]; });
+    return bx;
+}
+
+}  // namespace
+
+// The rows that reach the polygon stage (after the reading-order sort, before unclip / clip): sel_boxes [n][6] and, per row, its
+// row index in `boxes` (so that the caller can carry the detector's masks along, post_process.py:46-211).  *n_sel rows are written;
+// position i here is `out_order[k] - 1` of the row rd_layout_postprocess writes for it.
+extern "C" int rd_layout_postprocess_select(const float* boxes_in, int n, int ncol, int img_w, int img_h, const rd_layout_post_cfg* cfg,
+                                            float* sel_boxes, int32_t* sel_src, int32_t* n_sel) {
+    if (!cfg || !sel_boxes || !sel_src || !n_sel || n < 0 || (ncol != 6 && ncol != 7 && ncol != 8) || (n > 0 && !boxes_in)) return 1;
+    const std::vector<Box> bx = select_rows(boxes_in, n, ncol, img_w, img_h, cfg);
+    for (size_t i = 0; i < bx.size(); ++i) {
+        for (int c = 0; c < 6; ++c) sel_boxes[i * 6 + c] = bx[i].v[c];
+        sel_src[i] = bx[i].src;
+    }
+    *n_sel = (int32_t)bx.size();
+    return 0;
+}
+
+extern "C" int rd_layout_postprocess(const float* boxes_in, int n, int ncol, int img_w, int img_h, const rd_layout_post_cfg* cfg,
+                                     float* out, int32_t* out_order, int32_t* n_out) {
+    if (!cfg || !out || !out_order || !n_out || n < 0 || (ncol != 6 && ncol != 7 && ncol != 8) || (n > 0 && !boxes_in)) return 1;
+    *n_out = 0;
+    const std::vector<Box> bx = select_rows(boxes_in, n, ncol, img_w, img_h, cfg);
     // 6. unclip (post_process.py:611-662) + 7. clip / drop degenerate (post_process.py:566-608)
     int k = 0;
     for (size_t i = 0; i < bx.size(); ++i) {

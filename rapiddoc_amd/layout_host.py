@@ -1,6 +1,7 @@
 """Host side of the layout stage: what surrounds the PP-DocLayout network in the reference.
 
-* `LayoutPostProcess` ....... PPPostProcess rect mode (pp_doclayout/post_process.py:20-243) - C++ behind the C-ABI
+* `LayoutPostProcess` ....... PPPostProcess (pp_doclayout/post_process.py:20-243) - C++ behind the C-ABI; with the detector's
+  masks and a layout_shape_mode other than "rect", the polygon stage of layout_polygon.py runs between its sort and unclip steps
 * label / threshold / merge tables of the shipped models: data captured from
   rapid_doc/model/layout/rapid_layout_self/utils/typings.py:14-140 (tests/golden/layout_tables.json)
 """
@@ -22,7 +23,7 @@ class _Cfg(C.Structure):
 
 
 class LayoutPostProcess:
-    """Same constructor arguments and result dicts as the reference's PPPostProcess (rect mode)."""
+    """Same constructor arguments and result dicts as the reference's PPPostProcess."""
 
     def __init__(self, labels: Sequence[str], conf_thres: Union[float, Dict[int, float]] = 0.5, iou_thres: float = 0.5,
                  layout_nms: bool = True, layout_merge_bboxes_mode: Union[None, str, Dict[int, str]] = None,
@@ -30,6 +31,7 @@ class LayoutPostProcess:
         from . import _lib
         self._lib = _lib.load()
         self.labels = list(labels)
+        self.scale_size = scale_size
         n = len(self.labels)
         cfg = _Cfg()
         cfg.n_classes = n
@@ -76,15 +78,32 @@ class LayoutPostProcess:
         cfg.unclip_present = self._present.ctypes.data
         self._cfg = cfg
 
-    def __call__(self, boxes: np.ndarray, img_size: Tuple[int, int], masks=None, layout_shape_mode: Optional[str] = "rect"):
-        """boxes [n, 6|7|8] float32, img_size (width, height).  Returns the reference's list of dicts
-        {cls_id, label, score, coordinate, order}."""
-        if masks is not None and layout_shape_mode != "rect":
-            raise NotImplementedError("polygon output (masks) is not built; use layout_shape_mode='rect'")
+    def __call__(self, boxes: np.ndarray, img_size: Tuple[int, int], masks=None, layout_shape_mode: Optional[str] = "auto"):
+        """boxes [n, 6|7|8] float32, img_size (width, height), masks [n, hm, wm] or None.  Returns the reference's list of dicts
+        {cls_id, label, score, coordinate, order(, polygon_points)}; `polygon_points` only with masks and a mode other than "rect"
+        (post_process.py:40-41,213-218), and a box whose polygon came out as None is dropped (:600-603)."""
+        if layout_shape_mode == "rect":
+            masks = None
         b = np.ascontiguousarray(boxes, dtype=np.float32)
         if b.size == 0:
             return np.array([])
         n, ncol = b.shape
+        polygons = None
+        if masks is not None:
+            from . import layout_polygon
+            if self.scale_size is None:
+                raise ValueError("scale_size (the detector's input size) is needed to place boxes on the mask grid")
+            sel = np.zeros((n, 6), np.float32)
+            src = np.zeros(n, np.int32)
+            m = C.c_int32(0)
+            rc = self._lib.rd_layout_postprocess_select(b.ctypes.data, n, ncol, int(img_size[0]), int(img_size[1]), C.byref(self._cfg),
+                                                        sel.ctypes.data, src.ctypes.data, C.byref(m))
+            if rc != 0:
+                raise ValueError(f"The shape of boxes should be 6, 7 or 8 columns, instead of {ncol}")
+            if m.value == 0:
+                return np.array([])
+            scale_ratio = [h / s for h, s in zip(self.scale_size, img_size)]
+            polygons = layout_polygon.polygons_from_masks(sel[:m.value], np.asarray(masks)[src[:m.value]], scale_ratio, layout_shape_mode)
         out = np.zeros((n, 6), np.float32)
         order = np.zeros(n, np.int32)
         k = C.c_int32(0)
@@ -97,8 +116,13 @@ class LayoutPostProcess:
         res = []
         for i in range(k.value):
             r = out[i]
-            res.append({"cls_id": int(r[0]), "label": self.labels[int(r[0])], "score": float(r[1]),
-                        "coordinate": [float(r[2]), float(r[3]), float(r[4]), float(r[5])], "order": int(order[i])})
+            d = {"cls_id": int(r[0]), "label": self.labels[int(r[0])], "score": float(r[1]),
+                 "coordinate": [float(r[2]), float(r[3]), float(r[4]), float(r[5])], "order": int(order[i])}
+            if polygons is not None:
+                if polygons[order[i] - 1] is None:
+                    continue
+                d["polygon_points"] = polygons[order[i] - 1]
+            res.append(d)
         return res
 
     @staticmethod
@@ -134,7 +158,8 @@ def _overlap_over_smaller(a, b) -> float:
 def filter_overlap_boxes(layout_dets: Sequence[dict], use_custom_ocr: bool = False) -> List[dict]:
     """Drop 'reference' boxes, boxes thinner than 6 px, and - for pairs overlapping by > 0.7 of the smaller box - the
     smaller one (image / seal / chart are only compared with their own label; inline formulas are only touched in
-    custom-OCR mode, where an overlap > 0.5 removes the formula).  Rectangle mode (no polygon_points)."""
+    custom-OCR mode, where an overlap > 0.5 removes the formula).  With `polygon_points` on the first box of a pair, the pair is
+    left alone when the POLYGONS overlap by less than 0.7 of the smaller one (utils.py:150-155)."""
     boxes = [dict(d) for d in layout_dets if d["original_label"] != "reference"]
     dropped = set()
     for i in range(len(boxes)):
@@ -158,6 +183,10 @@ def filter_overlap_boxes(layout_dets: Sequence[dict], use_custom_ocr: bool = Fal
                         dropped.add(j)
                     continue
             if ov > 0.7:
+                if boxes[i].get("polygon_points"):
+                    from .layout_polygon import polygon_overlap_ratio
+                    if polygon_overlap_ratio(boxes[i]["polygon_points"], boxes[j]["polygon_points"], "small") < 0.7:
+                        continue
                 if ({li, lj} & _EXCLUSIVE_LABELS) and li != lj:
                     continue
                 ai = abs((ri[2] - ri[0]) * (ri[3] - ri[1]))
@@ -261,11 +290,16 @@ def category_map(model_family: str, markdown_ignore_labels: Sequence[str] = ()) 
 
 def to_layout_dets(post: Sequence[dict], model_family: str, ordered: bool, markdown_ignore_labels: Sequence[str] = ()) -> List[dict]:
     """LayoutPostProcess output -> the `layout_dets` dicts BatchAnalyze consumes: category_id, original_label,
-    original_order, poly [x0,y0,x1,y0,x1,y1,x0,y1], polygon_points, score rounded to 3 decimals."""
+    original_order, poly [x0,y0,x1,y0,x1,y1,x0,y1], polygon_points, score rounded to 3 decimals.  polygon_points: [[x, y], ...]
+    floats when EVERY box of the page has a polygon, else None for all of them (pp_doclayout/main.py:69-72, rapid_layout.py:93-98)."""
     cmap = category_map(model_family, markdown_ignore_labels)
+    polys = [d.get("polygon_points") for d in post]
+    if any(p is None for p in polys):
+        polys = [None] * len(polys)
     out = []
     for i, d in enumerate(post):
         x0, y0, x1, y1 = d["coordinate"]
+        pts = None if polys[i] is None else [[float(x), float(y)] for x, y in polys[i]]
         out.append({"category_id": cmap[d["label"]], "original_label": d["label"], "original_order": i if ordered else -1,
-                    "poly": [x0, y0, x1, y0, x1, y1, x0, y1], "polygon_points": None, "score": round(float(d["score"]), 3)})
+                    "poly": [x0, y0, x1, y0, x1, y1, x0, y1], "polygon_points": pts, "score": round(float(d["score"]), 3)})
     return out

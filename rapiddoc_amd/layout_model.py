@@ -87,9 +87,15 @@ class LayoutModel:
     """`batch_predict(images, batch_size) -> list[list[dict]]` exactly as `RapidLayoutModel.batch_predict` returns it."""
 
     def __init__(self, session, model_type: str = "pp_doclayoutv3", conf_thresh: Union[None, float, Dict[int, float]] = None,
-                 iou_thresh: float = 0.5, markdown_ignore_labels: Sequence[str] = DEFAULT_IGNORE, device: int = 0):
+                 iou_thresh: float = 0.5, markdown_ignore_labels: Sequence[str] = DEFAULT_IGNORE, device: int = 0,
+                 layout_shape_mode: str = "auto"):
+        """`layout_shape_mode` (typings.py:169, default "auto"): what becomes of the detector's instance masks when its session
+        returns them - "rect" ignores them, "poly" / "quad" / "auto" turn them into `polygon_points` (layout_polygon.py)."""
         if model_type not in _MODELS:
             raise ValueError(f"model_type must be one of {sorted(_MODELS)}")
+        if layout_shape_mode not in ("rect", "poly", "quad", "auto"):
+            raise ValueError("layout_shape_mode must be one of ['rect', 'poly', 'quad', 'auto']")
+        self.layout_shape_mode = layout_shape_mode
         self.session, self.model_type, self.m = session, model_type, _MODELS[model_type]
         self.device = torch.device("cuda", device)
         self.labels = list(session.characters)
@@ -121,11 +127,12 @@ class LayoutModel:
         pred = self.session(x if wants_device else x.cpu().numpy(), sf)
         outs = split_session_output(pred)
         res = []
+        mode = self.layout_shape_mode
         for pg, o in zip(pages, outs):
             h, w = int(pg.shape[0]), int(pg.shape[1])
-            if "masks" in o:
-                raise NotImplementedError("polygon mode (mask head): cv2 / shapely branch of PPPostProcess, not built")
-            datas = self.post(o["boxes"], [w, h], None, "rect")
+            if "masks" not in o:
+                mode = "rect"                              # stays "rect" for the rest of the chunk, like the reference (main.py:59-66)
+            datas = self.post(o["boxes"], [w, h], o.get("masks"), mode)
             datas = [] if isinstance(datas, np.ndarray) else datas
             dets = layout_host.to_layout_dets(datas, self.m["family"], self.m["ordered"], self.ignore)
             if self.m["family"] != "pp_doclayoutv2":
@@ -163,11 +170,13 @@ class SyntheticBoxSession:
     1 / scale_factor in-graph, onnxruntime/main.py:61-78).  Plumbing tests / BASELINE `configs[0]` only."""
 
     def __init__(self, labels: Sequence[str], boxes_per_page: int = 40, ncol: int = 6, seed: int = 0, size: int = 800,
-                 twins: Optional[Tuple[str, str, int]] = None):
+                 twins: Optional[Tuple[str, str, int]] = None, masks: bool = False):
         """`twins` = (label_a, label_b, k): the first k boxes of a page carry label_a and each gets a near-coincident copy
-        (2 px smaller all round, IoU > 0.9) labelled label_b - the situation `check_inline_formula` exists for."""
+        (2 px smaller all round, IoU > 0.9) labelled label_b - the situation `check_inline_formula` exists for.
+        `masks`: a third output like the instance-segmentation detectors give, u8 [sum n, size / 4, size / 4]: per box an ellipse,
+        a slanted quadrilateral or the full rectangle drawn in its patch of the mask grid."""
         self.characters = list(labels)
-        self.n, self.ncol, self.seed, self.size, self.twins = boxes_per_page, ncol, seed, size, twins
+        self.n, self.ncol, self.seed, self.size, self.twins, self.masks = boxes_per_page, ncol, seed, size, twins, masks
         self.calls: List[Tuple[Tuple[int, ...], np.ndarray]] = []
 
     def have_key(self, key: str = "character") -> bool:
@@ -203,4 +212,25 @@ class SyntheticBoxSession:
                 twin[:, 2:6] += np.float32([2, 2, -2, -2])
                 page = np.concatenate([page, twin], axis=0)
             rows.append(page)
-        return [np.concatenate(rows, axis=0), np.asarray([len(r) for r in rows], np.int32)]
+        out = [np.concatenate(rows, axis=0), np.asarray([len(r) for r in rows], np.int32)]
+        if self.masks:
+            g = self.size // 4
+            grids = []
+            for b, page in enumerate(rows):
+                sy, sx = scale_factor[b, 0] / 4, scale_factor[b, 1] / 4          # page pixels -> mask grid
+                m = np.zeros((len(page), g, g), np.uint8)
+                for i, r in enumerate(page):
+                    x0, x1 = int(np.floor(r[2] * sx)), min(g, max(int(np.ceil(r[4] * sx)), int(np.floor(r[2] * sx)) + 1))
+                    y0, y1 = int(np.floor(r[3] * sy)), min(g, max(int(np.ceil(r[5] * sy)), int(np.floor(r[3] * sy)) + 1))
+                    yy, xx = np.mgrid[:max(y1 - y0, 0), :max(x1 - x0, 0)]
+                    u, v = (xx + 0.5) / max(x1 - x0, 1), (yy + 0.5) / max(y1 - y0, 1)
+                    if i % 3 == 0:
+                        shape = ((u - 0.5) / 0.45) ** 2 + ((v - 0.5) / 0.42) ** 2 <= 1
+                    elif i % 3 == 1:
+                        shape = (u - 0.2 * (v - 0.5) > 0.12) & (u - 0.2 * (v - 0.5) < 0.88) & (v > 0.1) & (v < 0.9)
+                    else:
+                        shape = np.ones(u.shape, bool)
+                    m[i, y0:y1, x0:x1] = shape
+                grids.append(m)
+            out.append(np.concatenate(grids, axis=0))
+        return out

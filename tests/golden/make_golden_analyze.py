@@ -85,6 +85,13 @@ def _fake_cv2():
     cv2.getPerspectiveTransform = lambda src, dst: np.eye(3)
     cv2.warpPerspective = lambda img, M, size, borderMode=None, flags=None: np.zeros((int(size[1]), int(size[0]), 3), np.uint8)
 
+    def fill_poly(img, pts, color):       # crop_img's polygon mask (model_utils.py:114): this repo's primitive under OpenCV's name,
+        from rapiddoc_amd import layout_polygon      # as in make_golden_polygon.py - pins the code AROUND the call, not OpenCV's rasteriser
+        for p_ in pts:
+            layout_polygon.fill_poly(img, np.asarray(p_).reshape(-1, 2), int(color))
+        return img
+    cv2.fillPoly = fill_poly
+
     def _missing(name):
         raise AttributeError(f"cv2.{name} is not stood in for: the traced path must not reach it")
     cv2.__getattr__ = _missing
@@ -95,6 +102,10 @@ def import_reference():
     finder = _RefFinder()
     sys.meta_path.insert(0, finder)
     sys.modules["cv2"] = _fake_cv2()
+    if "shapely" not in sys.modules:                  # filter_overlap_boxes' polygon rule (utils.py:150-155): see make_golden_polygon.py
+        sys.path.insert(0, str(HERE))
+        import make_golden_polygon
+        sys.modules["shapely"], sys.modules["shapely.geometry"] = make_golden_polygon.fake_shapely()
     # the model registry imports every model wrapper: replaced by the recording registry below
     reg = types.ModuleType("rapid_doc.backend.pipeline.model_init")
     reg.AtomModelSingleton = type("AtomModelSingleton", (), {})      # rebound per trace in main()
@@ -179,7 +190,8 @@ class RecordingFormula:
         self.trace = trace
 
     def batch_predict(self, images, batch_size=1, **kw):
-        self.trace["formula_calls"].append({"batch_size": int(batch_size), "shapes": [list(np.asarray(i).shape[:2]) for i in images]})
+        self.trace["formula_calls"].append({"batch_size": int(batch_size), "shapes": [list(np.asarray(i).shape[:2]) for i in images],
+                                            "crc32": [zlib.crc32(np.ascontiguousarray(np.asarray(i)).tobytes()) for i in images]})
         return [f"\\\\frac{{{np.asarray(i).shape[0]}}}{{{np.asarray(i).shape[1]}}}" for i in images]
 
 
@@ -193,13 +205,29 @@ class RecordingLayout:
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def layout_for_page(rng, H, W):
-    """Prepared layout detections of one page (the dict schema of RapidLayoutModel.batch_predict, rapid_layout.py:58-107)."""
+def layout_for_page(rng, H, W, polygons=False):
+    """Prepared layout detections of one page (the dict schema of RapidLayoutModel.batch_predict, rapid_layout.py:58-107).
+    `polygons`: every box also carries `polygon_points` (what a detector with a mask head yields in the default "auto" shape mode):
+    the box with its corners cut, a slanted quadrilateral for formulas, and - for the two nearly coincident text boxes - the left and
+    the right half, so that the polygon rule of filter_overlap_boxes keeps both."""
     dets = []
 
-    def add(cat, label, x0, y0, x1, y1, score=0.9, order=None):
+    def add(cat, label, x0, y0, x1, y1, score=0.9, order=None, shape="cut"):
+        pts = None
+        if polygons:
+            w_, h_ = x1 - x0, y1 - y0
+            if shape == "cut":
+                c = min(w_, h_) * 0.25
+                pts = [[x0 + c, y0], [x1 - c, y0], [x1, y0 + c], [x1, y1 - c], [x1 - c, y1], [x0 + c, y1], [x0, y1 - c], [x0, y0 + c]]
+            elif shape == "slant":
+                pts = [[x0 + 0.1 * w_, y0], [x1, y0], [x1 - 0.1 * w_, y1], [x0, y1]]
+            elif shape == "left":
+                pts = [[x0, y0], [x0 + 0.55 * w_, y0], [x0 + 0.55 * w_, y1], [x0, y1]]
+            elif shape == "right":
+                pts = [[x0 + 0.45 * w_, y0], [x1, y0], [x1, y1], [x0 + 0.45 * w_, y1]]
+            pts = [[float(a), float(b)] for a, b in pts]
         dets.append({"category_id": cat, "original_label": label, "original_order": len(dets) if order is None else order,
-                     "poly": [x0, y0, x1, y0, x1, y1, x0, y1], "polygon_points": None, "score": round(float(score), 3)})
+                     "poly": [x0, y0, x1, y0, x1, y1, x0, y1], "polygon_points": pts, "score": round(float(score), 3)})
     y = 70.5
     add(0, "doc_title", 180.2, y, 1010.7, y + 58.4)                       # Title
     y += 90
@@ -209,12 +237,12 @@ def layout_for_page(rng, H, W):
         x1 = float(rng.choice([1100.2, 1050.0, 600.5]))
         add(1, "text", x0, y, x1, y + hgt)
         if k == 0:      # an inline formula inside the first paragraph (whited out of the det canvas, cut out of its lines)
-            add(13, "inline_formula", x0 + 200.3, y + 60.2, x0 + 330.8, y + 92.6, 0.8)
+            add(13, "inline_formula", x0 + 200.3, y + 60.2, x0 + 330.8, y + 92.6, 0.8, shape="slant")
         y += hgt + 24.6
-    add(14, "display_formula", 300.0, y, 900.0, y + 70.0, 0.85)            # an isolated formula: formula model only
+    add(14, "display_formula", 300.0, y, 900.0, y + 70.0, 0.85, shape="slant")   # an isolated formula: formula model only
     y += 95
-    add(1, "text", 90.0, y, 560.0, y + 130.0)
-    add(1, "text", 96.0, y + 4.0, 552.0, y + 122.0, 0.55)                  # almost the same box, lower score: filter_overlap_boxes
+    add(1, "text", 90.0, y, 560.0, y + 130.0, shape="left")
+    add(1, "text", 96.0, y + 4.0, 552.0, y + 122.0, 0.55, shape="right")   # almost the same box, lower score: filter_overlap_boxes
     add(3, "image", 620.0, y, 1100.0, y + 260.0, 0.9)                      # a figure: no OCR
     add(2, "abandon", 500.0, H - 60.0, 700.0, H - 25.0, 0.7)               # footer: OCR region (category 2)
     return dets
@@ -225,13 +253,14 @@ def main():
     from rapid_doc.backend.pipeline.model_list import AtomicModel
     from rapiddoc_amd.pages import synth_page
 
-    for seed, (n_pages, formula_enable, formula_level) in enumerate([(3, True, 0), (2, False, 0), (2, True, 1)]):
+    for seed, (n_pages, formula_enable, formula_level, polygons) in enumerate([(3, True, 0, False), (2, False, 0, False), (2, True, 1, False),
+                                                                               (2, True, 0, True)]):
         rng = np.random.default_rng(7000 + seed)
         trace = {"det_calls": [], "rec_calls": [], "formula_calls": [], "layout_calls": []}
         page_ids = [int(rng.integers(0, 1000)) for _ in range(n_pages)]
         pages = [synth_page(i)[0] for i in page_ids]
         H, W = pages[0].shape[:2]
-        dets = [layout_for_page(rng, H, W) for _ in range(n_pages)]
+        dets = [layout_for_page(rng, H, W, polygons) for _ in range(n_pages)]
         ocr = RecordingOcr(trace)
 
         class Registry:                      # rapid_doc/backend/pipeline/model_init.py:57-88 AtomModelSingleton

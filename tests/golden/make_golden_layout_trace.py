@@ -14,6 +14,8 @@ What is stood in for: the detector session (rapiddoc_amd.layout_model.SyntheticB
 the batch size, the page's position in the call and its scale factors - the same class the replay test plugs into this repo's
 LayoutModel), `cv2.resize` (a blank image of the requested size: pre-process PIXELS are pinned elsewhere), the engine factory /
 model download / image loader of RapidLayout.__init__, and the absent wheels (mocks, as in make_golden_analyze.py).
+The cases whose session returns instance MASKS go through the reference's polygon branch; there `cv2` / `shapely` are the thin
+modules of make_golden_polygon.py (this repo's C primitives behind OpenCV's / shapely's names - see that file for what this pins).
 The committed JSON holds page sizes, the recorded session calls (shapes, scale factors) and the reference's output dicts."""
 import importlib
 import json
@@ -26,6 +28,7 @@ import numpy as np
 HERE = Path(__file__).resolve().parent
 sys.path.insert(0, str(HERE))
 import make_golden_analyze as MGA  # noqa: E402
+import make_golden_polygon as MGP  # noqa: E402
 
 sys.path.insert(0, str(HERE.parents[1]))
 from rapiddoc_amd.layout_model import SyntheticBoxSession  # noqa: E402
@@ -34,9 +37,15 @@ from rapiddoc_amd.layout_model import SyntheticBoxSession  # noqa: E402
 def import_layout():
     finder = MGA._RefFinder()
     sys.meta_path.insert(0, finder)
-    cv2 = MGA._fake_cv2()
-    cv2.resize = lambda img, size, interpolation=None: np.zeros((int(size[1]), int(size[0]), 3), np.uint8)
+    cv2, poly_cv2 = MGA._fake_cv2(), MGP.fake_cv2()
+    for name in ("RETR_EXTERNAL", "CHAIN_APPROX_SIMPLE", "INTER_NEAREST", "findContours", "contourArea", "arcLength", "approxPolyDP",
+                 "minAreaRect", "boxPoints"):
+        setattr(cv2, name, getattr(poly_cv2, name))
+    # pages (3 channels) -> a blank image of the requested size; instance-mask crops (2-D) -> the nearest-neighbour primitive
+    cv2.resize = lambda img, size, interpolation=None: (np.zeros((int(size[1]), int(size[0]), 3), np.uint8) if np.ndim(img) == 3
+                                                        else poly_cv2.resize(img, size, interpolation))
     sys.modules["cv2"] = cv2
+    sys.modules["shapely"], sys.modules["shapely.geometry"] = MGP.fake_shapely()
     for _ in range(60):
         try:
             return importlib.import_module("rapid_doc.model.layout.rapid_layout")
@@ -62,14 +71,19 @@ def main():
     sizes = [(1684, 1191), (1000, 800), (842, 595), (1191, 1684), (640, 480)]
     cases = []
     for name, mt, labels, ncol, n_boxes, batch, cfg, twins in (
+            ("pp_doclayoutv3", ModelType.PP_DOCLAYOUTV3, list(d_v2), 7, 60, 2, {"masks": True}, None),
+            ("pp_doclayoutv3", ModelType.PP_DOCLAYOUTV3, list(d_v2), 7, 30, 5, {"masks": True, "layout_shape_mode": "rect"}, None),
+            ("pp_doclayoutv3", ModelType.PP_DOCLAYOUTV3, list(d_v2), 7, 30, 3, {"masks": True, "layout_shape_mode": "poly"}, None),
             ("pp_doclayoutv3", ModelType.PP_DOCLAYOUTV3, list(d_v2), 7, 60, 2, {}, None),
             ("pp_doclayout_plus_l", ModelType.PP_DOCLAYOUT_PLUS_L, list(d_plus), 6, 60, 3, {}, ["formula", "text", 3]),
             ("pp_doclayout_s", ModelType.PP_DOCLAYOUT_S, list(d_pp), 6, 80, 2, {}, ["formula", "text", 2]),
             ("pp_doclayout_l", ModelType.PP_DOCLAYOUT_L, list(d_pp), 6, 80, 5, {}, None),
             ("pp_doclayoutv3", ModelType.PP_DOCLAYOUTV3, list(d_v2), 7, 40, 1, {"conf_thresh": 0.6}, ["display_formula", "text", 2])):
         seed = len(cases)
+        cfg = dict(cfg)
+        with_masks = cfg.pop("masks", False)
         session = SyntheticBoxSession(labels, n_boxes, ncol, seed=seed, size={"pp_doclayout_s": 480, "pp_doclayout_l": 640}.get(name, 800),
-                                      twins=twins)
+                                      twins=twins, masks=with_masks)
         main_mod.get_engine = lambda engine_type: (lambda cfg_: session)
         model = RL.RapidLayoutModel(dict(model_type=mt, **cfg))
         pages = [np.zeros((h, w, 3), np.uint8) for h, w in sizes]
@@ -79,10 +93,11 @@ def main():
                   "poly": [float(v) for v in d["poly"]], "polygon_points": d["polygon_points"], "score": float(d["score"])} for d in page]
                 for page in out]
         cases.append({"model_type": name, "labels": labels, "ncol": ncol, "boxes_per_page": n_boxes, "seed": seed, "batch_size": batch, "twins": twins,
-                      "conf_thresh": cfg.get("conf_thresh"), "page_hw": [list(s) for s in sizes],
+                      "masks": with_masks, "layout_shape_mode": cfg.get("layout_shape_mode"), "conf_thresh": cfg.get("conf_thresh"), "page_hw": [list(s) for s in sizes],
                       "session_calls": [{"shape": list(shape), "scale_factor": sf.tolist()} for shape, sf in session.calls],
                       "layout_dets": dets})
-        print(f"{name}: {len(session.calls)} session calls, dets per page {[len(p) for p in dets]}")
+        print(f"{name}: {len(session.calls)} session calls, dets per page {[len(p) for p in dets]}, polygon sizes "
+              f"{sorted({len(d['polygon_points']) for p in dets for d in p if d['polygon_points'] is not None})}")
     (HERE / "layout_trace.json").write_text(json.dumps({"source": "rapid_doc/model/layout/rapid_layout.py + rapid_layout_self", "cases": cases}))
 
 

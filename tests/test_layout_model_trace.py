@@ -29,8 +29,9 @@ def _shape_only_preprocess(self, pages):
 def test_layout_wrapper_replays_the_reference_trace(case, monkeypatch):
     monkeypatch.setattr(LayoutModel, "preprocess", _shape_only_preprocess)
     size = {"pp_doclayout_s": 480, "pp_doclayout_l": 640}.get(case["model_type"], 800)
-    session = SyntheticBoxSession(case["labels"], case["boxes_per_page"], case["ncol"], seed=case["seed"], size=size, twins=case["twins"])
-    model = LayoutModel(session, case["model_type"], conf_thresh=case["conf_thresh"])
+    session = SyntheticBoxSession(case["labels"], case["boxes_per_page"], case["ncol"], seed=case["seed"], size=size, twins=case["twins"],
+                                  masks=case["masks"])
+    model = LayoutModel(session, case["model_type"], conf_thresh=case["conf_thresh"], layout_shape_mode=case["layout_shape_mode"] or "auto")
     pages = [np.zeros((h, w, 3), np.uint8) for h, w in case["page_hw"]]
     out = model.batch_predict(pages, case["batch_size"])
 
@@ -52,8 +53,22 @@ def test_layout_wrapper_replays_the_reference_trace(case, monkeypatch):
 
 
 def test_traces_cover_the_inline_formula_relabelling_and_reading_order():
-    cats = [{d["category_id"] for p in c["layout_dets"] for d in p} for c in TRACE["cases"]]
-    assert any(13 in s for s in cats[1:4]), "no InlineEquation produced by check_inline_formula in the pp_doclayout families"
-    for page in TRACE["cases"][0]["layout_dets"]:                          # V3: a reading order per box, 0 .. n-1 after the sort
+    by_type = {}
+    for c in TRACE["cases"]:
+        by_type.setdefault(c["model_type"], []).append(c)
+    cats = {d["category_id"] for c in by_type["pp_doclayout_s"] for p in c["layout_dets"] for d in p}
+    assert 13 in cats, "no InlineEquation produced by check_inline_formula in the pp_doclayout families"
+    for page in by_type["pp_doclayoutv3"][0]["layout_dets"]:               # V3: a reading order per box, 0 .. n-1 after the sort
         assert [d["original_order"] for d in page] == list(range(len(page)))
-    assert all(d["original_order"] == -1 for p in TRACE["cases"][3]["layout_dets"] for d in p)
+    assert all(d["original_order"] == -1 for p in by_type["pp_doclayout_l"][0]["layout_dets"] for d in p)
+
+
+def test_traces_cover_the_mask_branch_in_three_shape_modes():
+    masked = [c for c in TRACE["cases"] if c["masks"]]
+    assert {c["layout_shape_mode"] for c in masked} == {None, "rect", "poly"}          # None = the default, "auto"
+    for c in masked:
+        polys = [d["polygon_points"] for p in c["layout_dets"] for d in p]
+        if c["layout_shape_mode"] == "rect":
+            assert all(p is None for p in polys)
+        else:
+            assert all(p is not None for p in polys) and max(len(p) for p in polys) > 8 and min(len(p) for p in polys) == 4
