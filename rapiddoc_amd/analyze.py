@@ -19,12 +19,13 @@ reference's (one global argsort, chunks of 6), otherwise `rec_batch_num` is GPU 
 """
 from __future__ import annotations
 
+import math
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
 
-from . import layout_host, layout_polygon, ocr_host
+from . import layout_host, layout_polygon, ocr_host, table_host
 from .engine import preproc_resize_norm_batch
 
 OCR_TEXT, LOW_SCORE_TEXT = 15, 16                 # utils/enum_class.py:103-104
@@ -44,6 +45,17 @@ def _formula_boxes_in_crop(formulas: Sequence[dict], useful: Sequence[int]) -> L
             continue
         out.append([x0, y0, x1, y1])
     return out
+
+
+def _formulas_in_crop(formulas: Sequence[dict], useful: Sequence[int]):
+    """get_adjusted_mfdetrec_res again, keeping the formula each box belongs to (its `latex` travels with it for tables)."""
+    px, py, xmin, ymin, _xmax, _ymax, nw, nh = useful
+    for f in formulas:
+        x0, y0, x1, y1 = f["bbox"]
+        x0, y0, x1, y1 = x0 - xmin + px, y0 - ymin + py, x1 - xmin + px, y1 - ymin + py
+        if x1 < 0 or y1 < 0 or x0 > nw or y0 > nh:
+            continue
+        yield f, [x0, y0, x1, y1]
 
 
 def _int_box(b, h: int, w: int) -> Optional[List[int]]:
@@ -225,6 +237,106 @@ class RegionOcr:
         return out
 
 
+def table_crop_rect(det: dict) -> Optional[List[int]]:
+    """The table crop of the reference (batch_analyze.py:235-243): the box divided by 5, floor / ceil to integers
+    (normalize_to_int_bbox), times 5 again - i.e. snapped OUTWARDS to multiples of 5 px; slicing clips it at the page's far edges.
+    None for an empty box (the reference's own unpacking fails on that path; such a region is skipped here)."""
+    p = det["poly"]
+    b = np.asarray([float(v) / float(5) for v in (p[0], p[1], p[4], p[5])], dtype=np.float64)
+    x0, y0, x1, y1 = math.floor(b[0]), math.floor(b[1]), math.ceil(b[2]), math.ceil(b[3])
+    if x1 <= x0 or y1 <= y0:
+        return None
+    return [int(x0 * 5), int(y0 * 5), int(x1 * 5), int(y1 * 5)]
+
+
+class TableOcr:
+    """The reference's own table stage for a `predict`-shaped table model (seam S3, RapidTableModel.predict, rapid_table.py:120):
+    `_process_single_table` (analyze_utils.py:295-427) for pages that are OCR-ed (`ocr_enable`; the PDF-text-layer variant and the
+    orientation sub-stage are outside SURVEY s8 - a table is taken as upright, which is what the reference does when its
+    classifier answers "0").  Per table region, in page / layout order:
+
+      crop (`table_crop_rect`) -> formula boxes of the page in crop coordinates, with their `latex` (get_adjusted_mfdetrec_res,
+      return_text) -> detector on the crop with those boxes whited out, box_thresh 0.5 / unclip 1.6, boxes sorted and cut around the
+      formulas but NOT merged (`ocr(det, rec=False)`, rapid_ocr.py:257-281) -> every line cropped from the UNmasked image and
+      recognised in one call (`_run_table_ocr` :478-540, line level: `use_word_box=False`; the word-box variant lives in rapidocr's
+      `cal_rec_boxes`, absent) -> texts through `normalize_table_ocr_text` -> `table_model.predict(table_img RGB, [boxes, texts,
+      scores], fill_image_res, formula boxes, skip_text_in_image, use_img2table, skip_table_orientation=True)` -> the
+      `<table>...</table>` part of the answer becomes the region's `html`, and `formula_boxes` = every formula box of the page
+      divided by the page's render scale (:405-418).
+
+    The detector / recogniser are the pipeline's GPU engines; `det_raw_fn(canvas [1,h,w,3] u8 RGB, 1) -> [raw boxes [n,4,2]]` and
+    `rec_fn(canvas [1,h,w,3], quads [n,4,2]) -> [(text, score)]` replace them (tests replaying traces of the reference)."""
+
+    def __init__(self, pipeline, det_raw_fn=None, rec_fn=None, skip_text_in_image: bool = True, use_img2table: bool = False,
+                 table_formula_enable: bool = True):
+        self.pipe, self.rec_fn = pipeline, rec_fn
+        self.det = RegionOcr(pipeline, box_thresh=0.5, unclip_ratio=1.6, det_raw_fn=det_raw_fn)
+        self.skip_text_in_image, self.use_img2table, self.table_formula_enable = skip_text_in_image, use_img2table, table_formula_enable
+
+    def ocr_result(self, table: torch.Tensor, adjusted: Optional[List[dict]], det_maps_fn=None) -> list:
+        """table [h,w,3] u8 RGB -> [boxes, texts, scores] (three parallel lists) or [] when nothing was detected."""
+        h, w, _ = table.shape
+        canvas = table.unsqueeze(0)
+        det_canvas = canvas
+        if adjusted:
+            det_canvas = canvas.clone()
+            for f in adjusted:                          # _apply_mask_boxes_to_image
+                ib = _int_box(f["bbox"], h, w)
+                if ib:
+                    det_canvas[0, ib[1]:ib[3], ib[0]:ib[2]] = 255
+        if self.det.det_raw_fn is not None:
+            raw = self.det.det_raw_fn(det_canvas, 1)[0]
+        else:
+            raw = self.det._detect_group(det_canvas.contiguous(), det_maps_fn(table) if det_maps_fn is not None else None)[0]
+        if raw is None or len(raw) == 0:
+            return []
+        boxes = list(ocr_host.sorted_boxes(np.asarray(raw, dtype=np.float32)))
+        if adjusted:
+            boxes = ocr_host.update_det_boxes(boxes, adjusted)
+        if not boxes:
+            return []
+        quads = np.asarray(boxes, dtype=np.float32).reshape(-1, 4, 2)
+        if self.rec_fn is not None:
+            lines = self.rec_fn(canvas, quads)
+        else:
+            lines = self.pipe.rec_forward_sources([(canvas.contiguous(), [quads])], image_keys=[[0]])[0][0]
+        return [[q for q in quads], [table_host.normalize_table_ocr_text(t) for t, _s in lines], [s for _t, s in lines]]
+
+    def __call__(self, pages: torch.Tensor, layout_dets_per_page: Sequence[Sequence[dict]], table_model,
+                 page_scales: Optional[Sequence[float]] = None, det_maps_fn=None) -> int:
+        """Writes `html` (and `formula_boxes`) into the table detections IN PLACE; returns the number of tables handed to the model."""
+        n = 0
+        for p, dets in enumerate(layout_dets_per_page):
+            _ocr, tables, formulas = layout_host.split_regions(dets)
+            scale = 1.0 if page_scales is None else page_scales[p]
+            for t in tables:
+                rect = table_crop_rect(t)
+                if rect is None:
+                    continue
+                x0, y0, x1, y1 = rect
+                table = pages[p, y0:y1, x0:x1]
+                useful = [0, 0, x0, y0, x1, y1, int(table.shape[1]), int(table.shape[0])]
+                adjusted = None
+                if self.table_formula_enable:
+                    adjusted = []
+                    for f, box in _formulas_in_crop(formulas, useful):
+                        a = {"bbox": box}
+                        if f.get("latex"):
+                            a["latex"] = f["latex"]
+                        adjusted.append(a)
+                ocr_result = self.ocr_result(table, adjusted, det_maps_fn) if table.numel() else []
+                t.pop("layout_image_list", None)
+                html_code = table_model.predict(table.cpu().numpy(), ocr_result, [], adjusted, self.skip_text_in_image, self.use_img2table,
+                                                skip_table_orientation=True)
+                n += 1
+                if html_code and "<table>" in html_code and "</table>" in html_code:
+                    t["html"] = html_code[html_code.find("<table>"): html_code.rfind("</table>") + len("</table>")]
+                    fboxes = [f["bbox"] for f in formulas if "bbox" in f]
+                    if fboxes:
+                        t["formula_boxes"] = [[int(c / scale) for c in b] for b in fboxes]
+        return n
+
+
 class RegionTextModel:
     """The OCR seam S1 of the reference: an `ocr_config['custom_model']` object
     (`rapid_doc.model.custom.CustomBaseModel.batch_predict(image_list, **kwargs) -> list[str]`, model/custom/__init__.py:4-20),
@@ -271,8 +383,9 @@ class PageAnalyzer:
         3. formulas      `recognise_formulas` (:258-283) when a formula model is given
         4. OCR           det + rec of every text region (`RegionOcr`), or the custom-OCR seam (`RegionTextModel`-shaped object:
                          one string per region, :286-333) when `custom_ocr` is given
-        5. tables        `table_model.batch_predict(table crops)` (seam S1, :375-377) when a table model is given - the
-                         reference's own table networks are ONNX-only and not built
+        5. tables        `table_model.batch_predict(table crops, fill_image_res_list=...)` for a CustomBaseModel-shaped model (seam
+                         S1, :359-379), or `TableOcr` + `table_model.predict(...)` for a RapidTableModel-shaped one (seam S3,
+                         `_process_single_table`); the reference's own table NETWORKS are ONNX-only and not built
         6. (rec post-process is part of RegionOcr here: spans get text / score / LowScoreText demotion, analyze_utils.py:216-292)
 
     Every page is processed independently (`pages[p]` only feeds `out[p]`); the result is the reference's
@@ -282,7 +395,8 @@ class PageAnalyzer:
 
     def __init__(self, layout_model, pipeline, formula_model=None, table_model=None, custom_ocr=None, layout_batch_size: int = 1,
                  formula_level: int = 0, box_thresh: float = 0.3, unclip_ratio: float = 1.8, formula_batch_size: int = 1,
-                 formula_expand_px: int = 2, det_batch_num: Optional[int] = None, det_raw_fn=None, lang: str = "ch"):
+                 formula_expand_px: int = 2, det_batch_num: Optional[int] = None, det_raw_fn=None, lang: str = "ch",
+                 table_det_raw_fn=None, table_rec_fn=None):
         """Batch sizes default to the reference's (layout_config['batch_num'] / formula_config['batch_num'] = 1,
         batch_analyze.py:66-71); `det_batch_num` / `det_raw_fn`: see RegionOcr."""
         self.layout_model, self.pipe = layout_model, pipeline
@@ -290,8 +404,12 @@ class PageAnalyzer:
         self.layout_batch_size, self.formula_level = layout_batch_size, formula_level
         self.formula_batch_size, self.formula_expand_px = formula_batch_size, formula_expand_px
         self.ocr = RegionOcr(pipeline, box_thresh, unclip_ratio, lang, det_batch_num, det_raw_fn)
+        self.table_ocr = TableOcr(pipeline, det_raw_fn=table_det_raw_fn, rec_fn=table_rec_fn)
 
-    def __call__(self, pages: torch.Tensor, det_maps_fn=None) -> List[List[dict]]:
+    def __call__(self, pages: torch.Tensor, det_maps_fn=None, page_scales: Optional[Sequence[float]] = None,
+                 table_det_maps_fn=None) -> List[List[dict]]:
+        """`page_scales[p]`: the render scale the reference carries with every page (the `scale` of its input tuples); only the
+        `formula_boxes` written next to a table's `html` use it (analyze_utils.py:405-418).  Default 1."""
         assert pages.dtype == torch.uint8 and pages.dim() == 4 and (pages.is_cuda or self.ocr.det_raw_fn is not None)
         P, H, W, _ = pages.shape
         use_custom = self.custom_ocr is not None
@@ -322,18 +440,22 @@ class PageAnalyzer:
                                    "text": text, "vl_ocr": True})
         else:
             out = self.ocr(pages, dets, det_maps_fn=det_maps_fn)
-        # 5. tables through the CustomBaseModel seam
-        if self.table_model is not None:
+        # 5. tables: one pooled `batch_predict` of a CustomBaseModel-shaped model (seam S1, batch_analyze.py:359-379) or, for a
+        #    `predict`-shaped one (RapidTableModel, seam S3), the reference's own table stage with the table OCR on the GPU
+        if self.table_model is not None and hasattr(self.table_model, "batch_predict"):
+            crops, owners = [], []
             for p in range(P):
                 _o, tables, _f = layout_host.split_regions(dets[p])
-                crops, owners = [], []
                 for t in tables:
-                    x0, y0, x1, y1 = (int(v) for v in (t["poly"][0], t["poly"][1], t["poly"][4], t["poly"][5]))
-                    x0, y0, x1, y1 = max(0, x0), max(0, y0), min(W, x1), min(H, y1)
-                    if x1 > x0 and y1 > y0:
-                        crops.append(pages[p, y0:y1, x0:x1].cpu().numpy())
+                    rect = table_crop_rect(t)                  # snapped outwards to multiples of 5 px (batch_analyze.py:235-243)
+                    if rect is not None:
+                        crops.append(pages[p, rect[1]:rect[3], rect[0]:rect[2]].cpu().numpy())
                         owners.append(t)
-                for t, html in zip(owners, self.table_model.batch_predict(crops) if crops else []):
+            if crops:
+                for t, html in zip(owners, self.table_model.batch_predict(crops, fill_image_res_list=[[] for _ in crops])):
+                    t.pop("layout_image_list", None)
                     if html:
                         t["html"] = html
+        elif self.table_model is not None:
+            self.table_ocr(pages, dets, self.table_model, page_scales, det_maps_fn=table_det_maps_fn)
         return out

@@ -66,3 +66,27 @@ class TableStructureDecoder:
         """Reference signature (post_process.py:39-80): structure_probs [B, L, V]."""
         return self.decode_indices(structure_probs.argmax(axis=2), structure_probs.max(axis=2), bbox_preds, shape_list,
                                    [im.shape[:2] for im in ori_imgs])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# OCR text of a table line before it is matched into cells: rapid_doc/model/table/utils.py:7-36 `normalize_table_ocr_text`
+# (two known mis-readings of single cells, "<digit>號" -> the digit, then HTML escaping).  The tables are data of the reference.
+# ----------------------------------------------------------------------------------------------------------------------
+import html as _html
+import re as _re
+
+_SINGLE_CELL_FIXES = {"香": "否", "哦樂": "哦"}
+_FULLMATCH_FIXES = ((_re.compile(r"^([0-9])號$"), r"\1"),)
+
+
+def normalize_table_ocr_text(text) -> str:
+    if text is None:
+        return ""
+    text = str(text).strip()
+    text = _SINGLE_CELL_FIXES.get(text, text)
+    for pattern, replacement in _FULLMATCH_FIXES:
+        m = pattern.fullmatch(text)
+        if m:
+            text = m.expand(replacement)
+            break
+    return _html.escape(text)

@@ -126,3 +126,86 @@ def test_page_analyzer_replays_the_reference_trace(golden_dir, seed):
         assert len(mine) == len(theirs), (p, len(mine), len(theirs))
         for a, b in zip(mine, theirs):
             assert a == b, (p, a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the table stage (SURVEY row a17's host side): traces of BatchAnalyze with table_enable, tests/golden/make_golden_table_trace.py
+# ---------------------------------------------------------------------------------------------------------------------
+def table_text_and_score(h, w):          # == make_golden_table_trace.table_text_and_score
+    return ("香" if (h + w) % 7 == 0 else f"<{h}x{w}>"), ((h * 37 + w * 11) % 1000) / 1000.0
+
+
+@pytest.mark.parametrize("kind", ["traditional", "custom"])
+def test_table_stage_replays_the_reference_trace(golden_dir, kind):
+    """`traditional`: a `predict`-shaped table model - per table the reference crops (box snapped outwards to multiples of 5 px), whites the
+    page's formulas out of the detector's copy, detects (0.5 / 1.6, sorted, cut around formulas, NOT merged), recognises every line
+    from the unmasked crop, normalises / HTML-escapes the texts and calls predict(image, [boxes, texts, scores], [], formula boxes
+    with latex, True, False, skip_table_orientation=True); the answer's <table> part and the page's formula boxes / scale land on the
+    region.  Demanded back: the detector canvases and the table images byte for byte, every argument of every predict call, the
+    output dicts.  `custom`: ONE batch_predict over the tables of all pages with the same crops and fill_image_res_list."""
+    fx = json.loads((golden_dir / f"analyze_trace_table_{kind}.json").read_text())
+    tr = fx["trace"]
+    pages = torch.from_numpy(np.stack([synth_page(i)[0] for i in fx["page_ids"]]))
+    log = {"layout": [], "formula": [], "det": [], "rec": [], "table_det": [], "table": []}
+    det_calls, tdet_calls = iter(tr["det_calls"]), iter(tr["table_det_calls"])
+
+    def det_raw_fn(canvases, batch_size):
+        call = next(det_calls)
+        bgr = np.ascontiguousarray(canvases.numpy()[..., ::-1])
+        log["det"].append({"batch_size": batch_size, "shapes": [list(c.shape) for c in bgr],
+                           "crc32": [zlib.crc32(np.ascontiguousarray(c).tobytes()) for c in bgr]})
+        return [np.asarray(b, dtype=np.float32).reshape(-1, 4, 2) for b in call["boxes"]]
+
+    def table_det_raw_fn(canvas, batch_size):
+        call = next(tdet_calls)
+        bgr = np.ascontiguousarray(canvas.numpy()[0][..., ::-1])
+        log["table_det"].append({"shape": list(bgr.shape), "crc32": zlib.crc32(bgr.tobytes())})
+        return [np.asarray(call["boxes"], dtype=np.float32).reshape(-1, 4, 2)]
+
+    def table_rec_fn(canvas, quads):
+        _m, cw, ch, ok = quads_to_crop_matrices(np.asarray(quads, dtype=np.float64))
+        assert ok.all()
+        out = []
+        for w_, h_ in zip(cw.astype(int).tolist(), ch.astype(int).tolist()):
+            hh, ww = (w_, h_) if h_ / w_ >= 2 else (h_, w_)
+            out.append(table_text_and_score(hh, ww))
+        return out
+
+    class ReplayTable:
+        def predict(self, image, ocr_result, fill_image_res, mfd_res, skip_text_in_image, use_img2table, skip_table_orientation=False):
+            boxes, texts, scores = ocr_result if ocr_result else ([], [], [])
+            log["table"].append({"shape": list(image.shape), "crc32": zlib.crc32(np.ascontiguousarray(image).tobytes()),
+                                 "boxes": [np.asarray(b, dtype=np.float64).tolist() for b in boxes], "texts": list(texts),
+                                 "scores": [float(s) for s in scores], "fill_image_res": list(fill_image_res), "mfd_res": mfd_res,
+                                 "flags": [bool(skip_text_in_image), bool(use_img2table), bool(skip_table_orientation)]})
+            if len(texts) % 2 == 0:
+                return "<html><body>nothing found</body></html>"
+            return f"<html><body><table><tr><td>{len(texts)} lines</td></tr></table></body></html>"
+
+    class ReplayCustomTable:
+        def batch_predict(self, image_list, **kwargs):
+            log["table"].append({"shapes": [list(i.shape) for i in image_list],
+                                 "crc32": [zlib.crc32(np.ascontiguousarray(i).tobytes()) for i in image_list], "kwargs": kwargs})
+            return [f"<table><tr><td>{i.shape[0]}x{i.shape[1]}</td></tr></table>" if i.shape[0] > 150 else "" for i in image_list]
+
+    pa = analyze.PageAnalyzer(ReplayLayout(fx["layout_dets"], log["layout"]), ReplayPipe(log["rec"]), formula_model=ReplayFormula(log["formula"]),
+                              table_model=ReplayCustomTable() if kind == "custom" else ReplayTable(),
+                              layout_batch_size=fx["layout_batch_num"], formula_level=fx["formula_level"],
+                              formula_batch_size=fx["formula_batch_num"], det_batch_num=fx["ocr_config"]["Det.rec_batch_num"],
+                              det_raw_fn=det_raw_fn, table_det_raw_fn=table_det_raw_fn, table_rec_fn=table_rec_fn)
+    out = pa(pages, page_scales=[fx["page_scale"]] * len(pages))
+
+    assert log["layout"] == tr["layout_calls"] and log["formula"] == tr["formula_calls"]
+    assert [{k: c[k] for k in ("batch_size", "shapes", "crc32")} for c in tr["det_calls"]] == log["det"]
+    assert log["rec"] == tr["rec_calls"]
+    assert [{k: c[k] for k in ("shape", "crc32")} for c in tr["table_det_calls"]] == log["table_det"]
+    assert len(log["table"]) == len(tr["table_calls"]) > 0
+    for mine, theirs in zip(log["table"], tr["table_calls"]):
+        assert mine == theirs
+    if kind == "traditional":
+        assert any("否" in c["texts"] for c in tr["table_calls"]) and any(c["mfd_res"] for c in tr["table_calls"])
+    for p, (mine, theirs) in enumerate(zip(out, fx["output"])):
+        assert len(mine) == len(theirs), (p, len(mine), len(theirs))
+        for a, b in zip(mine, theirs):
+            assert a == b, (p, a, b)
+    assert sum(1 for page in out for d in page if "html" in d) == sum(1 for page in fx["output"] for d in page if "html" in d) > 0

@@ -75,3 +75,29 @@ def test_token_decoder_from_tokenizer_json(tmp_path):
     # an unbalanced \\left( is repaired by the LaTeX stage between tokenizer and fix_text (post_process.py:350-381)
     ids2 = [0] + tok.encode("\\left (x").ids + [2]
     assert F.make_token_decoder(str(path), None)(ids2) == latex_postprocess(tok.decode(ids2, skip_special_tokens=True))
+
+
+# ---- pinned to the reference's own PPPreProcess (tests/golden/make_golden_formula_pre.py: pre_process.py run unmodified, PIL for the
+# resampling, its four cv2 calls stood in for by their definitions) ---------------------------------------------------------------
+import json as _json
+import sys as _sys
+import zlib as _zlib
+from pathlib import Path as _Path
+
+import pytest as _pytest
+
+_GOLD = _Path(__file__).parent / "golden"
+_PRE = _json.loads((_GOLD / "formula_pre.json").read_text())["cases"]
+
+
+@_pytest.mark.parametrize("case", _PRE, ids=lambda c: f"{c['seed']}-{c['hw'][0]}x{c['hw'][1]}")
+def test_preprocess_matches_the_reference_byte_for_byte(case):
+    _sys.path.insert(0, str(_GOLD))
+    import make_golden_formula_pre as M               # only its seeded image generator (no reference import at module level)
+    img = M.make_image(case["seed"], *case["hw"])
+    decoded = F.decode_image(img)
+    assert list(decoded.shape) == case["decoded_shape"]
+    assert _zlib.crc32(np.ascontiguousarray(decoded).tobytes()) == case["decoded_crc32"]
+    x = F.preprocess([img])[0]
+    assert list(x.shape) == case["input_shape"] and str(x.dtype) == case["input_dtype"]
+    assert _zlib.crc32(np.ascontiguousarray(x).tobytes()) == case["input_crc32"]
