@@ -419,25 +419,40 @@ class PageAnalyzer:
         if self.formula_model is None or self.formula_level == 1:
             inline = layout_host.CATEGORY_ID["InlineEquation"]
             dets = [[d for d in page if d["category_id"] != inline] for page in dets]
-        # 3. formulas (region collection happens inside the helpers, per page)
+        # 2. region collection: writes the integer `bbox` into the formula detections before anything else touches them, so that the
+        #    fields of a detection also appear in the reference's ORDER (bbox, then latex) when the result is serialised
+        for page in dets:
+            layout_host.split_regions(page)
+        # 3. formulas
         if self.formula_model is not None:
             recognise_formulas(pages, dets, self.formula_model, self.formula_expand_px, self.formula_batch_size)
         # 4. OCR
         if use_custom:
+            # `_run_custom_ocr` (batch_analyze.py:286-333): every text region of the page BATCH in one call, BGR crops without a
+            # margin (crop_img: white outside the page and outside the region's polygon), one string per region
             out = [list(d) for d in dets]
+            crops, owners = [], []
             for p in range(P):
                 regions, _t, _f = layout_host.split_regions(dets[p])
-                crops, owners = [], []
                 for r in regions:
                     x0, y0, x1, y1 = (int(v) for v in (r["poly"][0], r["poly"][1], r["poly"][4], r["poly"][5]))
-                    x0, y0, x1, y1 = max(0, x0), max(0, y0), min(W, x1), min(H, y1)
-                    if x1 > x0 and y1 > y0:
-                        crops.append(np.ascontiguousarray(pages[p, y0:y1, x0:x1].cpu().numpy()[:, :, ::-1]))   # BGR (batch_analyze.py:300-304)
-                        owners.append(r)
-                for r, text in zip(owners, self.custom_ocr.batch_predict(crops) if crops else []):
-                    out[p].append({"category_id": OCR_TEXT, "original_label": r.get("original_label"),
-                                   "original_order": r.get("original_order", -1), "poly": list(r["poly"]), "score": 1,
-                                   "text": text, "vl_ocr": True})
+                    if x1 <= x0 or y1 <= y0:                  # (the reference's np.ones of a negative size raises)
+                        continue
+                    crop = np.full((y1 - y0, x1 - x0, 3), 255, np.uint8)
+                    x0c, y0c, x1c, y1c = max(0, x0), max(0, y0), min(W, x1), min(H, y1)
+                    if x1c > x0c and y1c > y0c:
+                        part = pages[p, y0c:y1c, x0c:x1c].cpu().numpy()
+                        if r.get("polygon_points"):
+                            part = part.copy()
+                            part[~layout_polygon.polygon_keep_mask(part.shape[:2], r["polygon_points"], x0, y0)] = 255
+                        crop[y0c - y0: y1c - y0, x0c - x0: x1c - x0] = part
+                    crops.append(np.ascontiguousarray(crop[:, :, ::-1]))          # BGR (:300)
+                    owners.append((p, r))
+            texts = self.custom_ocr.batch_predict(crops, batch_size=self.ocr.det_batch_num or 1) if crops else []
+            for (p, r), text in zip(owners, texts):
+                out[p].append({"poly": r["poly"], "category_id": OCR_TEXT, "score": 0.95, "text": text.strip() if text else "",
+                               "vl_ocr": True, "original_label": r.get("original_label"), "original_order": r.get("original_order"),
+                               "polygon_points": r.get("polygon_points")})
         else:
             out = self.ocr(pages, dets, det_maps_fn=det_maps_fn)
         # 5. tables: one pooled `batch_predict` of a CustomBaseModel-shaped model (seam S1, batch_analyze.py:359-379) or, for a

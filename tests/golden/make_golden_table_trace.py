@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Traces of the REFERENCE's table stage, run with recording stand-ins for the models (build container only).
 
-    python tests/golden/make_golden_table_trace.py        # writes tests/golden/analyze_trace_table_{traditional,custom}.json
+    python tests/golden/make_golden_table_trace.py        # writes tests/golden/analyze_trace_table_{traditional,custom,custom_ocr}.json
+                                                          # (the third: the custom-OCR seam of the same driver, tables off)
 
 What runs is the reference's code, unmodified (same import machinery as make_golden_analyze.py):
     rapid_doc/backend/pipeline/batch_analyze.py:78-164,230-256,351-410   BatchAnalyze.__call__ with table_enable: the table crop (the box
@@ -97,13 +98,15 @@ def main():
     ro.TextRecInput = lambda img, return_word_box=False: types.SimpleNamespace(img=img, return_word_box=return_word_box)   # rapidocr dataclasses
     ro.TextRecOutput = lambda imgs, txts, scores, words, elapse: types.SimpleNamespace(txts=list(txts), scores=list(scores), word_results=words)
 
-    for kind in ("traditional", "custom"):
-        rng = np.random.default_rng(8000 + (kind == "custom"))
+    for kind in ("traditional", "custom", "custom_ocr"):
+        rng = np.random.default_rng(8000 + ("traditional", "custom", "custom_ocr").index(kind))
         trace = {"det_calls": [], "rec_calls": [], "formula_calls": [], "layout_calls": [], "table_det_calls": [], "table_calls": []}
         page_ids = [int(rng.integers(0, 1000)) for _ in range(2)]
         pages = [synth_page(i)[0] for i in page_ids]
         H, W = pages[0].shape[:2]
         dets = [layout_with_tables(rng, H, W) for _ in pages]
+        if kind == "custom_ocr":              # one page with polygons on every box (crop_img's mask), one without
+            dets[0] = MGA.layout_for_page(rng, H, W, polygons=True)
         ocr = MGA.RecordingOcr(trace)
 
         def text_detector(img):
@@ -137,6 +140,13 @@ def main():
                                              "kwargs": {k: json.loads(json.dumps(v)) for k, v in kwargs.items()}})
                 return [f"<table><tr><td>{i.shape[0]}x{i.shape[1]}</td></tr></table>" if i.shape[0] > 150 else "" for i in image_list]
 
+        class CustomOcr(CustomBaseModel):     # seam S1 for OCR: one multi-line string per layout region (batch_analyze.py:286-333)
+            def batch_predict(self, image_list, **kwargs):
+                trace["custom_ocr_calls"] = trace.get("custom_ocr_calls", []) + [{
+                    "shapes": [list(i.shape) for i in image_list], "crc32": [zlib.crc32(np.ascontiguousarray(i).tobytes()) for i in image_list],
+                    "kwargs": dict(kwargs)}]
+                return [None if k % 4 == 3 else f"  region {k}: {i.shape[0]}x{i.shape[1]}\nsecond line " for k, i in enumerate(image_list)]
+
         class Registry:
             def get_atom_model(self, atom_model_name, **kw):
                 if atom_model_name == AtomicModel.ImgOrientationCls:
@@ -155,7 +165,7 @@ def main():
         class Model:
             device = "cpu"
             layout_model = MGA.RecordingLayout(trace, dets)
-            ocr_model = ocr
+            ocr_model = CustomOcr() if kind == "custom_ocr" else ocr
             formula_model = MGA.RecordingFormula(trace)
             table_model = CustomTable() if kind == "custom" else TableModel()
 
@@ -164,7 +174,7 @@ def main():
                 return Model()
         ocr_cfg = {"use_det_mode": "ocr", "Det.rec_batch_num": 3, "seal_enable": False}
         table_cfg = {"use_word_box": False, "table_image_enable": False}
-        analyzer = ba.BatchAnalyze(Manager(), batch_ratio=1, formula_enable=True, table_enable=True, layout_config={"batch_num": 2},
+        analyzer = ba.BatchAnalyze(Manager(), batch_ratio=1, formula_enable=True, table_enable=(kind != "custom_ocr"), layout_config={"batch_num": 2},
                                    ocr_config=ocr_cfg, table_config=table_cfg,
                                    formula_config={"formula_level": 0, "batch_num": 4, "bbox_expand_px": 2})
         ba.clean_vram = lambda *a, **k: None

@@ -125,7 +125,7 @@ def test_page_analyzer_replays_the_reference_trace(golden_dir, seed):
     for p, (mine, theirs) in enumerate(zip(out, ref)):
         assert len(mine) == len(theirs), (p, len(mine), len(theirs))
         for a, b in zip(mine, theirs):
-            assert a == b, (p, a, b)
+            assert a == b and list(a) == list(b), (p, a, b)          # same fields in the same order
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -207,5 +207,37 @@ def test_table_stage_replays_the_reference_trace(golden_dir, kind):
     for p, (mine, theirs) in enumerate(zip(out, fx["output"])):
         assert len(mine) == len(theirs), (p, len(mine), len(theirs))
         for a, b in zip(mine, theirs):
-            assert a == b, (p, a, b)
+            assert a == b and list(a) == list(b), (p, a, b)          # same fields in the same order
     assert sum(1 for page in out for d in page if "html" in d) == sum(1 for page in fx["output"] for d in page if "html" in d) > 0
+
+
+def test_custom_ocr_seam_replays_the_reference_trace(golden_dir):
+    """`_run_custom_ocr` (batch_analyze.py:286-333): one `batch_predict(bgr region crops, batch_size=Det.rec_batch_num)` over the text
+    regions of ALL pages (crops byte for byte - on the first page every region carries a polygon, so crop_img's mask is in them), one
+    result dict per region: score 0.95, stripped text, `vl_ocr`, the region's poly / polygon_points; no detector, no recogniser."""
+    fx = json.loads((golden_dir / "analyze_trace_table_custom_ocr.json").read_text())
+    tr = fx["trace"]
+    pages = torch.from_numpy(np.stack([synth_page(i)[0] for i in fx["page_ids"]]))
+    log = {"layout": [], "formula": [], "ocr": []}
+
+    class ReplayCustomOcr:
+        def batch_predict(self, image_list, **kwargs):
+            log["ocr"].append({"shapes": [list(i.shape) for i in image_list],
+                               "crc32": [zlib.crc32(np.ascontiguousarray(i).tobytes()) for i in image_list], "kwargs": dict(kwargs)})
+            return [None if k % 4 == 3 else f"  region {k}: {i.shape[0]}x{i.shape[1]}\nsecond line " for k, i in enumerate(image_list)]
+
+    def no_detector(canvases, batch_size):
+        raise AssertionError("the custom-OCR seam must not reach the detector")
+
+    pa = analyze.PageAnalyzer(ReplayLayout(fx["layout_dets"], log["layout"]), ReplayPipe([]), formula_model=ReplayFormula(log["formula"]),
+                              custom_ocr=ReplayCustomOcr(), layout_batch_size=fx["layout_batch_num"], formula_level=fx["formula_level"],
+                              formula_batch_size=fx["formula_batch_num"], det_batch_num=fx["ocr_config"]["Det.rec_batch_num"],
+                              det_raw_fn=no_detector)
+    out = pa(pages)
+    assert log["layout"] == tr["layout_calls"] and log["formula"] == tr["formula_calls"]
+    assert log["ocr"] == tr["custom_ocr_calls"] and len(log["ocr"]) == 1
+    assert not tr["det_calls"] and not tr["rec_calls"]
+    for p, (mine, theirs) in enumerate(zip(out, fx["output"])):
+        assert len(mine) == len(theirs), (p, len(mine), len(theirs))
+        for a, b in zip(mine, theirs):
+            assert a == b and list(a) == list(b), (p, a, b)          # same keys in the same order, too
