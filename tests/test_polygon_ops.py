@@ -200,3 +200,30 @@ def test_resize_nearest_takes_floor_of_the_scaled_index(LP):
     a = np.arange(5, dtype=np.uint8)[None, :].repeat(2, 0)
     assert LP.resize_nearest(a, 3, 2)[0].tolist() == [0, 1, 3]          # floor(i * 5 / 3)
     assert LP.resize_nearest(a, 10, 4).shape == (4, 10) and LP.resize_nearest(a, 10, 4)[3].tolist() == [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]
+
+
+def test_c_abi_return_codes_of_the_primitives():
+    """0 = ok, 1 = bad arguments, 2 = output capacity too small with the needed counts written back (include/rapiddoc_mi355.h)."""
+    import ctypes as C
+    lib = _lib.load()
+    m = np.zeros((8, 8), np.uint8)
+    m[1:3, 1:3] = 1
+    m[5:7, 4:8] = 1
+    n_c, n_p = C.c_int32(0), C.c_int32(0)
+    pts, counts = np.zeros((2, 2), np.int32), np.zeros(1, np.int32)
+    assert lib.rd_find_external_contours(m.ctypes.data, 8, 8, pts.ctypes.data, 2, counts.ctypes.data, 1, C.byref(n_c), C.byref(n_p)) == 2
+    assert (n_c.value, n_p.value) == (2, 8)
+    pts, counts = np.zeros((8, 2), np.int32), np.zeros(2, np.int32)
+    assert lib.rd_find_external_contours(m.ctypes.data, 8, 8, pts.ctypes.data, 8, counts.ctypes.data, 2, C.byref(n_c), C.byref(n_p)) == 0
+    assert counts.tolist() == [4, 4] and pts[:4].tolist() == [[4, 5], [4, 6], [7, 6], [7, 5]]
+    assert lib.rd_find_external_contours(None, 8, 8, pts.ctypes.data, 8, counts.ctypes.data, 2, C.byref(n_c), C.byref(n_p)) == 1
+    assert lib.rd_find_external_contours(m.ctypes.data, 0, 8, pts.ctypes.data, 8, counts.ctypes.data, 2, C.byref(n_c), C.byref(n_p)) == 1
+    out, n = np.zeros((4, 2), np.int32), C.c_int32(7)
+    assert lib.rd_approx_poly_dp(None, 0, 1.0, 1, out.ctypes.data, C.byref(n)) == 0 and n.value == 0          # an empty curve is not an error
+    assert lib.rd_approx_poly_dp(None, 3, 1.0, 1, out.ctypes.data, C.byref(n)) == 1
+    assert lib.rd_approx_poly_dp(pts.ctypes.data, 4, -1.0, 1, out.ctypes.data, C.byref(n)) == 1
+    assert lib.rd_min_area_rect_points(None, 4, out.ctypes.data) == 1
+    assert lib.rd_fill_poly(None, 8, 8, pts.ctypes.data, 4, 1) == 1
+    assert lib.rd_polygon_area(None, 4) == 0.0 and lib.rd_contour_area(None, 4) == 0.0 and lib.rd_arc_length(pts.ctypes.data, 1, 1) == 0.0
+    sel, src, k = np.zeros((4, 6), np.float32), np.zeros(4, np.int32), C.c_int32(0)
+    assert lib.rd_layout_postprocess_select(sel.ctypes.data, 4, 5, 100, 100, None, sel.ctypes.data, src.ctypes.data, C.byref(k)) == 1
