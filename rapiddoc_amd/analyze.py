@@ -66,6 +66,38 @@ def _int_box(b, h: int, w: int) -> Optional[List[int]]:
     return [x0, y0, x1, y1] if x1 > x0 and y1 > y0 else None
 
 
+def crop_region(pages: torch.Tensor, p: int, det: dict) -> Optional[np.ndarray]:
+    """`crop_img(det, page)[0]` with no margin (utils/model_utils.py:90-124): the integer box of the detection on a white canvas - page
+    pixels where the box lies on the page, white outside it and outside the detection's polygon, if it has one.  RGB u8 numpy; None
+    for an inverted box (the reference's np.ones of a negative size raises)."""
+    _P, H, W, _ = pages.shape
+    x0, y0, x1, y1 = (int(v) for v in (det["poly"][0], det["poly"][1], det["poly"][4], det["poly"][5]))
+    if x1 < x0 or y1 < y0:
+        return None
+    crop = np.full((y1 - y0, x1 - x0, 3), 255, np.uint8)
+    x0c, y0c, x1c, y1c = max(0, x0), max(0, y0), min(W, x1), min(H, y1)
+    if x1c > x0c and y1c > y0c:
+        part = pages[p, y0c:y1c, x0c:x1c].cpu().numpy()
+        if det.get("polygon_points"):
+            part = part.copy()
+            part[~layout_polygon.polygon_keep_mask(part.shape[:2], det["polygon_points"], x0, y0)] = 255
+        crop[y0c - y0: y1c - y0, x0c - x0: x1c - x0] = part
+    return crop
+
+
+def attach_table_images(pages: torch.Tensor, p: int, dets: Sequence[dict]) -> None:
+    """Second half of get_res_list_from_layout_res (utils/model_utils.py:181-194): every image region lying inside a table is attached
+    to that table's detection as `layout_image_list` = [{uuid, poly, pil_image}] (the table stage pops the field again; with tables
+    switched off it stays in the output, as in the reference)."""
+    import uuid
+    from PIL import Image
+    for im, tb in layout_host.images_inside_tables(dets):
+        crop = crop_region(pages, p, im)
+        if crop is None:
+            continue
+        tb.setdefault("layout_image_list", []).append({"uuid": str(uuid.uuid4()), "poly": im["poly"], "pil_image": Image.fromarray(crop)})
+
+
 def recognise_formulas(pages: torch.Tensor, layout_dets_per_page: Sequence[Sequence[dict]], formula_model,
                        expand_px: int = 2, batch_size: int = 16) -> int:
     """Formula branch of BatchAnalyze (batch_analyze.py:258-283): every formula region (category 8 / 13 / 14) is cropped
@@ -303,8 +335,10 @@ class TableOcr:
         return [[q for q in quads], [table_host.normalize_table_ocr_text(t) for t, _s in lines], [s for _t, s in lines]]
 
     def __call__(self, pages: torch.Tensor, layout_dets_per_page: Sequence[Sequence[dict]], table_model,
-                 page_scales: Optional[Sequence[float]] = None, det_maps_fn=None) -> int:
-        """Writes `html` (and `formula_boxes`) into the table detections IN PLACE; returns the number of tables handed to the model."""
+                 page_scales: Optional[Sequence[float]] = None, det_maps_fn=None, table_image_enable: bool = True) -> int:
+        """Writes `html` (and `formula_boxes` / `img_boxes`) into the table detections IN PLACE; returns the number of tables handed to
+        the model.  `table_image_enable`: hand the images that lie inside a table (`layout_image_list`) to the model as
+        `fill_image_res` (extract_table_fill_image's layout branch)."""
         n = 0
         for p, dets in enumerate(layout_dets_per_page):
             _ocr, tables, formulas = layout_host.split_regions(dets)
@@ -325,8 +359,9 @@ class TableOcr:
                             a["latex"] = f["latex"]
                         adjusted.append(a)
                 ocr_result = self.ocr_result(table, adjusted, det_maps_fn) if table.numel() else []
+                fill = layout_host.table_fill_images(t, useful) if table_image_enable else []
                 t.pop("layout_image_list", None)
-                html_code = table_model.predict(table.cpu().numpy(), ocr_result, [], adjusted, self.skip_text_in_image, self.use_img2table,
+                html_code = table_model.predict(table.cpu().numpy(), ocr_result, fill, adjusted, self.skip_text_in_image, self.use_img2table,
                                                 skip_table_orientation=True)
                 n += 1
                 if html_code and "<table>" in html_code and "</table>" in html_code:
@@ -334,6 +369,9 @@ class TableOcr:
                     fboxes = [f["bbox"] for f in formulas if "bbox" in f]
                     if fboxes:
                         t["formula_boxes"] = [[int(c / scale) for c in b] for b in fboxes]
+                    iboxes = [f["ori_bbox"] for f in fill if "bbox" in f]
+                    if iboxes:
+                        t["img_boxes"] = [[int(c / scale) for c in b] for b in iboxes]
         return n
 
 
@@ -396,7 +434,7 @@ class PageAnalyzer:
     def __init__(self, layout_model, pipeline, formula_model=None, table_model=None, custom_ocr=None, layout_batch_size: int = 1,
                  formula_level: int = 0, box_thresh: float = 0.3, unclip_ratio: float = 1.8, formula_batch_size: int = 1,
                  formula_expand_px: int = 2, det_batch_num: Optional[int] = None, det_raw_fn=None, lang: str = "ch",
-                 table_det_raw_fn=None, table_rec_fn=None):
+                 table_det_raw_fn=None, table_rec_fn=None, table_image_enable: bool = True):
         """Batch sizes default to the reference's (layout_config['batch_num'] / formula_config['batch_num'] = 1,
         batch_analyze.py:66-71); `det_batch_num` / `det_raw_fn`: see RegionOcr."""
         self.layout_model, self.pipe = layout_model, pipeline
@@ -405,6 +443,7 @@ class PageAnalyzer:
         self.formula_batch_size, self.formula_expand_px = formula_batch_size, formula_expand_px
         self.ocr = RegionOcr(pipeline, box_thresh, unclip_ratio, lang, det_batch_num, det_raw_fn)
         self.table_ocr = TableOcr(pipeline, det_raw_fn=table_det_raw_fn, rec_fn=table_rec_fn)
+        self.table_image_enable = table_image_enable          # table_config["table_image_enable"], default True (batch_analyze.py:75)
 
     def __call__(self, pages: torch.Tensor, det_maps_fn=None, page_scales: Optional[Sequence[float]] = None,
                  table_det_maps_fn=None) -> List[List[dict]]:
@@ -421,8 +460,9 @@ class PageAnalyzer:
             dets = [[d for d in page if d["category_id"] != inline] for page in dets]
         # 2. region collection: writes the integer `bbox` into the formula detections before anything else touches them, so that the
         #    fields of a detection also appear in the reference's ORDER (bbox, then latex) when the result is serialised
-        for page in dets:
+        for p, page in enumerate(dets):
             layout_host.split_regions(page)
+            attach_table_images(pages, p, page)
         # 3. formulas
         if self.formula_model is not None:
             recognise_formulas(pages, dets, self.formula_model, self.formula_expand_px, self.formula_batch_size)
@@ -435,17 +475,9 @@ class PageAnalyzer:
             for p in range(P):
                 regions, _t, _f = layout_host.split_regions(dets[p])
                 for r in regions:
-                    x0, y0, x1, y1 = (int(v) for v in (r["poly"][0], r["poly"][1], r["poly"][4], r["poly"][5]))
-                    if x1 <= x0 or y1 <= y0:                  # (the reference's np.ones of a negative size raises)
+                    crop = crop_region(pages, p, r)
+                    if crop is None:
                         continue
-                    crop = np.full((y1 - y0, x1 - x0, 3), 255, np.uint8)
-                    x0c, y0c, x1c, y1c = max(0, x0), max(0, y0), min(W, x1), min(H, y1)
-                    if x1c > x0c and y1c > y0c:
-                        part = pages[p, y0c:y1c, x0c:x1c].cpu().numpy()
-                        if r.get("polygon_points"):
-                            part = part.copy()
-                            part[~layout_polygon.polygon_keep_mask(part.shape[:2], r["polygon_points"], x0, y0)] = 255
-                        crop[y0c - y0: y1c - y0, x0c - x0: x1c - x0] = part
                     crops.append(np.ascontiguousarray(crop[:, :, ::-1]))          # BGR (:300)
                     owners.append((p, r))
             texts = self.custom_ocr.batch_predict(crops, batch_size=self.ocr.det_batch_num or 1) if crops else []
@@ -458,19 +490,22 @@ class PageAnalyzer:
         # 5. tables: one pooled `batch_predict` of a CustomBaseModel-shaped model (seam S1, batch_analyze.py:359-379) or, for a
         #    `predict`-shaped one (RapidTableModel, seam S3), the reference's own table stage with the table OCR on the GPU
         if self.table_model is not None and hasattr(self.table_model, "batch_predict"):
-            crops, owners = [], []
+            crops, owners, fills = [], [], []
             for p in range(P):
                 _o, tables, _f = layout_host.split_regions(dets[p])
                 for t in tables:
                     rect = table_crop_rect(t)                  # snapped outwards to multiples of 5 px (batch_analyze.py:235-243)
                     if rect is not None:
-                        crops.append(pages[p, rect[1]:rect[3], rect[0]:rect[2]].cpu().numpy())
+                        crop = pages[p, rect[1]:rect[3], rect[0]:rect[2]].cpu().numpy()
+                        useful = [0, 0, rect[0], rect[1], rect[2], rect[3], crop.shape[1], crop.shape[0]]
+                        fills.append(layout_host.table_fill_images(t, useful) if self.table_image_enable else [])
+                        crops.append(crop)
                         owners.append(t)
             if crops:
-                for t, html in zip(owners, self.table_model.batch_predict(crops, fill_image_res_list=[[] for _ in crops])):
+                for t, html in zip(owners, self.table_model.batch_predict(crops, fill_image_res_list=fills)):
                     t.pop("layout_image_list", None)
                     if html:
                         t["html"] = html
         elif self.table_model is not None:
-            self.table_ocr(pages, dets, self.table_model, page_scales, det_maps_fn=table_det_maps_fn)
+            self.table_ocr(pages, dets, self.table_model, page_scales, det_maps_fn=table_det_maps_fn, table_image_enable=self.table_image_enable)
         return out

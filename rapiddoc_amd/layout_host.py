@@ -197,7 +197,7 @@ def filter_overlap_boxes(layout_dets: Sequence[dict], use_custom_ocr: bool = Fal
 
 def split_regions(layout_dets: Sequence[dict]) -> Tuple[List[dict], List[dict], List[dict]]:
     """(ocr regions, table regions, formula regions with 'bbox') - get_res_list_from_layout_res (utils/model_utils.py:
-    162-196) without the image-in-table bookkeeping.  Like the reference it writes the integer 'bbox' INTO the formula
+    162-180; the image-in-table bookkeeping of :181-194 is `images_inside_tables`).  Like the reference it writes the integer 'bbox' INTO the formula
     detections (they are the caller's dicts: the field is part of the page's output)."""
     ocr, tables, formulas = [], [], []
     for d in layout_dets:
@@ -211,6 +211,46 @@ def split_regions(layout_dets: Sequence[dict]) -> Tuple[List[dict], List[dict], 
         elif cid == TABLE_CATEGORY_ID:
             tables.append(d)
     return ocr, tables, formulas
+
+
+def images_inside_tables(layout_dets: Sequence[dict], overlap_threshold: float = 0.8) -> List[Tuple[dict, dict]]:
+    """(image detection, table detection) pairs of get_res_list_from_layout_res' second loop (utils/model_utils.py:181-194): an image
+    region (category 3) belongs to every table at least `overlap_threshold` of whose own integer-box area lies inside the table's
+    integer box.  Image-major order, like the reference's loops."""
+    def rect_area(d):
+        p = d["poly"]
+        x0, y0, x1, y1 = int(p[0]), int(p[1]), int(p[4]), int(p[5])
+        return x0, y0, x1, y1, (x1 - x0) * (y1 - y0)
+    images = [d for d in layout_dets if int(d["category_id"]) in IMAGE_CATEGORY_IDS]
+    tables = [d for d in layout_dets if int(d["category_id"]) == TABLE_CATEGORY_ID]
+    pairs = []
+    for im in images:
+        a = rect_area(im)
+        for tb in tables:
+            b = rect_area(tb)
+            ix0, iy0, ix1, iy1 = max(a[0], b[0]), max(a[1], b[1]), min(a[2], b[2]), min(a[3], b[3])
+            if ix1 <= ix0 or iy1 <= iy0:
+                continue
+            if (ix1 - ix0) * (iy1 - iy0) >= overlap_threshold * a[4]:
+                pairs.append((im, tb))
+    return pairs
+
+
+def table_fill_images(table_det: dict, useful_list: Sequence[int]) -> List[dict]:
+    """extract_table_fill_image's layout branch (utils/span_pre_proc.py:245-259; the PDF-image branch needs the PDF): the images
+    region collection attached to this table (`layout_image_list`) get their page box (`ori_bbox`, `bbox`) and their corners in
+    table-crop coordinates (`ocr_bbox`); the SAME dicts are returned, like the reference."""
+    paste_x, paste_y, xmin, ymin = useful_list[:4]
+    out = []
+    for image in table_det.get("layout_image_list", []):
+        p = image["poly"]
+        bbox = [p[0], p[1], p[4], p[5]]
+        image["ori_bbox"] = bbox
+        x0, y0, x1, y1 = bbox[0] + paste_x - xmin, bbox[1] + paste_y - ymin, bbox[2] + paste_x - xmin, bbox[3] + paste_y - ymin
+        image["bbox"] = bbox
+        image["ocr_bbox"] = [[x0, y0], [x1, y0], [x1, y1], [x0, y1]]
+        out.append(image)
+    return out
 
 
 def crop_geometry(det: dict, paste_x: int = 0, paste_y: int = 0) -> List[int]:

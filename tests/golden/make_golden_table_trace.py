@@ -16,7 +16,8 @@ handed (image crc32, OCR boxes / texts / scores, formula boxes, flags) and answe
 recogniser inside a REAL RapidOcrModel object (`text_detector`: seeded boxes, records the canvas; `text_recognizer`: the recording
 stand-in of make_golden_recbatch.py whose text is a function of the crop's shape); the orientation classifier (answers "0": the
 orientation sub-stage is outside SURVEY s8); cv2 and the absent wheels as in make_golden_analyze.py.
-table_config = {use_word_box: False, table_image_enable: False}: the word-box variant lives in rapidocr's `cal_rec_boxes` (absent)."""
+table_config = {use_word_box: False}: the word-box variant lives in rapidocr's `cal_rec_boxes` (absent).  Images inside a table travel
+to the table model (`layout_image_list` -> extract_table_fill_image's layout branch; the page carries no PDF images)."""
 import importlib
 import json
 import sys
@@ -35,6 +36,18 @@ def table_text_and_score(h, w):
     """What the stand-in recogniser 'reads' from a table line crop: a function of its shape only (the recogniser loop sorts crops
     by aspect ratio, so a position in the call is not something both sides share)."""
     return ("香" if (h + w) % 7 == 0 else f"<{h}x{w}>"), ((h * 37 + w * 11) % 1000) / 1000.0
+
+
+def fill_summary(fill_image_res):
+    """What a table model is handed for the images inside a table, minus the random uuid; the PIL crop as size + crc32."""
+    out = []
+    for f in fill_image_res:
+        d = {k: json.loads(json.dumps(v)) for k, v in f.items() if k not in ("uuid", "pil_image")}
+        d["keys"] = list(f)
+        d["pil_size"] = list(f["pil_image"].size)
+        d["pil_crc32"] = zlib.crc32(np.ascontiguousarray(np.asarray(f["pil_image"])).tobytes())
+        out.append(d)
+    return out
 
 
 class TableRecognizer:
@@ -59,13 +72,15 @@ class TableRecognizer:
 
 def layout_with_tables(rng, H, W):
     dets = MGA.layout_for_page(rng, H, W)
-    y = max(d["poly"][5] for d in dets if d["original_label"] != "abandon") + 30.3
+    y = min(max(d["poly"][5] for d in dets if d["original_label"] != "abandon") + 30.3, H - 260.0)      # keep the table on the page
 
     def add(cat, label, x0, y0, x1, y1, score):
         dets.append({"category_id": cat, "original_label": label, "original_order": len(dets),
                      "poly": [x0, y0, x1, y0, x1, y1, x0, y1], "polygon_points": None, "score": score})
     add(5, "table", 101.7, y, 1083.2, y + 236.6, 0.93)                       # a table with an inline formula inside it
     add(13, "inline_formula", 420.4, y + 40.2, 560.9, y + 71.8, 0.81)
+    add(3, "image", 700.3, y + 100.6, 880.9, y + 200.2, 0.77)               # a picture inside that table: handed to the table model
+    add(3, "image", 1000.0, y + 150.0, 1150.0, y + 230.0, 0.6)               # one that only half lies in it (< 0.8 of its area): not
     add(5, "table", 641.0, 133.0, 1103.6, 248.2, 0.4)                        # a second, smaller table without formulas
     return dets
 
@@ -127,7 +142,7 @@ def main():
                 trace["table_calls"].append({
                     "shape": list(image.shape), "crc32": zlib.crc32(np.ascontiguousarray(image).tobytes()),
                     "boxes": [np.asarray(b, dtype=np.float64).tolist() for b in boxes], "texts": list(texts), "scores": [float(s) for s in scores],
-                    "fill_image_res": list(fill_image_res), "mfd_res": json.loads(json.dumps(mfd_res)),
+                    "fill_image_res": fill_summary(fill_image_res), "mfd_res": json.loads(json.dumps(mfd_res)),
                     "flags": [bool(skip_text_in_image), bool(use_img2table), bool(skip_table_orientation)]})
                 if len(texts) % 2 == 0:       # an answer without a table in it: the reference leaves the region without `html`
                     return "<html><body>nothing found</body></html>"
@@ -137,7 +152,8 @@ def main():
             def batch_predict(self, image_list, **kwargs):
                 trace["table_calls"].append({"shapes": [list(i.shape) for i in image_list],
                                              "crc32": [zlib.crc32(np.ascontiguousarray(i).tobytes()) for i in image_list],
-                                             "kwargs": {k: json.loads(json.dumps(v)) for k, v in kwargs.items()}})
+                                             "kwargs": {"fill_image_res_list": [fill_summary(f) for f in kwargs["fill_image_res_list"]]}
+                                             if set(kwargs) == {"fill_image_res_list"} else {"unexpected": sorted(kwargs)}})
                 return [f"<table><tr><td>{i.shape[0]}x{i.shape[1]}</td></tr></table>" if i.shape[0] > 150 else "" for i in image_list]
 
         class CustomOcr(CustomBaseModel):     # seam S1 for OCR: one multi-line string per layout region (batch_analyze.py:286-333)
@@ -173,13 +189,13 @@ def main():
             def get_model(self, **kw):
                 return Model()
         ocr_cfg = {"use_det_mode": "ocr", "Det.rec_batch_num": 3, "seal_enable": False}
-        table_cfg = {"use_word_box": False, "table_image_enable": False}
+        table_cfg = {"use_word_box": False}            # table_image_enable stays at its default, True
         analyzer = ba.BatchAnalyze(Manager(), batch_ratio=1, formula_enable=True, table_enable=(kind != "custom_ocr"), layout_config={"batch_num": 2},
                                    ocr_config=ocr_cfg, table_config=table_cfg,
                                    formula_config={"formula_level": 0, "batch_num": 4, "bbox_expand_px": 2})
         ba.clean_vram = lambda *a, **k: None
         from PIL import Image
-        out = analyzer([(Image.fromarray(p), 2.0, True, "ch", {"blocks": []}) for p in pages])
+        out = analyzer([(Image.fromarray(p), 2.0, True, "ch", {"blocks": [], "ori_image_list": []}) for p in pages])
 
         def clean(o):
             if isinstance(o, dict):

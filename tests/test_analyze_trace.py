@@ -131,6 +131,17 @@ def test_page_analyzer_replays_the_reference_trace(golden_dir, seed):
 # ---------------------------------------------------------------------------------------------------------------------
 # the table stage (SURVEY row a17's host side): traces of BatchAnalyze with table_enable, tests/golden/make_golden_table_trace.py
 # ---------------------------------------------------------------------------------------------------------------------
+def fill_summary(fill_image_res):        # == make_golden_table_trace.fill_summary
+    out = []
+    for f in fill_image_res:
+        d = {k: json.loads(json.dumps(v)) for k, v in f.items() if k not in ("uuid", "pil_image")}
+        d["keys"] = list(f)
+        d["pil_size"] = list(f["pil_image"].size)
+        d["pil_crc32"] = zlib.crc32(np.ascontiguousarray(np.asarray(f["pil_image"])).tobytes())
+        out.append(d)
+    return out
+
+
 def table_text_and_score(h, w):          # == make_golden_table_trace.table_text_and_score
     return ("香" if (h + w) % 7 == 0 else f"<{h}x{w}>"), ((h * 37 + w * 11) % 1000) / 1000.0
 
@@ -141,8 +152,9 @@ def test_table_stage_replays_the_reference_trace(golden_dir, kind):
     page's formulas out of the detector's copy, detects (0.5 / 1.6, sorted, cut around formulas, NOT merged), recognises every line
     from the unmasked crop, normalises / HTML-escapes the texts and calls predict(image, [boxes, texts, scores], [], formula boxes
     with latex, True, False, skip_table_orientation=True); the answer's <table> part and the page's formula boxes / scale land on the
-    region.  Demanded back: the detector canvases and the table images byte for byte, every argument of every predict call, the
-    output dicts.  `custom`: ONE batch_predict over the tables of all pages with the same crops and fill_image_res_list."""
+    region; a picture lying inside a table (>= 0.8 of its area) reaches the model as `fill_image_res` (page box, corners in crop
+    coordinates, the PIL crop) and its box / scale lands in `img_boxes`.  Demanded back: the detector canvases and the table images
+    byte for byte, every argument of every predict call, the output dicts.  `custom`: ONE batch_predict over the tables of all pages with the same crops and fill_image_res_list."""
     fx = json.loads((golden_dir / f"analyze_trace_table_{kind}.json").read_text())
     tr = fx["trace"]
     pages = torch.from_numpy(np.stack([synth_page(i)[0] for i in fx["page_ids"]]))
@@ -176,7 +188,7 @@ def test_table_stage_replays_the_reference_trace(golden_dir, kind):
             boxes, texts, scores = ocr_result if ocr_result else ([], [], [])
             log["table"].append({"shape": list(image.shape), "crc32": zlib.crc32(np.ascontiguousarray(image).tobytes()),
                                  "boxes": [np.asarray(b, dtype=np.float64).tolist() for b in boxes], "texts": list(texts),
-                                 "scores": [float(s) for s in scores], "fill_image_res": list(fill_image_res), "mfd_res": mfd_res,
+                                 "scores": [float(s) for s in scores], "fill_image_res": fill_summary(fill_image_res), "mfd_res": mfd_res,
                                  "flags": [bool(skip_text_in_image), bool(use_img2table), bool(skip_table_orientation)]})
             if len(texts) % 2 == 0:
                 return "<html><body>nothing found</body></html>"
@@ -185,7 +197,8 @@ def test_table_stage_replays_the_reference_trace(golden_dir, kind):
     class ReplayCustomTable:
         def batch_predict(self, image_list, **kwargs):
             log["table"].append({"shapes": [list(i.shape) for i in image_list],
-                                 "crc32": [zlib.crc32(np.ascontiguousarray(i).tobytes()) for i in image_list], "kwargs": kwargs})
+                                 "crc32": [zlib.crc32(np.ascontiguousarray(i).tobytes()) for i in image_list],
+                                 "kwargs": {k: [fill_summary(f) for f in v] for k, v in kwargs.items()}})
             return [f"<table><tr><td>{i.shape[0]}x{i.shape[1]}</td></tr></table>" if i.shape[0] > 150 else "" for i in image_list]
 
     pa = analyze.PageAnalyzer(ReplayLayout(fx["layout_dets"], log["layout"]), ReplayPipe(log["rec"]), formula_model=ReplayFormula(log["formula"]),
@@ -204,6 +217,7 @@ def test_table_stage_replays_the_reference_trace(golden_dir, kind):
         assert mine == theirs
     if kind == "traditional":
         assert any("否" in c["texts"] for c in tr["table_calls"]) and any(c["mfd_res"] for c in tr["table_calls"])
+        assert any(c["fill_image_res"] for c in tr["table_calls"]) and any("img_boxes" in d for page in fx["output"] for d in page)
     for p, (mine, theirs) in enumerate(zip(out, fx["output"])):
         assert len(mine) == len(theirs), (p, len(mine), len(theirs))
         for a, b in zip(mine, theirs):
