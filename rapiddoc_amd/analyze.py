@@ -305,8 +305,9 @@ class TableOcr:
         self.det = RegionOcr(pipeline, box_thresh=0.5, unclip_ratio=1.6, det_raw_fn=det_raw_fn)
         self.skip_text_in_image, self.use_img2table, self.table_formula_enable = skip_text_in_image, use_img2table, table_formula_enable
 
-    def ocr_result(self, table: torch.Tensor, adjusted: Optional[List[dict]], det_maps_fn=None) -> list:
-        """table [h,w,3] u8 RGB -> [boxes, texts, scores] (three parallel lists) or [] when nothing was detected."""
+    def ocr_result(self, table: torch.Tensor, adjusted: Optional[List[dict]], maps_override: Optional[torch.Tensor] = None) -> list:
+        """table [h,w,3] u8 RGB -> [boxes, texts, scores] (three parallel lists) or [] when nothing was detected.  `maps_override`
+        [1,1,dh,dw]: see RegionOcr._detect_group."""
         h, w, _ = table.shape
         canvas = table.unsqueeze(0)
         det_canvas = canvas
@@ -319,7 +320,7 @@ class TableOcr:
         if self.det.det_raw_fn is not None:
             raw = self.det.det_raw_fn(det_canvas, 1)[0]
         else:
-            raw = self.det._detect_group(det_canvas.contiguous(), det_maps_fn(table) if det_maps_fn is not None else None)[0]
+            raw = self.det._detect_group(det_canvas.contiguous(), maps_override)[0]
         if raw is None or len(raw) == 0:
             return []
         boxes = list(ocr_host.sorted_boxes(np.asarray(raw, dtype=np.float32)))
@@ -358,7 +359,11 @@ class TableOcr:
                         if f.get("latex"):
                             a["latex"] = f["latex"]
                         adjusted.append(a)
-                ocr_result = self.ocr_result(table, adjusted, det_maps_fn) if table.numel() else []
+                override = None
+                if det_maps_fn is not None and table.numel():      # (page, crop rectangle, det input size) -> maps [1,1,dh,dw]
+                    override = det_maps_fn(p, (x0, y0, x0 + int(table.shape[1]), y0 + int(table.shape[0])),
+                                           ocr_host.det_resize_shape(int(table.shape[0]), int(table.shape[1]), 960, "max"))
+                ocr_result = self.ocr_result(table, adjusted, override) if table.numel() else []
                 fill = layout_host.table_fill_images(t, useful) if table_image_enable else []
                 t.pop("layout_image_list", None)
                 html_code = table_model.predict(table.cpu().numpy(), ocr_result, fill, adjusted, self.skip_text_in_image, self.use_img2table,
