@@ -150,3 +150,22 @@ def test_inflight_checker_flags_a_hazard():
     assert len(mod.check(copied, ["k1"])) == 1
     split = kernel("\tglobal_load_dwordx4 v[8:11], v[2:3], off\n.LBB0_3:\n\ts_waitcnt vmcnt(0)")
     assert any("block boundary" in h[2] for h in mod.check(split, ["k1"]))
+
+
+def test_isa_mix_finds_the_inner_loops_of_the_dominant_kernels():
+    """tools/isa_mix.py (the static issue budget quoted in DESIGN.md s3c): the prefetching ws mixer's tile loop holds 72 MFMAs of the
+    16x16x32 shape and no vector-memory stores or plain loads (only LDS-DMA requests), the 16-wavefront GEMM's K loop 12 of the 32x32x16."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_mix", ROOT / "tools" / "isa_mix.py")
+    mix = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mix)
+    _hipcc()
+    for src, pat, shape, n_mfma in (("kernels_mixer_ws.hip", r"lc_mixer_ws_kernelILi192ELb0ELb0ELi0ELb1E", "f32_16x16x32_f16", 72),
+                                    ("kernels_gemm_h3_dma.hip", r"gemm_h3_dma16_kernelILi0E", "f32_32x32x16_f16", 12)):
+        bodies, _meta = mix.kernel_bodies(mix.asm_of(src))
+        name = min((n for n in bodies if re.search(pat, n)), key=len)
+        loops = mix.innermost_mfma_loops(bodies[name])
+        assert len(loops) == 1
+        c = mix.classify(bodies[name][loops[0][0]: loops[0][1] + 1])
+        assert c["mfma"] == {shape: n_mfma}
+        assert c["vmem_ld"] == 0 and c["vmem_st"] == 0 and c["vmem_ld_lds"] > 0 and c["barrier"] >= 1
