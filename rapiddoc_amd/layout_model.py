@@ -53,7 +53,13 @@ _MODELS: Dict[str, dict] = {
                            unclip=None, thresh=0.5),
     "pp_doclayout_s": dict(S=480, norm=(IMAGENET_MEAN, IMAGENET_STD), family="pp_doclayout", ordered=False, merge=None,
                            unclip=None, thresh=0.2),
+    # DocLayout-YOLO (model_handler/doc_layout/: letterbox to 1024 x 1024, one page per session call, the graph's own NMS);
+    # threshold 0.2 is RapidLayoutModel's default for it (rapid_layout.py:33-35)
+    "doclayout_docstructbench": dict(S=1024, yolo=True, family="doclayout_yolo", ordered=False, thresh=0.2),
 }
+# label -> category id of the DocLayout-YOLO classes: the position in this list, 'isolate_formula' -> 14 (rapid_layout.py:48-50,71-75)
+_YOLO_LABELS = ["title", "plain text", "abandon", "figure", "figure_caption", "table", "table_caption", "table_footnote",
+                "isolate_formula", "formula_caption", "10", "11", "12", "inline_formula", "isolated_formula", "ocr_text"]
 DEFAULT_IGNORE = ("number", "footnote", "header", "header_image", "footer", "footer_image", "aside_text")   # rapid_layout.py:42-43
 
 
@@ -101,6 +107,10 @@ class LayoutModel:
         self.labels = list(session.characters)
         self.ignore = tuple(markdown_ignore_labels)
         thr = conf_thresh if conf_thresh else self.m["thresh"]          # `if not cfg.conf_thresh` (rapid_layout_self/main.py:19)
+        self.conf_thresh = thr
+        if self.m.get("yolo"):
+            self.post = None
+            return
         self.post = layout_host.LayoutPostProcess(self.labels, thr, iou_thresh, layout_merge_bboxes_mode=self.m["merge"],
                                                   layout_unclip_ratio=self.m["unclip"], scale_size=(self.m["S"], self.m["S"]))
 
@@ -120,8 +130,68 @@ class LayoutModel:
             sf[i] = (S / t.shape[0], S / t.shape[1])
         return x, sf
 
+    # ------------------------------------------------------------------ DocLayout-YOLO: letterbox, one page per call
+    @staticmethod
+    def letterbox_geometry(h: int, w: int, S: int = 1024) -> Tuple[int, int, int, int]:
+        """(new_w, new_h, left, top) of LetterBox(new_shape=(S, S), auto=False, center=True) (doc_layout/utils.py:29-67)."""
+        r = min(S / h, S / w)
+        new_w, new_h = int(round(w * r)), int(round(h * r))
+        dw, dh = (S - new_w) / 2, (S - new_h) / 2
+        return new_w, new_h, int(round(dw - 0.1)), int(round(dh - 0.1))
+
+    def _resize_linear_u8(self, page: torch.Tensor, new_h: int, new_w: int) -> torch.Tensor:
+        """cv2.resize(img, (new_w, new_h), INTER_LINEAR) as float32 [3, new_h, new_w] holding the 8-bit results (GPU kernel)."""
+        return preproc_resize_norm(page.contiguous(), (new_h, new_w), scale=1.0, interp=1)
+
+    def preprocess_letterbox(self, page: Union[np.ndarray, torch.Tensor]) -> torch.Tensor:
+        """DocLayoutPreProcess (doc_layout/pre_process.py:13-26): letterbox with 114, channel order reversed, / 255 -> float32
+        [1, 3, S, S].  The division is the reference's float64 one (uint8 / 255, then float32), done as such on the result of the
+        8-bit resize."""
+        S = self.m["S"]
+        t = page if isinstance(page, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(page, dtype=np.uint8))
+        if t.device.type != "cuda" and torch.cuda.is_available():      # (without a GPU the resize below refuses a host tensor)
+            t = t.to(self.device, non_blocking=True)
+        h, w = int(t.shape[0]), int(t.shape[1])
+        new_w, new_h, left, top = self.letterbox_geometry(h, w, S)
+        canvas = torch.full((3, S, S), 114.0, dtype=torch.float32, device=t.device)
+        if (new_w, new_h) != (w, h):
+            canvas[:, top:top + new_h, left:left + new_w] = self._resize_linear_u8(t, new_h, new_w)
+        else:
+            canvas[:, top:top + new_h, left:left + new_w] = t.permute(2, 0, 1).to(torch.float32)
+        return (canvas.flip(0).to(torch.float64) / 255).to(torch.float32).unsqueeze(0).contiguous()
+
+    def _yolo_page(self, page) -> List[dict]:
+        """DocLayoutModelHandler.__call__ for one page + DocLayoutPostProcess (doc_layout/main.py:50-66, post_process.py:17-32,
+        utils.py:83-130): rows [x1, y1, x2, y2, conf, cls] of the letterboxed input -> page pixels (minus the padding, divided by the
+        gain, clipped), labels, then RapidLayoutModel's category ids."""
+        S = self.m["S"]
+        h, w = int(page.shape[0]), int(page.shape[1])
+        x = self.preprocess_letterbox(page)
+        wants_device = getattr(self.session, "accepts_device_tensors", False)
+        preds = np.asarray(self.session(x if wants_device else x.cpu().numpy())[0])
+        rows = np.array(preds[0][preds[0][..., 4] > self.conf_thresh])
+        gain = min(S / h, S / w)
+        pad = (round((S - w * gain) / 2 - 0.1), round((S - h * gain) / 2 - 0.1))
+        rows[..., 0] -= pad[0]
+        rows[..., 1] -= pad[1]
+        rows[..., 2] -= pad[0]
+        rows[..., 3] -= pad[1]
+        rows[..., :4] /= gain
+        rows[..., [0, 2]] = rows[..., [0, 2]].clip(0, w)
+        rows[..., [1, 3]] = rows[..., [1, 3]].clip(0, h)
+        dets = []
+        for r in rows:
+            label = self.labels[int(r[5])]
+            x0, y0, x1, y1 = r[0], r[1], r[2], r[3]                     # numpy float32 scalars, like the reference's dicts
+            dets.append({"category_id": 14 if label == "isolate_formula" else _YOLO_LABELS.index(label), "original_label": label,
+                         "original_order": -1, "poly": [x0, y0, x1, y0, x1, y1, x0, y1], "polygon_points": None,
+                         "score": round(float(r[4]), 3)})
+        return self._check_inline_formula(dets)
+
     # ------------------------------------------------------------------ handler: one chunk of pages
     def _chunk(self, pages) -> List[List[dict]]:
+        if self.m.get("yolo"):
+            return [self._yolo_page(pg) for pg in pages]
         x, sf = self.preprocess(pages)
         wants_device = getattr(self.session, "accepts_device_tensors", False)
         pred = self.session(x if wants_device else x.cpu().numpy(), sf)
@@ -162,6 +232,31 @@ class LayoutModel:
 
     def predict(self, image) -> List[dict]:
         return self.batch_predict([image], 1)[0]
+
+
+class SyntheticYoloSession:
+    """Stand-in for a DocLayout-YOLO session: `session(image f32[1,3,S,S]) -> [rows f32[1,N,6]]`, rows = [x1, y1, x2, y2, conf, cls]
+    in letterboxed-input pixels, deterministic in (seed, call index).  Some boxes reach into the padding (clipping)."""
+
+    def __init__(self, labels: Sequence[str], n: int = 40, seed: int = 0, size: int = 1024):
+        self.characters = list(labels)
+        self.n, self.seed, self.size = n, seed, size
+        self.calls: List[Tuple[Tuple[int, ...], int]] = []
+
+    def have_key(self, key: str = "character") -> bool:
+        return True
+
+    def __call__(self, image, scale_factor=None):
+        import zlib
+        image = np.asarray(image)
+        assert image.shape == (1, 3, self.size, self.size) and image.dtype == np.float32 and scale_factor is None
+        self.calls.append((tuple(image.shape), zlib.crc32(np.ascontiguousarray(image).tobytes())))
+        rng = np.random.default_rng([self.seed, len(self.calls)])
+        x0, y0 = rng.uniform(-20, 0.8 * self.size, self.n), rng.uniform(-20, 0.9 * self.size, self.n)
+        bw, bh = rng.uniform(20, 0.5 * self.size, self.n), rng.uniform(10, 0.2 * self.size, self.n)
+        rows = np.stack([x0, y0, x0 + bw, y0 + bh, rng.uniform(0.05, 0.99, self.n),
+                         rng.integers(0, len(self.characters), self.n).astype(np.float64)], axis=1).astype(np.float32)
+        return [rows[None]]
 
 
 class SyntheticBoxSession:

@@ -31,7 +31,7 @@ import make_golden_analyze as MGA  # noqa: E402
 import make_golden_polygon as MGP  # noqa: E402
 
 sys.path.insert(0, str(HERE.parents[1]))
-from rapiddoc_amd.layout_model import SyntheticBoxSession  # noqa: E402
+from rapiddoc_amd.layout_model import SyntheticBoxSession, SyntheticYoloSession, _YOLO_LABELS  # noqa: E402
 
 
 def import_layout():
@@ -44,6 +44,10 @@ def import_layout():
     # pages (3 channels) -> a blank image of the requested size; instance-mask crops (2-D) -> the nearest-neighbour primitive
     cv2.resize = lambda img, size, interpolation=None: (np.zeros((int(size[1]), int(size[0]), 3), np.uint8) if np.ndim(img) == 3
                                                         else poly_cv2.resize(img, size, interpolation))
+    # DocLayout-YOLO's letterbox (doc_layout/utils.py:56-66): constant border = np.pad
+    cv2.INTER_LINEAR, cv2.BORDER_CONSTANT = 1, 0
+    cv2.copyMakeBorder = lambda img, top, bottom, left, right, kind, value=None: np.stack(
+        [np.pad(img[..., c], ((top, bottom), (left, right)), constant_values=value[c]) for c in range(img.shape[2])], axis=-1)
     sys.modules["cv2"] = cv2
     sys.modules["shapely"], sys.modules["shapely.geometry"] = MGP.fake_shapely()
     for _ in range(60):
@@ -98,6 +102,24 @@ def main():
                       "layout_dets": dets})
         print(f"{name}: {len(session.calls)} session calls, dets per page {[len(p) for p in dets]}, polygon sizes "
               f"{sorted({len(d['polygon_points']) for p in dets for d in p if d['polygon_points'] is not None})}")
+    # ---- DocLayout-YOLO (model_handler/doc_layout/): letterbox geometry, one page per session call, box rescaling, category ids
+    yolo_cases = []
+    for seed, conf in ((0, None), (1, 0.45)):
+        session = SyntheticYoloSession(_YOLO_LABELS[:10] + ["inline_formula", "isolated_formula"], 50, seed=seed)
+        main_mod.get_engine = lambda engine_type: (lambda cfg_: session)
+        cfg = {"model_type": ModelType.DOCLAYOUT_DOCSTRUCTBENCH}
+        if conf:
+            cfg["conf_thresh"] = conf
+        model = RL.RapidLayoutModel(cfg)
+        ysizes = sizes + [(1024, 1024), (2048, 1000)]
+        out = model.batch_predict([np.zeros((h, w, 3), np.uint8) for h, w in ysizes], 3)
+        dets = [[{"category_id": int(d["category_id"]), "original_label": d["original_label"], "original_order": int(d["original_order"]),
+                  "poly": [float(v) for v in d["poly"]], "polygon_points": d["polygon_points"], "score": float(d["score"])} for d in page]
+                for page in out]
+        yolo_cases.append({"labels": session.characters, "n": 50, "seed": seed, "conf_thresh": conf, "page_hw": [list(s) for s in ysizes],
+                           "session_calls": [{"shape": list(sh), "crc32": crc} for sh, crc in session.calls], "layout_dets": dets})
+        print(f"doclayout_docstructbench: {len(session.calls)} session calls, dets per page {[len(p) for p in dets]}")
+    (HERE / "layout_trace_yolo.json").write_text(json.dumps({"cases": yolo_cases}))
     (HERE / "layout_trace.json").write_text(json.dumps({"source": "rapid_doc/model/layout/rapid_layout.py + rapid_layout_self", "cases": cases}))
 
 

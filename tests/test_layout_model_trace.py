@@ -72,3 +72,40 @@ def test_traces_cover_the_mask_branch_in_three_shape_modes():
             assert all(p is None for p in polys)
         else:
             assert all(p is not None for p in polys) and max(len(p) for p in polys) > 8 and min(len(p) for p in polys) == 4
+
+
+# ---- DocLayout-YOLO family (model_handler/doc_layout/): traces in tests/golden/layout_trace_yolo.json ------------------------------
+YOLO = json.loads((Path(__file__).parent / "golden" / "layout_trace_yolo.json").read_text())
+
+
+@pytest.mark.parametrize("case", YOLO["cases"], ids=lambda c: f"yolo-seed{c['seed']}")
+def test_doclayout_yolo_wrapper_replays_the_reference_trace(case, monkeypatch):
+    """LetterBox geometry (new size, left / top padding with 114), channel flip, float64 division by 255 -> the session input tensor
+    BYTE FOR BYTE (pages are blank and the stand-in for the linear resize returns a blank image on both sides: resize pixels are a GPU
+    test's business); one session call per page; rows -> page pixels (padding, gain, clip) in float32; labels -> category ids
+    ('isolate_formula' -> 14); the inline-formula rule; scores rounded to 3 decimals."""
+    from rapiddoc_amd.layout_model import SyntheticYoloSession
+    monkeypatch.setattr(LayoutModel, "_resize_linear_u8", lambda self, page, new_h, new_w: torch.zeros((3, new_h, new_w), dtype=torch.float32))
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    session = SyntheticYoloSession(case["labels"], case["n"], seed=case["seed"])
+    model = LayoutModel(session, "doclayout_docstructbench", conf_thresh=case["conf_thresh"])
+    out = model.batch_predict([np.zeros((h, w, 3), np.uint8) for h, w in case["page_hw"]], 3)
+    assert [{"shape": list(sh), "crc32": crc} for sh, crc in session.calls] == case["session_calls"]
+    assert len(out) == len(case["layout_dets"])
+    for pi, (mine, ref) in enumerate(zip(out, case["layout_dets"])):
+        assert len(mine) == len(ref), pi
+        for a, b in zip(mine, ref):
+            assert list(a) == list(b)
+            assert (a["category_id"], a["original_label"], a["original_order"], a["polygon_points"], float(a["score"])) == \
+                   (b["category_id"], b["original_label"], b["original_order"], b["polygon_points"], b["score"]), pi
+            assert [float(v) for v in a["poly"]] == b["poly"], pi
+    cats = {d["category_id"] for p in case["layout_dets"] for d in p}
+    assert 14 in cats and 1 in cats
+
+
+def test_letterbox_geometry_known_answers():
+    g = LayoutModel.letterbox_geometry
+    assert g(1684, 1191, 1024) == (724, 1024, 150, 0)            # portrait A4: 150 px of padding left and right
+    assert g(1024, 1024, 1024) == (1024, 1024, 0, 0)
+    assert g(1000, 2048, 1024) == (1024, 500, 0, 262)
+    assert g(480, 640, 1024) == (1024, 768, 0, 128)              # scaled UP (scaleup=True)
