@@ -68,3 +68,27 @@ def test_table_stage_on_the_gpu_engines(golden_dir):
     table = [d for d in out if d["category_id"] == 5][0]
     assert table["html"] == "<table><tr><td>%d</td></tr></table>" % len(lines)
     assert table["formula_boxes"] == [[150, 300, 210, 320]]
+
+
+@pytest.mark.xfail(strict=False, reason="written after the round's GPU budget was spent: first run is the driver's; XPASS = the letterbox "
+                                        "pre-process of the DocLayout-YOLO family is bit-equal to the restated cv2 arithmetic on the GPU")
+def test_doclayout_yolo_letterbox_on_the_gpu():
+    """LayoutModel.preprocess_letterbox (linear resize kernel + 114 padding + channel flip + float64 / 255) against
+    oracle/cv2_ops.resize_linear_u8 and numpy, bit for bit; then a whole batch_predict with the stand-in session."""
+    from oracle import cv2_ops as CV
+    from rapiddoc_amd.layout_model import LayoutModel, SyntheticYoloSession, _YOLO_LABELS
+    from rapiddoc_amd.pages import synth_batch
+    pages_np, _ = synth_batch(5, 2)
+    model = LayoutModel(SyntheticYoloSession(_YOLO_LABELS[:10], 30), "doclayout_docstructbench")
+    for page in (pages_np[0], np.ascontiguousarray(pages_np[1][:600, :1100])):
+        h, w = page.shape[:2]
+        new_w, new_h, left, top = LayoutModel.letterbox_geometry(h, w)
+        want = np.full((1024, 1024, 3), 114, np.uint8)
+        want[top:top + new_h, left:left + new_w] = CV.resize_linear_u8(page, (new_h, new_w))
+        want = (want[None][..., ::-1].transpose(0, 3, 1, 2) / 255).astype(np.float32)
+        got = model.preprocess_letterbox(page).cpu().numpy()
+        assert got.shape == (1, 3, 1024, 1024) and got.dtype == np.float32
+        assert np.array_equal(got, want)
+    out = model.batch_predict([pages_np[0], pages_np[1]], 2)
+    assert len(out) == 2 and all(len(p) > 0 for p in out)
+    assert all(0 <= d["poly"][0] <= d["poly"][4] <= 1191 and 0 <= d["poly"][1] <= d["poly"][5] <= 1684 for p in out for d in p)
