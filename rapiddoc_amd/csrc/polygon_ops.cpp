@@ -158,49 +158,65 @@ static void slab_xs(const double* a, int na, const double* b, int nb, std::vecto
 extern "C" int rd_find_external_contours(const uint8_t* mask, int h, int w, int32_t* pts_out, int max_pts, int32_t* counts_out,
                                          int max_contours, int32_t* n_contours, int32_t* n_pts) {
     if (!mask || h <= 0 || w <= 0 || !n_contours || !n_pts || max_pts < 0 || max_contours < 0) return 1;
-    const size_t n = (size_t)h * w;
-    std::vector<uint8_t> outside(n, 0), seen(n, 0);
-    std::vector<int32_t> stack;
-    // background 4-connected to the frame
-    auto seed = [&](int x, int y) {
-        const size_t s = (size_t)y * w + x;
-        if (!mask[s] && !outside[s]) { outside[s] = 1; stack.push_back((int32_t)s); }
-    };
-    for (int x = 0; x < w; ++x) { seed(x, 0); seed(x, h - 1); }
-    for (int y = 0; y < h; ++y) { seed(0, y); seed(w - 1, y); }
-    while (!stack.empty()) {
-        const int32_t q = stack.back();
-        stack.pop_back();
-        const int qy = q / w, qx = q - qy * w;
-        if (qx > 0) seed(qx - 1, qy);
-        if (qx < w - 1) seed(qx + 1, qy);
-        if (qy > 0) seed(qx, qy - 1);
-        if (qy < h - 1) seed(qx, qy + 1);
-    }
-    std::vector<std::vector<Pt>> found;
-    for (int y = 0; y < h; ++y)
-        for (int x = 0; x < w; ++x) {
-            const size_t s = (size_t)y * w + x;
-            if (!mask[s] || seen[s]) continue;
-            // flood the component so that its other pixels do not start a border
-            stack.clear();
-            stack.push_back((int32_t)s);
-            seen[s] = 1;
-            while (!stack.empty()) {
-                const int32_t q = stack.back();
-                stack.pop_back();
-                const int qy = q / w, qx = q - qy * w;
-                for (int k = 0; k < 8; ++k) {
-                    const int nx = qx + DX[k], ny = qy + DY[k];
-                    if (nx < 0 || ny < 0 || nx >= w || ny >= h) continue;
-                    const size_t t = (size_t)ny * w + nx;
-                    if (mask[t] && !seen[t]) { seen[t] = 1; stack.push_back((int32_t)t); }
-                }
+    // One raster pass over row RUNS instead of per-pixel flood fills: foreground runs are joined with the runs of the previous row
+    // they touch (8-connected: x ranges may differ by one), background runs with those they overlap (4-connected); node 0 of the
+    // background forest is "outside the image".  A component is external iff the background run left of its first pixel is outside.
+    struct Run { int x0, x1, id; };                       // [x0, x1)
+    std::vector<int> fg_parent, bg_parent(1, 0);
+    auto find = [](std::vector<int>& p, int a) { while (p[a] != a) { p[a] = p[p[a]]; a = p[a]; } return a; };
+    auto unite = [&](std::vector<int>& p, int a, int b) { a = find(p, a); b = find(p, b); if (a != b) p[a > b ? a : b] = a > b ? b : a; };
+    struct Start { int x, y, fg, bg_left; };              // first pixel of a foreground run whose component it may start
+    std::vector<Start> starts;
+    std::vector<Run> prev_fg, prev_bg, cur_fg, cur_bg;
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* row = mask + (size_t)y * w;
+        cur_fg.clear();
+        cur_bg.clear();
+        for (int x = 0; x < w;) {
+            const bool fg = row[x] != 0;
+            int e = x + 1;
+            while (e < w && (row[e] != 0) == fg) ++e;
+            if (fg) {
+                const int id = (int)fg_parent.size();
+                fg_parent.push_back(id);
+                cur_fg.push_back({x, e, id});
+            } else {
+                const int id = (int)bg_parent.size();
+                bg_parent.push_back(id);
+                cur_bg.push_back({x, e, id});
+                if (x == 0 || e == w || y == 0 || y == h - 1) unite(bg_parent, id, 0);
             }
-            if (x > 0 && !outside[s - 1]) continue;              // inside a hole of another component
-            found.emplace_back();
-            trace_outer_border(mask, h, w, x, y, found.back());
+            x = e;
         }
+        size_t j = 0;
+        for (const Run& r : cur_fg) {                        // 8-connected: touches [x0 - 1, x1 + 1) of the previous row
+            while (j < prev_fg.size() && prev_fg[j].x1 < r.x0) ++j;
+            for (size_t k = j; k < prev_fg.size() && prev_fg[k].x0 <= r.x1; ++k) unite(fg_parent, r.id, prev_fg[k].id);
+        }
+        j = 0;
+        for (const Run& r : cur_bg) {                        // 4-connected: overlaps [x0, x1) of the previous row
+            while (j < prev_bg.size() && prev_bg[j].x1 <= r.x0) ++j;
+            for (size_t k = j; k < prev_bg.size() && prev_bg[k].x0 < r.x1; ++k) unite(bg_parent, r.id, prev_bg[k].id);
+        }
+        size_t b = 0;
+        for (const Run& r : cur_fg) {                        // the background run that ends where this foreground run starts
+            while (b < cur_bg.size() && cur_bg[b].x1 < r.x0) ++b;
+            starts.push_back({r.x0, y, r.id, r.x0 == 0 ? 0 : cur_bg[b].id});
+        }
+        prev_fg.swap(cur_fg);
+        prev_bg.swap(cur_bg);
+    }
+    // the first run (raster order) of every component is its start pixel; later runs of the same component are dropped
+    std::vector<char> taken(fg_parent.size(), 0);
+    std::vector<std::vector<Pt>> found;
+    for (const Start& st : starts) {
+        const int root = find(fg_parent, st.fg);
+        if (taken[root]) continue;
+        taken[root] = 1;
+        if (find(bg_parent, st.bg_left) != 0) continue;      // inside a hole of another component
+        found.emplace_back();
+        trace_outer_border(mask, h, w, st.x, st.y, found.back());
+    }
     std::reverse(found.begin(), found.end());
     size_t total = 0;
     for (const auto& c : found) total += c.size();
