@@ -85,13 +85,24 @@ class Mi355LayoutBackboneSession(_BaseSession):
 
 
 def install_into_rapidocr() -> None:
-    """Replace rapidocr's torch engine by the MI355X sessions the same way the reference patches it
-    (rapid_doc/model/ocr/ocr_patch.py:95-105).  Needs the `rapidocr` package of the RapidDoc installation."""
-    import rapidocr.inference_engine.pytorch as rt  # noqa: WPS433 (third-party, only present in a RapidDoc install)
+    """Replace rapidocr's torch engine by the MI355X sessions at the places the reference patches it
+    (rapid_doc/model/ocr/ocr_patch.py:95-105): rapidocr >= 3.4.3 keeps `TorchInferSession` in `rapidocr.inference_engine.pytorch.main`
+    and re-exports it from the package - both names are replaced, like the reference does; older releases of the pinned range
+    (>= 3.4.0) keep it in `rapidocr.inference_engine.torch`.  Needs the `rapidocr` package of the RapidDoc installation."""
+    import importlib
 
     class _Dispatch:
         def __new__(cls, cfg):
-            task = str(getattr(cfg, "task_type", cfg.get("task_type", ""))).lower()
+            task = str(getattr(cfg, "task_type", None) or (cfg.get("task_type", "") if hasattr(cfg, "get") else "")).lower()
             return (Mi355DetSession if "det" in task else Mi355RecSession).from_cfg(cfg)
 
-    rt.TorchInferSession = _Dispatch
+    try:
+        main = importlib.import_module("rapidocr.inference_engine.pytorch.main")
+        pkg = importlib.import_module("rapidocr.inference_engine.pytorch")
+    except ModuleNotFoundError as e:
+        if not str(e.name or "").startswith("rapidocr.inference_engine.pytorch"):
+            raise
+        main, pkg = importlib.import_module("rapidocr.inference_engine.torch"), None
+    main.TorchInferSession = _Dispatch
+    if pkg is not None:
+        pkg.TorchInferSession = _Dispatch
