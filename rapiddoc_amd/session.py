@@ -93,7 +93,10 @@ def install_into_rapidocr() -> None:
 
     class _Dispatch:
         def __new__(cls, cfg):
-            task = str(getattr(cfg, "task_type", None) or (cfg.get("task_type", "") if hasattr(cfg, "get") else "")).lower()
+            # rapidocr's cfg carries `task_type`; the reference's session itself goes by the weight file's stem, the key of
+            # arch_config.yaml ("ch_PP-OCRv6_det_small", rapid_doc/model/ocr/torch.py:70-77): used when task_type is absent
+            get = (lambda k: getattr(cfg, k, None)) if not hasattr(cfg, "get") else (lambda k: cfg.get(k, None) or getattr(cfg, k, None))
+            task = str(get("task_type") or Path(str(get("model_path") or "")).stem).lower()
             return (Mi355DetSession if "det" in task else Mi355RecSession).from_cfg(cfg)
 
     try:

@@ -40,7 +40,9 @@ def test_install_replaces_the_session_class_and_dispatches_by_task(monkeypatch, 
     cls = holders[0].TorchInferSession
     assert cls({"task_type": "TaskType.DET", "model_path": "x.safetensors"}) == "det-session"
     assert cls(types.SimpleNamespace(task_type="rec", model_path="y.safetensors")) == "rec-session"
-    assert [b[0] for b in built] == ["det", "rec"]
+    assert cls({"model_path": "/w/ch_PP-OCRv6_det_small.safetensors"}) == "det-session"          # no task_type: the file's stem decides
+    assert cls({"model_path": "/w/ch_PP-OCRv6_rec_small.safetensors"}) == "rec-session"
+    assert [b[0] for b in built] == ["det", "rec", "det", "rec"]
 
 
 def test_install_without_rapidocr_fails_loudly(monkeypatch):
