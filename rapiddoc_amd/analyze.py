@@ -144,18 +144,28 @@ class RegionOcr:
         self.box_thresh, self.unclip_ratio, self.lang = box_thresh, unclip_ratio, lang
         self.det_batch_num, self.det_raw_fn = det_batch_num, det_raw_fn
 
+    def _pipe_for(self, lang: str):
+        """`pipeline` may be one PagePipeline (every page is of language `lang`) or a dict {language: PagePipeline} - the reference
+        asks its registry for one OCR model per language (analyze_utils.py:160-166, :246-250)."""
+        if isinstance(self.pipe, dict):
+            if lang not in self.pipe:
+                raise KeyError(f"no OCR pipeline for language {lang!r} (have {sorted(self.pipe)})")
+            return self.pipe[lang]
+        return self.pipe
+
     # ------------------------------------------------------------------ det on one size group
-    def _detect_group(self, canvases: torch.Tensor, maps_override: Optional[torch.Tensor] = None) -> List[np.ndarray]:
+    def _detect_group(self, canvases: torch.Tensor, maps_override: Optional[torch.Tensor] = None, pipe=None) -> List[np.ndarray]:
         """canvases [b, H64, W64, 3] u8 RGB on the GPU -> per image the detector's raw boxes [n,4,2] (group image coordinates,
         DB post-process order).  `maps_override` [b,1,dh,dw] replaces the network output as the post-process input (tests and
         benchmarks with random weights, whose maps carry no text); the det forward still runs."""
+        pipe = pipe if pipe is not None else self._pipe_for(self.lang)
         b, H, W, _ = canvases.shape
         dh, dw = ocr_host.det_resize_shape(H, W, 960, "max")
         # DetPreProcess: BGR, (x/255 - 0.5)/0.5 (rapid_ocr.py:474-536), the whole group in one launch
         x = preproc_resize_norm_batch(canvases, (dh, dw), mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), interp=1, swap_rb=True)
-        maps = self.pipe.det.det_forward(x)
-        if self.pipe.det.check_range_and_fallback():      # split-fp16 range guard (the pipeline's engines defer it)
-            maps = self.pipe.det.det_forward(x)
+        maps = pipe.det.det_forward(x)
+        if pipe.det.check_range_and_fallback():           # split-fp16 range guard (the pipeline's engines defer it)
+            maps = pipe.det.det_forward(x)
         if maps_override is not None:
             assert tuple(maps_override.shape) == tuple(maps.shape)
             maps = maps_override
@@ -173,10 +183,13 @@ class RegionOcr:
         return np.asarray(q, dtype=np.float32).reshape(-1, 4, 2)
 
     # ------------------------------------------------------------------ whole batch
-    def __call__(self, pages: torch.Tensor, layout_dets_per_page: Sequence[Sequence[dict]], det_maps_fn=None) -> List[List[dict]]:
+    def __call__(self, pages: torch.Tensor, layout_dets_per_page: Sequence[Sequence[dict]], det_maps_fn=None,
+                 page_langs: Optional[Sequence[str]] = None) -> List[List[dict]]:
         """pages [P,H,W,3] u8 RGB (GPU); returns, per page, the layout detections followed by their OcrText spans
         (`layout_res` of the reference after both OCR stages).  `det_maps_fn(regions, (gh, gw), (dh, dw))` may supply the
-        det maps of a size group (see `_detect_group`); regions = [(page, region dict, useful_list)]."""
+        det maps of a size group (see `_detect_group`); regions = [(page, region dict, useful_list)].
+        `page_langs[p]`: the language of page p (the `lang` of the reference's input tuples); regions are grouped by language first
+        and every language's lines are recognised by that language's pipeline in one pooled call."""
         assert pages.dtype == torch.uint8 and (pages.is_cuda or self.det_raw_fn is not None)
         P, H, W, _ = pages.shape
         out: List[List[dict]] = [list(d) for d in layout_dets_per_page]
@@ -190,8 +203,8 @@ class RegionOcr:
                 regions.append((p, r, useful, _formula_boxes_in_crop(formulas, useful)))
         if not regions:
             return out
-        groups = ocr_host.det_buckets([(u[7], u[6]) for _, _, u, _ in regions], [self.lang] * len(regions),
-                                      det_batch_num=len(regions))
+        langs = [self.lang if page_langs is None else page_langs[p] for p, _r, _u, _f in regions]
+        groups = ocr_host.det_buckets([(u[7], u[6]) for _, _, u, _ in regions], langs, det_batch_num=len(regions))
         pending = []                                   # per size group: (unmasked canvases, quads, spans, page of each image)
         for _lang, (gh, gw), members, _bs in groups:
             canv = torch.full((len(members), gh, gw, 3), 255, dtype=torch.uint8, device=pages.device)
@@ -218,9 +231,10 @@ class RegionOcr:
             if det_maps_fn is not None:
                 override = det_maps_fn([regions[i][:3] for i in members], (gh, gw), ocr_host.det_resize_shape(gh, gw, 960, "max"))
             if self.det_raw_fn is not None:
-                raw = self.det_raw_fn(det_canv, min(len(members), self.det_batch_num or len(members)))
+                fn = self.det_raw_fn[_lang] if isinstance(self.det_raw_fn, dict) else self.det_raw_fn
+                raw = fn(det_canv, min(len(members), self.det_batch_num or len(members)))
             else:
-                raw = self._detect_group(det_canv, override)
+                raw = self._detect_group(det_canv, override, self._pipe_for(_lang))
             boxes_per_img = [self._sort_merge(r) for r in raw]
             spans_per_img: List[List[dict]] = []
             quads_per_img: List[np.ndarray] = []
@@ -249,12 +263,18 @@ class RegionOcr:
                     quads.append(q)                    # the line crop is taken from the UNcorrected box (:381-383)
                 spans_per_img.append(spans)
                 quads_per_img.append(np.asarray(quads, dtype=np.float32).reshape(-1, 4, 2))
-            pending.append((canv, quads_per_img, spans_per_img, [regions[ridx][0] for ridx in members]))
+            pending.append((canv, quads_per_img, spans_per_img, [regions[ridx][0] for ridx in members], _lang))
         if not pending:
             return out
-        # rec: every line of the page batch in ONE pooled call (analyze_utils.py:216-252), ordered page by page
-        texts_all = self.pipe.rec_forward_sources([(c, q) for c, q, _s, _p in pending], image_keys=[pg for _c, _q, _s, pg in pending])
-        for (canv, _q, spans_per_img, pages_of), texts in zip(pending, texts_all):
+        # rec: every line of the page batch - per language - in ONE pooled call (analyze_utils.py:216-252), ordered page by page
+        texts_all: List = [None] * len(pending)
+        for lang in dict.fromkeys(e[4] for e in pending):
+            idx = [i for i, e in enumerate(pending) if e[4] == lang]
+            res = self._pipe_for(lang).rec_forward_sources([(pending[i][0], pending[i][1]) for i in idx],
+                                                           image_keys=[pending[i][3] for i in idx])
+            for i, r in zip(idx, res):
+                texts_all[i] = r
+        for (canv, _q, spans_per_img, pages_of, _lg), texts in zip(pending, texts_all):
             for k, p in enumerate(pages_of):
                 for span, (text, score) in zip(spans_per_img[k], texts[k]):
                     span["text"] = text
@@ -300,12 +320,13 @@ class TableOcr:
     `rec_fn(canvas [1,h,w,3], quads [n,4,2]) -> [(text, score)]` replace them (tests replaying traces of the reference)."""
 
     def __init__(self, pipeline, det_raw_fn=None, rec_fn=None, skip_text_in_image: bool = True, use_img2table: bool = False,
-                 table_formula_enable: bool = True):
+                 table_formula_enable: bool = True, lang: str = "ch"):
         self.pipe, self.rec_fn = pipeline, rec_fn
-        self.det = RegionOcr(pipeline, box_thresh=0.5, unclip_ratio=1.6, det_raw_fn=det_raw_fn)
+        self.det = RegionOcr(pipeline, box_thresh=0.5, unclip_ratio=1.6, lang=lang, det_raw_fn=det_raw_fn)
         self.skip_text_in_image, self.use_img2table, self.table_formula_enable = skip_text_in_image, use_img2table, table_formula_enable
 
-    def ocr_result(self, table: torch.Tensor, adjusted: Optional[List[dict]], maps_override: Optional[torch.Tensor] = None) -> list:
+    def ocr_result(self, table: torch.Tensor, adjusted: Optional[List[dict]], maps_override: Optional[torch.Tensor] = None,
+                   lang: Optional[str] = None) -> list:
         """table [h,w,3] u8 RGB -> [boxes, texts, scores] (three parallel lists) or [] when nothing was detected.  `maps_override`
         [1,1,dh,dw]: see RegionOcr._detect_group."""
         h, w, _ = table.shape
@@ -320,7 +341,7 @@ class TableOcr:
         if self.det.det_raw_fn is not None:
             raw = self.det.det_raw_fn(det_canvas, 1)[0]
         else:
-            raw = self.det._detect_group(det_canvas.contiguous(), maps_override)[0]
+            raw = self.det._detect_group(det_canvas.contiguous(), maps_override, self.det._pipe_for(lang or self.det.lang))[0]
         if raw is None or len(raw) == 0:
             return []
         boxes = list(ocr_host.sorted_boxes(np.asarray(raw, dtype=np.float32)))
@@ -332,11 +353,12 @@ class TableOcr:
         if self.rec_fn is not None:
             lines = self.rec_fn(canvas, quads)
         else:
-            lines = self.pipe.rec_forward_sources([(canvas.contiguous(), [quads])], image_keys=[[0]])[0][0]
+            lines = self.det._pipe_for(lang or self.det.lang).rec_forward_sources([(canvas.contiguous(), [quads])], image_keys=[[0]])[0][0]
         return [[q for q in quads], [table_host.normalize_table_ocr_text(t) for t, _s in lines], [s for _t, s in lines]]
 
     def __call__(self, pages: torch.Tensor, layout_dets_per_page: Sequence[Sequence[dict]], table_model,
-                 page_scales: Optional[Sequence[float]] = None, det_maps_fn=None, table_image_enable: bool = True) -> int:
+                 page_scales: Optional[Sequence[float]] = None, det_maps_fn=None, table_image_enable: bool = True,
+                 page_langs: Optional[Sequence[str]] = None) -> int:
         """Writes `html` (and `formula_boxes` / `img_boxes`) into the table detections IN PLACE; returns the number of tables handed to
         the model.  `table_image_enable`: hand the images that lie inside a table (`layout_image_list`) to the model as
         `fill_image_res` (extract_table_fill_image's layout branch)."""
@@ -363,7 +385,7 @@ class TableOcr:
                 if det_maps_fn is not None and table.numel():      # (page, crop rectangle, det input size) -> maps [1,1,dh,dw]
                     override = det_maps_fn(p, (x0, y0, x0 + int(table.shape[1]), y0 + int(table.shape[0])),
                                            ocr_host.det_resize_shape(int(table.shape[0]), int(table.shape[1]), 960, "max"))
-                ocr_result = self.ocr_result(table, adjusted, override) if table.numel() else []
+                ocr_result = self.ocr_result(table, adjusted, override, None if page_langs is None else page_langs[p]) if table.numel() else []
                 fill = layout_host.table_fill_images(t, useful) if table_image_enable else []
                 t.pop("layout_image_list", None)
                 html_code = table_model.predict(table.cpu().numpy(), ocr_result, fill, adjusted, self.skip_text_in_image, self.use_img2table,
@@ -447,11 +469,11 @@ class PageAnalyzer:
         self.layout_batch_size, self.formula_level = layout_batch_size, formula_level
         self.formula_batch_size, self.formula_expand_px = formula_batch_size, formula_expand_px
         self.ocr = RegionOcr(pipeline, box_thresh, unclip_ratio, lang, det_batch_num, det_raw_fn)
-        self.table_ocr = TableOcr(pipeline, det_raw_fn=table_det_raw_fn, rec_fn=table_rec_fn)
+        self.table_ocr = TableOcr(pipeline, det_raw_fn=table_det_raw_fn, rec_fn=table_rec_fn, lang=lang)
         self.table_image_enable = table_image_enable          # table_config["table_image_enable"], default True (batch_analyze.py:75)
 
     def __call__(self, pages: torch.Tensor, det_maps_fn=None, page_scales: Optional[Sequence[float]] = None,
-                 table_det_maps_fn=None) -> List[List[dict]]:
+                 table_det_maps_fn=None, page_langs: Optional[Sequence[str]] = None) -> List[List[dict]]:
         """`page_scales[p]`: the render scale the reference carries with every page (the `scale` of its input tuples); only the
         `formula_boxes` written next to a table's `html` use it (analyze_utils.py:405-418).  Default 1."""
         assert pages.dtype == torch.uint8 and pages.dim() == 4 and (pages.is_cuda or self.ocr.det_raw_fn is not None)
@@ -491,7 +513,7 @@ class PageAnalyzer:
                                "vl_ocr": True, "original_label": r.get("original_label"), "original_order": r.get("original_order"),
                                "polygon_points": r.get("polygon_points")})
         else:
-            out = self.ocr(pages, dets, det_maps_fn=det_maps_fn)
+            out = self.ocr(pages, dets, det_maps_fn=det_maps_fn, page_langs=page_langs)
         # 5. tables: one pooled `batch_predict` of a CustomBaseModel-shaped model (seam S1, batch_analyze.py:359-379) or, for a
         #    `predict`-shaped one (RapidTableModel, seam S3), the reference's own table stage with the table OCR on the GPU
         if self.table_model is not None and hasattr(self.table_model, "batch_predict"):
@@ -512,5 +534,6 @@ class PageAnalyzer:
                     if html:
                         t["html"] = html
         elif self.table_model is not None:
-            self.table_ocr(pages, dets, self.table_model, page_scales, det_maps_fn=table_det_maps_fn, table_image_enable=self.table_image_enable)
+            self.table_ocr(pages, dets, self.table_model, page_scales, det_maps_fn=table_det_maps_fn, table_image_enable=self.table_image_enable,
+                           page_langs=page_langs)
         return out

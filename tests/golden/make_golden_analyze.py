@@ -163,13 +163,15 @@ def det_boxes_for(h, w, key):
 
 
 class RecordingOcr:
-    def __init__(self, trace):
-        self.trace = trace
+    def __init__(self, trace, lang=None):
+        self.trace, self.lang = trace, lang       # `lang`: only set (and recorded) in the multi-language trace
 
     def det_batch_predict(self, img_list, max_batch_size=8):
         imgs = [np.asarray(im) for im in img_list]
         call = {"batch_size": int(max_batch_size), "shapes": [list(im.shape) for im in imgs],
                 "crc32": [zlib.crc32(np.ascontiguousarray(im).tobytes()) for im in imgs], "boxes": []}
+        if self.lang:
+            call["lang"] = self.lang
         out = []
         for im in imgs:
             b = det_boxes_for(im.shape[0], im.shape[1], zlib.crc32(np.ascontiguousarray(im).tobytes()) & 0xffff)
@@ -181,7 +183,7 @@ class RecordingOcr:
     def ocr(self, img, det=True, rec=True, tqdm_enable=False, **kw):
         assert det is False
         crops = [np.asarray(c) for c in img]
-        self.trace["rec_calls"].append({"shapes": [list(c.shape[:2]) for c in crops]})
+        self.trace["rec_calls"].append(dict({"shapes": [list(c.shape[:2]) for c in crops]}, **({"lang": self.lang} if self.lang else {})))
         return [[rec_text_and_score(c.shape[0], c.shape[1], k) for k, c in enumerate(crops)]]
 
 
@@ -253,8 +255,9 @@ def main():
     from rapid_doc.backend.pipeline.model_list import AtomicModel
     from rapiddoc_amd.pages import synth_page
 
-    for seed, (n_pages, formula_enable, formula_level, polygons) in enumerate([(3, True, 0, False), (2, False, 0, False), (2, True, 1, False),
-                                                                               (2, True, 0, True)]):
+    for seed, (n_pages, formula_enable, formula_level, polygons, langs) in enumerate([
+            (3, True, 0, False, None), (2, False, 0, False, None), (2, True, 1, False, None), (2, True, 0, True, None),
+            (3, True, 0, False, ["ch", "en", "ch"])]):              # the last one: pages of two languages in one batch
         rng = np.random.default_rng(7000 + seed)
         trace = {"det_calls": [], "rec_calls": [], "formula_calls": [], "layout_calls": []}
         page_ids = [int(rng.integers(0, 1000)) for _ in range(n_pages)]
@@ -262,12 +265,13 @@ def main():
         H, W = pages[0].shape[:2]
         dets = [layout_for_page(rng, H, W, polygons) for _ in range(n_pages)]
         ocr = RecordingOcr(trace)
+        ocr_by_lang = {lg: RecordingOcr(trace, lg) for lg in dict.fromkeys(langs or [])}
 
         class Registry:                      # rapid_doc/backend/pipeline/model_init.py:57-88 AtomModelSingleton
             def get_atom_model(self, atom_model_name, **kw):
                 assert atom_model_name == AtomicModel.OCR, atom_model_name
                 trace.setdefault("atom_model_requests", []).append({k: v for k, v in kw.items() if k in ("lang",)})
-                return ocr
+                return ocr_by_lang[kw["lang"]] if langs else ocr
         reg.AtomModelSingleton = Registry
         ba.AtomModelSingleton = Registry
         sys.modules["rapid_doc.backend.pipeline.analyze_utils"].AtomModelSingleton = Registry
@@ -288,7 +292,7 @@ def main():
                                    formula_config={"formula_level": formula_level, "batch_num": 4, "bbox_expand_px": 2})
         ba.clean_vram = lambda *a, **k: None
         from PIL import Image
-        inputs = [(Image.fromarray(p), 2.0, True, "ch", {}) for p in pages]
+        inputs = [(Image.fromarray(p), 2.0, True, (langs[i] if langs else "ch"), {}) for i, p in enumerate(pages)]
         out = analyzer(inputs)
 
         def clean(o):
@@ -299,7 +303,7 @@ def main():
             if isinstance(o, (np.floating, np.integer)):
                 return o.item()
             return o
-        fixture = {"seed": seed, "page_ids": page_ids, "page_hw": [H, W], "formula_enable": formula_enable, "formula_level": formula_level,
+        fixture = {"seed": seed, "page_langs": langs, "page_ids": page_ids, "page_hw": [H, W], "formula_enable": formula_enable, "formula_level": formula_level,
                    "ocr_config": ocr_cfg, "layout_batch_num": 2, "formula_batch_num": 4, "layout_dets": dets,
                    "trace": clean(trace), "output": clean(out)}
         (HERE / f"analyze_trace_seed{seed}.json").write_text(json.dumps(fixture))

@@ -255,3 +255,45 @@ def test_custom_ocr_seam_replays_the_reference_trace(golden_dir):
         assert len(mine) == len(theirs), (p, len(mine), len(theirs))
         for a, b in zip(mine, theirs):
             assert a == b and list(a) == list(b), (p, a, b)          # same keys in the same order, too
+
+
+def test_two_languages_in_one_page_batch_replay_the_reference_trace(golden_dir):
+    """Pages of different languages in one batch (analyze_utils.py:150-166, :222-250): detector groups by language first (in order of
+    first appearance), then by 64-px size bucket; one pooled recogniser call PER LANGUAGE, each through that language's model."""
+    fx = json.loads((golden_dir / "analyze_trace_seed4.json").read_text())
+    tr, langs = fx["trace"], fx["page_langs"]
+    assert sorted(set(langs)) == ["ch", "en"]
+    pages = torch.from_numpy(np.stack([synth_page(i)[0] for i in fx["page_ids"]]))
+    log = {"layout": [], "formula": [], "det": [], "rec": {lg: [] for lg in dict.fromkeys(langs)}}
+    det_calls = iter(tr["det_calls"])
+
+    def det_for(lang):
+        def det_raw_fn(canvases, batch_size):
+            call = next(det_calls)
+            bgr = np.ascontiguousarray(canvases.numpy()[..., ::-1])
+            log["det"].append({"batch_size": batch_size, "shapes": [list(c.shape) for c in bgr], "lang": lang,
+                               "crc32": [zlib.crc32(np.ascontiguousarray(c).tobytes()) for c in bgr]})
+            return [np.asarray(b, dtype=np.float32).reshape(-1, 4, 2) for b in call["boxes"]]
+        return det_raw_fn
+
+    pa = analyze.PageAnalyzer(ReplayLayout(fx["layout_dets"], log["layout"]), {lg: ReplayPipe(log["rec"][lg]) for lg in log["rec"]},
+                              formula_model=ReplayFormula(log["formula"]), layout_batch_size=fx["layout_batch_num"],
+                              formula_level=fx["formula_level"], formula_batch_size=fx["formula_batch_num"],
+                              det_batch_num=fx["ocr_config"]["Det.rec_batch_num"], det_raw_fn={lg: det_for(lg) for lg in log["rec"]})
+    out = pa(pages, page_langs=langs)
+    assert log["layout"] == tr["layout_calls"] and log["formula"] == tr["formula_calls"]
+    assert [{k: c[k] for k in ("batch_size", "shapes", "lang", "crc32")} for c in tr["det_calls"]] == log["det"]
+    assert next(det_calls, None) is None
+    assert [c["lang"] for c in tr["rec_calls"]] == list(log["rec"])                      # one call per language, first appearance first
+    for c in tr["rec_calls"]:
+        assert log["rec"][c["lang"]] == [{"shapes": c["shapes"]}]
+    for p, (mine, theirs) in enumerate(zip(out, fx["output"])):
+        assert len(mine) == len(theirs), (p, len(mine), len(theirs))
+        for a, b in zip(mine, theirs):
+            assert a == b and list(a) == list(b), (p, a, b)
+
+
+def test_a_language_without_a_pipeline_fails_loudly():
+    ocr = analyze.RegionOcr({"ch": object()})
+    with pytest.raises(KeyError):
+        ocr._pipe_for("en")
