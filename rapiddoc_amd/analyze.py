@@ -161,8 +161,8 @@ class RegionOcr:
         pipe = pipe if pipe is not None else self._pipe_for(self.lang)
         b, H, W, _ = canvases.shape
         dh, dw = ocr_host.det_resize_shape(H, W, 960, "max")
-        # DetPreProcess: BGR, (x/255 - 0.5)/0.5 (rapid_ocr.py:474-536), the whole group in one launch
-        x = preproc_resize_norm_batch(canvases, (dh, dw), mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), interp=1, swap_rb=True)
+        # DetPreProcess: BGR, (x/255 - Det.mean)/Det.std (rapid_ocr.py:61-62,474-536), the whole group in one launch
+        x = preproc_resize_norm_batch(canvases, (dh, dw), mean=ocr_host.DET_MEAN, std=ocr_host.DET_STD, interp=1, swap_rb=True)
         maps = pipe.det.det_forward(x)
         if pipe.det.check_range_and_fallback():           # split-fp16 range guard (the pipeline's engines defer it)
             maps = pipe.det.det_forward(x)

@@ -39,6 +39,14 @@ def det_resize_shape(h: int, w: int, limit_side_len: int = 960, limit_type: str 
     return rh, rw
 
 
+# Normalisation of the detector's input.  rapidocr's own default is mean = std = 0.5; RapidDoc overrides it with the ImageNet constants
+# the PP-OCR detectors were trained with (`"Det.mean"` / `"Det.std"` of RapidOcrModel's default_params, rapid_doc/model/ocr/rapid_ocr.py:
+# 61-62, read by the patched TextDetector.__init__, ocr_patch.py:139-142, and handed to DetPreProcess).  They are applied to the channels
+# in the order the image has at that point - BGR - exactly as listed (B gets 0.485), like the reference does.
+DET_MEAN = (0.485, 0.456, 0.406)
+DET_STD = (0.229, 0.224, 0.225)
+
+
 def det_buckets(region_hw: Sequence[Tuple[int, int]], langs: Sequence[str], det_batch_num: int = 1, stride: int = 64):
     """Grouping of the text-region crops for batched detection (`_run_ocr_det_batch`,
     rapid_doc/backend/pipeline/analyze_utils.py:150-189): first by language in order of first appearance, then by the

@@ -201,12 +201,12 @@ class PagePipeline:
 
     def det_preprocess(self, pages: torch.Tensor) -> Tuple[torch.Tensor, Tuple[int, int]]:
         """64-px bucket of the page region with its 50-px white margin, then DetPreProcess (analyze_utils.py:129-188): BGR,
-        (x/255 - 0.5)/0.5, one launch for the batch."""
+        (x/255 - mean)/std with RapidDoc's Det.mean / Det.std (ocr_host.DET_MEAN), one launch for the batch."""
         P, H, W, _ = pages.shape
         bh, bw = -(-(H + 100) // 64) * 64, -(-(W + 100) // 64) * 64
         dh, dw = ocr_host.det_resize_shape(bh, bw, DET_LIMIT, "max")
         out = self._buf("det_x", P * 3 * dh * dw).view(P, 3, dh, dw)
-        x = preproc_resize_norm_batch(pages, (dh, dw), mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), interp=1, swap_rb=True, out=out)
+        x = preproc_resize_norm_batch(pages, (dh, dw), mean=ocr_host.DET_MEAN, std=ocr_host.DET_STD, interp=1, swap_rb=True, out=out)
         return x, (dh, dw)
 
     def det_forward(self, pages: torch.Tensor) -> Tuple[torch.Tensor, Tuple[int, int]]:

@@ -28,15 +28,22 @@ def test_cubic_preprocess_is_pixel_exact(hw, out_hw):
     assert np.abs(got - CV.layout_preprocess(img, out_hw[0])[0]).max() < 1e-6 if out_hw[0] == out_hw[1] else True
 
 
+@pytest.mark.parametrize("norm", ["rapidocr-default", "rapiddoc"])
 @pytest.mark.parametrize("hw,out_hw", [((1784, 1291), (960, 704)), ((128, 448), (128, 448)), ((70, 333), (64, 320))])
-def test_linear_preprocess_is_pixel_exact(hw, out_hw):
-    """rapidocr DetPreProcess resize (cv2 INTER_LINEAR) -> BGR, (x / 255 - 0.5) / 0.5."""
+def test_linear_preprocess_is_pixel_exact(hw, out_hw, norm):
+    """rapidocr DetPreProcess resize (cv2 INTER_LINEAR) -> BGR, (x / 255 - mean) / std: with rapidocr's own default (0.5 / 0.5) and
+    with the constants RapidDoc configures it with (Det.mean / Det.std, rapid_ocr.py:61-62 - what the product path uses)."""
+    from rapiddoc_amd import ocr_host
     from rapiddoc_amd.engine import preproc_resize_norm
+    mean, std = ((0.5, 0.5, 0.5), (0.5, 0.5, 0.5)) if norm == "rapidocr-default" else (ocr_host.DET_MEAN, ocr_host.DET_STD)
     img = np.random.default_rng(hw[1]).integers(0, 256, (*hw, 3), dtype=np.uint8)
-    got = preproc_resize_norm(torch.from_numpy(img).cuda(), out_hw, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), interp=1,
-                              swap_rb=True).cpu().numpy()
+    got = preproc_resize_norm(torch.from_numpy(img).cuda(), out_hw, mean=mean, std=std, interp=1, swap_rb=True).cpu().numpy()
     ref = CV.resize_linear_u8(img, out_hw)[:, :, ::-1].transpose(2, 0, 1)
-    assert np.array_equal(_to_u8((got * 0.5 + 0.5)), ref.astype(np.int64))
+    m, s_ = np.float32(mean).reshape(3, 1, 1), np.float32(std).reshape(3, 1, 1)
+    assert np.array_equal(_to_u8(got * s_ + m), ref.astype(np.int64))
+    # the reference normalises in float64 and rounds to float32 at the end (DetPreProcess.normalize)
+    want = ((ref.astype("float32") * (1 / 255.0) - np.array(mean).reshape(3, 1, 1)) / np.array(std).reshape(3, 1, 1)).astype(np.float32)
+    assert np.abs(got - want).max() < 2e-6
 
 
 def test_line_crops_match_get_rotate_crop_image_and_resize_norm_img():

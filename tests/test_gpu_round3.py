@@ -104,7 +104,7 @@ def test_bench_plan_det_b32_matches_oracle(bench_pipe):
     st = O.as_torch_state(states["ppocrv6_det"])
     for i in (0, 13, 31):
         # the batched pre-process launch == the per-image one (bit for bit; that one is pinned to oracle/cv2_ops.py)
-        one = preproc_resize_norm(pages[i], (dh, dw), mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), interp=1, swap_rb=True)
+        one = preproc_resize_norm(pages[i], (dh, dw), mean=ocr_host.DET_MEAN, std=ocr_host.DET_STD, interp=1, swap_rb=True)
         assert torch.equal(one, x[i])
         with torch.no_grad():
             ref = O.det_forward(st, x[i:i + 1].cpu()).numpy()
