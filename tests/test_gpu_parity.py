@@ -319,8 +319,23 @@ def test_split_gemm_tails_match_fp64(M, K, N):
     assert float((y[M:] - 777.0).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("C_,M", [(48, 1000), (96, 4097), (192, 333), (192, 12800 + 5), (192, 70001), (96, 40000 + 3)])
-@pytest.mark.parametrize("variant", [0, 100, 200, 201, 202, 204, 208, 300, 400, 401, 404, 408])
+_MIXER_SHAPES = [(48, 1000), (96, 4097), (192, 333), (192, 12800 + 5), (192, 70001), (96, 40000 + 3)]
+
+
+def _mixer_variant_covers(variant, C_):
+    """Which (variant, C) pairs rd_debug_time_mixer instantiates: 0 = fp32 debug entry (C = 192), 100 = round-1 split-fp16 (any C),
+    200.. = weight-streaming (C = 96 / 192), 300 = resident weights (C = 96), 400.. = prefetching form (C = 192)."""
+    if variant == 0 or variant >= 400:
+        return C_ == 192
+    if variant >= 300:
+        return C_ == 96
+    if variant >= 200:
+        return C_ in (96, 192)
+    return True
+
+
+@pytest.mark.parametrize("C_,M,variant", [(c, m, v) for v in (0, 100, 200, 201, 202, 204, 208, 300, 400, 401, 404, 408)
+                                          for c, m in _MIXER_SHAPES if _mixer_variant_covers(v, c)])
 def test_fused_mixer_kernels_match_fp64(C_, M, variant):
     """Fused channel mixer x + W2 gelu(W1 x + b1) + b2 (rec_lcnetv4.py:226-236): fp32-MFMA kernel (variant 0, C = 192
     only in the debug entry), round-1 split-fp16 kernel (variant 100) and the weight-streaming kernel (200; +1 lock step, +4 per-wavefront
@@ -329,14 +344,6 @@ def test_fused_mixer_kernels_match_fp64(C_, M, variant):
     resident-weights kernel of the narrow blocks (300) on ragged pixel counts incl. several persistent rounds, against fp64."""
     import ctypes as C
     from rapiddoc_amd import _lib
-    if variant == 0 and C_ != 192:
-        pytest.skip("the fp32 debug entry is instantiated for C = 192")
-    if variant >= 300 and C_ != 96:
-        pytest.skip("the resident-weights kernel (300) covers C = 96")
-    if variant >= 200 and C_ == 48:
-        pytest.skip("the weight-streaming kernel covers C = 96 / 192")
-    if variant >= 400 and C_ != 192:
-        pytest.skip("the prefetching form covers C = 192")
     lib = _lib.load()
     lib.rd_debug_time_mixer.restype = C.c_float
     lib.rd_debug_time_mixer.argtypes = [C.c_int] * 4 + [C.c_void_p] * 6

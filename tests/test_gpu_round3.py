@@ -95,6 +95,7 @@ def bench_pipe(golden_dir):
 
 
 def test_bench_plan_det_b32_matches_oracle(bench_pipe):
+    from rapiddoc_amd import ocr_host
     from rapiddoc_amd.engine import preproc_resize_norm
     pipe, states, pages, _np, _boxes = bench_pipe
     x, (dh, dw) = pipe.det_preprocess(pages)

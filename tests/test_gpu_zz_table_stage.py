@@ -1,5 +1,4 @@
-"""GPU: the table stage (analyze.TableOcr) on the real det / rec engines.  In a file of its own that sorts after the other GPU tests:
-it was written after the round's GPU budget was spent, so its first run is the driver's."""
+"""GPU: the table stage (analyze.TableOcr) on the real det / rec engines.  In a file of its own that sorts after the other GPU tests."""
 import numpy as np
 import pytest
 import torch
@@ -7,8 +6,6 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.xfail(strict=False, reason="written after the round's GPU budget was spent: first run is the driver's; XPASS = the table stage "
-                                        "works on the real engines (its host logic is pinned on CPU by tests/test_analyze_trace.py)")
 def test_table_stage_on_the_gpu_engines(golden_dir):
     """analyze.TableOcr through the real det / rec engines: a `predict`-shaped table model receives the table crop, one OCR line per
     synthetic text line inside the table (boxes in crop coordinates, strings, float scores) and the formula box inside it."""
@@ -70,8 +67,6 @@ def test_table_stage_on_the_gpu_engines(golden_dir):
     assert table["formula_boxes"] == [[150, 300, 210, 320]]
 
 
-@pytest.mark.xfail(strict=False, reason="written after the round's GPU budget was spent: first run is the driver's; XPASS = the letterbox "
-                                        "pre-process of the DocLayout-YOLO family is bit-equal to the restated cv2 arithmetic on the GPU")
 def test_doclayout_yolo_letterbox_on_the_gpu():
     """LayoutModel.preprocess_letterbox (linear resize kernel + 114 padding + channel flip + float64 / 255) against
     oracle/cv2_ops.resize_linear_u8 and numpy, bit for bit; then a whole batch_predict with the stand-in session."""
