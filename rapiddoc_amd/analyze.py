@@ -171,7 +171,7 @@ class RegionOcr:
             maps = maps_override
         # DB post-process with the maps staying in HBM (ocr_host.db_postprocess_device: everything on the device, one copy back)
         res = ocr_host.db_postprocess_device(maps.contiguous(), [(H, W)] * b, thresh=0.3, box_thresh=self.box_thresh,
-                                             unclip_ratio=self.unclip_ratio)
+                                             unclip_ratio=self.unclip_ratio, cache=pipe.db_ws)
         return [boxes.astype(np.float32) for boxes, _scores in res]
 
     @staticmethod

@@ -1115,8 +1115,14 @@ void Builder::ctc_head(const std::string& prefix, const TView& x, const TView& i
 }
 
 Plan::~Plan() {
+    // a plan is dropped only by the LRU of Engine::plan_for (rare): wait for the stream an exec was last launched on before
+    // freeing it - its kernel arguments live in the exec
     for (auto& g : graphs)
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.exec) {
+            (void)hipStreamSynchronize(g.stream);
+            (void)hipGraphExecDestroy(g.exec);
+        }
+    (void)hipGetLastError();
 }
 
 // =================================================================================================
@@ -1139,8 +1145,36 @@ Engine::Engine(int device, const std::string& kind) : device_(device), kind_(kin
     RD_CHECK(device >= 0 && device < count, "device id out of range");
 }
 
+void Engine::retire_graph(hipGraphExec_t exec, hipStream_t s) {
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, s) == hipSuccess) {
+        retired_graphs_.push_back({exec, ev});
+        return;
+    }
+    if (ev) (void)hipEventDestroy(ev);
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(s);            // no event: wait, then free
+    (void)hipGraphExecDestroy(exec);
+}
+
+void Engine::sweep_retired_graphs(bool wait) {
+    size_t keep = 0;
+    for (auto& r : retired_graphs_) {
+        if (wait) (void)hipEventSynchronize(r.done);
+        if (wait || hipEventQuery(r.done) == hipSuccess) {
+            (void)hipGraphExecDestroy(r.exec);
+            (void)hipEventDestroy(r.done);
+        } else {
+            retired_graphs_[keep++] = r;
+        }
+    }
+    retired_graphs_.resize(keep);
+    (void)hipGetLastError();                  // hipErrorNotReady of the queries
+}
+
 Engine::~Engine() {
     (void)hipSetDevice(device_);
+    sweep_retired_graphs(true);
     for (auto ev : events_) (void)hipEventDestroy(ev);
     if (arena_) (void)hipFree(arena_);
     if (range_flag_) (void)hipFree(range_flag_);
@@ -1293,6 +1327,7 @@ void Engine::run(int B, int H, int W, int flags, const std::vector<void*>& ext, 
                 if (g.arena == ctx.arena && g.stream == s && g.ext == ext) { slot = &g; break; }
             if (slot && slot->exec) {
                 slot->last_use = ++plan_clock_;
+                plan.graph_evictions = 0;     // replays do happen for this plan
                 RD_HIP(hipGraphLaunch(slot->exec, s));
                 return;
             }
@@ -1315,12 +1350,26 @@ void Engine::run(int B, int H, int W, int flags, const std::vector<void*>& ext, 
                 (void)hipGetLastError();
                 plan.graph_broken = true;     // this plan does not capture: direct launches from now on
             } else {
+                if (!retired_graphs_.empty()) sweep_retired_graphs(false);
                 if (plan.graphs.size() >= kMaxGraphSlots) {
                     auto victim = plan.graphs.begin();
                     for (auto j = plan.graphs.begin(); j != plan.graphs.end(); ++j)
                         if (j->last_use < victim->last_use) victim = j;
-                    if (victim->exec) (void)hipGraphExecDestroy(victim->exec);
+                    if (victim->exec) retire_graph(victim->exec, victim->stream);   // possibly still in flight: freed after its event
                     plan.graphs.erase(victim);
+                    if (++plan.graph_evictions > kMaxGraphEvictions) {
+                        // the callers' pointers do not repeat for this plan (more live pointer sets than slots): every slot is
+                        // evicted before it is seen again, so capturing only costs - launch directly from now on
+                        for (auto& g : plan.graphs)
+                            if (g.exec) retire_graph(g.exec, g.stream);
+                        plan.graphs.clear();
+                        plan.graph_broken = true;
+                    }
+                }
+                if (plan.graph_broken) {
+                    for (const OpRecord& op : plan.ops) op.run(plan, ctx);
+                    RD_HIP(hipGetLastError());
+                    return;
                 }
                 GraphSlot g;
                 g.ext = ext; g.arena = ctx.arena; g.stream = s; g.last_use = ++plan_clock_;

@@ -118,6 +118,7 @@ struct Plan {
     mutable uint64_t last_use = 0;   // Engine::plan_for's LRU clock
     mutable std::vector<GraphSlot> graphs;   // Engine::run: hipGraph replays of this plan (at most kMaxGraphSlots)
     mutable bool graph_broken = false;       // a capture of this plan failed once: launch directly from then on
+    mutable unsigned graph_evictions = 0;    // slots dropped for newer pointer sets: past kMaxGraphEvictions the plan stops capturing
     std::vector<TView> outputs;  // model specific
     float* vptr(const TView& v, const RunCtx& c) const {
         const Buf& b = bufs[v.buf];
@@ -269,7 +270,14 @@ class Engine {
     std::map<std::tuple<int, int, int, int>, std::unique_ptr<Plan>> plans_;
     uint64_t plan_clock_ = 0;
     static constexpr size_t kMaxPlans = 512;   // least recently used plans are dropped beyond this
-    static constexpr size_t kMaxGraphSlots = 4;
+    static constexpr size_t kMaxGraphSlots = 8;
+    static constexpr unsigned kMaxGraphEvictions = 32;   // a plan whose external pointers keep changing never replays: stop capturing it
+    // Captured execs that lost their slot.  An exec may have been launched microseconds ago on an asynchronous stream, so it is
+    // parked with an event recorded on that stream and destroyed only once the event has completed (sweep_retired_graphs).
+    struct RetiredGraph { hipGraphExec_t exec; hipEvent_t done; };
+    std::vector<RetiredGraph> retired_graphs_;
+    void retire_graph(hipGraphExec_t exec, hipStream_t s);
+    void sweep_retired_graphs(bool wait);
     bool graphs_ = true;                       // RD_GRAPHS=0 switches the hipGraph replays off
     uint8_t* arena_ = nullptr;
     size_t arena_bytes_ = 0;

@@ -276,18 +276,18 @@ def db_postprocess(prob: np.ndarray, src_hw: Sequence[Tuple[int, int]], thresh: 
     return res
 
 
-_DB_WS: dict = {}      # (device, B, H, max_runs, max_candidates) -> cached device buffers of the device post-process
-
-
 def db_postprocess_device(prob_dev, src_hw: Sequence[Tuple[int, int]], thresh: float = 0.3, box_thresh: float = 0.5,
                           unclip_ratio: float = 1.6, use_dilation: bool = True, max_candidates: int = 1000, max_out: int = 2048,
-                          max_runs: int = 65536, stats: dict = None) -> List[Tuple[np.ndarray, List[float]]]:
+                          max_runs: int = 65536, stats: dict = None, cache: dict = None) -> List[Tuple[np.ndarray, List[float]]]:
     """`db_postprocess` with NOTHING on the host (`rd_db_boxes_device`): `prob_dev` is the CUDA tensor [B,1,H,W] /
     [B,H,W] the det forward wrote; bitmap runs, region labelling, min-area rectangles, scores, unclip and the final filter run
     as six kernels on the current stream, and ONE device-to-host copy brings the finished boxes (a few KB).  Same boxes in the
     same order as the host path (tests/test_gpu_image_ops.py).  Falls back to the host path if a page has more than `max_runs`
-    bitmap runs (noise maps)."""
-    import ctypes as C
+    bitmap runs (noise maps).
+
+    `cache` is the CALLER's dict of device workspaces / result buffers keyed by shape: one per PagePipeline / RegionOcr, i.e.
+    one per host thread and HIP stream (PagePipelinePool runs one pipeline per thread; a process-wide cache would hand two
+    streams the same union-find arrays).  None = allocate for this call only."""
     import time
 
     import torch
@@ -301,12 +301,12 @@ def db_postprocess_device(prob_dev, src_hw: Sequence[Tuple[int, int]], thresh: f
     st = torch.cuda.current_stream().cuda_stream
     t0 = time.perf_counter()
     mo = int(min(max_out, max_candidates))
-    key = (dev, B, H, max_runs, max_candidates, mo)
-    bufs = _DB_WS.get(key)
+    key = (dev, B, H, W, max_runs, max_candidates, mo)
+    bufs = cache.get(key) if cache is not None else None
     if bufs is None:
         nbytes = lib.rd_db_boxes_workspace(B, H, W, max_runs, max_candidates)
-        if len(_DB_WS) > 8:
-            _DB_WS.clear()
+        if cache is not None and len(cache) > 8:
+            cache.clear()
         # results: int32 [B + 1] counts (+ overflow flag), padded to 64 bytes, then [B][mo] boxes of 9 floats - one buffer,
         # one copy
         head = (4 * (B + 1) + 63) // 64 * 64
@@ -314,7 +314,8 @@ def db_postprocess_device(prob_dev, src_hw: Sequence[Tuple[int, int]], thresh: f
                 "res": torch.empty(head + B * mo * 36, dtype=torch.uint8, device=p.device),
                 "res_h": torch.empty(head + B * mo * 36, dtype=torch.uint8, pin_memory=True),
                 "hw": torch.empty((B, 2), dtype=torch.int32, device=p.device), "hw_key": None}
-        _DB_WS[key] = bufs
+        if cache is not None:
+            cache[key] = bufs
     hw_np = np.ascontiguousarray(np.asarray(src_hw, dtype=np.int32).reshape(B, 2))
     if bufs["hw_key"] != hw_np.tobytes():
         bufs["hw"].copy_(torch.from_numpy(hw_np), non_blocking=False)

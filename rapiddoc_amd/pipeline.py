@@ -89,9 +89,13 @@ def quads_to_crop_matrices(quads: np.ndarray) -> Tuple[np.ndarray, np.ndarray, n
     A[:, 1::2, 6], A[:, 1::2, 7] = -v * x, -v * y
     b[:, 0::2], b[:, 1::2] = u, v
     # a singular system (three collinear corners, repeated points) must not abort the whole page batch
+    # scale-aware test: a homography of the crop rectangle exists iff no three corners of the quad are collinear - every corner
+    # triangle must have an area that is not vanishing next to the crop's (an absolute bound on det(A), whose entries reach
+    # coordinate^2, lets near-collinear quads through)
     with np.errstate(all="ignore"):
-        det = np.linalg.det(A)
-    ok &= np.isfinite(det) & (np.abs(det) > 1e-9)
+        for i, j, k in ((0, 1, 2), (1, 2, 3), (2, 3, 0), (3, 0, 1)):
+            cross = (q[:, j, 0] - q[:, i, 0]) * (q[:, k, 1] - q[:, i, 1]) - (q[:, j, 1] - q[:, i, 1]) * (q[:, k, 0] - q[:, i, 0])
+            ok &= np.isfinite(cross) & (np.abs(cross) > 1e-6 * cw * ch)
     A[~ok] = np.eye(8)
     h = np.linalg.solve(A, b[..., None])[..., 0]
     return np.concatenate([h, np.ones((n, 1))], axis=1), cw, ch, ok
@@ -171,6 +175,7 @@ class PagePipeline:
         self._ctc_table = torch.from_numpy(tab).to(self.tdev)
         self.device_ctc = True
         self.device_db = True            # DB post-process with the maps staying in HBM (ocr_host.db_postprocess_device)
+        self.db_ws: dict = {}            # its device workspaces / pinned result buffers: per pipeline = per host thread and stream
         # recogniser in two stages: the batches run only the backbone (each into its slice of one token buffer) on their
         # streams, then the LightSVTR neck + CTC head run ONCE over all lines (rd_rec_tail_forward); RD_REC_TWO_STAGE=0: whole
         # network batch by batch
@@ -504,7 +509,7 @@ class PagePipeline:
         """`boxes_from_maps` with the maps staying in HBM (ocr_host.db_postprocess_device)."""
         P = maps_dev.shape[0]
         res = ocr_host.db_postprocess_device(maps_dev, [page_hw] * P, thresh=0.3, box_thresh=box_thresh, unclip_ratio=unclip_ratio,
-                                             stats=self.stats)
+                                             stats=self.stats, cache=self.db_ws)
         out = []
         for boxes, _scores in res:
             if len(boxes) == 0:
@@ -551,7 +556,7 @@ class PagePipeline:
         P, H, W, _ = pages.shape
         results = [PageResult() for _ in range(P)]
         prob_maps, det_hw = self.det_forward(pages)
-        self.last_det = (prob_maps, det_hw)
+        self.last_det = (prob_maps, det_hw)         # a VIEW of the engine's output buffer: valid until the next det forward of this shape
         src = None
         if quads_per_page is None:
             src = det_maps_override if det_maps_override is not None else prob_maps
@@ -561,9 +566,9 @@ class PagePipeline:
             self.layout_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.layout_stream):
                 feats = self.layout_forward(pages)
-            if self.keep_feats:
-                for i in range(P):
-                    results[i].layout_feats = [f[i] for f in feats]
+                if self.keep_feats:                   # copies: the engine re-uses its output tensors on the next call of this shape
+                    for i in range(P):
+                        results[i].layout_feats = [f[i].clone() for f in feats]
         if quads_per_page is None:
             quads_per_page = self.boxes_from_maps_device(src.contiguous(), (H, W)) if self.device_db else self._boxes_via_host_maps(src, (H, W))
         texts = self.rec_forward_lines(pages, quads_per_page)

@@ -228,3 +228,18 @@ def test_detector_and_recogniser_settings_are_the_ones_rapiddoc_configures(golde
     assert (t.det.box_thresh, t.det.unclip_ratio) == (table["Det.box_thresh"], table["Det.unclip_ratio"]) == (0.5, 1.6)
     assert g["page"]["enable_merge_det_boxes"] is True and g["table"]["enable_merge_det_boxes"] is False
     assert page["Rec.rec_keys_path"] == "ppocrv6_small_dict.txt" and page["Det.model_path"] == "ch_PP-OCRv6_det_small.safetensors"
+
+
+def test_degenerate_quads_are_skipped_not_warped():
+    """quads_to_crop_matrices: a quad with three (nearly) collinear corners has no usable homography - `ok` is False for it at
+    any coordinate scale (the reference's cv2.warpPerspective raises there), and well-formed neighbours are untouched."""
+    from rapiddoc_amd.pipeline import quads_to_crop_matrices
+    good = np.array([[100, 200], [900, 200], [900, 232], [100, 232]], np.float32)
+    collinear = np.array([[100, 200], [500, 200], [900, 200], [100, 232]], np.float32)
+    nearly = np.array([[100, 200], [500, 200.0001], [900, 200], [100, 232]], np.float32)
+    repeated = np.array([[100, 200], [100, 200], [900, 232], [100, 232]], np.float32)
+    skewed = np.array([[100, 200], [900, 210], [905, 242], [98, 236]], np.float32)
+    mats, cw, ch, ok = quads_to_crop_matrices(np.stack([good, collinear, nearly, repeated, skewed, good * 0.1]))
+    assert ok.tolist() == [True, False, False, False, True, True]
+    assert np.allclose(mats[0], [1, 0, 100, 0, 1, 200, 0, 0, 1]) and (cw[0], ch[0]) == (800.0, 32.0)
+    assert np.isfinite(mats).all()
