@@ -39,6 +39,12 @@ def _throughput_rule(args):
     return "chunks of %d aspect-sorted lines, width rounded up to x%d" % (args.rec_batch, args.rec_width_multiple)
 
 
+def _strict_rule(n_lines):
+    return ("the reference's batching result: one global np.argsort of all %d lines, chunks of 6, every line padded to int(48 * max ratio of "
+            "ITS chunk) (rapid_ocr.py:404-449); launches are runs of that sorted list sized by rd_rec_plan_chunks, every line computed at its "
+            "own padded width inside the launch tensor (rd_rec_backbone_forward_lines)" % n_lines)
+
+
 def load_states():
     from rapiddoc_amd import weights as W
     g = ROOT / "tests" / "golden"
@@ -178,10 +184,11 @@ def main():
     ap.add_argument("--inflight", type=int, default=1, help="page batches (steps) in flight per GPU: each runs a whole batch on its own "
                     "pipeline / host thread, so the GPU has the next batch's det + layout while this one decodes")
     ap.add_argument("--workers", type=int, default=1, help="page-batch shards in flight per GPU (host stages of one overlap GPU stages of the other)")
-    ap.add_argument("--rec-mode", choices=("throughput", "strict"), default="throughput",
-                    help="rec batching of the TIMED steps: throughput = chunks of --rec-batch lines, width rounded up to --rec-width-multiple; "
-                         "strict = the reference's own batching (one global argsort, chunks of 6, width int(48 * max ratio), "
-                         "rapid_ocr.py:404-449).  The other mode is measured in a short post-pass and reported next to it")
+    ap.add_argument("--rec-mode", choices=("throughput", "strict"), default="strict",
+                    help="rec batching of the TIMED steps: strict (default, the product's default) = the reference's own batching result "
+                         "(one global argsort, chunks of 6, every line at the padded width int(48 * max ratio) of ITS chunk, "
+                         "rapid_ocr.py:404-449) in GPU-sized launches (rd_rec_backbone_forward_lines); throughput = every line at its "
+                         "launch's width.  The other mode is measured in a short post-pass and reported next to it")
     ap.add_argument("--vary-pages", type=int, default=1,
                     help="K > 1: K different page sets, step i runs set i mod K (a real document stream never repeats a batch: every "
                          "step then meets new line widths / token counts, i.e. the plan caches and the tail's bucketing are exercised; "
@@ -429,9 +436,7 @@ def main():
         key = "strict_rec_batching" if other == "strict" else "throughput_rec_batching"
         extra[key] = {"pages_s": round(P / sec, 3), "ms_per_step": round(sec * 1e3, 3), "steps": 3, "warmup": 2,
                       "rec_launch_batches": int(pool2.stats.get("rec_batches", 0)),
-                      "rule": "one global np.argsort of all %d lines, chunks of 6, padded width int(48 * max ratio of the chunk) "
-                              "(rapid_ocr.py:404-449); chunks of equal width share a launch" % n_lines if other == "strict"
-                              else _throughput_rule(args)}
+                      "rule": _strict_rule(n_lines) if other == "strict" else _throughput_rule(args)}
         del pool2
         if pipe.det.precision == "auto":
             for e in pool.engines:
@@ -459,8 +464,9 @@ def main():
                                     "MFMA kernels', tests/test_gpu_parity.py::test_fused_mixer_kernels_match_fp64 / test_split_gemm_*), "
                                     "fp32 MFMA for the rest; range-guarded with fp32 fallback (DESIGN.md s3)"
                                     if pipe.det.precision == "auto" else pipe.det.precision,
-                       "rec_batching": args.rec_mode if args.rec_mode == "strict" else
+                       "rec_batching": "strict: " + _strict_rule(n_lines) if args.rec_mode == "strict" else
                                        "throughput (%s; the reference's own batching is timed in strict_rec_batching)" % _throughput_rule(args),
+                       "rec_launch_batches": int(pool.stats.get("rec_batches", 0)),
                        "pages_per_gpu": P, "global_pages": n_global, "pages_gathered": len(out), "result_crc32": result_crc,
                        "page_sets_cycled": K_sets,
                        "lines_per_step": n_lines, "host_stage_ms": host_stats,

@@ -77,6 +77,16 @@ int rd_rec_backbone_forward(rd_handle* h, const float* x_nchw_dev, int B, int W,
                             void* stream);
 int rd_rec_tail_forward(rd_handle* h, const float* tokens_dev, int n_tokens, int n_lines, int max_tokens, const int32_t* seg_dev,
                         const int32_t* tokinfo_dev, int32_t* idx_dev, float* prob_dev, void* ws_dev, size_t ws_bytes, void* stream);
+/* The backbone stage over text lines of DIFFERENT reference padded widths in one launch.  The reference pads every line to the
+ * width of its own chunk of `rec_batch_num` = 6 lines (rapid_ocr.py:404-449: imgW = int(48 * max w/h of the chunk)) and the
+ * network's output for a line depends on that width (conv borders, SE pooling extent, LightSVTR attention over the padded columns),
+ * so GPU-sized batches of mixed chunks must still give every line ITS width: x [B,3,48,W] holds line b in columns [0, w_b) (zeros
+ * beyond), line_tab_dev = int32 [B][4] = (w_b, (w_b - 1) / 2 + 1, ((w_b - 1) / 2) / 2 + 1, first token of the line in tokens_dev);
+ * line b writes rd_rec_seq_len(w_b) tokens there.  Results per line == rd_rec_backbone_forward on [1,3,48,w_b].
+ * rd_query_workspace(h, B, 0, W, RD_REC_STAGE_BACKBONE | RD_REC_LINE_WIDTHS) sizes the workspace. */
+#define RD_REC_LINE_WIDTHS 32
+int rd_rec_backbone_forward_lines(rd_handle* h, const float* x_nchw_dev, int B, int W, const int32_t* line_tab_dev, float* tokens_dev,
+                                  void* ws_dev, size_t ws_bytes, void* stream);
 /* number of CTC time steps the rec network emits for input width W (stride-2 stem x2, then avg-pool (3,2)) */
 int rd_rec_seq_len(int W);
 
@@ -163,6 +173,13 @@ int rd_line_resize_norm_batch(int device_id, const rd_line_crop_desc* descs_dev,
  * entry, entry 0 = blank.  row_bytes >= 16 + T * max_len. */
 int rd_ctc_collapse(int device_id, const int32_t* idx_bt_dev, const float* prob_bt_dev, int B, int T, const uint8_t* char_table_dev,
                     int max_len, int n_classes, uint8_t* out_dev, int row_bytes, void* stream);
+/* The same over RAGGED lines as rd_rec_tail_forward leaves them: line b = seg_dev[2 b + 1] tokens (<= max_tokens <= 65535) starting at
+ * token seg_dev[2 b] of idx_dev / prob_dev.  kept_cols_dev (may be NULL): uint16 [n_lines][max_tokens], the time step of every kept
+ * character in order (n_kept of them, header field 2) - the `selection` rapidocr's CTCLabelDecode passes to get_word_info when
+ * return_word_box is set (RapidDoc's patched version: rapid_doc/model/ocr/ocr_patch.py:333-389; table OCR default, analyze_utils.py:308). */
+int rd_ctc_collapse_lines(int device_id, const int32_t* idx_dev, const float* prob_dev, int n_lines, const int32_t* seg_dev, int max_tokens,
+                          const uint8_t* char_table_dev, int max_len, int n_classes, uint8_t* out_dev, int row_bytes, uint16_t* kept_cols_dev,
+                          void* stream);
 
 /* DB post-process (HOST pointers, runs on the host like the reference's): probability maps [B][H][W] -> text boxes.
  * Replaces rapidocr DBPostProcess.__call__ as patched in rapid_doc/model/ocr/ocr_patch.py:223-241 (box_type "quad",

@@ -120,6 +120,15 @@ int rd_rec_backbone_forward(rd_handle* h, const float* x, int B, int W, float* t
         h->eng->run(B, 48, W, rd::REC_STAGE_BACKBONE, {(void*)x, (void*)tokens}, ws, ws_bytes, (hipStream_t)stream);
     });
 }
+int rd_rec_backbone_forward_lines(rd_handle* h, const float* x, int B, int W, const int32_t* line_tab, float* tokens, void* ws, size_t ws_bytes,
+                                  void* stream) {
+    return guarded(h, [&] {
+        RD_CHECK(h->eng && h->eng->kind() == "ppocrv6_rec", "handle is not a ppocrv6_rec model");
+        RD_CHECK(x && tokens && line_tab && B > 0, "null input/output");
+        h->eng->run(B, 48, W, rd::REC_STAGE_BACKBONE | rd::REC_LINE_WIDTHS, {(void*)x, (void*)tokens, (void*)line_tab}, ws, ws_bytes,
+                    (hipStream_t)stream);
+    });
+}
 int rd_rec_tail_forward(rd_handle* h, const float* tokens, int n_tokens, int n_lines, int max_tokens, const int32_t* seg,
                         const int32_t* tokinfo, int32_t* idx, float* prob, void* ws, size_t ws_bytes, void* stream) {
     return guarded(h, [&] {
@@ -246,7 +255,16 @@ int rd_ctc_collapse(int device_id, const int32_t* idx, const float* prob, int B,
                     uint8_t* out, int row_bytes, void* stream) {
     if (!idx || !prob || !ctab || !out || B < 0 || T <= 0 || max_len <= 0 || n_classes <= 0) return 1;
     if (hipSetDevice(device_id) != hipSuccess) return 1;
-    if (rd::launch_ctc_collapse(idx, prob, B, T, ctab, max_len, n_classes, out, row_bytes, (hipStream_t)stream) != 0) return 1;
+    if (rd::launch_ctc_collapse(idx, prob, B, T, nullptr, ctab, max_len, n_classes, out, row_bytes, nullptr, (hipStream_t)stream) != 0) return 1;
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int rd_ctc_collapse_lines(int device_id, const int32_t* idx, const float* prob, int n_lines, const int32_t* seg, int max_tokens,
+                          const uint8_t* ctab, int max_len, int n_classes, uint8_t* out, int row_bytes, uint16_t* kept_cols, void* stream) {
+    if (!idx || !prob || !seg || !ctab || !out || n_lines < 0 || max_tokens <= 0 || max_len <= 0 || n_classes <= 0) return 1;
+    if (hipSetDevice(device_id) != hipSuccess) return 1;
+    if (rd::launch_ctc_collapse(idx, prob, n_lines, max_tokens, seg, ctab, max_len, n_classes, out, row_bytes, kept_cols, (hipStream_t)stream) != 0)
+        return 1;
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

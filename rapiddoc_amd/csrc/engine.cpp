@@ -695,11 +695,14 @@ TView Builder::stem_front(const std::string& w1, const std::string& bn1, const s
     if (!fused) {
         // the four separate kernels (fp32 precision mode, unsupported widths, and - in PREPARE mode - the weight folding of both forms)
         TView e = stem3x3s2(w1, bn1, xin, ACT_RELU);
+        mask_cols(e, 1);                 // (line table only: beyond a line's own width e / a / cat are the next layer's zero padding)
         TView a = conv(w2a, "", bn2a, e, g2, ACT_RELU);
+        mask_cols(a, 1);
         TView cat = alloc(e.n, e.h, e.w, 2 * c1);
         TView cat_pool = slice(cat, 0, c1), cat_b = slice(cat, c1, c1);
         maxpool2x2s1(e, cat_pool);
         conv(w2b, "", bn2b, a, g2, ACT_RELU, &cat_b);
+        mask_cols(cat_b, 1);             // (the pool half is zero there already: e >= 0 is)
         release(e);
         release(a);
         if (!planning() && stem_fused_supported(c1) && !pb_->has(fkey + "#img")) {
@@ -741,11 +744,28 @@ TView Builder::stem_front(const std::string& w1, const std::string& bn1, const s
     r.bytes = 4.0 * ((double)xin.n * xin.c * xin.h * xin.w + (double)xin.n * oh * ow * 2 * c1);
     const TView xv = xin, yv = cat;
     unsigned* flag = range_flag_;
-    r.run = [xv, yv, img, bias, c1, flag](const Plan& pl, const RunCtx& c) {
-        launch_stem_fused(c1, pl.vptr(xv, c), xv.n, xv.h, xv.w, xv.c, img, bias, pl.vptr(yv, c), pl.ld(yv), flag, c.stream);
+    const bool has_lt = has_lt_;
+    const TView ltv = lt_;
+    r.run = [xv, yv, img, bias, c1, flag, has_lt, ltv](const Plan& pl, const RunCtx& c) {
+        launch_stem_fused(c1, pl.vptr(xv, c), xv.n, xv.h, xv.w, xv.c, img, bias, pl.vptr(yv, c), pl.ld(yv), flag, c.stream,
+                          has_lt ? reinterpret_cast<const int32_t*>(pl.vptr(ltv, c)) : nullptr);
     };
     emit(std::move(r));
     return cat;
+}
+
+void Builder::mask_cols(const TView& v, int col) {
+    if (!has_lt_ || !planning()) return;
+    OpRecord r;
+    r.name = "mask_cols";
+    r.kind = "mask";
+    r.bytes = 4.0 * v.pixels() * v.c;
+    const TView yv = v, ltv = lt_;
+    r.run = [yv, ltv, col](const Plan& pl, const RunCtx& c) {
+        launch_mask_cols(pl.vptr(yv, c), pl.ld(yv), yv.n, yv.h, yv.w, yv.c, reinterpret_cast<const int32_t*>(pl.vptr(ltv, c)) + col,
+                         kLineTabStride, c.stream);
+    };
+    emit(std::move(r));
 }
 
 TView Builder::dwconv(const std::string& wname, const std::string& bname, const std::string& bn, const TView& x,
@@ -807,13 +827,20 @@ TView Builder::dwconv(const std::string& wname, const std::string& bname, const 
     const bool ragged = tokinfo != nullptr;
     RD_CHECK(!ragged || (kh == 1 && g.sw == 1 && x.n == 1 && x.h == 1 && x.w < (1 << 30)), "ragged depthwise conv: 1 x k over one token row");
     const TView tiv = ragged ? *tokinfo : TView{};
-    r.run = [p, xv, yv, rv, has_res, has_gap, gpv, ragged, tiv](const Plan& pl, const RunCtx& cx) {
+    const bool has_lt = has_lt_ && !ragged;
+    RD_CHECK(!has_lt || (g.sw == 1 && ow == x.w), "line table: depthwise convs keep the width (stride (s, 1), 'same' padding)");
+    const TView ltv = lt_;
+    r.run = [p, xv, yv, rv, has_res, has_gap, gpv, ragged, tiv, has_lt, ltv](const Plan& pl, const RunCtx& cx) {
         DwParams q = p;
         q.x = pl.vptr(xv, cx);
         q.y = pl.vptr(yv, cx);
         q.res = has_res ? pl.vptr(rv, cx) : nullptr;
         q.gap_partial = has_gap ? pl.vptr(gpv, cx) : nullptr;
         q.tokinfo = ragged ? reinterpret_cast<const int32_t*>(pl.vptr(tiv, cx)) : nullptr;
+        if (has_lt) {
+            q.line_w = reinterpret_cast<const int32_t*>(pl.vptr(ltv, cx)) + 2;
+            q.line_w_stride = kLineTabStride;
+        }
         launch_dwconv(q, cx.stream);
     };
     emit(std::move(r));
@@ -845,8 +872,12 @@ TView Builder::avgpool3x2(const TView& x, const TView* out) {
     r.kind = "pool";
     r.bytes = 4.0 * (x.pixels() * x.c + y.pixels() * y.c);
     const TView xv = x, yv = y;
-    r.run = [xv, yv](const Plan& pl, const RunCtx& c) {
-        launch_avgpool3x2(pl.vptr(xv, c), pl.ld(xv), pl.vptr(yv, c), pl.ld(yv), xv.n, xv.h, xv.w, xv.c, c.stream);
+    const bool has_lt = has_lt_;
+    RD_CHECK(!has_lt || oh == 1, "line table: the pooled map is one row of tokens per line");
+    const TView ltv = lt_;
+    r.run = [xv, yv, has_lt, ltv](const Plan& pl, const RunCtx& c) {
+        launch_avgpool3x2(pl.vptr(xv, c), pl.ld(xv), pl.vptr(yv, c), pl.ld(yv), xv.n, xv.h, xv.w, xv.c, c.stream,
+                          has_lt ? reinterpret_cast<const int32_t*>(pl.vptr(ltv, c)) : nullptr);
     };
     emit(std::move(r));
     return y;
@@ -860,6 +891,7 @@ TView Builder::se_gate(const std::string& w1n, const std::string& b1n, const std
     RD_CHECK(c <= 512, "SE width above 512 channels (se_fc_kernel reads a row of W1 with two 16-byte loads per lane): " + w1n);
     const int hw = x.h * x.w;
     const bool fused_gap = pre && pre->chunks > 0;  // the producing depthwise conv already wrote the partial sums
+    RD_CHECK(!has_lt_ || fused_gap, "line table: the SE pooling sums must come from the depthwise kernel (it leaves out the columns beyond a line)");
     const int chunks = fused_gap ? pre->chunks : std::max(1, std::min(64, hw / 256));
     TView partial = fused_gap ? pre->partial : alloc_raw((size_t)x.n * chunks * c);
     TView gate = alloc(x.n, 1, 1, c);
@@ -895,10 +927,17 @@ TView Builder::se_gate(const std::string& w1n, const std::string& b1n, const std
         r.kind = "se_fc";
         r.flops = 4.0 * x.n * c * cr;
         const TView pv = partial, gv = gate;
-        r.run = [p, pv, gv](const Plan& pl, const RunCtx& cx) {
+        const bool has_lt = has_lt_;
+        const TView ltv = lt_;
+        p.H = x.h;
+        r.run = [p, pv, gv, has_lt, ltv](const Plan& pl, const RunCtx& cx) {
             SeFcParams q = p;
             q.partial = pl.vptr(pv, cx);
             q.scale = pl.vptr(gv, cx);
+            if (has_lt) {
+                q.line_w = reinterpret_cast<const int32_t*>(pl.vptr(ltv, cx)) + 2;
+                q.line_w_stride = kLineTabStride;
+            }
             launch_se_fc(q, cx.stream);
         };
         emit(std::move(r));

@@ -155,6 +155,12 @@ class Builder {
     void release(const TView& v);
     TView alloc_raw(size_t nfloats);  // scratch as [1,1,1,n]
 
+    // The recogniser's per-line width table (rd_kernels.h LineTab, an int32 external [B][4]): from here on stem_front, dwconv,
+    // se_gate and avgpool3x2 treat image n as line_tab[n]-wide (REC_LINE_WIDTHS plans only).
+    void set_line_table(const TView& t) { lt_ = t; has_lt_ = true; }
+    // zero the columns >= line_tab[n][col] of v (no-op without a line table): the separate-kernel stem of the fp32 mode
+    void mask_cols(const TView& v, int col);
+
     // --- layers.  `key` = reference state-dict prefix of the layer.
     struct ConvGeom {
         int kh = 1, kw = 1, sh = 1, sw = 1, pt = 0, pl = 0, pb = 0, pr = 0;
@@ -215,6 +221,8 @@ class Builder {
     Plan* plan_;
     struct Block { size_t off, size; bool free; };
     std::vector<Block> blocks_;
+    TView lt_;
+    bool has_lt_ = false;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -290,7 +298,9 @@ void build_ppocrv6_det(Builder& b, int B, int H, int W);
 // REC_STAGE_BACKBONE: image -> pooled tokens only (ext[1] = [B][T][C] out).  REC_STAGE_TAIL: the LightSVTR neck + CTC head over
 // the tokens of MANY batches at once (B = text lines, H = longest line in tokens, W = all tokens; ext: 0 tokens, 1 idx,
 // 2 prob, 4 seg int32 [B][2], 5 tokinfo int32 [W]) - see build_ppocrv6_rec
-enum RecFlags : int { REC_UNFUSED_CTC = 1, REC_WANT_SOFTMAX = 2, REC_WANT_LOGITS = 4, REC_STAGE_BACKBONE = 8, REC_STAGE_TAIL = 16 };
+// REC_LINE_WIDTHS (with REC_STAGE_BACKBONE): ext[2] = LineTab int32 [B][4] (rd_kernels.h) - every line is computed at ITS OWN padded
+// width inside the shared [B,3,48,W] tensor and writes its own number of tokens at its own offset of ext[1]
+enum RecFlags : int { REC_UNFUSED_CTC = 1, REC_WANT_SOFTMAX = 2, REC_WANT_LOGITS = 4, REC_STAGE_BACKBONE = 8, REC_STAGE_TAIL = 16, REC_LINE_WIDTHS = 32 };
 void build_ppocrv6_rec(Builder& b, int B, int H, int W, int flags);
 void build_pphgnetv2_b4(Builder& b, int B, int H, int W);
 // PP-FormulaNet_plus encoder; flags bit 0: the caller's image has 1 channel (replicated to 3 like the reference)

@@ -298,16 +298,22 @@ __device__ float np_pairwise_sum_f32(const float* a, int n) {
     return np_pairwise_sum_f32(a, n2) + np_pairwise_sum_f32(a + n2, n - n2);
 }
 
-__global__ void __launch_bounds__(256) ctc_collapse_kernel(const int32_t* __restrict__ idx, const float* __restrict__ prob, int T,
-                                                           const uint8_t* __restrict__ ctab, int max_len, int n_classes,
-                                                           uint8_t* __restrict__ out, int row_bytes) {
+// seg == nullptr: line b is idx[b * T .. b * T + T).  seg != nullptr (ragged lines, the batched recogniser tail): line b is the
+// seg[2 b + 1] <= T tokens starting at token seg[2 b].  kept_cols (optional, uint16 [lines][T]): the time step of every kept
+// character, in order - what rapidocr's CTCLabelDecode hands to get_word_info as `selection` (word boxes, ocr_patch.py:333-389).
+__global__ void __launch_bounds__(256) ctc_collapse_kernel(const int32_t* __restrict__ idx, const float* __restrict__ prob, int Tmax,
+                                                           const int32_t* __restrict__ seg, const uint8_t* __restrict__ ctab, int max_len,
+                                                           int n_classes, uint8_t* __restrict__ out, int row_bytes,
+                                                           uint16_t* __restrict__ kept_cols) {
     extern __shared__ unsigned char smem[];
     float* kept = reinterpret_cast<float*>(smem);                  // [T] kept probabilities, compacted
-    int* scan = reinterpret_cast<int*>(smem + (size_t)T * 4);      // [2][256] scan scratch
+    int* scan = reinterpret_cast<int*>(smem + (size_t)Tmax * 4);   // [2][256] scan scratch
     __shared__ int carry_k, carry_b;
     const int line = blockIdx.x, tid = threadIdx.x;
-    const int32_t* row = idx + (size_t)line * T;
-    const float* prow = prob + (size_t)line * T;
+    const size_t first = seg ? (size_t)seg[2 * line] : (size_t)line * Tmax;
+    const int T = seg ? min(seg[2 * line + 1], Tmax) : Tmax;
+    const int32_t* row = idx + first;
+    const float* prow = prob + first;
     uint8_t* orow = out + (size_t)line * row_bytes;
     if (tid == 0) carry_k = carry_b = 0;
     __syncthreads();
@@ -335,6 +341,7 @@ __global__ void __launch_bounds__(256) ctc_collapse_kernel(const int32_t* __rest
         const int pos_k = carry_k + sk[tid] - keep, pos_b = carry_b + sb[tid] - len;
         if (keep) {
             kept[pos_k] = prow[t];
+            if (kept_cols) kept_cols[(size_t)line * Tmax + pos_k] = (uint16_t)t;
             const uint8_t* src = ctab + (size_t)id * (max_len + 1) + 1;
             for (int b = 0; b < len; ++b) orow[16 + pos_b + b] = src[b];
         }
@@ -357,13 +364,13 @@ __global__ void __launch_bounds__(256) ctc_collapse_kernel(const int32_t* __rest
 }
 
 namespace rd {
-int launch_ctc_collapse(const int32_t* idx, const float* prob, int B, int T, const uint8_t* ctab, int max_len, int n_classes,
-                        uint8_t* out, int row_bytes, hipStream_t s) {
+int launch_ctc_collapse(const int32_t* idx, const float* prob, int B, int T, const int32_t* seg, const uint8_t* ctab, int max_len, int n_classes,
+                        uint8_t* out, int row_bytes, uint16_t* kept_cols, hipStream_t s) {
     if (B <= 0 || T <= 0) return 0;
-    if (row_bytes < 16 + T * max_len) return 1;
+    if (row_bytes < 16 + T * max_len || T > 65535) return 1;
     const size_t sh = (size_t)T * 4 + 2 * 256 * sizeof(int);
     if (sh > 60000) return 1;
-    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(B), dim3(256), sh, s, idx, prob, T, ctab, max_len, n_classes, out, row_bytes);
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(B), dim3(256), sh, s, idx, prob, T, seg, ctab, max_len, n_classes, out, row_bytes, kept_cols);
     return 0;
 }
 }  // namespace rd

@@ -41,6 +41,7 @@ __global__ void __launch_bounds__(256) dwconv_kernel(DwParams p) {
         const float* xb = p.x + (size_t)b * p.H * p.W * p.xld + c;
         const int ih0 = oh * p.SH - p.PT, iw0 = ow * p.SW - p.PL;
         int w_lo = 0, w_hi = p.W;                 // valid input columns: the row, or this token's text line (ragged rows)
+        if (p.line_w) w_hi = min(p.W, p.line_w[b * p.line_w_stride]);
         if (p.tokinfo) {
             const int ti = p.tokinfo[pix];
             w_lo = ow - (ti & 0xffff);
@@ -80,6 +81,8 @@ __global__ void __launch_bounds__(256) dwconv_tiled_kernel(DwParams p, int c4n, 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const f32x4 bias = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c) : zero4;
     f32x4 gsum = zero4;
+    // the image's own width under a line table (rd_kernels.h LineTab): columns beyond it are padding to the loads and to the SE sums
+    const int wlim = p.line_w ? min(p.W, p.line_w[n * p.line_w_stride]) : p.W;
     const int g_end = min(groups, (chunk + 1) * gpb);
     for (int g = chunk * gpb + pl; g < g_end; g += lanes_p) {
         // column-major over (row, w-group): a block walks DOWN a strip of columns, so the KH-1 input rows shared by
@@ -109,7 +112,7 @@ __global__ void __launch_bounds__(256) dwconv_tiled_kernel(DwParams p, int c4n, 
             }
             if constexpr (!(dbg & 4)) {
 #pragma unroll
-                for (int j = 0; j < NCOL; ++j) row[j] = ((unsigned)(iw0 + j) < (unsigned)p.W) ? row[j] : zero4;
+                for (int j = 0; j < NCOL; ++j) row[j] = ((unsigned)(iw0 + j) < (unsigned)wlim) ? row[j] : zero4;
             }
 #pragma unroll
             for (int kw = 0; kw < KW; ++kw) {
@@ -125,7 +128,7 @@ __global__ void __launch_bounds__(256) dwconv_tiled_kernel(DwParams p, int c4n, 
                 f32x4 v = act4(acc[t], p.act);
                 if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (pix0 + t) * p.rld + c);
                 if (!(dbg & 1)) *reinterpret_cast<f32x4*>(p.y + (pix0 + t) * p.yld + c) = v;
-                gsum += v;
+                if (ow0 + t < wlim) gsum += v;
             }
         }
     }
@@ -161,6 +164,7 @@ __global__ void __launch_bounds__(256) dwconv3x3_col_kernel(DwParams p, int c4n,
 #pragma unroll
     for (int k = 0; k < 9; ++k) wv[k] = *reinterpret_cast<const f32x4*>(p.w + (size_t)k * p.C + c);
     f32x4 gsum = zero4;
+    const int wlim = p.line_w ? min(p.W, p.line_w[n * p.line_w_stride]) : p.W;
     const int g_end = min(groups_w, (chunk + 1) * gpb);
     for (int g = chunk * gpb + pl; g < g_end; g += lanes_p) {
         const int ow0 = g * TW, iw0 = ow0 - 1;
@@ -169,7 +173,7 @@ __global__ void __launch_bounds__(256) dwconv3x3_col_kernel(DwParams p, int c4n,
 #pragma unroll
         for (int j = 0; j < NCOL; ++j) {
             coff[j] = (size_t)min(max(iw0 + j, 0), p.W - 1) * p.xld;      // unconditional loads from clamped columns, masked after
-            cok[j] = (unsigned)(iw0 + j) < (unsigned)p.W;
+            cok[j] = (unsigned)(iw0 + j) < (unsigned)wlim;
         }
         auto load_row = [&](int ih, f32x4* row) {
             const float* xr = xb + (size_t)ih * p.W * p.xld;
@@ -204,7 +208,7 @@ __global__ void __launch_bounds__(256) dwconv3x3_col_kernel(DwParams p, int c4n,
                     f32x4 v = act4(a, p.act);
                     if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (pix0 + t) * p.rld + c);
                     *reinterpret_cast<f32x4*>(p.y + (pix0 + t) * p.yld + c) = v;
-                    gsum += v;
+                    if (ow0 + t < wlim) gsum += v;
                 }
             }
 #pragma unroll
@@ -368,7 +372,7 @@ void launch_maxpool2x2s1(const float* x, int xld, float* y, int yld, int N, int 
 }
 
 __global__ void __launch_bounds__(256) avgpool3x2_kernel(const float* x, int xld, float* y, int yld, int N, int H,
-                                                         int W, int C, int OH, int OW) {
+                                                         int W, int C, int OH, int OW, const int32_t* line_tab) {
     const int c4n = C >> 2;
     const long total = (long)N * OH * OW * c4n;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -385,13 +389,33 @@ __global__ void __launch_bounds__(256) avgpool3x2_kernel(const float* x, int xld
                 acc += *reinterpret_cast<const f32x4*>(
                     x + (((size_t)b * H + oh * 3 + kh) * W + ow * 2 + kw) * xld + c);
         acc *= (1.f / 6.f);
-        *reinterpret_cast<f32x4*>(y + (size_t)pix * yld + c) = acc;
+        if (line_tab) {     // compact token buffer: line b owns rows [tok_off, tok_off + w4 / 2) (OH == 1)
+            const int t_b = line_tab[b * kLineTabStride + 2] >> 1;
+            if (ow < t_b) *reinterpret_cast<f32x4*>(y + (size_t)(line_tab[b * kLineTabStride + 3] + ow) * yld + c) = acc;
+        } else {
+            *reinterpret_cast<f32x4*>(y + (size_t)pix * yld + c) = acc;
+        }
     }
 }
-void launch_avgpool3x2(const float* x, int xld, float* y, int yld, int N, int H, int W, int C, hipStream_t s) {
+void launch_avgpool3x2(const float* x, int xld, float* y, int yld, int N, int H, int W, int C, hipStream_t s, const int32_t* line_tab) {
     const int OH = (H - 3) / 3 + 1, OW = (W - 2) / 2 + 1;
     const long total = (long)N * OH * OW * (C >> 2);
-    hipLaunchKernelGGL(avgpool3x2_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, xld, y, yld, N, H, W, C, OH, OW);
+    hipLaunchKernelGGL(avgpool3x2_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, xld, y, yld, N, H, W, C, OH, OW, line_tab);
+}
+
+__global__ void __launch_bounds__(256) mask_cols_kernel(float* y, int yld, int H, int W, int C, const int32_t* line_w, int stride, long total) {
+    const int c4n = C >> 2;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % c4n) << 2;
+        const long pix = idx / c4n;
+        const int w = pix % W;
+        const int b = pix / ((long)W * H);
+        if (w >= line_w[b * stride]) *reinterpret_cast<f32x4*>(y + (size_t)pix * yld + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+void launch_mask_cols(float* y, int yld, int N, int H, int W, int C, const int32_t* line_w, int stride, hipStream_t s) {
+    const long total = (long)N * H * W * (C >> 2);
+    hipLaunchKernelGGL(mask_cols_kernel, dim3(grid_for(total)), dim3(256), 0, s, y, yld, H, W, C, line_w, stride, total);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -437,6 +461,7 @@ __global__ void __launch_bounds__(256) se_fc_kernel(SeFcParams p) {
     float* part = hid + ((p.Cr + 3) & ~3);
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // 1. pooled mean: thread (slice, channel quad) adds every KS-th partial row, then the KS slices are added in order
+    const float inv_hw = p.line_w ? 1.f / (float)(p.H * p.line_w[n * p.line_w_stride]) : p.inv_hw;   // a line's own extent under a line table
     const int c4n = p.C >> 2;
     const int KS = max(1, min(8, 256 / c4n));
     if (tid < KS * c4n) {
@@ -449,7 +474,7 @@ __global__ void __launch_bounds__(256) se_fc_kernel(SeFcParams p) {
     for (int c = tid; c < p.C; c += 256) {
         float s = 0.f;
         for (int sl = 0; sl < KS; ++sl) s += part[sl * p.C + c];
-        mean[c] = s * p.inv_hw;
+        mean[c] = s * inv_hw;
     }
     __syncthreads();
     // 2. hidden units: a wavefront takes Cr / 4 consecutive units, eight at a time: lanes across the channels (16-byte coalesced

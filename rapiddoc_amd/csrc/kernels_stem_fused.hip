@@ -59,6 +59,7 @@ struct StemFusedParams {
     float* y; int yld;                          // cat NHWC [N][H2][W2][2 C1]: p at channel 0, b at channel C1
     int H2, W2, tiles_x, tiles_y;
     unsigned* range_flag;
+    const int32_t* line_tab;                    // optional per-image widths (rd_kernels.h LineTab): image n is line_tab[4 n + 1] e-columns wide
     int dbg;                                    // developer: RD_STEM_DBG ablation bits (results garbage): 1 no stem1, 2 no stem2a, 4 no pool, 8 no stem2b, 16 no patch traffic
 };
 
@@ -160,8 +161,11 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
         if (!(p.dbg & 16)) store_patch(ty0, tx0);
         __syncthreads();
 
+        // the image's own e / a / cat width: p.W2, or - under a line table - the text line's (columns beyond it are computed but
+        // stored as the zero padding stem2a, the pool, stem2b and stem3 expect there)
+        const int W2n = p.line_tab ? min(p.W2, p.line_tab[n * kLineTabStride + 1]) : p.W2;
         // a tile whose whole e halo lies inside the map needs no per-element bounds tests (most tiles)
-        const bool inner = ty0 + SF_EH <= p.H2 && tx0 + SF_EW <= p.W2;
+        const bool inner = ty0 + SF_EH <= p.H2 && tx0 + SF_EW <= W2n;
 
         // ---------------- stem1: e = ReLU(conv3x3 s2 (patch)) on the matrix cores, K = 3 kernel rows x 16 slots.  The bias rides in
         // the accumulator init; non-finite values are not tested here: they reach stem2b's outputs and the pool, which are
@@ -215,7 +219,7 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
                         int cx = rx + off, cy = ry;
                         if (cx >= SF_EW) { cx -= SF_EW; cy += 1; }
                         float v = fmaxf(fmaf(acc2[nb][r], 1.f / 2048.f, acc1[nb][r]), 0.f);
-                        if (ty0 + cy >= p.H2 || tx0 + cx >= p.W2) v = 0.f;        // beyond the map: the zero padding of stem2a / the pool
+                        if (ty0 + cy >= p.H2 || tx0 + cx >= W2n) v = 0.f;        // beyond the map: the zero padding of stem2a / the pool
                         if (mr0 + off < SF_EH * SF_EW && nn < C1) dst[off * G::SE] = v;
                     }
                 }
@@ -269,7 +273,7 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
                     int cx = rx + off, cy = ry;
                     if (cx >= SF_AW) { cx -= SF_AW; cy += 1; }
                     float v = fmaxf(fmaf(acc2[r], 1.f / 2048.f, acc1[r]), 0.f);
-                    if (ty0 + cy >= p.H2 || tx0 + cx >= p.W2 || !real) v = 0.f;   // padding of stem2b; zero pad channels
+                    if (ty0 + cy >= p.H2 || tx0 + cx >= W2n || !real) v = 0.f;   // padding of stem2b; zero pad channels
                     if (mr0 + off < SF_AH * SF_AW && lane_on) dst[off * G::SA] = v;
                 }
             }
@@ -355,7 +359,8 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
                         const int off = (r & 3) + 8 * (r >> 2);
                         const float v = fmaf(acc2[nb][r], 1.f / 2048.f, acc1[nb][r]);
                         emax = max(emax, __float_as_uint(v) & 0x7fffffffu);
-                        if (gy < p.H2 && tx0 + 4 * lhi + off < p.W2 && nn < C1) yrow[(size_t)off * p.yld + nn] = fmaxf(v, 0.f);
+                        if (gy < p.H2 && tx0 + 4 * lhi + off < p.W2 && nn < C1)
+                            yrow[(size_t)off * p.yld + nn] = tx0 + 4 * lhi + off < W2n ? fmaxf(v, 0.f) : 0.f;   // (zero beyond a line's own width)
                     }
                 }
             }
@@ -412,7 +417,7 @@ static void sf_launch(StemFusedParams& p, hipStream_t s, int n_cu) {
 
 // x NCHW [N][in_ch][H][W] -> cat NHWC [N][H2][W2][2 c1] (row stride yld floats)
 void launch_stem_fused(int c1, const float* x, int N, int H, int W, int in_ch, const uint16_t* wimg, const float* bias, float* y, int yld,
-                       unsigned* range_flag, hipStream_t s) {
+                       unsigned* range_flag, hipStream_t s, const int32_t* line_tab) {
     static const int n_cu = [] {
         int dev = 0, n = 256;
         (void)hipGetDevice(&dev);
@@ -427,6 +432,7 @@ void launch_stem_fused(int c1, const float* x, int N, int H, int W, int in_ch, c
     p.tiles_y = (p.H2 + SF_TH - 1) / SF_TH;
     p.tiles_x = (p.W2 + SF_TW - 1) / SF_TW;
     p.range_flag = range_flag;
+    p.line_tab = line_tab;
     static const int dbg = [] { const char* e = getenv("RD_STEM_DBG"); return e ? atoi(e) : 0; }();
     p.dbg = dbg;
     if (c1 == 24) sf_launch<24>(p, s, n_cu);

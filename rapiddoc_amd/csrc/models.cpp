@@ -205,9 +205,13 @@ void build_ppocrv6_rec(Builder& b, int B, int H, int W, int flags) {
         RD_CHECK(H == 48, "rec input height must be 48");
         RD_CHECK(W >= 16, "rec input width must be >= 16");
         TView x = b.external(0, B, H, W, 3);
+        if (flags & REC_LINE_WIDTHS) {
+            RD_CHECK(backbone_only, "rec: per-line widths belong to the backbone stage");
+            b.set_line_table(b.external(2, B, 1, 1, kLineTabStride));
+        }
         std::vector<TView> f = lcnetv4(b, x, kRecSmall, 48, 96, false);
         if (backbone_only) {
-            RD_CHECK((flags & ~REC_STAGE_BACKBONE) == 0, "rec backbone stage takes no other flag");
+            RD_CHECK((flags & ~(REC_STAGE_BACKBONE | REC_LINE_WIDTHS)) == 0, "rec backbone stage takes no other flag");
             TView out = b.external(1, B, 1, (f[0].w - 2) / 2 + 1, f[0].c);
             b.avgpool3x2(f[0], &out);
             b.release(f[0]);

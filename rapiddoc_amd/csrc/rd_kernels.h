@@ -79,8 +79,18 @@ void launch_stem_conv3x3s2(const StemParams& p, hipStream_t s);
 // one kernel, x NCHW -> cat NHWC [N][H2][W2][2 c1] = [pool | stem2b]; split-fp16 matrix cores; c1 in {24, 32, 48}
 bool stem_fused_supported(int c1);
 void prepare_stem_fused_weights(int c1, const float* w1_stem_layout, const float* w2a_folded, const float* w2b_folded, std::vector<uint16_t>& img);
+// line_tab (optional): the recogniser's per-line width table (LineTab below) - every image n is treated as if it were only
+// line_tab[4 n] columns wide: e / a / cat beyond its own half-resolution width are the zero padding the next layer expects
 void launch_stem_fused(int c1, const float* x, int N, int H, int W, int in_ch, const uint16_t* wimg, const float* bias, float* y, int yld,
-                       unsigned* range_flag, hipStream_t s);
+                       unsigned* range_flag, hipStream_t s, const int32_t* line_tab = nullptr);
+
+// Per-line widths of a recogniser launch (REC_LINE_WIDTHS): text lines of DIFFERENT reference padded widths share one [B,3,48,W]
+// tensor and every line is computed exactly as if it had been padded to its own width only (rapid_ocr.py:404-449 pads a line to
+// its chunk-of-6's width; LightSVTR, the SE pooling and the conv borders all see that width).  int32 [B][4]:
+//   0: w_in  the line's reference padded width (columns >= w_in of x are zero)
+//   1: w2 = (w_in - 1) / 2 + 1 after stem1            2: w4 = (w2 - 1) / 2 + 1 after stem3 = the width of every block
+//   3: first token of the line in the token buffer (the line has w4 / 2 tokens)
+constexpr int kLineTabStride = 4;
 
 struct DwParams {
     const float* x; int xld;
@@ -96,6 +106,9 @@ struct DwParams {
     // ragged rows (the recogniser's batched tail): the tensor is [1][1][W = all tokens][C], token i sits at position
     // tokinfo[i] & 0xffff of a text line of tokinfo[i] >> 16 tokens and the kernel's horizontal taps stop at the line's ends
     const int32_t* tokinfo = nullptr;
+    // per-image valid width (LineTab column 2; stride-1 'same' convs only): input columns >= line_w[n * line_w_stride] read as the
+    // conv's zero padding and are left out of the SE partial sums
+    const int32_t* line_w = nullptr; int line_w_stride = 0;
     int dbg = 0;                // developer (RD_DW_DBG): 1 no stores, 2 no loads - timing only
 };
 void launch_dwconv(const DwParams& p, hipStream_t s);
@@ -106,7 +119,10 @@ int dwconv_gap_chunks(const DwParams& p);
 // 2x2 stride-1 max-pool over an input zero-padded by one pixel on the right/bottom (stem branch b)
 void launch_maxpool2x2s1(const float* x, int xld, float* y, int yld, int N, int H, int W, int C, hipStream_t s);
 // avg_pool2d(kernel (3,2), stride (3,2)) - rec height collapse
-void launch_avgpool3x2(const float* x, int xld, float* y, int yld, int N, int H, int W, int C, hipStream_t s);
+// line_tab: image n writes its w4 / 2 tokens at row line_tab[4 n + 3] of y (compact token buffer) instead of [n][OW]
+void launch_avgpool3x2(const float* x, int xld, float* y, int yld, int N, int H, int W, int C, hipStream_t s, const int32_t* line_tab = nullptr);
+// y[n, :, w >= line_w[n * stride], :] = 0 (the separate-kernel stem of the fp32 mode under a line table)
+void launch_mask_cols(float* y, int yld, int N, int H, int W, int C, const int32_t* line_w, int stride, hipStream_t s);
 
 // Squeeze-excite: deterministic two-stage global average pool, tiny FCs, then y = x * (alpha + s)
 void launch_gap_partial(const float* x, int xld, int N, int HW, int C, float* partial, int chunks, hipStream_t s);
@@ -116,6 +132,7 @@ struct SeFcParams {
     const float* w2; const float* b2;  // [C][Cr], [C]
     int gate;                          // ACT_HSIG (x/6+.5) or ACT_HSIG_PADDLE (.2x+.5)
     float* scale;                      // [N][C]
+    const int32_t* line_w = nullptr; int line_w_stride = 0; int H = 0;   // per-image pooling extent H x line_w[n * stride] instead of 1 / inv_hw
 };
 void launch_se_fc(const SeFcParams& p, hipStream_t s);
 bool det_head_tail_supported(int cin, int cmid, int cout);
@@ -226,8 +243,8 @@ size_t db_boxes_workspace_bytes(int B, int H, int max_runs, int max_cand);
 int launch_db_boxes(const float* prob, int B, int H, int W, const int32_t* src_hw_dev, float thresh, float box_thresh, float unclip_ratio,
                     int dilate, int max_cand, int max_runs, void* ws, size_t ws_bytes, void* out_boxes, int max_out, int32_t* n_out_dev,
                     hipStream_t s);
-int launch_ctc_collapse(const int32_t* idx, const float* prob, int B, int T, const uint8_t* ctab, int max_len, int n_classes,
-                        uint8_t* out, int row_bytes, hipStream_t s);
+int launch_ctc_collapse(const int32_t* idx, const float* prob, int B, int T, const int32_t* seg, const uint8_t* ctab, int max_len, int n_classes,
+                        uint8_t* out, int row_bytes, uint16_t* kept_cols, hipStream_t s);
 
 }  // namespace rd
 

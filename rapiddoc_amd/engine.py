@@ -16,6 +16,15 @@ REC_UNFUSED_CTC, REC_WANT_SOFTMAX, REC_WANT_LOGITS = 1, 2, 4
 KINDS = ("ppocrv6_det", "ppocrv6_rec", "pphgnetv2_b4", "pphgnetv2_b6_formula", "ppformulanet_head")
 
 
+def rec_line_table(widths, first_tokens) -> np.ndarray:
+    """int32 [B, 4] line table of rd_rec_backbone_forward_lines (include/rapiddoc_mi355.h): (w, width after stem1, width after stem3 =
+    the blocks' width, first token); a line of padded width w yields (w4 // 2) = rd_rec_seq_len(w) tokens."""
+    w = np.asarray(widths, dtype=np.int64).reshape(-1)
+    w2 = (w - 1) // 2 + 1
+    w4 = (w2 - 1) // 2 + 1
+    return np.ascontiguousarray(np.stack([w, w2, w4, np.asarray(first_tokens, dtype=np.int64).reshape(-1)], axis=1).astype(np.int32))
+
+
 def ragged_tables(line_lengths: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     """(seg int32 [n][2] = (first token, tokens) per line, tokinfo int32 [n_tokens] = position | tokens << 16)."""
     lens = np.asarray(line_lengths, dtype=np.int64)
@@ -193,6 +202,26 @@ class RdEngine:
 
         def launch():
             self._chk(self._l.rd_rec_backbone_forward(self._h, x.data_ptr(), B, W_, tokens_out.data_ptr(), None, 0, _stream_ptr()))
+            self._log()
+        self._guarded(launch)
+        return tokens_out
+
+    def rec_backbone_forward_lines(self, x: torch.Tensor, line_tab: torch.Tensor, tokens_out: torch.Tensor) -> torch.Tensor:
+        """The backbone stage over lines of DIFFERENT reference padded widths (rd_rec_backbone_forward_lines): x [B,3,48,W] with
+        line b in columns [0, w_b), `line_tab` = `rec_line_table(widths, first tokens)` on the device, `tokens_out` the token buffer
+        the table's offsets refer to.  Line b's tokens == rec_backbone_forward(x[b:b+1, :, :, :w_b])."""
+        x = self._prep(x)
+        B, Cc, H, W_ = x.shape
+        if H != 48:
+            raise EngineError("rec input height must be 48")
+        if line_tab.dtype != torch.int32 or not line_tab.is_cuda or line_tab.numel() != 4 * B or not line_tab.is_contiguous():
+            raise EngineError("line_tab must be a contiguous int32 device tensor [B, 4]")
+        if not tokens_out.is_contiguous() or tokens_out.dtype != torch.float32:
+            raise EngineError("tokens_out must be a contiguous float32 tensor")
+
+        def launch():
+            self._chk(self._l.rd_rec_backbone_forward_lines(self._h, x.data_ptr(), B, W_, line_tab.data_ptr(), tokens_out.data_ptr(), None, 0,
+                                                            _stream_ptr()))
             self._log()
         self._guarded(launch)
         return tokens_out

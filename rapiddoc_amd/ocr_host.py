@@ -237,6 +237,39 @@ def rec_batches_adaptive(wh_ratios: Sequence[float], img_h: int = REC_IMG_H, img
     return out
 
 
+def rec_batches_lines(wh_ratios: Sequence[float], rec_batch_num: int = 6, img_h: int = REC_IMG_H, img_w: int = REC_IMG_W,
+                      launch_multiple: int = 32, n_min: int = 16, n_max: int = 160, n_step: int = 2,
+                      n_cu: int = 256) -> Tuple[List[Tuple[np.ndarray, int]], np.ndarray]:
+    """The reference's batching RESULT at GPU launch sizes.  Every line keeps the padded width the reference gives it - the imgW of
+    its own chunk of `rec_batch_num` lines of the one global `np.argsort` (`rec_batches(strict=True)`, rapid_ocr.py:411-440) - and
+    the launches are runs of that sorted list whose sizes `rd_rec_plan_chunks` picks for the chip, each launch tensor as wide as
+    its widest line rounded up to `launch_multiple` (the recogniser computes a line at its own width inside the wider tensor:
+    rd_rec_backbone_forward_lines).  Returns ([(indices into the input, launch width)], reference width per line in the order of
+    the concatenated indices)."""
+    ref = rec_batches(wh_ratios, rec_batch_num, img_h, img_w, width_multiple=1, strict=True)
+    if not ref:
+        return [], np.zeros(0, np.int64)
+    order = np.concatenate([c for c, _w in ref])
+    line_w = np.concatenate([np.full(len(c), w, dtype=np.int64) for c, w in ref])      # non-decreasing: the chunks are sorted by ratio
+    total = len(order)
+    import ctypes as C
+
+    from . import _lib
+    lib = _lib.load()
+    w32 = np.ascontiguousarray((line_w + launch_multiple - 1) // launch_multiple * launch_multiple, dtype=np.int32)
+    sizes = np.zeros(total, dtype=np.int32)
+    n_out = C.c_int32(0)
+    rc = lib.rd_rec_plan_chunks(w32.ctypes.data, total, n_min, n_max, n_step, n_cu, sizes.ctypes.data, total, C.byref(n_out))
+    if rc != 0:
+        raise RuntimeError("rd_rec_plan_chunks failed")
+    out, i = [], 0
+    for n in sizes[: n_out.value].tolist():
+        out.append((order[i: i + n], int(w32[i + n - 1])))
+        i += n
+    assert i == total
+    return out, line_w
+
+
 def rec_resized_width(w: float, h: float, wpad: int, img_h: int = REC_IMG_H) -> int:
     """resize_norm_img: resized_w = min(imgW, ceil(imgH * w/h))."""
     return int(min(wpad, math.ceil(img_h * (w / h))))

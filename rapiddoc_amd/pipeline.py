@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib, ocr_host
-from .engine import RdEngine, pad_tail_lengths, preproc_resize_norm, preproc_resize_norm_batch
+from .engine import RdEngine, pad_tail_lengths, rec_line_table, preproc_resize_norm, preproc_resize_norm_batch
 
 LAYOUT_SIZE = 800          # PP-DocLayout-L/plus-L/V2/V3 input (pp_doclayout/main.py:17-29)
 DET_LIMIT = 960            # rapidocr Det.limit_side_len (rapid_ocr.py:517-518)
@@ -115,24 +115,28 @@ class PageResult:
 class PagePipeline:
     def __init__(self, states: Dict[str, object], device: int = 0, characters: Optional[Sequence[str]] = None,
                  rec_batch_num: Optional[int] = None, rec_width_multiple: int = 32, keep_feats: bool = False, n_rec_streams: int = 4,
-                 rec_mode: str = "throughput", rec_chunking: Optional[str] = None):
+                 rec_mode: Optional[str] = None, rec_chunking: Optional[str] = None):
         """`states`: {'ppocrv6_det': ..., 'ppocrv6_rec': ..., 'pphgnetv2_b4': ...}, each a .safetensors path,
         bytes, or name->ndarray dict.
 
         `rec_mode`: how the text lines are batched for the recogniser.  A line's logits depend on its batch's padded width
         (LightSVTR attends over the zero-padded columns), so the batching is part of the result:
-          "strict"      the reference's batching, result for result: every line of the call pooled, ONE
+          "strict"      (the default) the reference's batching, result for result: every line of the call pooled, ONE
                         `np.argsort(ratios)` with numpy's default sort, chunks of `rec_batch_num` = 6 (rapidocr's default),
-                        padded width int(48 * max ratio of the chunk) (rapid_ocr.py:404-449); chunks of equal padded width
-                        share a launch (same tensors per line, fewer launches).  `rec_batch_num` / `rec_width_multiple` are
-                        ignored.
-          "throughput"  GPU-sized chunks (`rec_batch_num` lines, default 64) of the same aspect-sorted list, padded width
+                        every line padded to int(48 * max ratio of ITS chunk) (rapid_ocr.py:404-449).  The launches are
+                        GPU-sized all the same: runs of the sorted list (sizes from `rd_rec_plan_chunks`) share one tensor
+                        and the backbone computes every line at its own padded width inside it
+                        (`rd_rec_backbone_forward_lines`; `ocr_host.rec_batches_lines`).  `rec_batch_num` /
+                        `rec_width_multiple` are ignored.  (With RD_REC_TWO_STAGE=0: one launch per distinct padded width.)
+          "throughput"  (chosen when `rec_batch_num` or `rec_chunking` is given without a mode) GPU-sized chunks (`rec_batch_num` lines, default 64) of the same aspect-sorted list, padded width
                         rounded up to `rec_width_multiple`: same per-tensor parity with the oracle, different padded
                         widths than the reference would have used.  `rec_chunking="adaptive"` (the default when no
                         `rec_batch_num` is given - what bench.py measures) lets the chunk SIZE follow the width:
                         `ocr_host.rec_batches_adaptive` picks, chunk by chunk, the size with the most lines per estimated
                         microsecond, i.e. tile counts of the persistent kernels that fill whole rounds of the 256 CUs (64 lines
                         of width 1056 are 3.09 rounds of mixer tiles and cost four)."""
+        if rec_mode is None:
+            rec_mode = "strict" if rec_batch_num is None and rec_chunking is None else "throughput"
         if rec_mode not in ("strict", "throughput"):
             raise ValueError("rec_mode must be 'strict' or 'throughput'")
         if rec_chunking is None:
@@ -147,6 +151,7 @@ class PagePipeline:
             rec_batch_num, rec_width_multiple = 6, 1
         self.device = device
         self.tdev = torch.device("cuda", device)
+        self.n_cu = int(torch.cuda.get_device_properties(self.tdev).multi_processor_count)   # the chunk planners' round size
         # several forwards are in flight at once here, so the engines defer the split-fp16 range guard: run_batch (det,
         # layout) and rec_forward_lines (rec) call check_range_and_fallback() before any result is used
         # (reuse_outputs: the engines hand out the same output tensors for the same shape - every result is consumed inside the
@@ -264,6 +269,29 @@ class PagePipeline:
                 done.record(st)
         return rows, done
 
+    def _collapse_lines(self, idx_all: torch.Tensor, prob_all: torch.Tensor, tables: torch.Tensor, n_lines: int, max_tokens: int, st,
+                        want_cols: bool = False):
+        """Device CTC collapse of the RAGGED lines of one tail call (`tables` = its seg / tokinfo tensor; the first `n_lines` are the
+        real ones) on stream `st` + the D2H of the rows into pinned memory; returns (rows, event) or (rows, event, kept columns)."""
+        with torch.cuda.stream(st):
+            row_bytes = (16 + max_tokens * self._ctc_max_len + 15) // 16 * 16
+            rows = torch.empty((n_lines, row_bytes), dtype=torch.uint8, device=idx_all.device)
+            cols = torch.empty((n_lines, max_tokens), dtype=torch.int16, device=idx_all.device) if want_cols else None
+            rc = self._lib.rd_ctc_collapse_lines(self.device, idx_all.data_ptr(), prob_all.data_ptr(), n_lines, tables.data_ptr(), max_tokens,
+                                                 self._ctc_table.data_ptr(), self._ctc_max_len, len(self.characters), rows.data_ptr(),
+                                                 row_bytes, cols.data_ptr() if want_cols else None, st.cuda_stream)
+            if rc != 0:
+                raise RuntimeError("rd_ctc_collapse_lines failed")
+            rows_h = torch.empty((n_lines, row_bytes), dtype=torch.uint8, pin_memory=True)
+            rows_h.copy_(rows, non_blocking=True)
+            cols_h = None
+            if want_cols:
+                cols_h = torch.empty((n_lines, max_tokens), dtype=torch.int16, pin_memory=True)
+                cols_h.copy_(cols, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(st)
+        return (rows_h, done, cols_h) if want_cols else (rows_h, done)
+
     def _rec_forward_sources_once(self, sources, image_keys=None):
         t0 = time.perf_counter()
         dev = sources[0][0].device
@@ -302,16 +330,22 @@ class PagePipeline:
         eff_h = np.where(rots_a == 1, cws_a, chs_a)
         ratios = (eff_w / eff_h).tolist()
         strict = self.rec_mode == "strict"
-        if not strict and self.rec_chunking == "adaptive":
-            batches = ocr_host.rec_batches_adaptive(ratios, width_multiple=self.rec_width_multiple)
+        two_stage = self.rec_two_stage
+        lines_mode = strict and two_stage          # reference widths per LINE inside GPU-sized launches
+        if lines_mode:
+            batches, line_w = ocr_host.rec_batches_lines(ratios, n_cu=self.n_cu)
+        elif not strict and self.rec_chunking == "adaptive":
+            batches = ocr_host.rec_batches_adaptive(ratios, width_multiple=self.rec_width_multiple, n_cu=self.n_cu)
         else:
             batches = ocr_host.rec_batches(ratios, self.rec_batch_num, width_multiple=self.rec_width_multiple, strict=strict,
                                            merge_equal_width=strict)
         order_all = np.concatenate([c for c, _ in batches])
         wpad_all = np.concatenate([np.full(len(c), w) for c, w in batches])
+        if not lines_mode:
+            line_w = wpad_all                           # every line of a launch is as wide as the launch
         descs = np.zeros(n, dtype=LINE_DTYPE)
         descs["page"] = page_of[keep][order_all]
-        descs["out_w"] = np.minimum(wpad_all, np.ceil(ocr_host.REC_IMG_H * (eff_w / eff_h)[order_all])).astype(np.int32)
+        descs["out_w"] = np.minimum(line_w, np.ceil(ocr_host.REC_IMG_H * (eff_w / eff_h)[order_all])).astype(np.int32)
         descs["crop_w"] = cws_a[order_all].astype(np.int32)
         descs["crop_h"] = chs_a[order_all].astype(np.int32)
         descs["m"] = mats[order_all]
@@ -363,32 +397,37 @@ class PagePipeline:
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(main)
-        two_stage = self.rec_two_stage
         S = len(self.rec_engines)
         if two_stage:
             # the batches run the backbone only, each into its slice of one token buffer; the neck + CTC head then run once per
             # GROUP of S consecutive batches (one per stream) on the tail stream, under the backbones of the next group
-            seq = [self._lib.rd_rec_seq_len(int(w)) for _c, w in batches]
+            w2_ = (np.asarray(line_w, dtype=np.int64) - 1) // 2 + 1
+            seq_line = ((w2_ - 1) // 2 + 1) // 2                  # tokens per line (rd_rec_seq_len of its padded width)
             groups = [list(range(g, min(g + S, len(batches)))) for g in range(0, len(batches), S)]
-            group_lens = [np.concatenate([np.full(len(batches[bi][0]), seq[bi], dtype=np.int64) for bi in grp]) for grp in groups]
+            group_lens = [seq_line[int(starts[grp[0]]): int(starts[grp[-1] + 1])] for grp in groups]
             # every group's tail call is padded with dummy lines onto a coarse (lines, longest line, tokens) grid: the plan cache
             # of the tail handle then sees a handful of keys instead of a new one per group (engine.pad_tail_lengths)
             group_pad = [pad_tail_lengths(l) for l in group_lens]
             group_base = np.cumsum([0] + [int(lp.sum()) for lp, _t in group_pad])
-            tok_lo = [0] * len(batches)
+            first_tok = np.zeros(n, np.int64)                      # first token of every line in the token buffer
             for gi, grp in enumerate(groups):
-                off = int(group_base[gi])
-                for bi in grp:
-                    tok_lo[bi] = off
-                    off += len(batches[bi][0]) * seq[bi]
+                lo, hi = int(starts[grp[0]]), int(starts[grp[-1] + 1])
+                first_tok[lo:hi] = int(group_base[gi]) + np.cumsum(seq_line[lo:hi]) - seq_line[lo:hi]
+            tok_lo = [int(first_tok[int(starts[bi])]) for bi in range(len(batches))]
             dim = self.rec.rec_token_dim
             tokens = self._buf("rec_tokens", int(group_base[-1]) * dim).view(int(group_base[-1]), dim)
             for gi in range(len(groups)):         # the dummy lines' tokens: finite values (their outputs are ignored)
                 tokens[int(group_base[gi]) + int(group_lens[gi].sum()): int(group_base[gi + 1])].zero_()
             group_tables = [self.rec_tail.rec_tail_tables(lp, dev, out=self._buf(("tail_tab", gi), 2 * len(lp) + int(lp.sum()), torch.int32))
                             for gi, (lp, _t) in enumerate(group_pad)]   # uploaded now, used later
+            if lines_mode:
+                tab_h = torch.from_numpy(rec_line_table(line_w, first_tok)).pin_memory()
+                linetab = self._buf("rec_linetab", 4 * n, torch.int32).view(n, 4)
+                linetab.copy_(tab_h, non_blocking=True)
+                self._keep_linetab = tab_h                        # the pinned source must outlive the asynchronous copy
             ready.record(main)
             self.tail_stream.wait_event(ready)
+        group_rows = {}
 
         def run_tail(gi):
             grp = groups[gi]
@@ -400,9 +439,18 @@ class PagePipeline:
                 idx_all, prob_all = self.rec_tail.rec_tail_forward(
                     tokens[t_lo:t_hi], group_pad[gi][0], group_tables[gi], max_tokens=group_pad[gi][1],
                     out=(self._buf(("tail_idx", gi), n_tok, torch.int32), self._buf(("tail_prob", gi), n_tok)))
+            if lines_mode:
+                # ragged lines: ONE collapse launch over the group's real lines (the seg table of the tail call), one copy back
+                n_real = len(group_lens[gi])
+                rows, done = self._collapse_lines(idx_all, prob_all, group_tables[gi], n_real, group_pad[gi][1], self.tail_stream)
+                kept = (idx_all.clone(), prob_all.clone()) if self.keep_rec_inputs else None
+                group_rows[gi] = (rows, done, kept)
+                for bi in grp:
+                    outs[bi] = (None, None, done, outs[bi][3], None)
+                return
             done = None
             for bi in grp:
-                nb, t = len(batches[bi][0]), seq[bi]
+                nb, t = len(batches[bi][0]), int(seq_line[int(starts[bi])])
                 lo = tok_lo[bi] - t_lo
                 hi = lo + nb * t
                 idx, prob = idx_all[lo:hi].view(nb, t), prob_all[lo:hi].view(nb, t)
@@ -433,8 +481,13 @@ class PagePipeline:
                                                          ocr_host.REC_IMG_H, wpad, 1, x.data_ptr(), st.cuda_stream)   # stage 2
                 if rc != 0:
                     raise RuntimeError("rd_line_resize_norm_batch failed")
-                if two_stage:
-                    self.rec_engines[k].rec_backbone_forward(x, tokens[tok_lo[bi]: tok_lo[bi] + nb * seq[bi]])
+                if lines_mode:
+                    self.rec_engines[k].rec_backbone_forward_lines(x, linetab[pos: pos + nb], tokens)
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    outs.append((None, None, ev, x.clone() if self.keep_rec_inputs else x, None))
+                elif two_stage:
+                    self.rec_engines[k].rec_backbone_forward(x, tokens[tok_lo[bi]: tok_lo[bi] + nb * int(seq_line[pos])])
                     ev = torch.cuda.Event()
                     ev.record(st)
                     outs.append((None, None, ev, x.clone() if self.keep_rec_inputs else x, None))
@@ -452,21 +505,41 @@ class PagePipeline:
         # overlaps the GPU work of the batches still in flight
         t_dec = 0.0
         if self.keep_rec_inputs:
-            self.last_rec_batches = [(keep[np.asarray(chunk)], x, idx, prob) for (chunk, _w), (idx, prob, _d, x, _r) in zip(batches, outs)]
             self.last_rec_crop_sizes = (cws_a.astype(np.int64), chs_a.astype(np.int64), rots_a, keep)
-        for (chunk, wpad), (idx, prob, done, _x, rows) in zip(batches, outs):
-            done.synchronize()
-            if rows is not None:
+        if lines_mode:
+            self.last_rec_batches = []
+            for gi, grp in enumerate(groups):
+                rows, done, kept = group_rows[gi]
+                done.synchronize()
                 t1 = time.perf_counter()
+                lo = int(starts[grp[0]])
                 dec = ocr_host.parse_ctc_rows(rows.numpy())
-            else:
-                idx_h, prob_h = idx.cpu().numpy(), prob.cpu().numpy()
-                t1 = time.perf_counter()
-                dec = ocr_host.ctc_decode(idx_h, prob_h, self.characters)
-            for j, i in enumerate(chunk):
-                t, s = dec[j]
-                texts[int(keep[i])] = (t, ocr_host.format_score(s))
-            t_dec += time.perf_counter() - t1
+                for j, (t, sc) in enumerate(dec):
+                    texts[int(keep[order_all[lo + j]])] = (t, ocr_host.format_score(sc))
+                t_dec += time.perf_counter() - t1
+                if kept is not None:        # tests: per rec batch (pooled line ids, input tensor, reference width per line, per-line idx, prob)
+                    g0 = int(group_base[gi])
+                    for bi in grp:
+                        a, e = int(starts[bi]), int(starts[bi + 1])
+                        sl = [(int(first_tok[i]) - g0, int(seq_line[i])) for i in range(a, e)]
+                        self.last_rec_batches.append((keep[np.asarray(batches[bi][0])], outs[bi][3], np.asarray(line_w[a:e]),
+                                                      [kept[0][o: o + t] for o, t in sl], [kept[1][o: o + t] for o, t in sl]))
+        else:
+            if self.keep_rec_inputs:
+                self.last_rec_batches = [(keep[np.asarray(chunk)], x, idx, prob) for (chunk, _w), (idx, prob, _d, x, _r) in zip(batches, outs)]
+            for (chunk, wpad), (idx, prob, done, _x, rows) in zip(batches, outs):
+                done.synchronize()
+                if rows is not None:
+                    t1 = time.perf_counter()
+                    dec = ocr_host.parse_ctc_rows(rows.numpy())
+                else:
+                    idx_h, prob_h = idx.cpu().numpy(), prob.cpu().numpy()
+                    t1 = time.perf_counter()
+                    dec = ocr_host.ctc_decode(idx_h, prob_h, self.characters)
+                for j, i in enumerate(chunk):
+                    t, s = dec[j]
+                    texts[int(keep[i])] = (t, ocr_host.format_score(s))
+                t_dec += time.perf_counter() - t1
         self.stats["t_decode_ms"] = t_dec * 1e3
         for st in self.rec_streams + [self.tail_stream]:
             main.wait_stream(st)

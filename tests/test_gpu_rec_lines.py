@@ -1,0 +1,197 @@
+"""GPU: the recogniser over text lines of DIFFERENT reference padded widths in one launch (rd_rec_backbone_forward_lines + the ragged
+tail + rd_ctc_collapse_lines) - the strict rec mode of PagePipeline.  The reference pads a line to the width of its own chunk of six
+(rapid_ocr.py:404-449) and the network's output depends on that width, so "the reference's result at GPU launch sizes" means: line b of a
+launch == the network run on x[b:b+1, :, :, :w_b] alone.  Checked against the oracle (oracle/nets.py, pinned to the reference's BaseModel)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets as O
+from rapiddoc_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _state(golden_dir, kind="ppocrv6_rec"):
+    return W.synth_state_dict(W.load_manifest(golden_dir / f"manifest_{kind}.json"), 0)
+
+
+def _lines_input(widths, W_launch, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.zeros((len(widths), 3, 48, W_launch))
+    for b, w in enumerate(widths):
+        x[b, :, :, :w] = torch.rand((3, 48, w), generator=g) * 2 - 1
+    return x
+
+
+@pytest.mark.parametrize("precision", ["auto", "fp32"])
+@pytest.mark.parametrize("widths,W_launch", [([320, 320, 323, 401, 517, 640, 638, 77, 16], 672), ([321], 352), ([1000, 1003, 1056], 1056)])
+def test_backbone_lines_equal_the_per_line_forward_and_the_oracle(golden_dir, precision, widths, W_launch):
+    from rapiddoc_amd.engine import RdEngine, rec_line_table
+    st_np = _state(golden_dir)
+    eng = RdEngine("ppocrv6_rec").load_weights(st_np)
+    eng.set_precision(precision)
+    st = O.as_torch_state(st_np)
+    x = _lines_input(widths, W_launch, seed=len(widths))
+    w = np.asarray(widths)
+    T = (((w - 1) // 2 + 1 - 1) // 2 + 1) // 2
+    first = np.cumsum(T) - T + 3                               # (+3: offsets are honoured, not assumed to start at 0)
+    tab = torch.from_numpy(rec_line_table(w, first)).cuda()
+    dim = eng.rec_token_dim
+    tokens = torch.full((int(first[-1] + T[-1]) + 2, dim), 777.0, device="cuda")
+    eng.rec_backbone_forward_lines(x.cuda(), tab, tokens)
+    torch.cuda.synchronize()
+    got = tokens.cpu()
+    assert float((got[:3] - 777.0).abs().max()) == 0.0 and float((got[-2:] - 777.0).abs().max()) == 0.0     # nothing outside the lines' slots
+    for b, wb in enumerate(widths):
+        xb = x[b:b + 1, :, :, :wb].contiguous()
+        with torch.no_grad():
+            ref = O.rec_forward(st, xb, return_all=True)["backbone"]          # [1, 384, 1, T]
+        ref = ref[0, :, 0, :].t()
+        assert ref.shape[0] == T[b] == eng._l.rd_rec_seq_len(int(wb))
+        mine = got[first[b]: first[b] + T[b]]
+        scale = max(1.0, float(ref.abs().max()))
+        assert float((mine - ref).abs().max()) < TOL * scale, (b, wb)
+        alone = eng.rec_backbone_forward(xb.cuda()).cpu()[0]                  # the same line as a launch of its own
+        assert float((mine - alone).abs().max()) < 2e-4 * scale, (b, wb)
+    assert not eng.range_overflow()
+
+
+def test_collapse_lines_equals_the_host_decode(golden_dir):
+    """rd_ctc_collapse_lines over ragged lines == ocr_host.ctc_decode line by line (strings, confidences bit for bit) and its kept
+    columns are the time steps of the kept characters."""
+    import ctypes as C
+    from rapiddoc_amd import _lib, ocr_host
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    chars = ["blank"] + [chr(0x4E00 + i) for i in range(200)] + [" "]
+    tab, max_len = ocr_host.char_table(chars)
+    lens = [40, 1, 133, 7, 300]
+    seg = np.zeros((len(lens), 2), np.int32)
+    seg[:, 1] = lens
+    seg[:, 0] = np.cumsum(lens) - lens + 5
+    n_tok = int(seg[-1].sum())
+    idx = rng.integers(0, 6, n_tok).astype(np.int32) * rng.integers(0, 2, n_tok).astype(np.int32) * 37 % len(chars)
+    prob = rng.uniform(0.1, 1.0, n_tok).astype(np.float32)
+    Tmax = 304
+    row_bytes = (16 + Tmax * max_len + 15) // 16 * 16
+    d = lambda a: torch.from_numpy(a).cuda()
+    idx_d, prob_d, seg_d, tab_d = d(idx), d(prob), d(seg.reshape(-1)), d(tab)
+    rows = torch.zeros((len(lens), row_bytes), dtype=torch.uint8, device="cuda")
+    cols = torch.full((len(lens), Tmax), -1, dtype=torch.int16, device="cuda")
+    rc = lib.rd_ctc_collapse_lines(0, idx_d.data_ptr(), prob_d.data_ptr(), len(lens), seg_d.data_ptr(), Tmax, tab_d.data_ptr(), max_len, len(chars),
+                                   rows.data_ptr(), row_bytes, cols.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    dec = ocr_host.parse_ctc_rows(rows.cpu().numpy())
+    n_kept = rows.cpu().numpy()[:, 8:12].copy().view("<i4")[:, 0]
+    for b, (f, t) in enumerate(seg.tolist()):
+        want = ocr_host.ctc_decode(idx[None, f:f + t], prob[None, f:f + t], chars)[0]
+        assert dec[b][0] == want[0] and np.float32(dec[b][1]) == np.float32(want[1])
+        row = idx[f:f + t]
+        keep = [i for i in range(t) if row[i] != 0 and (i == 0 or row[i] != row[i - 1])]
+        assert n_kept[b] == len(keep) and cols.cpu().numpy()[b, :len(keep)].tolist() == keep
+
+
+def _reference_rec_chunks(crop_hw, rec_batch_num=6):
+    """rapid_ocr.py:404-449 restated independently of rapiddoc_amd: [(indices, imgW)] for crops of the given (h, w)."""
+    width_list = [w / float(h) for h, w in crop_hw]
+    indices = np.argsort(np.array(width_list))
+    out = []
+    for beg in range(0, len(crop_hw), rec_batch_num):
+        end = min(len(crop_hw), beg + rec_batch_num)
+        max_wh_ratio = 320 / 48
+        for ino in range(beg, end):
+            h, w = crop_hw[indices[ino]]
+            max_wh_ratio = max(max_wh_ratio, w * 1.0 / h)
+        out.append(([int(indices[i]) for i in range(beg, end)], int(48 * max_wh_ratio)))
+    return out
+
+
+def check_lines_against_oracle(pipe, st_rec, flat_lines, batch_ids=None, per_batch=None):
+    """Every kept rec batch of a strict-mode call: each line's (idx, prob) == the oracle run on that line's tensor cut at the line's
+    reference width, and the strings / scores the call returned are the decode of exactly those.  Returns {pooled line: width}."""
+    from rapiddoc_amd import ocr_host
+    got_w = {}
+    ids = range(len(pipe.last_rec_batches)) if batch_ids is None else batch_ids
+    for bi in ids:
+        chunk, x, line_w, idxs, probs = pipe.last_rec_batches[bi]
+        sel = range(len(chunk)) if per_batch is None else sorted(set(np.linspace(0, len(chunk) - 1, per_batch).astype(int).tolist()))
+        for j in sel:
+            wj = int(line_w[j])
+            assert wj <= x.shape[3] and (wj == x.shape[3] or float(x[j, :, :, wj:].abs().max()) == 0.0)
+            with torch.no_grad():
+                lg = O.rec_forward(st_rec, x[j:j + 1, :, :, :wj].cpu().contiguous())
+            ridx, rprob = O.ctc_greedy_stats(lg)
+            top2 = torch.topk(lg, 2, dim=2).values
+            safe = ((top2[..., 0] - top2[..., 1]) > 1e-2).numpy()[0]
+            idx, prob = idxs[j].cpu().numpy(), probs[j].cpu().numpy()
+            assert idx.shape == (lg.shape[1],)
+            assert (idx == ridx.numpy()[0])[safe].all()
+            assert np.abs(prob - rprob.numpy()[0])[safe].max() < TOL
+            t, s = ocr_host.ctc_decode(idx[None], prob[None], pipe.characters)[0]
+            i = int(chunk[j])
+            assert flat_lines[i][1] == t and flat_lines[i][2] == ocr_host.format_score(s)
+        for j, i in enumerate(chunk.tolist()):
+            got_w[int(i)] = int(line_w[j])
+    return got_w
+
+
+def test_strict_mode_gives_every_line_its_reference_width_in_gpu_sized_launches(golden_dir):
+    from rapiddoc_amd.pages import synth_batch
+    from rapiddoc_amd.pipeline import PagePipeline, render_text_maps
+    states = {k: _state(golden_dir, k) for k in ("ppocrv6_det", "ppocrv6_rec")}
+    pipe = PagePipeline(states, n_rec_streams=4)
+    assert pipe.rec_mode == "strict"                          # the default
+    pipe.keep_rec_inputs = True
+    pages_np, boxes = synth_batch(7, 3)
+    pages = torch.from_numpy(pages_np).cuda()
+    maps = render_text_maps(boxes, pages_np.shape[1:3], pipe.det_preprocess(pages[:1])[1], pages.device)
+    res = pipe.run_batch(pages, None, det_maps_override=maps)
+    flat = [ln for r in res for ln in r.lines]
+    n = len(flat)
+    assert n == 135
+    cw, ch, rot, keep = pipe.last_rec_crop_sizes
+    crop_hw = [(int(cw[i]), int(ch[i])) if rot[i] else (int(ch[i]), int(cw[i])) for i in range(n)]   # (h, w) of the image rec sees
+    expected = _reference_rec_chunks(crop_hw)
+    assert len(expected) == 23
+    want_w = {i: w for idxs, w in expected for i in idxs}
+    got_w = check_lines_against_oracle(pipe, O.as_torch_state(states["ppocrv6_rec"]), flat)
+    assert got_w == want_w                                    # every line sees exactly the padded width the reference gives it
+    assert len(pipe.last_rec_batches) < 12                    # ... in launches of GPU size, not 23 chunks of six
+    order = [int(i) for chunk, *_ in pipe.last_rec_batches for i in chunk.tolist()]
+    assert order == [i for idxs, _w in expected for i in idxs]    # the launches are runs of the reference's sorted order
+    # zero right-padding starts at min(imgW, ceil(48 * w / h)) (resize_norm_img)
+    chunk, x, line_w, _i, _p = pipe.last_rec_batches[-1]
+    for j, i in enumerate(chunk.tolist()):
+        h, w = crop_hw[i]
+        rw = min(int(line_w[j]), int(np.ceil(48 * (w / float(h)))))
+        assert rw == x.shape[3] or float(x[j, :, :, rw:].abs().max()) == 0.0
+    # the same strings and scores as the one-launch-per-width form of the strict mode (RD_REC_TWO_STAGE=0 path)
+    pipe.rec_two_stage = False
+    pipe.keep_rec_inputs = False
+    res1 = pipe.run_batch(pages, None, det_maps_override=maps)
+    for a, b in zip(res, res1):
+        assert [t for _q, t, _s in a.lines] == [t for _q, t, _s in b.lines]
+        assert max(abs(sa - sb) for (_q, _t, sa), (_q2, _t2, sb) in zip(a.lines, b.lines)) <= 1e-3
+
+
+def test_strict_mode_falls_back_to_fp32_with_the_line_table(golden_dir):
+    """The split-fp16 range guard under the line table: an engine forced to fp32 (the separate stem kernels + mask_cols) returns the
+    same strings."""
+    from rapiddoc_amd.pages import synth_batch
+    from rapiddoc_amd.pipeline import PagePipeline, render_text_maps
+    states = {k: _state(golden_dir, k) for k in ("ppocrv6_det", "ppocrv6_rec")}
+    pipe = PagePipeline(states, n_rec_streams=2)
+    pages_np, boxes = synth_batch(3, 1)
+    pages = torch.from_numpy(pages_np).cuda()
+    maps = render_text_maps(boxes, pages_np.shape[1:3], pipe.det_preprocess(pages[:1])[1], pages.device)
+    a = pipe.run_batch(pages, None, det_maps_override=maps)
+    for e in pipe.rec_engines + [pipe.rec_tail]:
+        e.set_precision("fp32")
+    pipe.keep_rec_inputs = True
+    b = pipe.run_batch(pages, None, det_maps_override=maps)
+    flat = [ln for r in b for ln in r.lines]
+    check_lines_against_oracle(pipe, O.as_torch_state(states["ppocrv6_rec"]), flat, per_batch=4)
+    assert [t for _q, t, _s in a[0].lines] == [t for _q, t, _s in b[0].lines]

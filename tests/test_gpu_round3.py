@@ -198,6 +198,7 @@ def test_strict_rec_mode_is_the_reference_batching(golden_dir):
     states = _states(golden_dir, ("ppocrv6_det", "ppocrv6_rec"))
     pipe = PagePipeline(states, rec_mode="strict", n_rec_streams=4, rec_batch_num=64)     # rec_batch_num is ignored in strict mode
     assert pipe.rec_batch_num == 6 and pipe.rec_width_multiple == 1
+    pipe.rec_two_stage = False           # the whole-network form: one launch per distinct padded width (tests/test_gpu_rec_lines.py: the default form)
     pipe.keep_rec_inputs = True
     pages_np, boxes = synth_batch(7, 3)
     pages = torch.from_numpy(pages_np).cuda()
@@ -314,7 +315,7 @@ def test_page_analyzer_replays_the_reference_trace_on_the_gpu(golden_dir, seed):
     # ... in the reference's chunks of 6 (one global argsort over the pooled list)
     expected = _reference_rec_chunks([tuple(s) for s in shapes])
     want_w = {i: w for idxs, w in expected for i in idxs}
-    got_w = {int(i): int(x.shape[3]) for chunk, x, _i, _p in pipe.last_rec_batches for i in chunk.tolist()}
+    got_w = {int(i): int(line_w[j]) for chunk, _x, line_w, _i, _p in pipe.last_rec_batches for j, i in enumerate(chunk.tolist())}
     assert got_w == want_w
     # ... and every page's output is the reference's, except what the (random-weight) recogniser read
     for mine, theirs in zip(out, fx["output"]):

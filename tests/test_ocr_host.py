@@ -243,3 +243,26 @@ def test_degenerate_quads_are_skipped_not_warped():
     assert ok.tolist() == [True, False, False, False, True, True]
     assert np.allclose(mats[0], [1, 0, 100, 0, 1, 200, 0, 0, 1]) and (cw[0], ch[0]) == (800.0, 32.0)
     assert np.isfinite(mats).all()
+
+
+def test_rec_batches_lines_keeps_reference_widths_in_gpu_sized_launches():
+    """ocr_host.rec_batches_lines: the launches are runs of the reference's sorted order, every line carries the imgW of its own
+    reference chunk of six (rapid_ocr.py:411-440), a launch is as wide as its widest line rounded up to 32."""
+    rng = np.random.default_rng(5)
+    for n in (1, 5, 6, 7, 95, 1440):
+        ratios = np.concatenate([rng.uniform(0.3, 6.0, n // 3), rng.uniform(6.0, 40.0, n - n // 3)]).tolist()
+        ref = H.rec_batches(ratios, 6, strict=True)
+        launches, line_w = H.rec_batches_lines(ratios)
+        order = np.concatenate([c for c, _w in launches])
+        assert order.tolist() == np.concatenate([c for c, _w in ref]).tolist()
+        assert line_w.tolist() == [w for c, w in ref for _ in c]
+        assert all(w >= 320 for w in line_w.tolist()) and (np.diff(line_w) >= 0).all()
+        pos = 0
+        for c, W_launch in launches:
+            ws = line_w[pos: pos + len(c)]
+            assert W_launch % 32 == 0 and W_launch == (int(ws.max()) + 31) // 32 * 32
+            pos += len(c)
+        if n >= 95:
+            assert len(launches) < len(ref) / 2 and max(len(c) for c, _w in launches) <= 160
+    empty = H.rec_batches_lines([])
+    assert empty[0] == [] and len(empty[1]) == 0
