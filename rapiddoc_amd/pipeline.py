@@ -443,7 +443,10 @@ class PagePipeline:
                 # ragged lines: ONE collapse launch over the group's real lines (the seg table of the tail call), one copy back
                 n_real = len(group_lens[gi])
                 rows, done = self._collapse_lines(idx_all, prob_all, group_tables[gi], n_real, group_pad[gi][1], self.tail_stream)
-                kept = (idx_all.clone(), prob_all.clone()) if self.keep_rec_inputs else None
+                kept = None
+                if self.keep_rec_inputs:
+                    with torch.cuda.stream(self.tail_stream):        # (after the tail call, on its stream)
+                        kept = (idx_all.clone(), prob_all.clone())
                 group_rows[gi] = (rows, done, kept)
                 for bi in grp:
                     outs[bi] = (None, None, done, outs[bi][3], None)
