@@ -30,16 +30,20 @@ def needs_build() -> bool:
     return any(d.stat().st_mtime > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> Path:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = True, extra_flags: tuple = (), out: Path = None) -> Path:
+    """`extra_flags` / `out`: developer A/B builds of the same sources into another file (tools/ab_variants.py); the product is
+    always the default call."""
+    variant = out is not None
+    if not variant and not force and not needs_build():
         return OUT
     hipcc = _hipcc()
-    objdir = PKG / "build"
-    objdir.mkdir(exist_ok=True)
+    objdir = PKG / "build" / (Path(out).stem if variant else "")
+    objdir.mkdir(parents=True, exist_ok=True)
+    OUT_ = Path(out) if variant else OUT
 
     def compile_one(src: str) -> Path:
         obj = objdir / (src + ".o")
-        cmd = [hipcc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+        cmd = [hipcc, *FLAGS, *extra_flags, "-c", str(CSRC / src), "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -49,16 +53,16 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    tmp = OUT.with_name(OUT.name + f".tmp{os.getpid()}")      # link aside, then rename: readers never see a partial file
+    tmp = OUT_.with_name(OUT_.name + f".tmp{os.getpid()}")      # link aside, then rename: readers never see a partial file
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(tmp)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         tmp.unlink(missing_ok=True)
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    os.replace(tmp, OUT)
+    os.replace(tmp, OUT_)
     if verbose:
-        print(f"built {OUT} ({OUT.stat().st_size/1e6:.1f} MB)")
-    return OUT
+        print(f"built {OUT_} ({OUT_.stat().st_size/1e6:.1f} MB)")
+    return OUT_
 
 
 if __name__ == "__main__":

@@ -34,6 +34,23 @@ __device__ __forceinline__ float rd_gelu(float v) {
 // (v >= 0: 0.5 v (2 - p t e) ; v < 0: 0.5 v (p t e)), with z' = z sqrt(log2 e) so that exp(-z^2) = exp2(-z'^2) is one v_exp_f32 with a
 // negated input, and the 0.5 folded into p's coefficients.  7.5 plain + 2 transcendental instructions per element (rd_gelu: ~12 + 2).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifdef RD_GELU_SCALAR
+__device__ __forceinline__ float rd_gelu1s(float v) {
+    constexpr float SQ = 1.2011224087864498f;
+    constexpr float S = 0.70710678118654752440f * SQ, D = 0.3275911f / SQ;
+    const float a = fabsf(v);
+    const float zp = a * S;
+    const float t = __builtin_amdgcn_rcpf(fmaf(zp, D, 1.f));
+    float pl = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+    pl = fmaf(pl, t, 0.5f * 1.421413741f);
+    pl = fmaf(pl, t, 0.5f * -0.284496736f);
+    pl = fmaf(pl, t, 0.5f * 0.254829592f);
+    const float q = (a * t) * pl;
+    const float e = __builtin_amdgcn_exp2f(-(zp * zp));
+    return fmaf(-q, e, fmaxf(v, 0.f));
+}
+__device__ __forceinline__ f32x2 rd_gelu2(f32x2 v) { return f32x2{rd_gelu1s(v[0]), rd_gelu1s(v[1])}; }
+#else
 __device__ __forceinline__ f32x2 rd_gelu2(f32x2 v) {
     constexpr float SQ = 1.2011224087864498f;                       // sqrt(log2 e)
     constexpr float S = 0.70710678118654752440f * SQ, D = 0.3275911f / SQ;
@@ -51,6 +68,7 @@ __device__ __forceinline__ f32x2 rd_gelu2(f32x2 v) {
     const f32x2 r = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
     return r - q * e;
 }
+#endif
 
 __device__ __forceinline__ float rd_act(float v, int act) {
     switch (act) {

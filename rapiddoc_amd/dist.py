@@ -3,8 +3,18 @@ activations or weights.  The only collective is the result reassembly: ragged pe
 serialised, lengths all-gathered, then one padded uint8 all-gather (RCCL over xGMI on GPU, gloo on CPU).
 The payload is KBs per page - latency-bound, a single collective per page batch.
 
-Wire format (flat little-endian bytes, no pickle - a peer's bytes are data, never code):
-    u32 n_pages, then per page: i64 global page index, u32 n_lines, then per line: f64 score, u32 n_utf8, utf-8 bytes."""
+Wire format v1 - text lines only (flat little-endian bytes, no pickle - a peer's bytes are data, never code):
+    u32 n_pages, then per page: i64 global page index, u32 n_lines, then per line: f64 score, u32 n_utf8, utf-8 bytes.
+
+Wire format v2 - whole per-page results (`gather_page_dets`): what `BatchAnalyze.__call__` returns per page is a list of
+`layout_dets` dicts (category_id, poly, polygon_points, score, text / latex / html, nested spans, ...) and
+`pipeline_analyze.py:221-228` re-associates exactly those lists with (pdf, page); `analyze.PageAnalyzer` returns the same shape.
+    magic b"RDP2", u32 n_pages, then per page: i64 global page index, one VALUE (the page's list of dicts).
+    VALUE = one tag byte + payload:  N None | T / F bool | i int64 | I arbitrary-size int (u32 n + decimal ascii) | d float64 |
+    s str (u32 n + utf-8) | b bytes (u32 n + raw) | l list / t tuple (u32 n + n VALUEs) | m dict (u32 n + n x (VALUE key, VALUE)) |
+    a numpy array (u8 len + dtype.str ascii, u8 ndim, ndim x i64 shape, raw C-order bytes).
+Numpy scalars travel as the Python number they convert to (float32 -> the same value as float64).  Still flat bytes: decoding
+never imports, evaluates or calls anything named by the peer."""
 from __future__ import annotations
 
 import struct
@@ -50,25 +60,190 @@ def decode_page_results(blob: bytes) -> List[Tuple[int, PageLines]]:
     return pages
 
 
-def gather_page_results(local: Sequence[Tuple[int, PageLines]], dist=None, device: Optional[torch.device] = None) -> List[Tuple[int, PageLines]]:
-    """local: [(global_page_idx, [(text, score), ...])] of this rank -> the full list sorted by page index, on every rank."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return sorted(((int(i), [(str(t), float(s)) for t, s in l]) for i, l in local), key=lambda t: t[0])
+# ---------------------------------------------------------------------------------------------------------------------
+# wire format v2: arbitrary page results (lists / dicts / numbers / strings / arrays)
+# ---------------------------------------------------------------------------------------------------------------------
+_MAGIC2 = b"RDP2"
+_MAX_DEPTH = 64
+
+
+def _enc_value(v, out: list, depth: int = 0) -> None:
+    import numpy as np
+    if depth > _MAX_DEPTH:
+        raise ValueError("page result nested deeper than %d levels" % _MAX_DEPTH)
+    if v is None:
+        out.append(b"N")
+    elif isinstance(v, (bool, np.bool_)):
+        out.append(b"T" if v else b"F")
+    elif isinstance(v, (int, np.integer)):
+        iv = int(v)
+        if -(1 << 63) <= iv < (1 << 63):
+            out.append(b"i" + struct.pack("<q", iv))
+        else:
+            digits = str(iv).encode("ascii")
+            out.append(b"I" + struct.pack("<I", len(digits)) + digits)
+    elif isinstance(v, (float, np.floating)):
+        out.append(b"d" + struct.pack("<d", float(v)))
+    elif isinstance(v, str):
+        b = v.encode("utf-8")
+        out.append(b"s" + struct.pack("<I", len(b)))
+        out.append(b)
+    elif isinstance(v, (bytes, bytearray)):
+        out.append(b"b" + struct.pack("<I", len(v)))
+        out.append(bytes(v))
+    elif isinstance(v, (list, tuple)):
+        out.append((b"l" if isinstance(v, list) else b"t") + struct.pack("<I", len(v)))
+        for x in v:
+            _enc_value(x, out, depth + 1)
+    elif isinstance(v, dict):
+        out.append(b"m" + struct.pack("<I", len(v)))
+        for k, x in v.items():
+            _enc_value(k, out, depth + 1)
+            _enc_value(x, out, depth + 1)
+    elif isinstance(v, np.ndarray):
+        if v.dtype.hasobject:
+            raise TypeError("object arrays do not travel")
+        dt = v.dtype.str.encode("ascii")
+        a = np.ascontiguousarray(v)
+        out.append(b"a" + struct.pack("<B", len(dt)) + dt + struct.pack("<B", a.ndim) + struct.pack("<%dq" % a.ndim, *a.shape))
+        out.append(a.tobytes())
+    else:
+        raise TypeError("page results carry numbers, strings, lists, tuples, dicts and arrays - not %s" % type(v).__name__)
+
+
+def _dec_value(view: memoryview, pos: int, depth: int = 0):
+    import numpy as np
+    if depth > _MAX_DEPTH:
+        raise ValueError("page-result blob nested deeper than %d levels" % _MAX_DEPTH)
+    tag = bytes(view[pos:pos + 1])
+    pos += 1
+    if tag == b"N":
+        return None, pos
+    if tag == b"T":
+        return True, pos
+    if tag == b"F":
+        return False, pos
+    if tag == b"i":
+        return struct.unpack_from("<q", view, pos)[0], pos + 8
+    if tag == b"d":
+        return struct.unpack_from("<d", view, pos)[0], pos + 8
+    if tag in (b"s", b"b", b"I"):
+        (n,) = struct.unpack_from("<I", view, pos)
+        pos += 4
+        if pos + n > len(view):
+            raise ValueError("page-result blob: truncated")
+        raw = bytes(view[pos:pos + n])
+        if tag == b"s":
+            return raw.decode("utf-8"), pos + n
+        if tag == b"I":
+            return int(raw.decode("ascii")), pos + n
+        return raw, pos + n
+    if tag in (b"l", b"t"):
+        (n,) = struct.unpack_from("<I", view, pos)
+        pos += 4
+        if n > len(view) - pos:                      # every element is at least one byte
+            raise ValueError("page-result blob: truncated")
+        items = []
+        for _ in range(n):
+            x, pos = _dec_value(view, pos, depth + 1)
+            items.append(x)
+        return (items if tag == b"l" else tuple(items)), pos
+    if tag == b"m":
+        (n,) = struct.unpack_from("<I", view, pos)
+        pos += 4
+        if 2 * n > len(view) - pos:
+            raise ValueError("page-result blob: truncated")
+        d = {}
+        for _ in range(n):
+            k, pos = _dec_value(view, pos, depth + 1)
+            x, pos = _dec_value(view, pos, depth + 1)
+            d[k] = x
+        return d, pos
+    if tag == b"a":
+        (nd,) = struct.unpack_from("<B", view, pos)
+        dt = np.dtype(bytes(view[pos + 1:pos + 1 + nd]).decode("ascii"))
+        pos += 1 + nd
+        if dt.hasobject:
+            raise ValueError("page-result blob: object dtype")
+        (ndim,) = struct.unpack_from("<B", view, pos)
+        shape = struct.unpack_from("<%dq" % ndim, view, pos + 1)
+        pos += 1 + 8 * ndim
+        if any(x < 0 for x in shape):
+            raise ValueError("page-result blob: negative dimension")
+        count = 1
+        for x in shape:
+            count *= x
+        nbytes = count * dt.itemsize
+        if pos + nbytes > len(view):
+            raise ValueError("page-result blob: truncated")
+        return np.frombuffer(bytes(view[pos:pos + nbytes]), dtype=dt).reshape(shape).copy(), pos + nbytes
+    raise ValueError("page-result blob: unknown tag %r" % tag)
+
+
+def encode_page_dets(local: Sequence[Tuple[int, object]]) -> bytes:
+    """[(global page index, that page's result - e.g. PageAnalyzer's list of layout_dets dicts)] -> wire format v2."""
+    out = [_MAGIC2, struct.pack("<I", len(local))]
+    for idx, dets in local:
+        out.append(struct.pack("<q", int(idx)))
+        _enc_value(dets, out)
+    return b"".join(out)
+
+
+def decode_page_dets(blob: bytes) -> List[Tuple[int, object]]:
+    view = memoryview(blob)
+    if bytes(view[:4]) != _MAGIC2:
+        raise ValueError("page-result blob: not wire format v2")
+    try:
+        (n,), pos = struct.unpack_from("<I", view, 4), 8
+        pages = []
+        for _ in range(n):
+            (idx,) = struct.unpack_from("<q", view, pos)
+            dets, pos = _dec_value(view, pos + 8)
+            pages.append((idx, dets))
+    except struct.error as e:
+        raise ValueError("page-result blob: truncated") from e
+    if pos != len(blob):
+        raise ValueError("page-result blob: trailing bytes")
+    return pages
+
+
+def _all_gather_blobs(blob: bytes, dist, device: Optional[torch.device] = None) -> List[bytes]:
+    """One int64 all-gather of the lengths, one padded uint8 all-gather of the payloads -> every rank's blob, in rank order."""
     world = dist.get_world_size()
-    backend = dist.get_backend()
     if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    blob = encode_page_results(local)
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     n = torch.tensor([len(blob)], dtype=torch.int64, device=device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n)
     sizes = [int(s.item()) for s in sizes]
     cap = max(max(sizes), 1)
     buf = torch.zeros(cap, dtype=torch.uint8, device=device)
-    buf[: len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+    if len(blob):
+        buf[: len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
     out = [torch.empty(cap, dtype=torch.uint8, device=device) for _ in range(world)]
     dist.all_gather(out, buf)
+    return [out[r][: sizes[r]].cpu().numpy().tobytes() for r in range(world)]
+
+
+def gather_page_dets(local: Sequence[Tuple[int, object]], dist=None, device: Optional[torch.device] = None) -> List[Tuple[int, object]]:
+    """local: [(global_page_idx, page result)] of this rank -> every rank's pages merged and sorted by page index, on every rank
+    (north_star: "an RCCL all-gather over xGMI only to reassemble per-document results"; the reference re-associates the per-page
+    `layout_dets` lists by index in pipeline_analyze.py:221-228).  A single rank goes through the same encode / decode, so that
+    the merged result of N ranks equals the single-rank result object for object."""
+    blob = encode_page_dets(local)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return sorted(decode_page_dets(blob), key=lambda t: t[0])
+    merged: List[Tuple[int, object]] = []
+    for b in _all_gather_blobs(blob, dist, device):
+        merged.extend(decode_page_dets(b))
+    return sorted(merged, key=lambda t: t[0])
+
+
+def gather_page_results(local: Sequence[Tuple[int, PageLines]], dist=None, device: Optional[torch.device] = None) -> List[Tuple[int, PageLines]]:
+    """local: [(global_page_idx, [(text, score), ...])] of this rank -> the full list sorted by page index, on every rank."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return sorted(((int(i), [(str(t), float(s)) for t, s in l]) for i, l in local), key=lambda t: t[0])
     merged: List[Tuple[int, PageLines]] = []
-    for r in range(world):
-        merged.extend(decode_page_results(out[r][: sizes[r]].cpu().numpy().tobytes()))
+    for b in _all_gather_blobs(encode_page_results(local), dist, device):
+        merged.extend(decode_page_results(b))
     return sorted(merged, key=lambda t: t[0])
