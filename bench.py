@@ -8,8 +8,10 @@
 A "step" = one pass of the hot path over one batch of 32 synthetic 1684x1191 pages per GPU (BASELINE.json
 configs[1]): PPHGNetV2-B4 backbone @800x800 (the PP-DocLayout-L/V2/V3 backbone; neck/decoder are ONNX-only and
 absent), PP-OCRv6-small det @960x704, PP-OCRv6-small rec on the 45 text lines of every page, fused
-CTC argmax, host CTC decode.  Pages are resident in HBM as u8 when the timed region starts; weights are
-seed-0 synthetic (no checkpoints exist offline) - throughput is weight independent.
+CTC argmax, host CTC decode.  A document STREAM: --vary-pages different page sets (default 8) cycle through the steps, and every
+step's pages start in pinned HOST memory and are uploaded inside the timed region (copy stream, batch i + 1 under batch i;
+--resident-pages --vary-pages 1 = rounds 1-3: one set, resident in HBM).  Weights are seed-0 synthetic (no checkpoints exist
+offline) - throughput is weight independent.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -189,10 +191,15 @@ def main():
                          "(one global argsort, chunks of 6, every line at the padded width int(48 * max ratio) of ITS chunk, "
                          "rapid_ocr.py:404-449) in GPU-sized launches (rd_rec_backbone_forward_lines); throughput = every line at its "
                          "launch's width.  The other mode is measured in a short post-pass and reported next to it")
-    ap.add_argument("--vary-pages", type=int, default=1,
-                    help="K > 1: K different page sets, step i runs set i mod K (a real document stream never repeats a batch: every "
-                         "step then meets new line widths / token counts, i.e. the plan caches and the tail's bucketing are exercised; "
-                         "the default re-runs one set, like the reference's own benchmark loop would)")
+    ap.add_argument("--vary-pages", type=int, default=8,
+                    help="K different page sets, step i runs set i mod K: a document stream does not repeat a batch, so the steps keep "
+                         "meeting new line widths / token counts (plan caches, hipGraph slots and the tail's bucketing are exercised, and "
+                         "with K > --warmup the timed region builds the plans of the sets it has not seen: config.plan_cache_misses). "
+                         "1 = re-run one set (what rounds 1-3 measured)")
+    ap.add_argument("--resident-pages", action="store_true",
+                    help="keep the page sets in HBM and skip the host -> device upload of every step (rounds 1-3); default: the pages of "
+                         "every step start in pinned HOST memory, like the arrays the reference hands to a batch (batch_analyze.py:108-111), "
+                         "and are uploaded inside the timed region by PageUploader (copy stream, batch i + 1 under batch i)")
     ap.add_argument("--no-extra-passes", action="store_true", help="skip the post-passes (other rec mode, fp32 precision, backbone alone)")
     args = ap.parse_args()
 
@@ -227,7 +234,7 @@ def main():
     if dist:
         dist.barrier()
     from rapiddoc_amd.pages import synth_batch
-    from rapiddoc_amd.pipeline import PagePipelinePool, boxes_to_quads, render_text_maps
+    from rapiddoc_amd.pipeline import PagePipelinePool, PageUploader, boxes_to_quads, render_text_maps
     from rapiddoc_amd.dist import gather_page_results
 
     states = load_states()
@@ -245,11 +252,20 @@ def main():
     pages_np, boxes = synth_pages(my_pages)
     pages = torch.from_numpy(pages_np).cuda()
     K_sets = max(1, args.vary_pages)
-    # further page sets (--vary-pages): the same shard positions of later "documents" (page ids offset by n_global * k)
-    page_sets = [(pages, boxes)]
+    upload = not args.resident_pages
+    # page sets (--vary-pages): the same shard positions of later "documents" (page ids offset by n_global * k).  With the upload in
+    # the timed region they live in pinned host memory (a renderer would write them there), else in HBM.
+    def place(arr):
+        if not upload:
+            return torch.from_numpy(arr).cuda()
+        t = PageUploader.pinned_like(arr.shape)
+        t.copy_(torch.from_numpy(arr))
+        return t
+    page_sets = [(place(pages_np), boxes)]
     for k in range(1, K_sets):
         pk, bk = synth_pages([i + n_global * k for i in my_pages])
-        page_sets.append((torch.from_numpy(pk).cuda(), bk))
+        page_sets.append((place(pk), bk))
+    uploader = PageUploader(dev_index, n_buffers=2) if upload else None
     if args.only == "backbone":
         return bench_backbone(args, pool, pages, rank, world, dist, backend)
     # random-weight det maps carry no text, so the DB post-process stage gets maps rendered from the generator's own
@@ -260,11 +276,25 @@ def main():
     quads = None
     step_no = [0]
 
-    def compute(k=0):
+    def compute(k=0, ticket=None):
+        """One step on pool k.  `ticket`: (PageUploader ticket, set index) of pages already travelling; else the step's own set is taken
+        (resident, or - pinned host pages - uploaded by run_batch on the spot)."""
+        if ticket is None:
+            si = step_no[0] % K_sets
+            step_no[0] += 1
+            pg = page_sets[si][0]
+        else:
+            tk, si = ticket
+            pg = uploader.wait(tk)
+        res = pools[k].run_batch(pg, quads, det_maps_override=set_maps[si])
+        if ticket is not None:
+            uploader.release(tk)
+        return [(my_pages[i], [(t, s) for _, t, s in r.lines]) for i, r in enumerate(res)]
+
+    def next_ticket():
         si = step_no[0] % K_sets
         step_no[0] += 1
-        res = pools[k].run_batch(page_sets[si][0], quads, det_maps_override=set_maps[si])
-        return [(my_pages[i], [(t, s) for _, t, s in r.lines]) for i, r in enumerate(res)]
+        return uploader.submit(page_sets[si][0]), si
 
     def step():
         return gather_page_results(compute(0), dist)
@@ -275,9 +305,14 @@ def main():
         if len(pools) == 1:
             out = None
             trace = os.environ.get("RD_BENCH_STEP_TIMES") == "1"      # developer: per-step host times on stderr
-            for _ in range(n):
+            nxt = next_ticket() if upload and n > 0 else None       # the first batch's upload is exposed, the others run under a batch
+            for i in range(n):
                 ts = time.perf_counter()
-                out = step()
+                if upload:
+                    cur, nxt = nxt, (next_ticket() if i + 1 < n else None)
+                    out = gather_page_results(compute(0, cur), dist)
+                else:
+                    out = step()
                 if trace:
                     torch.cuda.synchronize()
                     print("step %.1f ms" % ((time.perf_counter() - ts) * 1e3), file=sys.stderr)
@@ -318,10 +353,20 @@ def main():
         for k in range(len(pools)):
             gather_page_results(compute(k), dist)
     fence()
+    plans_before = sum(e.plan_stats()["plans_built"] for q in pools for e in q.engines)
     t0 = time.perf_counter()
     out = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
+    plan_stats = [e.plan_stats() for q in pools for e in q.engines]
+    plan_misses = sum(p["plans_built"] for p in plan_stats) - plans_before
+    h2d_ms = None
+    if upload:          # one batch's upload alone, outside the timed region (inside it the copies run under the previous batch)
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        uploader.wait(uploader.submit(page_sets[0][0]))
+        torch.cuda.synchronize()
+        h2d_ms = (time.perf_counter() - th) * 1e3
     if dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -469,6 +514,12 @@ def main():
                        "rec_launch_batches": int(pool.stats.get("rec_batches", 0)),
                        "pages_per_gpu": P, "global_pages": n_global, "pages_gathered": len(out), "result_crc32": result_crc,
                        "page_sets_cycled": K_sets,
+                       "pages_start_in": "pinned host memory: every step's %.0f MB are uploaded inside the timed region (PageUploader: copy "
+                                         "stream, batch i + 1 under batch i; the first batch's copy is exposed)" % (pages_np.nbytes / 1e6)
+                                         if upload else "HBM (resident, --resident-pages)",
+                       "h2d_ms_per_batch_alone": None if h2d_ms is None else round(h2d_ms, 3),
+                       "plan_cache_misses": int(plan_misses),     # per-shape plans built INSIDE the timed region (new rec / tail shapes of unseen page sets)
+                       "hipgraph": {"captures": int(sum(p["graph_captures"] for p in plan_stats)), "replays": int(sum(p["graph_replays"] for p in plan_stats))},
                        "lines_per_step": n_lines, "host_stage_ms": host_stats,
                        "host_ms_per_step_max_over_ranks": round(host_ms_max, 2), "cores_per_rank": cores_per_rank,
                        "range_fallbacks": int(sum(e.range_fallbacks for q in pools for e in q.engines)),   # engines that left the split-fp16 mode (0 = the dtype claim holds)

@@ -275,6 +275,11 @@ int rd_rec_plan_chunks(const int32_t* wpad_sorted, int n, int n_min, int n_max, 
 int rd_set_precision(rd_handle* h, const char* mode);
 int rd_range_status(rd_handle* h, void* stream);
 
+/* Cache behaviour of a handle since rd_create: per-shape plans built, hipGraph captures and hipGraph replays (each may be NULL).
+ * A forward on a new (B, H, W, flags) builds a plan on the host; the second time a (plan, pointers, stream) triple shows up it is
+ * captured, from the third on replayed.  bench.py reports the plans a non-repeating document stream builds inside its timed region. */
+int rd_plan_stats(rd_handle* h, uint64_t* plans_built, uint64_t* graph_captures, uint64_t* graph_replays);
+
 /* per-op HIP-event timing of the NEXT forward calls; rd_profile_json returns the last call's table as a JSON
  * array [{"name","kind","cfg","flops","bytes","ms"}, ...] owned by the handle. */
 int rd_set_profiling(rd_handle* h, int on);

@@ -56,6 +56,7 @@ SYMBOLS = {
     "rd_fill_poly": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     "rd_set_precision": (C.c_int, [C.c_void_p, C.c_char_p]),
     "rd_range_status": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rd_plan_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rd_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "rd_profile_json": (C.c_char_p, [C.c_void_p]),
 }

@@ -443,6 +443,14 @@ int rd_range_status(rd_handle* h, void* stream) {
     return rc != 0 ? -1 : out;
 }
 
+int rd_plan_stats(rd_handle* h, uint64_t* plans_built, uint64_t* graph_captures, uint64_t* graph_replays) {
+    if (!h || !h->eng) return 1;
+    if (plans_built) *plans_built = h->eng->plans_built();
+    if (graph_captures) *graph_captures = h->eng->graph_captures();
+    if (graph_replays) *graph_replays = h->eng->graph_replays();
+    return 0;
+}
+
 int rd_set_profiling(rd_handle* h, int on) {
     return guarded(h, [&] { if (h->eng) h->eng->set_profiling(on != 0); });
 }

@@ -1288,6 +1288,7 @@ const Plan& Engine::plan_for(int B, int H, int W, int flags) {
             if (j->second->last_use < victim->second->last_use) victim = j;
         plans_.erase(victim);
     }
+    ++plans_built_;
     auto plan = std::make_unique<Plan>();
     Builder b(Mode::PLAN, &store_, &params_, plan.get(), precision_ == PREC_H3, precision_ == PREC_AUTO, range_flag_);
     build(b, B, H, W, flags);
@@ -1367,6 +1368,7 @@ void Engine::run(int B, int H, int W, int flags, const std::vector<void*>& ext, 
             if (slot && slot->exec) {
                 slot->last_use = ++plan_clock_;
                 plan.graph_evictions = 0;     // replays do happen for this plan
+                ++graph_replays_;
                 RD_HIP(hipGraphLaunch(slot->exec, s));
                 return;
             }
@@ -1381,6 +1383,7 @@ void Engine::run(int B, int H, int W, int flags, const std::vector<void*>& ext, 
                 if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
                 if (graph) (void)hipGraphDestroy(graph);
                 if (ok) {
+                    ++graph_captures_;
                     slot->exec = exec;
                     slot->last_use = ++plan_clock_;
                     RD_HIP(hipGraphLaunch(exec, s));

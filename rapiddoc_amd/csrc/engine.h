@@ -241,6 +241,11 @@ class Engine {
     // run with caller-provided externals (model specific order); ws may be null (internal arena)
     void run(int B, int H, int W, int flags, const std::vector<void*>& ext, void* ws, size_t ws_bytes, hipStream_t s);
 
+    // plans built / hipGraph captures / hipGraph replays since the handle was created (a document stream keeps meeting new shapes:
+    // bench.py reports how many of them fell into its timed region)
+    uint64_t plans_built() const { return plans_built_; }
+    uint64_t graph_captures() const { return graph_captures_; }
+    uint64_t graph_replays() const { return graph_replays_; }
     void set_profiling(bool on) { profiling_ = on; }
     const std::vector<ProfileEntry>& last_profile() const { return profile_; }
     std::string profile_json() const;
@@ -277,6 +282,7 @@ class Engine {
     WeightStore store_;
     std::map<std::tuple<int, int, int, int>, std::unique_ptr<Plan>> plans_;
     uint64_t plan_clock_ = 0;
+    uint64_t plans_built_ = 0, graph_captures_ = 0, graph_replays_ = 0;
     static constexpr size_t kMaxPlans = 512;   // least recently used plans are dropped beyond this
     static constexpr size_t kMaxGraphSlots = 8;
     static constexpr unsigned kMaxGraphEvictions = 32;   // a plan whose external pointers keep changing never replays: stop capturing it

@@ -343,6 +343,12 @@ class RdEngine:
         return rc == 1
 
     # ------------------------------------------------------------------ profiling
+    def plan_stats(self) -> dict:
+        """{plans_built, graph_captures, graph_replays} of this handle since it was created (rd_plan_stats)."""
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._l.rd_plan_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"plans_built": int(a.value), "graph_captures": int(b.value), "graph_replays": int(c.value)}
+
     def set_profiling(self, on: bool):
         self._chk(self._l.rd_set_profiling(self._h, 1 if on else 0))
         self._profiling = bool(on)

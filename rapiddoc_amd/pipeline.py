@@ -613,7 +613,12 @@ class PagePipeline:
                   det_maps_override: Optional[torch.Tensor] = None) -> List[PageResult]:
         """`_run_batch_once` plus the range guard of the split-fp16 kernels (include/rapiddoc_mi355.h, rd_range_status):
         an engine that met an operand outside the fp16 range is switched to native fp32 for good and the batch is
-        repeated, so a result is never silently wrong."""
+        repeated, so a result is never silently wrong.  `pages`: [P,H,W,3] uint8 RGB on the GPU, or host pages (numpy / CPU tensor,
+        what the reference's caller holds: batch_analyze.py:108-111), which are uploaded first - a stream of batches should go through
+        `PageUploader` instead, whose copies run under the previous batch."""
+        if isinstance(pages, np.ndarray) or not pages.is_cuda:
+            src = torch.from_numpy(np.ascontiguousarray(pages)) if isinstance(pages, np.ndarray) else pages.contiguous()
+            pages = src.to(self.tdev, non_blocking=src.is_pinned())
         results = self._run_batch_once(pages, quads_per_page, det_maps_override)
         # det and the layout backbone (the rec engines are guarded inside rec_forward_lines)
         engines = [self.det] + ([self.layout] if self.layout is not None else [])
@@ -675,6 +680,78 @@ def render_text_maps(boxes_per_page: Sequence[np.ndarray], page_hw: Tuple[int, i
     return maps.to(device)
 
 
+class PageUploader:
+    """Host -> device upload of a STREAM of page batches.  The reference hands host arrays to every batch
+    (`np.array(image)` per page, batch_analyze.py:108-111); on the GPU the 6 MB a page weighs (192 MB per 32-page batch, ~4 ms of
+    PCIe) must not sit in front of the networks, so: `n_buffers` device buffers, the copy of batch i + 1 enqueued on a copy stream of
+    its own while batch i computes, and an event per batch that the consumer's stream waits on.
+
+        up = PageUploader(device)
+        nxt = up.submit(first_batch)                    # numpy [P,H,W,3] u8 or a CPU tensor (pinned: truly asynchronous)
+        for batch in rest:
+            cur, nxt = nxt, up.submit(batch)            # batch i + 1 travels under batch i's kernels
+            results = pipe.run_batch(up.wait(cur))      # the current stream waits for ITS pages only
+
+    A buffer is re-used `n_buffers` submits later; `submit` makes the copy stream wait for the work that was enqueued on the
+    consumer's stream when `wait` handed the buffer out - the caller must have ENQUEUED everything that reads a batch before the
+    submit that recycles its buffer (true for the loop above with n_buffers >= 2).  Pageable sources are staged through a pinned
+    buffer of the uploader (one host memcpy); render into `pinned_like(...)` buffers to avoid it."""
+
+    def __init__(self, device: int = 0, n_buffers: int = 2):
+        self.tdev = torch.device("cuda", device)
+        self.stream = torch.cuda.Stream(device=self.tdev)
+        self.n = max(2, n_buffers)
+        self._dev: List[Optional[torch.Tensor]] = [None] * self.n
+        self._pin: List[Optional[torch.Tensor]] = [None] * self.n
+        self._released: List[Optional[torch.cuda.Event]] = [None] * self.n
+        self._i = 0
+        self.bytes_uploaded = 0
+
+    @staticmethod
+    def pinned_like(shape) -> torch.Tensor:
+        """A pinned uint8 host buffer to render pages into (its upload needs no staging copy)."""
+        return torch.empty(tuple(shape), dtype=torch.uint8, pin_memory=True)
+
+    def submit(self, pages_host) -> Tuple[torch.Tensor, torch.cuda.Event, int]:
+        src = torch.from_numpy(pages_host) if isinstance(pages_host, np.ndarray) else pages_host
+        assert not src.is_cuda and src.dtype == torch.uint8 and src.dim() == 4 and src.is_contiguous()
+        k = self._i % self.n
+        self._i += 1
+        if self._dev[k] is None or self._dev[k].numel() < src.numel():
+            self._dev[k] = torch.empty(int(src.numel() * 1.1) + 256, dtype=torch.uint8, device=self.tdev)
+        dst = self._dev[k][: src.numel()].view(src.shape)
+        if self._released[k] is not None:
+            self.stream.wait_event(self._released[k])              # the batch that used this buffer has been consumed (enqueued work done)
+        if not src.is_pinned():
+            if self._pin[k] is None or self._pin[k].numel() < src.numel():
+                self._pin[k] = torch.empty(int(src.numel() * 1.1) + 256, dtype=torch.uint8, pin_memory=True)
+            self.stream.synchronize()                              # the staging buffer's previous copy has left the host
+            stage = self._pin[k][: src.numel()].view(src.shape)
+            stage.copy_(src)
+            src = stage
+        with torch.cuda.stream(self.stream):
+            dst.copy_(src, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.bytes_uploaded += src.numel()
+        return dst, ev, k
+
+    def wait(self, ticket: Tuple[torch.Tensor, torch.cuda.Event, int]) -> torch.Tensor:
+        """The device tensor of a submitted batch, valid on the CURRENT stream from here on."""
+        dst, ev, k = ticket
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ev)
+        return dst
+
+    def release(self, ticket) -> None:
+        """Call after the work that reads the batch has been enqueued on the current stream: its buffer may be recycled once that
+        work is done."""
+        _dst, _ev, k = ticket
+        rel = torch.cuda.Event()
+        rel.record(torch.cuda.current_stream())
+        self._released[k] = rel
+
+
 class PagePipelinePool:
     """`workers` PagePipelines on one GPU, each fed a contiguous shard of the page batch from its own host thread and HIP
     streams.  A page batch has host stages between its GPU stages (det maps -> DB post-process -> crop descriptors;
@@ -697,6 +774,9 @@ class PagePipelinePool:
 
     def run_batch(self, pages: torch.Tensor, quads_per_page: Optional[Sequence[np.ndarray]] = None,
                   det_maps_override: Optional[torch.Tensor] = None) -> List[PageResult]:
+        if isinstance(pages, np.ndarray) or not pages.is_cuda:      # host pages: one upload for all shards (see PagePipeline.run_batch)
+            src = torch.from_numpy(np.ascontiguousarray(pages)) if isinstance(pages, np.ndarray) else pages.contiguous()
+            pages = src.to(self.pipes[0].tdev, non_blocking=src.is_pinned())
         P = pages.shape[0]
         n = min(len(self.pipes), max(1, P))
         bounds = [P * k // n for k in range(n + 1)]
