@@ -174,12 +174,13 @@ int rd_line_resize_norm_batch(int device_id, const rd_line_crop_desc* descs_dev,
 int rd_ctc_collapse(int device_id, const int32_t* idx_bt_dev, const float* prob_bt_dev, int B, int T, const uint8_t* char_table_dev,
                     int max_len, int n_classes, uint8_t* out_dev, int row_bytes, void* stream);
 /* The same over RAGGED lines as rd_rec_tail_forward leaves them: line b = seg_dev[2 b + 1] tokens (<= max_tokens <= 65535) starting at
- * token seg_dev[2 b] of idx_dev / prob_dev.  kept_cols_dev (may be NULL): uint16 [n_lines][max_tokens], the time step of every kept
- * character in order (n_kept of them, header field 2) - the `selection` rapidocr's CTCLabelDecode passes to get_word_info when
- * return_word_box is set (RapidDoc's patched version: rapid_doc/model/ocr/ocr_patch.py:333-389; table OCR default, analyze_utils.py:308). */
+ * token seg_dev[2 b] of idx_dev / prob_dev.  kept_cols_dev / kept_conf_dev (each may be NULL): uint16 / float32 [n_lines][max_tokens],
+ * the time step and the probability of every kept character in order (n_kept of them, header field 2) - the `selection` and the
+ * `conf_list` rapidocr's CTCLabelDecode hands to get_word_info / WordInfo when return_word_box is set (RapidDoc's patched
+ * get_word_info and cal_ocr_word_box: rapid_doc/model/ocr/ocr_patch.py:264-389; table OCR default, analyze_utils.py:308). */
 int rd_ctc_collapse_lines(int device_id, const int32_t* idx_dev, const float* prob_dev, int n_lines, const int32_t* seg_dev, int max_tokens,
                           const uint8_t* char_table_dev, int max_len, int n_classes, uint8_t* out_dev, int row_bytes, uint16_t* kept_cols_dev,
-                          void* stream);
+                          float* kept_conf_dev, void* stream);
 
 /* DB post-process (HOST pointers, runs on the host like the reference's): probability maps [B][H][W] -> text boxes.
  * Replaces rapidocr DBPostProcess.__call__ as patched in rapid_doc/model/ocr/ocr_patch.py:223-241 (box_type "quad",

@@ -310,18 +310,23 @@ class TableOcr:
       crop (`table_crop_rect`) -> formula boxes of the page in crop coordinates, with their `latex` (get_adjusted_mfdetrec_res,
       return_text) -> detector on the crop with those boxes whited out, box_thresh 0.5 / unclip 1.6, boxes sorted and cut around the
       formulas but NOT merged (`ocr(det, rec=False)`, rapid_ocr.py:257-281) -> every line cropped from the UNmasked image and
-      recognised in one call (`_run_table_ocr` :478-540, line level: `use_word_box=False`; the word-box variant lives in rapidocr's
-      `cal_rec_boxes`, absent) -> texts through `normalize_table_ocr_text` -> `table_model.predict(table_img RGB, [boxes, texts,
+      recognised in one call (`_run_table_ocr` :478-540).  `use_word_box` (the reference's default, analyze_utils.py:308): the OCR result
+      handed on is one entry per WORD / CJK character - `ocr(det=False, return_word_box=True)` (rapid_ocr.py:282-299) -> per line the
+      words with boxes in table coordinates (rapiddoc_amd/word_boxes.py: RapidDoc's patched get_word_info / cal_ocr_word_box and
+      calc_word_boxes pinned to the reference, rapidocr's own box arithmetic restated and unpinned), lines whose word list came back
+      empty shift the pairing exactly as the reference's zip does (rapid_ocr.py:295); `use_word_box=False`: one entry per line
+      -> texts through `normalize_table_ocr_text` -> `table_model.predict(table_img RGB, [boxes, texts,
       scores], fill_image_res, formula boxes, skip_text_in_image, use_img2table, skip_table_orientation=True)` -> the
       `<table>...</table>` part of the answer becomes the region's `html`, and `formula_boxes` = every formula box of the page
       divided by the page's render scale (:405-418).
 
     The detector / recogniser are the pipeline's GPU engines; `det_raw_fn(canvas [1,h,w,3] u8 RGB, 1) -> [raw boxes [n,4,2]]` and
-    `rec_fn(canvas [1,h,w,3], quads [n,4,2]) -> [(text, score)]` replace them (tests replaying traces of the reference)."""
+    `rec_fn(canvas [1,h,w,3], quads [n,4,2]) -> [(text, score)]` (with `use_word_box`: `[(text, score, [(word, conf, box) ...])]`, what
+    rapidocr's cal_rec_boxes leaves per line) replace them (tests replaying traces of the reference)."""
 
     def __init__(self, pipeline, det_raw_fn=None, rec_fn=None, skip_text_in_image: bool = True, use_img2table: bool = False,
-                 table_formula_enable: bool = True, lang: str = "ch"):
-        self.pipe, self.rec_fn = pipeline, rec_fn
+                 table_formula_enable: bool = True, lang: str = "ch", use_word_box: bool = True):
+        self.pipe, self.rec_fn, self.use_word_box = pipeline, rec_fn, use_word_box
         self.det = RegionOcr(pipeline, box_thresh=0.5, unclip_ratio=1.6, lang=lang, det_raw_fn=det_raw_fn)
         self.skip_text_in_image, self.use_img2table, self.table_formula_enable = skip_text_in_image, use_img2table, table_formula_enable
 
@@ -350,11 +355,33 @@ class TableOcr:
         if not boxes:
             return []
         quads = np.asarray(boxes, dtype=np.float32).reshape(-1, 4, 2)
+        if self.use_word_box:
+            return self._word_level(canvas, quads, h, w, lang)
         if self.rec_fn is not None:
             lines = self.rec_fn(canvas, quads)
         else:
             lines = self.det._pipe_for(lang or self.det.lang).rec_forward_sources([(canvas.contiguous(), [quads])], image_keys=[[0]])[0][0]
         return [[q for q in quads], [table_host.normalize_table_ocr_text(t) for t, _s in lines], [s for _t, s in lines]]
+
+    def _word_level(self, canvas: torch.Tensor, quads: np.ndarray, h: int, w: int, lang: Optional[str]) -> list:
+        """`_run_table_ocr` with table_use_word_box (analyze_utils.py:478-540): [word boxes, word texts, word confidences]."""
+        from . import word_boxes as WB
+        if self.rec_fn is not None:
+            lines = self.rec_fn(canvas, quads)                     # [(text, score, [(word, conf, box)])]
+        else:
+            raw = self.det._pipe_for(lang or self.det.lang).rec_forward_sources([(canvas.contiguous(), [quads])], image_keys=[[0]],
+                                                                                want_words=True)[0][0]
+            infos = [WB.decode_word_info(t, ws["cols"], ws["confs"], ws["n_steps"], ws["wh_ratio"], ws["max_wh_ratio"]) if ws else WB.WordInfo()
+                     for t, _s, ws in raw]
+            crop_hw = [ws["crop_hw"] if ws else (1, 1) for _t, _s, ws in raw]
+            word_lines = WB.cal_rec_boxes(crop_hw, [q for q in quads], [t for t, _s, _w in raw], infos)
+            lines = [(t, s, wl) for (t, s, _w), wl in zip(raw, word_lines)]
+        origin = WB.calc_word_boxes([wl for _t, _s, wl in lines], h, w)     # (lines without words drop out: rapid_ocr.py:325-326)
+        rec_res = list(zip([t for t, _s, _w in lines], [s for _t, s, _w in lines], origin))      # rapid_ocr.py:295 - zip, as it is
+        out = []
+        for _q, res in zip(quads, rec_res):
+            out.extend([wr[2], table_host.normalize_table_ocr_text(wr[0]), wr[1]] for wr in res[2])
+        return [list(x) for x in zip(*out)] if out else []
 
     def __call__(self, pages: torch.Tensor, layout_dets_per_page: Sequence[Sequence[dict]], table_model,
                  page_scales: Optional[Sequence[float]] = None, det_maps_fn=None, table_image_enable: bool = True,
@@ -461,7 +488,7 @@ class PageAnalyzer:
     def __init__(self, layout_model, pipeline, formula_model=None, table_model=None, custom_ocr=None, layout_batch_size: int = 1,
                  formula_level: int = 0, box_thresh: float = 0.3, unclip_ratio: float = 1.8, formula_batch_size: int = 1,
                  formula_expand_px: int = 2, det_batch_num: Optional[int] = None, det_raw_fn=None, lang: str = "ch",
-                 table_det_raw_fn=None, table_rec_fn=None, table_image_enable: bool = True):
+                 table_det_raw_fn=None, table_rec_fn=None, table_image_enable: bool = True, table_use_word_box: bool = True):
         """Batch sizes default to the reference's (layout_config['batch_num'] / formula_config['batch_num'] = 1,
         batch_analyze.py:66-71); `det_batch_num` / `det_raw_fn`: see RegionOcr."""
         self.layout_model, self.pipe = layout_model, pipeline
@@ -469,7 +496,8 @@ class PageAnalyzer:
         self.layout_batch_size, self.formula_level = layout_batch_size, formula_level
         self.formula_batch_size, self.formula_expand_px = formula_batch_size, formula_expand_px
         self.ocr = RegionOcr(pipeline, box_thresh, unclip_ratio, lang, det_batch_num, det_raw_fn)
-        self.table_ocr = TableOcr(pipeline, det_raw_fn=table_det_raw_fn, rec_fn=table_rec_fn, lang=lang)
+        # table_config["use_word_box"], default True (analyze_utils.py:308): word-level OCR entries for the table model
+        self.table_ocr = TableOcr(pipeline, det_raw_fn=table_det_raw_fn, rec_fn=table_rec_fn, lang=lang, use_word_box=table_use_word_box)
         self.table_image_enable = table_image_enable          # table_config["table_image_enable"], default True (batch_analyze.py:75)
 
     def __call__(self, pages: torch.Tensor, det_maps_fn=None, page_scales: Optional[Sequence[float]] = None,

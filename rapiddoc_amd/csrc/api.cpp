@@ -255,15 +255,17 @@ int rd_ctc_collapse(int device_id, const int32_t* idx, const float* prob, int B,
                     uint8_t* out, int row_bytes, void* stream) {
     if (!idx || !prob || !ctab || !out || B < 0 || T <= 0 || max_len <= 0 || n_classes <= 0) return 1;
     if (hipSetDevice(device_id) != hipSuccess) return 1;
-    if (rd::launch_ctc_collapse(idx, prob, B, T, nullptr, ctab, max_len, n_classes, out, row_bytes, nullptr, (hipStream_t)stream) != 0) return 1;
+    if (rd::launch_ctc_collapse(idx, prob, B, T, nullptr, ctab, max_len, n_classes, out, row_bytes, nullptr, nullptr, (hipStream_t)stream) != 0) return 1;
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 int rd_ctc_collapse_lines(int device_id, const int32_t* idx, const float* prob, int n_lines, const int32_t* seg, int max_tokens,
-                          const uint8_t* ctab, int max_len, int n_classes, uint8_t* out, int row_bytes, uint16_t* kept_cols, void* stream) {
+                          const uint8_t* ctab, int max_len, int n_classes, uint8_t* out, int row_bytes, uint16_t* kept_cols, float* kept_conf,
+                          void* stream) {
     if (!idx || !prob || !seg || !ctab || !out || n_lines < 0 || max_tokens <= 0 || max_len <= 0 || n_classes <= 0) return 1;
     if (hipSetDevice(device_id) != hipSuccess) return 1;
-    if (rd::launch_ctc_collapse(idx, prob, n_lines, max_tokens, seg, ctab, max_len, n_classes, out, row_bytes, kept_cols, (hipStream_t)stream) != 0)
+    if (rd::launch_ctc_collapse(idx, prob, n_lines, max_tokens, seg, ctab, max_len, n_classes, out, row_bytes, kept_cols, kept_conf,
+                                (hipStream_t)stream) != 0)
         return 1;
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }

@@ -304,7 +304,7 @@ __device__ float np_pairwise_sum_f32(const float* a, int n) {
 __global__ void __launch_bounds__(256) ctc_collapse_kernel(const int32_t* __restrict__ idx, const float* __restrict__ prob, int Tmax,
                                                            const int32_t* __restrict__ seg, const uint8_t* __restrict__ ctab, int max_len,
                                                            int n_classes, uint8_t* __restrict__ out, int row_bytes,
-                                                           uint16_t* __restrict__ kept_cols) {
+                                                           uint16_t* __restrict__ kept_cols, float* __restrict__ kept_conf) {
     extern __shared__ unsigned char smem[];
     float* kept = reinterpret_cast<float*>(smem);                  // [T] kept probabilities, compacted
     int* scan = reinterpret_cast<int*>(smem + (size_t)Tmax * 4);   // [2][256] scan scratch
@@ -342,6 +342,7 @@ __global__ void __launch_bounds__(256) ctc_collapse_kernel(const int32_t* __rest
         if (keep) {
             kept[pos_k] = prow[t];
             if (kept_cols) kept_cols[(size_t)line * Tmax + pos_k] = (uint16_t)t;
+            if (kept_conf) kept_conf[(size_t)line * Tmax + pos_k] = prow[t];
             const uint8_t* src = ctab + (size_t)id * (max_len + 1) + 1;
             for (int b = 0; b < len; ++b) orow[16 + pos_b + b] = src[b];
         }
@@ -365,12 +366,12 @@ __global__ void __launch_bounds__(256) ctc_collapse_kernel(const int32_t* __rest
 
 namespace rd {
 int launch_ctc_collapse(const int32_t* idx, const float* prob, int B, int T, const int32_t* seg, const uint8_t* ctab, int max_len, int n_classes,
-                        uint8_t* out, int row_bytes, uint16_t* kept_cols, hipStream_t s) {
+                        uint8_t* out, int row_bytes, uint16_t* kept_cols, float* kept_conf, hipStream_t s) {
     if (B <= 0 || T <= 0) return 0;
     if (row_bytes < 16 + T * max_len || T > 65535) return 1;
     const size_t sh = (size_t)T * 4 + 2 * 256 * sizeof(int);
     if (sh > 60000) return 1;
-    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(B), dim3(256), sh, s, idx, prob, T, seg, ctab, max_len, n_classes, out, row_bytes, kept_cols);
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(B), dim3(256), sh, s, idx, prob, T, seg, ctab, max_len, n_classes, out, row_bytes, kept_cols, kept_conf);
     return 0;
 }
 }  // namespace rd

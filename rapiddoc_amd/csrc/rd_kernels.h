@@ -244,7 +244,7 @@ int launch_db_boxes(const float* prob, int B, int H, int W, const int32_t* src_h
                     int dilate, int max_cand, int max_runs, void* ws, size_t ws_bytes, void* out_boxes, int max_out, int32_t* n_out_dev,
                     hipStream_t s);
 int launch_ctc_collapse(const int32_t* idx, const float* prob, int B, int T, const int32_t* seg, const uint8_t* ctab, int max_len, int n_classes,
-                        uint8_t* out, int row_bytes, uint16_t* kept_cols, hipStream_t s);
+                        uint8_t* out, int row_bytes, uint16_t* kept_cols, float* kept_conf, hipStream_t s);
 
 }  // namespace rd
 

@@ -239,16 +239,17 @@ def rec_batches_adaptive(wh_ratios: Sequence[float], img_h: int = REC_IMG_H, img
 
 def rec_batches_lines(wh_ratios: Sequence[float], rec_batch_num: int = 6, img_h: int = REC_IMG_H, img_w: int = REC_IMG_W,
                       launch_multiple: int = 32, n_min: int = 16, n_max: int = 160, n_step: int = 2,
-                      n_cu: int = 256) -> Tuple[List[Tuple[np.ndarray, int]], np.ndarray]:
+                      n_cu: int = 256, with_ratio: bool = False):
     """The reference's batching RESULT at GPU launch sizes.  Every line keeps the padded width the reference gives it - the imgW of
     its own chunk of `rec_batch_num` lines of the one global `np.argsort` (`rec_batches(strict=True)`, rapid_ocr.py:411-440) - and
     the launches are runs of that sorted list whose sizes `rd_rec_plan_chunks` picks for the chip, each launch tensor as wide as
     its widest line rounded up to `launch_multiple` (the recogniser computes a line at its own width inside the wider tensor:
     rd_rec_backbone_forward_lines).  Returns ([(indices into the input, launch width)], reference width per line in the order of
-    the concatenated indices)."""
+    the concatenated indices); `with_ratio=True` adds the chunk's `max_wh_ratio` per line (what CTCLabelDecode scales a line's time steps
+    by when word boxes are asked for)."""
     ref = rec_batches(wh_ratios, rec_batch_num, img_h, img_w, width_multiple=1, strict=True)
     if not ref:
-        return [], np.zeros(0, np.int64)
+        return ([], np.zeros(0, np.int64), np.zeros(0)) if with_ratio else ([], np.zeros(0, np.int64))
     order = np.concatenate([c for c, _w in ref])
     line_w = np.concatenate([np.full(len(c), w, dtype=np.int64) for c, w in ref])      # non-decreasing: the chunks are sorted by ratio
     total = len(order)
@@ -267,6 +268,9 @@ def rec_batches_lines(wh_ratios: Sequence[float], rec_batch_num: int = 6, img_h:
         out.append((order[i: i + n], int(w32[i + n - 1])))
         i += n
     assert i == total
+    if with_ratio:
+        line_ratio = np.concatenate([np.full(len(c), max(img_w / img_h, max(float(wh_ratios[j]) for j in c))) for c, _w in ref])
+        return out, line_w, line_ratio
     return out, line_w
 
 

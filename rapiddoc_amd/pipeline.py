@@ -228,7 +228,7 @@ class PagePipeline:
         return self.rec_forward_sources([(pages, quads_per_page)])[0]
 
     def rec_forward_sources(self, sources: Sequence[Tuple[torch.Tensor, Sequence[np.ndarray]]],
-                            image_keys: Optional[Sequence[Sequence[int]]] = None):
+                            image_keys: Optional[Sequence[Sequence[int]]] = None, want_words: bool = False):
         """`sources`: [(images [P,H,W,3] u8 on the GPU, text-line quads per image)] - image arrays of DIFFERENT sizes whose
         lines are recognised TOGETHER, the way the reference pools every line of a page batch per language before it sorts
         and chunks them (analyze_utils.py:216-252 -> rapid_ocr.py:404-472).  Returns, per source, per image, [(text, score)]
@@ -236,15 +236,17 @@ class PagePipeline:
         e.g. the page a region crop came from - the reference pools page by page), which only matters to the strict mode's
         sort when two lines have exactly the same aspect ratio.  Carries the split-fp16 range guard of its rec engines (every caller - run_batch,
         analyze.RegionOcr, RegionTextModel - gets it): a tripped engine is switched to native fp32 and the lines are
-        recognised again."""
-        out = self._rec_forward_sources_once(sources, image_keys)
+        recognised again.  `want_words` (strict two-stage mode only): every line comes back as (text, score, words) with
+        words = {cols, confs, n_steps, wh_ratio, max_wh_ratio, crop_hw} - the kept characters' time steps and probabilities and the
+        numbers rapidocr's CTCLabelDecode / cal_rec_boxes turn into word boxes (rapiddoc_amd/word_boxes.py; table OCR, analyze_utils.py:308)."""
+        out = self._rec_forward_sources_once(sources, image_keys, want_words)
         # a pass can trip a LATER stage only once the earlier one runs in fp32 (an overflowed backbone feeds the tail NaNs or
         # finite-but-huge tokens), so check after every pass; a tripped engine stays in fp32, which bounds the loop
         for _ in range(3):
             if not any([e.check_range_and_fallback() for e in self.rec_engines + [self.rec_tail]]):     # list: check every engine
                 break
             self.stats["range_fallbacks"] = self.stats.get("range_fallbacks", 0) + 1
-            out = self._rec_forward_sources_once(sources, image_keys)
+            out = self._rec_forward_sources_once(sources, image_keys, want_words)
         return out
 
     def _collapse_rows(self, idx: torch.Tensor, prob: torch.Tensor, nb: int, st, record: bool = True):
@@ -277,22 +279,26 @@ class PagePipeline:
             row_bytes = (16 + max_tokens * self._ctc_max_len + 15) // 16 * 16
             rows = torch.empty((n_lines, row_bytes), dtype=torch.uint8, device=idx_all.device)
             cols = torch.empty((n_lines, max_tokens), dtype=torch.int16, device=idx_all.device) if want_cols else None
+            confs = torch.empty((n_lines, max_tokens), dtype=torch.float32, device=idx_all.device) if want_cols else None
             rc = self._lib.rd_ctc_collapse_lines(self.device, idx_all.data_ptr(), prob_all.data_ptr(), n_lines, tables.data_ptr(), max_tokens,
                                                  self._ctc_table.data_ptr(), self._ctc_max_len, len(self.characters), rows.data_ptr(),
-                                                 row_bytes, cols.data_ptr() if want_cols else None, st.cuda_stream)
+                                                 row_bytes, cols.data_ptr() if want_cols else None, confs.data_ptr() if want_cols else None,
+                                                 st.cuda_stream)
             if rc != 0:
                 raise RuntimeError("rd_ctc_collapse_lines failed")
             rows_h = torch.empty((n_lines, row_bytes), dtype=torch.uint8, pin_memory=True)
             rows_h.copy_(rows, non_blocking=True)
             cols_h = None
             if want_cols:
-                cols_h = torch.empty((n_lines, max_tokens), dtype=torch.int16, pin_memory=True)
-                cols_h.copy_(cols, non_blocking=True)
+                cols_h = (torch.empty((n_lines, max_tokens), dtype=torch.int16, pin_memory=True),
+                          torch.empty((n_lines, max_tokens), dtype=torch.float32, pin_memory=True))
+                cols_h[0].copy_(cols, non_blocking=True)
+                cols_h[1].copy_(confs, non_blocking=True)
             done = torch.cuda.Event()
             done.record(st)
         return (rows_h, done, cols_h) if want_cols else (rows_h, done)
 
-    def _rec_forward_sources_once(self, sources, image_keys=None):
+    def _rec_forward_sources_once(self, sources, image_keys=None, want_words=False):
         t0 = time.perf_counter()
         dev = sources[0][0].device
         # flat line list in source-major, image-major order (the reference's pooled order: pages, then a page's spans)
@@ -321,7 +327,7 @@ class PagePipeline:
         n_all = len(quads)
         keep = np.nonzero(ok)[0]                      # degenerate quads (zero-area / collinear corners) get ("", 0.0)
         n = len(keep)
-        texts: List[Tuple[str, float]] = [("", 0.0)] * n_all
+        texts: List[tuple] = [("", 0.0, None) if want_words else ("", 0.0)] * n_all
         if n == 0:
             return self._scatter_texts(texts, src_of, page_of, n_img, perm)
         mats, cws_a, chs_a = mats[keep], cws_a[keep], chs_a[keep]
@@ -332,8 +338,10 @@ class PagePipeline:
         strict = self.rec_mode == "strict"
         two_stage = self.rec_two_stage
         lines_mode = strict and two_stage          # reference widths per LINE inside GPU-sized launches
+        if want_words and not lines_mode:
+            raise RuntimeError("word boxes need the strict two-stage recogniser (rec_mode='strict', RD_REC_TWO_STAGE unset)")
         if lines_mode:
-            batches, line_w = ocr_host.rec_batches_lines(ratios, n_cu=self.n_cu)
+            batches, line_w, line_ratio = ocr_host.rec_batches_lines(ratios, n_cu=self.n_cu, with_ratio=True)
         elif not strict and self.rec_chunking == "adaptive":
             batches = ocr_host.rec_batches_adaptive(ratios, width_multiple=self.rec_width_multiple, n_cu=self.n_cu)
         else:
@@ -442,12 +450,16 @@ class PagePipeline:
             if lines_mode:
                 # ragged lines: ONE collapse launch over the group's real lines (the seg table of the tail call), one copy back
                 n_real = len(group_lens[gi])
-                rows, done = self._collapse_lines(idx_all, prob_all, group_tables[gi], n_real, group_pad[gi][1], self.tail_stream)
+                cols_h = None
+                if want_words:
+                    rows, done, cols_h = self._collapse_lines(idx_all, prob_all, group_tables[gi], n_real, group_pad[gi][1], self.tail_stream, True)
+                else:
+                    rows, done = self._collapse_lines(idx_all, prob_all, group_tables[gi], n_real, group_pad[gi][1], self.tail_stream)
                 kept = None
                 if self.keep_rec_inputs:
                     with torch.cuda.stream(self.tail_stream):        # (after the tail call, on its stream)
                         kept = (idx_all.clone(), prob_all.clone())
-                group_rows[gi] = (rows, done, kept)
+                group_rows[gi] = (rows, done, kept, cols_h)
                 for bi in grp:
                     outs[bi] = (None, None, done, outs[bi][3], None)
                 return
@@ -512,12 +524,24 @@ class PagePipeline:
         if lines_mode:
             self.last_rec_batches = []
             for gi, grp in enumerate(groups):
-                rows, done, kept = group_rows[gi]
+                rows, done, kept, cols_h = group_rows[gi]
                 done.synchronize()
                 t1 = time.perf_counter()
                 lo = int(starts[grp[0]])
-                dec = ocr_host.parse_ctc_rows(rows.numpy())
+                rows_np = rows.numpy()
+                dec = ocr_host.parse_ctc_rows(rows_np)
+                if want_words:
+                    n_kept = rows_np[:, 8:12].copy().view("<i4")[:, 0]
+                    cols_np, confs_np = cols_h[0].numpy(), cols_h[1].numpy()
                 for j, (t, sc) in enumerate(dec):
+                    if want_words:       # (raw score: the reference's ocr(det=False) returns rapidocr's float as it is, rapid_ocr.py:295-297)
+                        i = int(order_all[lo + j])
+                        k = int(n_kept[j])
+                        words = {"cols": cols_np[j, :k].astype(np.int64).tolist(), "confs": confs_np[j, :k].astype(np.float64).tolist(),
+                                 "n_steps": int(seq_line[lo + j]), "wh_ratio": float(ratios[i]), "max_wh_ratio": float(line_ratio[lo + j]),
+                                 "crop_hw": (int(eff_h[i]), int(eff_w[i]))}
+                        texts[int(keep[i])] = (t, sc, words)
+                        continue
                     texts[int(keep[order_all[lo + j]])] = (t, ocr_host.format_score(sc))
                 t_dec += time.perf_counter() - t1
                 if kept is not None:        # tests: per rec batch (pooled line ids, input tensor, reference width per line, per-line idx, prob)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Traces of the REFERENCE's table stage, run with recording stand-ins for the models (build container only).
 
-    python tests/golden/make_golden_table_trace.py        # writes tests/golden/analyze_trace_table_{traditional,custom,custom_ocr}.json
+    python tests/golden/make_golden_table_trace.py        # writes tests/golden/analyze_trace_table_{traditional,custom,custom_ocr,traditional_words}.json
                                                           # (the third: the custom-OCR seam of the same driver, tables off)
 
 What runs is the reference's code, unmodified (same import machinery as make_golden_analyze.py):
@@ -16,8 +16,10 @@ handed (image crc32, OCR boxes / texts / scores, formula boxes, flags) and answe
 recogniser inside a REAL RapidOcrModel object (`text_detector`: seeded boxes, records the canvas; `text_recognizer`: the recording
 stand-in of make_golden_recbatch.py whose text is a function of the crop's shape); the orientation classifier (answers "0": the
 orientation sub-stage is outside SURVEY s8); cv2 and the absent wheels as in make_golden_analyze.py.
-table_config = {use_word_box: False}: the word-box variant lives in rapidocr's `cal_rec_boxes` (absent).  Images inside a table travel
-to the table model (`layout_image_list` -> extract_table_fill_image's layout branch; the page carries no PDF images)."""
+table_config = {use_word_box: False} for the first three traces; `traditional_words` runs the reference's DEFAULT ({}: use_word_box True,
+analyze_utils.py:308): `ocr(det=False, return_word_box=True)` -> rapidocr's cal_rec_boxes (absent: a recording stand-in whose words are a
+function of the line crop's shape and box, `table_words_for`) -> calc_word_boxes / map_boxes_to_original -> one OCR entry per word.
+Images inside a table travel to the table model (`layout_image_list` -> extract_table_fill_image's layout branch; the page carries no PDF images)."""
 import importlib
 import json
 import sys
@@ -36,6 +38,25 @@ def table_text_and_score(h, w):
     """What the stand-in recogniser 'reads' from a table line crop: a function of its shape only (the recogniser loop sorts crops
     by aspect ratio, so a position in the call is not something both sides share)."""
     return ("香" if (h + w) % 7 == 0 else f"<{h}x{w}>"), ((h * 37 + w * 11) % 1000) / 1000.0
+
+
+def table_words_for(h, w, dt_box):
+    """What the stand-in `cal_rec_boxes` answers for a table line (word, confidence, box) - a function of the line crop's shape and of its
+    detection box only: (h + w) % 4 words (NONE for some lines: the reference then drops the line from the word results and its zip with
+    the texts shifts, rapid_ocr.py:295,325-326), one of them without a box now and then (skipped, :318-319), boxes partly outside the
+    table image (clipped by map_boxes_to_original) with fractional corners (truncated by the int32 cast)."""
+    q = np.asarray(dt_box, dtype=np.float64).reshape(4, 2)
+    words = []
+    for j in range((h + w) % 4):
+        if (h * 3 + w + j) % 11 == 0:
+            words.append((f"gone{j}", 0.5, None))
+            continue
+        a, b = j / 4.0, (j + 1) / 4.0
+        tl, tr, br, bl = q[0] + a * (q[1] - q[0]), q[0] + b * (q[1] - q[0]), q[3] + b * (q[2] - q[3]), q[3] + a * (q[2] - q[3])
+        box = [[float(tl[0]) - 0.6 - (700.0 if (h + j) % 13 == 0 else 0.0), float(tl[1]) + 0.3], [float(tr[0]) + 0.6, float(tr[1]) + 0.3],
+               [float(br[0]) + 0.6, float(br[1]) + 0.7 + (900.0 if (w + j) % 17 == 0 else 0.0)], [float(bl[0]) - 0.6, float(bl[1]) + 0.7]]
+        words.append((("香<" if (h + w + j) % 5 == 0 else "w") + f"{j}:{h}x{w}", round(((h * 7 + w * 3 + j) % 1000) / 1000.0, 5), box))
+    return words
 
 
 def fill_summary(fill_image_res):
@@ -66,8 +87,9 @@ class TableRecognizer:
 
     def postprocess_op(self, preds, return_word_box, wh_ratio_list=None, max_wh_ratio=None):
         out = [table_text_and_score(h, w) for h, w in self.chunk]
+        words = [("word-info", h, w) if return_word_box else None for h, w in self.chunk]     # rapidocr's WordInfo: opaque to the reference
         self.chunk = []
-        return out, [None] * len(out)
+        return out, words
 
 
 def layout_with_tables(rng, H, W):
@@ -113,8 +135,9 @@ def main():
     ro.TextRecInput = lambda img, return_word_box=False: types.SimpleNamespace(img=img, return_word_box=return_word_box)   # rapidocr dataclasses
     ro.TextRecOutput = lambda imgs, txts, scores, words, elapse: types.SimpleNamespace(txts=list(txts), scores=list(scores), word_results=words)
 
-    for kind in ("traditional", "custom", "custom_ocr"):
-        rng = np.random.default_rng(8000 + ("traditional", "custom", "custom_ocr").index(kind))
+    kinds = ("traditional", "custom", "custom_ocr", "traditional_words")
+    for kind in kinds:
+        rng = np.random.default_rng(8000 + kinds.index(kind))
         trace = {"det_calls": [], "rec_calls": [], "formula_calls": [], "layout_calls": [], "table_det_calls": [], "table_calls": []}
         page_ids = [int(rng.integers(0, 1000)) for _ in range(2)]
         pages = [synth_page(i)[0] for i in page_ids]
@@ -135,6 +158,15 @@ def main():
         table_ocr = object.__new__(ro.RapidOcrModel)
         table_ocr.text_detector, table_ocr.text_recognizer = text_detector, TableRecognizer()
         table_ocr.is_seal, table_ocr.enable_merge_det_boxes, table_ocr.drop_score = False, False, 0.5
+
+        def cal_rec_boxes(imgs, dt_boxes, rec_res, return_single_char_box):      # rapidocr's CalRecBoxes.__call__ (absent): recording stand-in
+            assert len(imgs) == len(dt_boxes) == len(rec_res.txts) and return_single_char_box is False
+            assert all(wi == ("word-info", i.shape[0], i.shape[1]) for wi, i in zip(rec_res.word_results, imgs))
+            trace["table_word_calls"] = trace.get("table_word_calls", []) + [{"shapes": [list(i.shape) for i in imgs],
+                                                                              "dt_boxes": [np.asarray(b).tolist() for b in dt_boxes]}]
+            rec_res.word_results = tuple(table_words_for(i.shape[0], i.shape[1], b) for i, b in zip(imgs, dt_boxes))
+            return rec_res
+        table_ocr.ocr_engine = types.SimpleNamespace(cal_rec_boxes=cal_rec_boxes, return_single_char_box=False)
 
         class TableModel:                     # the traditional seam: RapidTableModel.predict (rapid_table.py:120)
             def predict(self, image, ocr_result, fill_image_res, mfd_res, skip_text_in_image, use_img2table, skip_table_orientation=False):
@@ -189,7 +221,8 @@ def main():
             def get_model(self, **kw):
                 return Model()
         ocr_cfg = {"use_det_mode": "ocr", "Det.rec_batch_num": 3, "seal_enable": False}
-        table_cfg = {"use_word_box": False}            # table_image_enable stays at its default, True
+        # table_image_enable stays at its default, True; "traditional_words" runs the reference's DEFAULT table config (use_word_box True)
+        table_cfg = {} if kind == "traditional_words" else {"use_word_box": False}
         analyzer = ba.BatchAnalyze(Manager(), batch_ratio=1, formula_enable=True, table_enable=(kind != "custom_ocr"), layout_config={"batch_num": 2},
                                    ocr_config=ocr_cfg, table_config=table_cfg,
                                    formula_config={"formula_level": 0, "batch_num": 4, "bbox_expand_px": 2})

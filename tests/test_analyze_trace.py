@@ -146,7 +146,22 @@ def table_text_and_score(h, w):          # == make_golden_table_trace.table_text
     return ("香" if (h + w) % 7 == 0 else f"<{h}x{w}>"), ((h * 37 + w * 11) % 1000) / 1000.0
 
 
-@pytest.mark.parametrize("kind", ["traditional", "custom"])
+def table_words_for(h, w, dt_box):       # == make_golden_table_trace.table_words_for
+    q = np.asarray(dt_box, dtype=np.float64).reshape(4, 2)
+    words = []
+    for j in range((h + w) % 4):
+        if (h * 3 + w + j) % 11 == 0:
+            words.append((f"gone{j}", 0.5, None))
+            continue
+        a, b = j / 4.0, (j + 1) / 4.0
+        tl, tr, br, bl = q[0] + a * (q[1] - q[0]), q[0] + b * (q[1] - q[0]), q[3] + b * (q[2] - q[3]), q[3] + a * (q[2] - q[3])
+        box = [[float(tl[0]) - 0.6 - (700.0 if (h + j) % 13 == 0 else 0.0), float(tl[1]) + 0.3], [float(tr[0]) + 0.6, float(tr[1]) + 0.3],
+               [float(br[0]) + 0.6, float(br[1]) + 0.7 + (900.0 if (w + j) % 17 == 0 else 0.0)], [float(bl[0]) - 0.6, float(bl[1]) + 0.7]]
+        words.append((("香<" if (h + w + j) % 5 == 0 else "w") + f"{j}:{h}x{w}", round(((h * 7 + w * 3 + j) % 1000) / 1000.0, 5), box))
+    return words
+
+
+@pytest.mark.parametrize("kind", ["traditional", "custom", "traditional_words"])
 def test_table_stage_replays_the_reference_trace(golden_dir, kind):
     """`traditional`: a `predict`-shaped table model - per table the reference crops (box snapped outwards to multiples of 5 px), whites the
     page's formulas out of the detector's copy, detects (0.5 / 1.6, sorted, cut around formulas, NOT merged), recognises every line
@@ -174,13 +189,23 @@ def test_table_stage_replays_the_reference_trace(golden_dir, kind):
         log["table_det"].append({"shape": list(bgr.shape), "crc32": zlib.crc32(bgr.tobytes())})
         return [np.asarray(call["boxes"], dtype=np.float32).reshape(-1, 4, 2)]
 
+    word_box = fx["table_config"].get("use_word_box", True)      # the reference's default: True (analyze_utils.py:308)
+    assert word_box == (kind == "traditional_words")
+
     def table_rec_fn(canvas, quads):
         _m, cw, ch, ok = quads_to_crop_matrices(np.asarray(quads, dtype=np.float64))
         assert ok.all()
         out = []
-        for w_, h_ in zip(cw.astype(int).tolist(), ch.astype(int).tolist()):
+        for q, w_, h_ in zip(quads, cw.astype(int).tolist(), ch.astype(int).tolist()):
             hh, ww = (w_, h_) if h_ / w_ >= 2 else (h_, w_)
-            out.append(table_text_and_score(hh, ww))
+            if word_box:        # + what rapidocr's cal_rec_boxes leaves per line (the generator's stand-in: a function of crop shape and box)
+                out.append(table_text_and_score(hh, ww) + (table_words_for(hh, ww, q),))
+            else:
+                out.append(table_text_and_score(hh, ww))
+        if word_box:
+            log.setdefault("table_words", []).append({"shapes": [[int(ch_), int(cw_), 3] if not (ch_ / cw_ >= 2) else [int(cw_), int(ch_), 3]
+                                                                 for cw_, ch_ in zip(cw.astype(int).tolist(), ch.astype(int).tolist())],
+                                                      "dt_boxes": [np.asarray(q, dtype=np.float32).tolist() for q in quads]})
         return out
 
     class ReplayTable:
@@ -205,8 +230,12 @@ def test_table_stage_replays_the_reference_trace(golden_dir, kind):
                               table_model=ReplayCustomTable() if kind == "custom" else ReplayTable(),
                               layout_batch_size=fx["layout_batch_num"], formula_level=fx["formula_level"],
                               formula_batch_size=fx["formula_batch_num"], det_batch_num=fx["ocr_config"]["Det.rec_batch_num"],
-                              det_raw_fn=det_raw_fn, table_det_raw_fn=table_det_raw_fn, table_rec_fn=table_rec_fn)
+                              det_raw_fn=det_raw_fn, table_det_raw_fn=table_det_raw_fn, table_rec_fn=table_rec_fn, table_use_word_box=word_box)
     out = pa(pages, page_scales=[fx["page_scale"]] * len(pages))
+    if word_box:       # the crops and boxes rapidocr's cal_rec_boxes was called with, and the reference's zip quirk was exercised
+        assert log["table_words"] == tr["table_word_calls"]
+        n_lines = sum(len(c["shapes"]) for c in tr["table_word_calls"])
+        assert any(len(table_words_for(s_[0], s_[1], b)) == 0 for c in tr["table_word_calls"] for s_, b in zip(c["shapes"], c["dt_boxes"])) and n_lines > 10
 
     assert log["layout"] == tr["layout_calls"] and log["formula"] == tr["formula_calls"]
     assert [{k: c[k] for k in ("batch_size", "shapes", "crc32")} for c in tr["det_calls"]] == log["det"]

@@ -80,8 +80,9 @@ def test_collapse_lines_equals_the_host_decode(golden_dir):
     idx_d, prob_d, seg_d, tab_d = d(idx), d(prob), d(seg.reshape(-1)), d(tab)
     rows = torch.zeros((len(lens), row_bytes), dtype=torch.uint8, device="cuda")
     cols = torch.full((len(lens), Tmax), -1, dtype=torch.int16, device="cuda")
+    confs = torch.full((len(lens), Tmax), -1.0, dtype=torch.float32, device="cuda")
     rc = lib.rd_ctc_collapse_lines(0, idx_d.data_ptr(), prob_d.data_ptr(), len(lens), seg_d.data_ptr(), Tmax, tab_d.data_ptr(), max_len, len(chars),
-                                   rows.data_ptr(), row_bytes, cols.data_ptr(), None)
+                                   rows.data_ptr(), row_bytes, cols.data_ptr(), confs.data_ptr(), None)
     assert rc == 0
     torch.cuda.synchronize()
     dec = ocr_host.parse_ctc_rows(rows.cpu().numpy())
@@ -92,6 +93,7 @@ def test_collapse_lines_equals_the_host_decode(golden_dir):
         row = idx[f:f + t]
         keep = [i for i in range(t) if row[i] != 0 and (i == 0 or row[i] != row[i - 1])]
         assert n_kept[b] == len(keep) and cols.cpu().numpy()[b, :len(keep)].tolist() == keep
+        assert np.array_equal(confs.cpu().numpy()[b, :len(keep)], prob[f:f + t][keep])
 
 
 def _reference_rec_chunks(crop_hw, rec_batch_num=6):

@@ -6,9 +6,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_table_stage_on_the_gpu_engines(golden_dir):
+@pytest.mark.parametrize("word_box", [False, True])
+def test_table_stage_on_the_gpu_engines(golden_dir, word_box):
     """analyze.TableOcr through the real det / rec engines: a `predict`-shaped table model receives the table crop, one OCR line per
-    synthetic text line inside the table (boxes in crop coordinates, strings, float scores) and the formula box inside it."""
+    synthetic text line inside the table (boxes in crop coordinates, strings, float scores) and the formula box inside it.  `word_box`
+    (the reference's default, analyze_utils.py:308): one entry per word / CJK character instead - built from the device's kept time steps
+    and probabilities (rd_ctc_collapse_lines) by rapiddoc_amd/word_boxes.py; every word box lies inside its line's box."""
     import json
     from rapiddoc_amd import weights as W
     from rapiddoc_amd.analyze import PageAnalyzer
@@ -34,12 +37,12 @@ def test_table_stage_on_the_gpu_engines(golden_dir):
             return "<html><table><tr><td>%d</td></tr></table></html>" % (len(ocr_result[0]) if ocr_result else 0)
 
     states = {k: W.synth_state_dict(W.load_manifest(golden_dir / f"manifest_{k}.json"), 0) for k in ("ppocrv6_det", "ppocrv6_rec")}
-    pipe = PagePipeline(states, rec_batch_num=32, n_rec_streams=2)
+    pipe = PagePipeline(states, n_rec_streams=2)            # (strict rec mode, the default: word boxes need its per-line widths)
     class Formula:                       # (without a formula model the driver drops inline formulas, like the reference)
         def batch_predict(self, imgs, batch_size=16):
             return ["x" for _ in imgs]
 
-    an = PageAnalyzer(LayoutModel(Session(), "pp_doclayoutv3"), pipe, formula_model=Formula(), table_model=Table())
+    an = PageAnalyzer(LayoutModel(Session(), "pp_doclayoutv3"), pipe, formula_model=Formula(), table_model=Table(), table_use_word_box=word_box)
     pages_np, boxes = synth_batch(0, 1)
     lines = [lb for lb in np.asarray(boxes[0], dtype=np.float64).reshape(-1, 4)
              if lb[0] >= TAB[0] and lb[2] <= TAB[2] and lb[1] >= TAB[1] and lb[3] <= TAB[3]
@@ -60,10 +63,22 @@ def test_table_stage_on_the_gpu_engines(golden_dir):
     assert image.shape == (TAB[3] - TAB[1], TAB[2] - TAB[0], 3) and fill == [] and flags == (True, False, True)
     assert mfd == [{"bbox": [300 - TAB[0], 600 - TAB[1], 420 - TAB[0], 640 - TAB[1]], "latex": "x"}]
     bxs, texts, scores = ocr_result
-    assert len(bxs) == len(texts) == len(scores) == len(lines)
+    assert len(bxs) == len(texts) == len(scores)
     assert all(np.asarray(b).shape == (4, 2) for b in bxs) and all(isinstance(t, str) for t in texts) and all(0.0 <= float(s) <= 1.0 for s in scores)
+    if not word_box:
+        assert len(bxs) == len(lines)
+    else:
+        # random weights read CJK strings: one box per character, the characters of a line share its height and stay inside the table image
+        assert len(bxs) >= len(lines) and all(len(t) == 1 for t in texts)
+        b = np.asarray(bxs, dtype=np.float64)
+        assert b[..., 0].min() >= 0 and b[..., 0].max() <= image.shape[1] and b[..., 1].min() >= 0 and b[..., 1].max() <= image.shape[0]
+        assert (b[:, 1, 0] >= b[:, 0, 0]).all() and (b[:, 2, 1] >= b[:, 1, 1]).all()
+        rows = {}
+        for q in b:
+            rows.setdefault((int(q[0, 1]), int(q[2, 1])), []).append(q)
+        assert len(rows) <= len(lines) + 2                      # the boxes group into (about) one row per text line
     table = [d for d in out if d["category_id"] == 5][0]
-    assert table["html"] == "<table><tr><td>%d</td></tr></table>" % len(lines)
+    assert table["html"] == "<table><tr><td>%d</td></tr></table>" % len(texts)
     assert table["formula_boxes"] == [[150, 300, 210, 320]]
 
 
