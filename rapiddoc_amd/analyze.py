@@ -482,13 +482,15 @@ class PageAnalyzer:
 
     Every page is processed independently (`pages[p]` only feeds `out[p]`); the result is the reference's
     `images_layout_res`: per page the filtered layout detections, formula `latex` fields filled in place, followed by the
-    OcrText spans.  Not built (reference sub-stages outside SURVEY 8): orientation classification, checkbox detection, seal
-    OCR, the 'txt' det mode (PDF text layer)."""
+    OcrText spans, then (7.) `text` written into the seal regions (`_run_seal_ocr`).  Not built (reference sub-stages outside SURVEY 8):
+    orientation classification (off by default: USE_DOC_ORIENTATION_CLASSIFY), checkbox detection (off by default), the 'txt' det mode
+    (PDF text layer)."""
 
     def __init__(self, layout_model, pipeline, formula_model=None, table_model=None, custom_ocr=None, layout_batch_size: int = 1,
                  formula_level: int = 0, box_thresh: float = 0.3, unclip_ratio: float = 1.8, formula_batch_size: int = 1,
                  formula_expand_px: int = 2, det_batch_num: Optional[int] = None, det_raw_fn=None, lang: str = "ch",
-                 table_det_raw_fn=None, table_rec_fn=None, table_image_enable: bool = True, table_use_word_box: bool = True):
+                 table_det_raw_fn=None, table_rec_fn=None, table_image_enable: bool = True, table_use_word_box: bool = True,
+                 seal_model=None, seal_enable: bool = True):
         """Batch sizes default to the reference's (layout_config['batch_num'] / formula_config['batch_num'] = 1,
         batch_analyze.py:66-71); `det_batch_num` / `det_raw_fn`: see RegionOcr."""
         self.layout_model, self.pipe = layout_model, pipeline
@@ -499,6 +501,10 @@ class PageAnalyzer:
         # table_config["use_word_box"], default True (analyze_utils.py:308): word-level OCR entries for the table model
         self.table_ocr = TableOcr(pipeline, det_raw_fn=table_det_raw_fn, rec_fn=table_rec_fn, lang=lang, use_word_box=table_use_word_box)
         self.table_image_enable = table_image_enable          # table_config["table_image_enable"], default True (batch_analyze.py:75)
+        # 7. seal OCR (ocr_config["seal_enable"], default True, batch_analyze.py:62,150-151): `seal_model` = the RapidOcrModel-shaped object
+        #    the reference obtains with get_atom_model(OCR, is_seal=True) - `.ocr(bgr crop, det=True, rec=True) -> [[(box, (text, score)), ...]]`.
+        #    Its seal detector is ONNX-only (not built): pages WITH a seal region and no model to read it fail loudly.
+        self.seal_model, self.seal_enable = seal_model, seal_enable
 
     def __call__(self, pages: torch.Tensor, det_maps_fn=None, page_scales: Optional[Sequence[float]] = None,
                  table_det_maps_fn=None, page_langs: Optional[Sequence[str]] = None) -> List[List[dict]]:
@@ -564,4 +570,44 @@ class PageAnalyzer:
         elif self.table_model is not None:
             self.table_ocr(pages, dets, self.table_model, page_scales, det_maps_fn=table_det_maps_fn, table_image_enable=self.table_image_enable,
                            page_langs=page_langs)
+        if self.seal_enable:
+            self._run_seal_ocr(pages, out)
         return out
+
+    def _run_seal_ocr(self, pages: torch.Tensor, out: List[List[dict]]) -> int:
+        """`BatchAnalyze._run_seal_ocr` (batch_analyze.py:415-470): every region the layout model labelled `seal` is cropped (crop_img, no
+        margin, polygon whited out), handed over as BGR and gets `text` = the LIST of the lines read in it - from the custom OCR model when
+        its batch_predict takes `is_seal` (one string, split at newlines), else from the seal OCR model (malformed / empty items skipped one
+        by one, no score threshold; a crop nothing was read in keeps no `text`).  Returns the number of seal regions."""
+        import inspect
+        items = []
+        for p, page in enumerate(out):
+            for d in page:
+                if d.get("original_label") == "seal":
+                    crop = crop_region(pages, p, d)
+                    if crop is None:
+                        raise ValueError("seal region with an inverted box")          # (the reference's np.ones raises)
+                    items.append((np.ascontiguousarray(crop[:, :, ::-1]), d))
+        custom = self.custom_ocr is not None and "is_seal" in inspect.signature(self.custom_ocr.batch_predict).parameters
+        for crop_bgr, d in items:
+            if custom:
+                texts = self.custom_ocr.batch_predict([crop_bgr], is_seal=True)[0].split("\n")
+            else:
+                if self.seal_model is None:
+                    raise RuntimeError("the page holds a seal region and seal OCR is enabled (the reference's default), but no seal_model was "
+                                       "given: the seal detector / recogniser are ONNX-only and not part of this build - pass a "
+                                       "RapidOcrModel-shaped `seal_model` or seal_enable=False")
+                res = self.seal_model.ocr(crop_bgr, det=True, rec=True)[0]
+                if not res:
+                    continue
+                texts = []
+                for item in res:
+                    if not item or len(item) != 2:
+                        continue
+                    rec = item[1]
+                    if not rec or len(rec) < 1:
+                        continue
+                    if rec[0]:
+                        texts.append(rec[0])
+            d["text"] = texts
+        return len(items)

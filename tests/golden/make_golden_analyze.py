@@ -255,21 +255,48 @@ def main():
     from rapid_doc.backend.pipeline.model_list import AtomicModel
     from rapiddoc_amd.pages import synth_page
 
-    for seed, (n_pages, formula_enable, formula_level, polygons, langs) in enumerate([
-            (3, True, 0, False, None), (2, False, 0, False, None), (2, True, 1, False, None), (2, True, 0, True, None),
-            (3, True, 0, False, ["ch", "en", "ch"])]):              # the last one: pages of two languages in one batch
-        rng = np.random.default_rng(7000 + seed)
+    # seeds 0-4 were cut with ocr_config["seal_enable"] = False; 5 and 6 run the reference's DEFAULT (the key absent -> True,
+    # batch_analyze.py:62): 5 = the pages and layout of seed 0 (no seal region: the seal stage must leave the output alone), 6 = two seal
+    # regions (one with a polygon) -> _run_seal_ocr (batch_analyze.py:415-470) with a recording seal OCR model
+    for seed, (n_pages, formula_enable, formula_level, polygons, langs, seal) in enumerate([
+            (3, True, 0, False, None, None), (2, False, 0, False, None, None), (2, True, 1, False, None, None), (2, True, 0, True, None, None),
+            (3, True, 0, False, ["ch", "en", "ch"], None),              # pages of two languages in one batch
+            (3, True, 0, False, None, "default"), (2, True, 0, False, None, "regions")]):
+        rng = np.random.default_rng(7000 + (0 if seed == 5 else seed))
         trace = {"det_calls": [], "rec_calls": [], "formula_calls": [], "layout_calls": []}
         page_ids = [int(rng.integers(0, 1000)) for _ in range(n_pages)]
         pages = [synth_page(i)[0] for i in page_ids]
         H, W = pages[0].shape[:2]
         dets = [layout_for_page(rng, H, W, polygons) for _ in range(n_pages)]
+        if seal == "regions":
+            def seal_det(x0, y0, x1, y1, pts, order):
+                return {"category_id": 3, "original_label": "seal", "original_order": order, "poly": [x0, y0, x1, y0, x1, y1, x0, y1],
+                        "polygon_points": pts, "score": 0.88}
+            dets[0].append(seal_det(820.4, 1300.2, 1040.9, 1510.7, None, len(dets[0])))
+            dets[1].append(seal_det(130.0, 1330.0, 330.0, 1520.0, [[230.0, 1330.0], [330.0, 1425.0], [230.0, 1520.0], [130.0, 1425.0]], len(dets[1])))
+            dets[1].append(seal_det(900.3, 60.1, 1100.2, 180.8, None, len(dets[1])))
         ocr = RecordingOcr(trace)
         ocr_by_lang = {lg: RecordingOcr(trace, lg) for lg in dict.fromkeys(langs or [])}
+
+        class SealOcr:                       # `get_atom_model(OCR, is_seal=True)`: ocr(bgr crop, det=True, rec=True) -> [[box, (text, score)], ...]
+            def ocr(self, img, det=True, rec=True, **kw):
+                assert det is True and rec is True and not kw
+                img = np.asarray(img)
+                k = len(trace.setdefault("seal_calls", []))
+                trace["seal_calls"].append({"shape": list(img.shape), "crc32": zlib.crc32(np.ascontiguousarray(img).tobytes())})
+                if k == 2:
+                    return [None]            # nothing read: the region keeps no `text`
+                box = [[1.0, 2.0], [30.0, 2.0], [30.0, 12.0], [1.0, 12.0]]
+                return [[[box, (f"seal {k} line a {img.shape[0]}x{img.shape[1]}", 0.91)], None, [box], [box, ()], [box, ("", 0.4)],
+                         [box, (f"line b", 0.2)]]]      # malformed / empty items are skipped one by one (batch_analyze.py:456-467)
 
         class Registry:                      # rapid_doc/backend/pipeline/model_init.py:57-88 AtomModelSingleton
             def get_atom_model(self, atom_model_name, **kw):
                 assert atom_model_name == AtomicModel.OCR, atom_model_name
+                if kw.get("is_seal"):
+                    assert set(kw) == {"is_seal"}
+                    trace["seal_model_requests"] = trace.get("seal_model_requests", 0) + 1
+                    return SealOcr()
                 trace.setdefault("atom_model_requests", []).append({k: v for k, v in kw.items() if k in ("lang",)})
                 return ocr_by_lang[kw["lang"]] if langs else ocr
         reg.AtomModelSingleton = Registry
@@ -287,6 +314,8 @@ def main():
             def get_model(self, **kw):
                 return Model()
         ocr_cfg = {"use_det_mode": "ocr", "Det.rec_batch_num": 3, "seal_enable": False}
+        if seal:
+            del ocr_cfg["seal_enable"]       # the reference's default: True
         analyzer = ba.BatchAnalyze(Manager(), batch_ratio=1, formula_enable=formula_enable, table_enable=False,
                                    layout_config={"batch_num": 2}, ocr_config=ocr_cfg,
                                    formula_config={"formula_level": formula_level, "batch_num": 4, "bbox_expand_px": 2})

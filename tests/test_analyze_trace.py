@@ -90,10 +90,15 @@ class ReplayPipe:
         return out
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 5, 6])
 def test_page_analyzer_replays_the_reference_trace(golden_dir, seed):
+    """Seeds 0-3: traces cut with ocr_config["seal_enable"] = False.  5 and 6: the reference's DEFAULT (seal OCR on, batch_analyze.py:62) -
+    5 = seed 0's pages (no seal region: same output), 6 = three seal regions, one with a polygon, one nothing is read in: the crops
+    handed to the seal OCR model byte for byte, the `text` lists written into the regions."""
     fx = json.loads((golden_dir / f"analyze_trace_seed{seed}.json").read_text())
     tr = fx["trace"]
+    seal_on = fx["ocr_config"].get("seal_enable", True)
+    assert seal_on == (seed >= 5)
     pages = torch.from_numpy(np.stack([synth_page(i)[0] for i in fx["page_ids"]]))      # CPU tensor: the networks are stood in for
     assert list(pages.shape[1:3]) == fx["page_hw"]
     log = {"layout": [], "formula": [], "det": [], "rec": []}
@@ -106,12 +111,27 @@ def test_page_analyzer_replays_the_reference_trace(golden_dir, seed):
                            "crc32": [zlib.crc32(np.ascontiguousarray(c).tobytes()) for c in bgr]})
         return [np.asarray(b, dtype=np.float32).reshape(-1, 4, 2) for b in call["boxes"]]
 
+    class ReplaySeal:                 # == make_golden_analyze.SealOcr
+        def ocr(self, img, det=True, rec=True, **kw):
+            assert det is True and rec is True and not kw
+            k = len(log.setdefault("seal", []))
+            log["seal"].append({"shape": list(img.shape), "crc32": zlib.crc32(np.ascontiguousarray(img).tobytes())})
+            if k == 2:
+                return [None]
+            box = [[1.0, 2.0], [30.0, 2.0], [30.0, 12.0], [1.0, 12.0]]
+            return [[[box, (f"seal {k} line a {img.shape[0]}x{img.shape[1]}", 0.91)], None, [box], [box, ()], [box, ("", 0.4)], [box, ("line b", 0.2)]]]
+
     formula_model = ReplayFormula(log["formula"]) if fx["formula_enable"] else None
     pa = analyze.PageAnalyzer(ReplayLayout(fx["layout_dets"], log["layout"]), ReplayPipe(log["rec"]), formula_model=formula_model,
                               layout_batch_size=fx["layout_batch_num"], formula_level=fx["formula_level"],
                               formula_batch_size=fx["formula_batch_num"], det_batch_num=fx["ocr_config"]["Det.rec_batch_num"],
-                              det_raw_fn=det_raw_fn)
+                              det_raw_fn=det_raw_fn, seal_model=ReplaySeal() if seed == 6 else None, seal_enable=seal_on)
     out = pa(pages)
+    assert log.get("seal", []) == tr.get("seal_calls", [])
+    if seed == 6:
+        assert len(log["seal"]) == 3 and sum(1 for page in out for d in page if d.get("original_label") == "seal" and "text" in d) == 2
+    if seed == 5:
+        assert out == json.loads((golden_dir / "analyze_trace_seed0.json").read_text())["output"]
 
     # ---- calls
     assert log["layout"] == tr["layout_calls"]
@@ -320,6 +340,26 @@ def test_two_languages_in_one_page_batch_replay_the_reference_trace(golden_dir):
         assert len(mine) == len(theirs), (p, len(mine), len(theirs))
         for a, b in zip(mine, theirs):
             assert a == b and list(a) == list(b), (p, a, b)
+
+
+def test_a_seal_region_without_a_seal_model_fails_loudly(golden_dir):
+    """seal OCR is on by default (like the reference); its networks are not part of this build: a page with a seal region says so."""
+    fx = json.loads((golden_dir / "analyze_trace_seed6.json").read_text())
+    pages = torch.from_numpy(np.stack([synth_page(i)[0] for i in fx["page_ids"]]))
+    calls = iter(fx["trace"]["det_calls"])
+    pa = analyze.PageAnalyzer(ReplayLayout(fx["layout_dets"], []), ReplayPipe([]), formula_model=ReplayFormula([]),
+                              layout_batch_size=2, formula_batch_size=4, det_batch_num=3,
+                              det_raw_fn=lambda c, b: [np.asarray(x, dtype=np.float32).reshape(-1, 4, 2) for x in next(calls)["boxes"]])
+    with pytest.raises(RuntimeError, match="seal"):
+        pa(pages)
+
+    class CustomWithSeal:             # the custom-OCR seam with an `is_seal` parameter reads the seals itself (batch_analyze.py:433-437)
+        def batch_predict(self, image_list, is_seal=False, **kw):
+            return ["first\nsecond" if is_seal else "region"] * len(image_list)
+    pa = analyze.PageAnalyzer(ReplayLayout(fx["layout_dets"], []), ReplayPipe([]), custom_ocr=CustomWithSeal(), layout_batch_size=2,
+                              det_raw_fn=lambda c, b: [])          # (CPU pages: the detector is never reached on the custom-OCR path)
+    out = pa(pages)
+    assert [d["text"] for page in out for d in page if d.get("original_label") == "seal"] == [["first", "second"]] * 3
 
 
 def test_a_language_without_a_pipeline_fails_loudly():
