@@ -128,6 +128,41 @@ def measure_backbone(pipe, pages, steps, warmup, dist=None, backend="nccl"):
                          "note": "peak = FLOP-weighted harmonic mix of 838.9 (split-fp16 layers) and 157.3 TFLOP/s (fp32-MFMA layers)"}}
 
 
+def measure_formula():
+    """PP-FormulaNet_plus-M (BASELINE config 3's formula stage; not part of `value`): the PPHGNetV2-B6 encoder at B = 32 (98.945 GFLOP per
+    384x384 formula) and the greedy MBart decode at B = 8 / 32 (64 new tokens on 144 encoder states), synthetic weights."""
+    from rapiddoc_amd import weights as W
+    from rapiddoc_amd.engine import RdEngine
+    man = W.load_manifest(ROOT / "tests" / "golden" / "manifest_ppformulanet_plus_m_m8.json")
+    man = [(n, (2562, 512) if n.endswith("embed_positions.weight") else s_, d) for n, s_, d in man]     # the full 2560-token position table
+    st = W.synth_state_dict(man, 0)
+    enc_eng = RdEngine("pphgnetv2_b6_formula").load_weights({k: v for k, v in st.items() if k.startswith("backbone.")})
+    dec_eng = RdEngine("ppformulanet_head").load_weights({k: v for k, v in st.items() if k.startswith("head.")})
+    out = {"what": "PP-FormulaNet_plus-M, synthetic weights; encoder = PPHGNetV2-B6 @384x384 (98.945 GFLOP / formula), decode = greedy MBart, "
+                   "64 new tokens over 144 encoder states"}
+    x = torch.rand((32, 1, 384, 384), device="cuda") * 2 - 1
+    enc_eng.formula_encoder_forward(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        enc_eng.formula_encoder_forward(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    out["encoder_b32"] = {"ms": round(dt * 1e3, 3), "formulas_s": round(32 / dt, 1), "tflops": round(98.945e9 * 32 / dt / 1e12, 1)}
+    for B in (8, 32):
+        enc = torch.randn((B, 144, 2048), device="cuda") * 3
+        dec_eng.formula_decode(enc, 8)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ids = dec_eng.formula_decode(enc, 64)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        steps = int(ids.shape[1]) - 1
+        out["decode_b%d" % B] = {"ms_per_step": round(dt * 1e3 / steps, 4), "tokens_s": round(B * steps / dt, 0), "steps": steps}
+    del enc_eng, dec_eng
+    return out
+
+
 def bench_backbone(args, pool, pages, rank, world, dist, backend):
     """--only backbone: the backbone measurement as the whole job (north_star's >= 40 % MFMA item)."""
     m = measure_backbone(pool.pipes[0], pages, args.steps, args.warmup, dist, backend)
@@ -491,6 +526,7 @@ def main():
                                             "what": "RD_PRECISION=fp32: every dense layer on v_mfma_f32_32x32x2_f32, same pages"}
             for e in pool.engines:
                 e.set_precision("auto")
+        extra["formula"] = measure_formula()
         m = measure_backbone(pipe, pages, 5, 2)
         extra["backbone"] = {"metric": "pages/sec (PP-DocLayout backbone only: pre-process + PPHGNetV2-B4 @800x800)",
                              "pages_s": round(P * 5 / m["dt"], 3), "ms_per_step": round(m["dt"] / 5 * 1e3, 3), "steps": 5, "warmup": 2,

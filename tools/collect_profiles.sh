@@ -7,15 +7,18 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-timeout 600 python bench.py --dump-profile $O/${TAG}_bench_per_kernel.csv 2>/dev/null | tail -1 > $O/${TAG}_bench.json
+timeout 600 python bench.py --steps 20 --warmup 5 --dump-profile $O/${TAG}_bench_per_kernel.csv 2>/dev/null | tail -1 > $O/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$TAG -o s -- python $R/bench.py --no-cpu-baseline --no-extra-passes > /tmp/rp.log 2>&1
+# (the profiled passes run the round-1..3 form of the workload - one resident page set - so that per-kernel figures stay comparable
+#  across rounds and a pass does not spend 20 s synthesising eight page sets; the kernels and their launch sizes are the same)
+ONE="--vary-pages 1 --resident-pages"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$TAG -o s -- python $R/bench.py --no-cpu-baseline --no-extra-passes $ONE > /tmp/rp.log 2>&1
 cp /tmp/rp_$TAG/s_kernel_stats.csv $O/${TAG}_rocprofv3_kernel_stats.csv
 # same workload with the recognition batches on ONE stream: per-kernel durations without co-running kernels (these are
 # the durations bench.py's roofline pass measures with HIP events, so the two must agree)
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rq_$TAG -o s -- python $R/bench.py --no-cpu-baseline --no-extra-passes --rec-streams 1 > /tmp/rq.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rq_$TAG -o s -- python $R/bench.py --no-cpu-baseline --no-extra-passes --rec-streams 1 $ONE > /tmp/rq.log 2>&1
 cp /tmp/rq_$TAG/s_kernel_stats.csv $O/${TAG}_rocprofv3_kernel_stats_1stream.csv
-B="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra-passes --rec-streams 1"
+B="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra-passes --rec-streams 1 $ONE"
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d /tmp/p1_$TAG -o a -- $B > /tmp/p1.log 2>&1
 python $R/tools/pmc_summary.py $(find /tmp/p1_$TAG -name "*counter_collection.csv" | head -1) $O/${TAG}_pmc_sq.csv > /dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -24,7 +27,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python $R/tools/pmc_traffic.py $O/${TAG}_pmc_FETCH_SIZE.csv $O/${TAG}_pmc_WRITE_SIZE.csv $O/${TAG}_pmc_traffic.json "collection ${TAG}, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bench.py --steps 1 --rec-streams 1" > /dev/null
 timeout 200 python $R/bench.py --only backbone 2>/dev/null | tail -1 > $O/${TAG}_bench_backbone.json
-timeout 200 python $R/bench.py --rec-mode strict --no-cpu-baseline --no-extra-passes 2>/dev/null | tail -1 > $O/${TAG}_bench_strict.json
+timeout 200 python $R/bench.py --rec-mode throughput --no-cpu-baseline --no-extra-passes $ONE 2>/dev/null | tail -1 > $O/${TAG}_bench_throughput_mode.json
+timeout 200 python $R/bench.py --no-cpu-baseline --no-extra-passes $ONE 2>/dev/null | tail -1 > $O/${TAG}_bench_resident_one_set.json
 cat $O/${TAG}_bench.json | cut -c1-900
 head -8 $O/${TAG}_rocprofv3_kernel_stats.csv | cut -c1-140
 # microbenchmarks behind DESIGN.md s3c: the ws mixer (round-2 form 200 vs prefetching form 400) and its ablations, each in its own process
