@@ -8,7 +8,7 @@
 #include <cmath>
 #include <cstdint>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define RD_HD __host__ __device__ inline
 #else
 #define RD_HD inline

@@ -92,7 +92,27 @@ __device__ __forceinline__ void dma_finish_tile(const ConvParams& p, const f32x1
     }
 }
 
-__global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn, int ntiles) {
+// order 0: tile w of step i = XCD-contiguous chunk + i * gridDim / 8 (the N tiles of an M tile run AT THE SAME TIME on neighbouring CUs of one
+// XCD: the A tile is fetched from HBM once and fanned out by that XCD's L2);  order 1: workgroup b owns the contiguous run
+// [b * per, (b + 1) * per) - the N tiles of an M tile run ONE AFTER THE OTHER on one CU: every CU streams a DIFFERENT A tile on its first
+// pass (256 x more distinct bytes in flight against the HBM latency) and re-reads it from L2 / MALL on the others.
+__device__ __forceinline__ int gemm_tile_of(int v, int ntiles, int order) {
+    if (order == 0) {
+        const int xcd = v & 7, j = v >> 3, q = ntiles >> 3, r = ntiles & 7;
+        return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int G = (int)gridDim.x, per = (ntiles + G - 1) / G;
+    const int b = v % G, i = v / G;
+    const int w = b * per + i;
+    return (i < per && w < ntiles) ? w : -1;
+}
+__device__ __forceinline__ bool gemm_has_tile(int v, int ntiles, int order) {
+    if (order == 0) return v < ntiles;
+    const int G = (int)gridDim.x, per = (ntiles + G - 1) / G;
+    return v / G < per && (v % G) * per + v / G < ntiles;
+}
+
+__global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn, int ntiles, int order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -114,8 +134,7 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
     const int kc0 = 4 * ((lane & 7) ^ ((lane >> 4) & 7));
     unsigned boff = 0;      // elements from wh / wl
     auto setup_tile = [&](int v) {
-        const int xcd = v & 7, j = v >> 3, q = ntiles >> 3, r = ntiles & 7;
-        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        const int w = gemm_tile_of(v, ntiles, order);
         const int tile_m = w / ntn;
         m0 = tile_m * DM;
         n0 = (w - tile_m * ntn) * DN;
@@ -152,6 +171,7 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
     unsigned emax = 0;
     bool fresh = true;
     int v = blockIdx.x;
+    if (!gemm_has_tile(v, ntiles, order)) return;       // (order 1: the last workgroups may own no tile)
     setup_tile(v);
     issue_tile(0, 0);
     if (KT > 1) issue_tile(1, 1);
@@ -217,7 +237,7 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
         asm volatile("s_barrier" ::: "memory");
         const int em0 = m0, en0 = n0;
         const int vnext = v + (int)gridDim.x;
-        const bool has_next = vnext < ntiles;
+        const bool has_next = gemm_has_tile(vnext, ntiles, order);
         if (has_next) {
             setup_tile(vnext);
             issue_tile(0, 0);
@@ -247,7 +267,7 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
 // wavefront's MFMAs to issue while one splits.  Costs: every A row tile is read and split by 4 wavefronts instead of 2.
 // ABL (developer, RD_GEMM_DBG; results garbage): 1 no stores, 2 no MFMAs, 4 no activation / residual in the epilogue, 8 no epilogue
 template <int ABL>
-__global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int ntn, int ntiles) {
+__global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int ntn, int ntiles, int order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..15
@@ -263,8 +283,7 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
     const float* asrc[2];
     const _Float16* bsrc;
     auto setup_tile = [&](int v) {
-        const int xcd = v & 7, j = v >> 3, q = ntiles >> 3, r = ntiles & 7;
-        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        const int w = gemm_tile_of(v, ntiles, order);
         const int tile_m = w / ntn;
         m0 = tile_m * DM;
         n0 = (w - tile_m * ntn) * DN;
@@ -305,6 +324,7 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
     unsigned emax = 0;
     bool fresh = true;
     int v = blockIdx.x;
+    if (!gemm_has_tile(v, ntiles, order)) return;       // (order 1: the last workgroups may own no tile)
     setup_tile(v);
     issue_tile(0, 0);
     if (KT > 1) issue_tile(1, 1);
@@ -344,7 +364,7 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
         asm volatile("s_barrier" ::: "memory");
         const int em0 = m0, en0 = n0;
         const int vnext = v + (int)gridDim.x;
-        const bool has_next = vnext < ntiles;
+        const bool has_next = gemm_has_tile(vnext, ntiles, order);
         if (has_next) {
             setup_tile(vnext);
             issue_tile(0, 0);
@@ -418,6 +438,8 @@ void launch_gemm_h3_dma(const ConvParams& p, hipStream_t s) {
         return n > 0 ? n : 256;
     }();
     const size_t sh = (size_t)D_NSTAGE * D_STAGE;
+    static const int order_env = [] { const char* e = getenv("RD_GEMM_ORDER"); return e ? atoi(e) : 0; }();
+    const int order = order_env;
     static unsigned long long lds_ok = 0, lds_ok16 = 0;
     rd_allow_dynamic_lds((const void*)gemm_h3_dma_kernel, sh, lds_ok);
     // measured (TFLOP/s, 8 vs 16 wavefronts): K192 117 / 127, K384 162 / 172, K768 214 / 215, K2176 263 / 252, K4096 288 / 274:
@@ -434,7 +456,7 @@ void launch_gemm_h3_dma(const ConvParams& p, hipStream_t s) {
     do {                                                                                                             \
         static unsigned long long ok_ = 0;                                                                           \
         rd_allow_dynamic_lds((const void*)gemm_h3_dma16_kernel<A>, sh, ok_);                                         \
-        hipLaunchKernelGGL(gemm_h3_dma16_kernel<A>, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(1024), sh, s, p, ntn, ntiles); \
+        hipLaunchKernelGGL(gemm_h3_dma16_kernel<A>, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(1024), sh, s, p, ntn, ntiles, order); \
     } while (0)
         switch (dbg) {
             case 1: RD_DMA16(1); break;
@@ -448,7 +470,7 @@ void launch_gemm_h3_dma(const ConvParams& p, hipStream_t s) {
         (void)lds_ok16;
         return;
     }
-    hipLaunchKernelGGL(gemm_h3_dma_kernel, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), sh, s, p, ntn, ntiles);
+    hipLaunchKernelGGL(gemm_h3_dma_kernel, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), sh, s, p, ntn, ntiles, order);
 }
 
 }  // namespace rd
