@@ -19,6 +19,7 @@
 // the DMA from its tap, padding taps from a zero page, BN = 32 / 64 / 128): no faster than the register-staged kernel on
 // the stem and 3x3 layers (81 vs 92 TFLOP/s at N = 48..64) - with 3..27 K tiles per output tile those layers are bound by
 // the per-tile fixed costs, not by the staging path.
+#include <cstdio>
 #include <cstdlib>
 
 #include "rd_device.h"
@@ -112,10 +113,26 @@ __device__ __forceinline__ bool gemm_has_tile(int v, int ntiles, int order) {
     return v / G < per && (v % G) * per + v / G < ntiles;
 }
 
-__global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn, int ntiles, int order) {
+// trace (developer, RD_GEMM_TRACE=1; nullptr otherwise): wavefronts 0 and 4 of workgroup 0 stamp s_memtime at the phase boundaries of their
+// first 60 K-tile iterations into the 16 KB of LDS behind the three stages; copied out at the end (tools/mb_gemm_trace.py prints the deltas)
+#define RD_GSTAMP(slot)                                                                                   \
+    do {                                                                                                  \
+        if constexpr (TRACE) if (tr && it < 60) {                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            unsigned long long t_;                                                                        \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+            if (lane == 0) trl[it * 8 + (slot)] = t_;                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+        }                                                                                                 \
+    } while (0)
+template <bool TRACE>
+__global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn, int ntiles, int order, unsigned long long* trace) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool tr = TRACE && trace != nullptr && blockIdx.x == 0 && (wave == 0 || wave == 4);
+    unsigned long long* trl = reinterpret_cast<unsigned long long*>(smem + D_NSTAGE * D_STAGE + (wave == 4 ? 8192 : 0));
+    int it = 0;
     const int wm = wave;      // 8 x 1 wavefronts of 32 x 128: every A row tile is split (2 VALU per element) by ONE wavefront
                               // (round 1: 4 x 2 of 64 x 64, split twice; VALU time is not hidden on this chip)
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -188,9 +205,12 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
             // every wavefront is done reading stage (kt + 2) % 3, which the next DMAs overwrite
             // (the first K tile after an epilogue waits for everything: the epilogue's stores share the counter and are
             //  not ordered against the DMA loads)
+            RD_GSTAMP(0);
             if (kt + 1 < KT && (kt > 0 || fresh)) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            RD_GSTAMP(1);
             if (kt + 2 < KT) issue_tile(kt + 2, stage >= 1 ? stage - 1 : 2);
+            RD_GSTAMP(2);
             const unsigned char* st = smem + stage * D_STAGE;
             // both A fragments and the B fragments of k-step 0 are read up front, both splits done before the first MFMA; the B
             // fragments of k-step 1 are read under the MFMAs of k-step 0 (all 16 up front do not fit 256 VGPRs next to 128 accumulators)
@@ -210,6 +230,7 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
                 }
                 split8(xa[0][0], xa[0][1], ah0, al0);
                 split8(xa[1][0], xa[1][1], ah1, al1);
+                RD_GSTAMP(3);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[j], acc1[j], 0, 0, 0);
@@ -217,6 +238,7 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
                     acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[j], acc2[j], 0, 0, 0);
                 }
             }
+            RD_GSTAMP(4);
             {
                 f16x8 bh[4], bl[4];
 #pragma unroll
@@ -231,6 +253,8 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
                     acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh[j], acc2[j], 0, 0, 0);
                 }
             }
+            RD_GSTAMP(5);
+            if constexpr (TRACE) ++it;
             stage = stage == 2 ? 0 : stage + 1;
         }
         // every wavefront must be past its last LDS read before the next output tile's DMAs land in stages 0 / 1
@@ -244,6 +268,7 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
             if (KT > 1) issue_tile(1, 1);
         }
         // ---- epilogue (bias, activation, residual, range guard on the pre-activation value: kernels_conv_h3.hip)
+        if constexpr (TRACE) { if (it > 0) { --it; RD_GSTAMP(6); ++it; } }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = en0 + j * 32 + l31;
@@ -251,12 +276,18 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
             const float bv = p.bias ? p.bias[n] : 0.f;
             dma_finish_tile(p, acc1[j], acc2[j], em0 + wm * 32 + 4 * lhi, n, bv, emax);
         }
+        if constexpr (TRACE) { if (it > 0) { --it; RD_GSTAMP(7); ++it; } }
         if (!has_next) break;
         v = vnext;
         fresh = false;
     }
     if (emax >= 0x7f800000u && p.range_flag) atomicOr(p.range_flag, 1u);
+    if constexpr (TRACE) {
+        if (tr && lane == 0)
+            for (int i = 0; i < 60 * 8; ++i) trace[(wave == 4 ? 512 : 0) + i] = trl[i];
+    }
 }
+#undef RD_GSTAMP
 
 // ------------------------------------------------------------------------------------------------------------------
 // 16-wavefront variant of the same pipeline: 256x128 tile, wavefronts as 8 x 2 with 32x64 each (64 accumulator registers
@@ -441,7 +472,7 @@ void launch_gemm_h3_dma(const ConvParams& p, hipStream_t s) {
     static const int order_env = [] { const char* e = getenv("RD_GEMM_ORDER"); return e ? atoi(e) : 0; }();
     const int order = order_env;
     static unsigned long long lds_ok = 0, lds_ok16 = 0;
-    rd_allow_dynamic_lds((const void*)gemm_h3_dma_kernel, sh, lds_ok);
+    rd_allow_dynamic_lds((const void*)gemm_h3_dma_kernel<false>, sh, lds_ok);
     // measured (TFLOP/s, 8 vs 16 wavefronts): K192 117 / 127, K384 162 / 172, K768 214 / 215, K2176 263 / 252, K4096 288 / 274:
     // the K loop itself runs at the same ~1.8 us per K tile with two or four wavefronts per SIMD (it is not latency hiding
     // inside a SIMD that is missing); the 16-wavefront tile only drains its prologue / epilogue faster, which shows for short K
@@ -470,7 +501,31 @@ void launch_gemm_h3_dma(const ConvParams& p, hipStream_t s) {
         (void)lds_ok16;
         return;
     }
-    hipLaunchKernelGGL(gemm_h3_dma_kernel, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), sh, s, p, ntn, ntiles, order);
+    static const bool trace_on = [] { const char* e = getenv("RD_GEMM_TRACE"); return e && e[0] == '1'; }();
+    if (trace_on) {      // developer: phase stamps of workgroup 0 (one launch, synchronous; prints cycles per phase to stderr)
+        static unsigned long long* tbuf = nullptr;
+        static unsigned long long tok = 0;
+        if (!tbuf) (void)hipMalloc(&tbuf, 1024 * sizeof(unsigned long long));
+        (void)hipMemset(tbuf, 0, 1024 * sizeof(unsigned long long));
+        rd_allow_dynamic_lds((const void*)gemm_h3_dma_kernel<true>, sh + 16384, tok);
+        hipLaunchKernelGGL(gemm_h3_dma_kernel<true>, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), sh + 16384, s, p, ntn, ntiles, order, tbuf);
+        (void)hipStreamSynchronize(s);
+        unsigned long long h[1024];
+        (void)hipMemcpy(h, tbuf, sizeof(h), hipMemcpyDeviceToHost);
+        static int printed = 0;
+        if (printed++ < 1) {
+            const int KT = (p.K + DK - 1) / DK;
+            fprintf(stderr, "gemm trace M=%d K=%d N=%d KT=%d (cycles of s_memtime, 100 MHz-independent shader clock): it: wait issue reads+split mfma0 mfma1 | epilogue\n", p.M, p.K, p.Ng, KT);
+            for (int w = 0; w < 2; ++w)
+                for (int i = 0; i < 60 && h[w * 512 + i * 8 + 5]; ++i) {
+                    const unsigned long long* t = h + w * 512 + i * 8;
+                    fprintf(stderr, "w%d it %2d: %6llu %6llu %6llu %6llu %6llu | next-top %6llu  epi %6llu\n", w * 4, i, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3],
+                            t[5] - t[4], (i + 1 < 60 && h[w * 512 + (i + 1) * 8]) ? h[w * 512 + (i + 1) * 8] - t[5] : 0ull, t[7] > t[6] ? t[7] - t[6] : 0ull);
+                }
+        }
+        return;
+    }
+    hipLaunchKernelGGL(gemm_h3_dma_kernel<false>, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), sh, s, p, ntn, ntiles, order, (unsigned long long*)nullptr);
 }
 
 }  // namespace rd

@@ -77,7 +77,7 @@ def test_known_register_budgets(tables):
     """The two LDS-DMA GEMMs: the 8-wavefront kernel must fit the 256 registers of two wavefronts per SIMD, the 16-wavefront one
     the 128 of four."""
     rows = {n: (v, s, p) for n, v, s, p in tables["kernels_gemm_h3_dma.hip"]}
-    k8 = next(v for n, v in rows.items() if "gemm_h3_dma_kernel" in n)
+    k8 = next(v for n, v in rows.items() if "gemm_h3_dma_kernelILb0E" in n)
     k16 = next(v for n, v in rows.items() if "gemm_h3_dma16_kernelILi0E" in n)
     assert k8[0] <= 256 and k8[1:] == (0, 0)
     assert k16[0] <= 128 and k16[1:] == (0, 0)

@@ -24,7 +24,7 @@ CSRC = ROOT / "rapiddoc_amd" / "csrc"
 HOT = [
     ("lc_mixer_ws_kernel<192> (prefetching form)", "kernels_mixer_ws.hip", r"lc_mixer_ws_kernelILi192ELb0ELb0ELi0ELb1E"),
     ("gemm_h3_dma16_kernel", "kernels_gemm_h3_dma.hip", r"gemm_h3_dma16_kernelILi0E"),
-    ("gemm_h3_dma_kernel", "kernels_gemm_h3_dma.hip", r"gemm_h3_dma_kernelE"),
+    ("gemm_h3_dma_kernel", "kernels_gemm_h3_dma.hip", r"gemm_h3_dma_kernelILb0E"),
     ("dwconv3x3 (tiled, 8 wide)", "kernels_misc.hip", r"dwconv_tiled_kernelILi3ELi3ELi1ELi8ELi0E"),
     ("lc_mixer_res_kernel<96>", "kernels_mixer_res.hip", r"lc_mixer_res_kernelILi96E"),
     ("stem_fused_kernel<48>", "kernels_stem_fused.hip", r"stem_fused_kernelILi48E"),
