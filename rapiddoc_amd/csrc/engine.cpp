@@ -367,7 +367,7 @@ TView Builder::conv(const std::string& wname, const std::string& bname, const st
         p.wh = reinterpret_cast<const uint16_t*>(pb_->ptr(key + "#wh"));
         p.wl = reinterpret_cast<const uint16_t*>(pb_->ptr(key + "#wl"));
         p.range_flag = range_flag_;
-        r.cfg = std::string(conv_stream_h3_applies(p) ? "stream" : conv_direct_h3_applies(p) ? "direct" : gemm_h3_dma_applies(p) ? (K <= 384 ? "dma16w256x128" : "dma256x128") : cout > 96 ? "256x128" : cout > 64 ? "128x96"
+        r.cfg = std::string(conv_stream_h3_applies(p) ? "stream" : conv_direct_h3_applies(p) ? "direct" : gemm_h3_dma_applies(p) ? (gemm_h3_dma_uses16(p) ? "dma16w256x128" : "dma256x128") : cout > 96 ? "256x128" : cout > 64 ? "128x96"
                             : (cout > 32 && p.M >= 65536) ? "256x64" : K <= 256 || cout <= 32 ? "128x32" : "128x64") + "/h3";
     }
     r.run = [p, xv, yv, rv, av, has_res, has_as, h3](const Plan& pl, const RunCtx& c) mutable {

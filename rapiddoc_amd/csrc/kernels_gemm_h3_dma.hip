@@ -20,6 +20,7 @@
 // the stem and 3x3 layers (81 vs 92 TFLOP/s at N = 48..64) - with 3..27 K tiles per output tile those layers are bound by
 // the per-tile fixed costs, not by the staging path.
 #include <cstdio>
+#include <type_traits>
 #include <cstdlib>
 
 #include "rd_device.h"
@@ -125,7 +126,11 @@ __device__ __forceinline__ bool gemm_has_tile(int v, int ntiles, int order) {
             __builtin_amdgcn_sched_barrier(0);                                                            \
         }                                                                                                 \
     } while (0)
-template <bool TRACE>
+// IL (round 4): the six LDS-DMA pieces of tile kt + 2 are issued BETWEEN the MFMA groups of tile kt instead of in front of them.  The phase
+// stamps of the round-3 form (RD_GEMM_TRACE, tools/mb_gemm_trace.py; K = 768, per K tile and SIMD) read: barrier skew + DMA issue 500-750
+// cycles + fragment reads / split 200-450 with the matrix pipe idle, then 2 x 24 MFMAs (1536) - a DMA piece costs its wavefront 80-125 issue
+// cycles, and the two wavefronts of a SIMD pay them at the same time.  Between MFMAs the same pieces issue while the pipe works.
+template <bool TRACE, bool IL>
 __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn, int ntiles, int order, unsigned long long* trace) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -175,6 +180,19 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
         dma16(wh + (boff + (unsigned)k0), base + D_A_BYTES + (unsigned)wave * 1024u, smem);
         dma16(wl + (boff + (unsigned)k0), base + D_A_BYTES + D_B_BYTES + (unsigned)wave * 1024u, smem);
     };
+    // one of the six pieces of a tile (0-3: A rows, 4 / 5: weight planes), fenced so that it stays where it is written
+    auto issue_piece = [&](int kt, int stage, int piece) {
+        const unsigned base = (unsigned)stage * D_STAGE;
+        const int k0 = kt * DK;
+        __builtin_amdgcn_sched_barrier(0);
+        if (piece < 4)
+            dma16(p.x + (aoff[piece] + (unsigned)min(k0 + (kc0 ^ (16 * (piece & 1))), K - 4)), base + (unsigned)(4 * wave + piece) * 1024u, smem);
+        else if (piece == 4)
+            dma16(wh + (boff + (unsigned)k0), base + D_A_BYTES + (unsigned)wave * 1024u, smem);
+        else
+            dma16(wl + (boff + (unsigned)k0), base + D_A_BYTES + D_B_BYTES + (unsigned)wave * 1024u, smem);
+        __builtin_amdgcn_sched_barrier(0);
+    };
 
     // ---- fragment addressing (byte offsets inside a stage)
     // A: [ks] first of the two chunks (k-step 1 = k-step 0 with bit 2 of the chunk index flipped, the partner chunk is the
@@ -200,7 +218,7 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
             for (int r = 0; r < 16; ++r) acc1[j][r] = acc2[j][r] = 0.f;
 
         int stage = 0;
-        for (int kt = 0; kt < KT; ++kt) {
+        auto k_tile = [&](int kt, auto pf_c) {
             // tile kt has landed (this wavefront's own DMAs: all but the newest 6), then everybody's; the barrier also says
             // every wavefront is done reading stage (kt + 2) % 3, which the next DMAs overwrite
             // (the first K tile after an epilogue waits for everything: the epilogue's stores share the counter and are
@@ -209,25 +227,27 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
             if (kt + 1 < KT && (kt > 0 || fresh)) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             RD_GSTAMP(1);
-            if (kt + 2 < KT) issue_tile(kt + 2, stage >= 1 ? stage - 1 : 2);
+            constexpr bool pf = decltype(pf_c)::value;       // tile kt + 2 exists (compile time: no branch inside the MFMA groups)
+            const int pstage = stage >= 1 ? stage - 1 : 2;
+            if constexpr (!IL) {
+                if constexpr (pf) issue_tile(kt + 2, pstage);
+            }
             RD_GSTAMP(2);
             const unsigned char* st = smem + stage * D_STAGE;
-            // both A fragments and the B fragments of k-step 0 are read up front, both splits done before the first MFMA; the B
-            // fragments of k-step 1 are read under the MFMAs of k-step 0 (all 16 up front do not fit 256 VGPRs next to 128 accumulators)
-            f32x4 xa[2][2];
+            if constexpr (IL) {
+                f32x4 xa[2][2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                xa[ks][0] = *reinterpret_cast<const f32x4*>(st + a_off(ks));
-                xa[ks][1] = *reinterpret_cast<const f32x4*>(st + (a_off(ks) ^ 16));
-            }
-            f16x8 ah0, al0, ah1, al1;
-            {
-                f16x8 bh[4], bl[4];
+                for (int ks = 0; ks < 2; ++ks) {
+                    xa[ks][0] = *reinterpret_cast<const f32x4*>(st + a_off(ks));
+                    xa[ks][1] = *reinterpret_cast<const f32x4*>(st + (a_off(ks) ^ 16));
+                }
+                f16x8 bh[4], bl[4], bh1[4], bl1[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     bh[j] = *reinterpret_cast<const f16x8*>(st + b_off(j, 0));
                     bl[j] = *reinterpret_cast<const f16x8*>(st + b_off(j, 0) + D_B_BYTES);
                 }
+                f16x8 ah0, al0, ah1, al1;
                 split8(xa[0][0], xa[0][1], ah0, al0);
                 split8(xa[1][0], xa[1][1], ah1, al1);
                 RD_GSTAMP(3);
@@ -236,26 +256,70 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
                     acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[j], acc1[j], 0, 0, 0);
                     acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[j], acc2[j], 0, 0, 0);
                     acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[j], acc2[j], 0, 0, 0);
+                    // under these MFMAs: one A piece of tile kt + 2, and the k-step-1 weight fragments of column block j
+                    if constexpr (pf) issue_piece(kt + 2, pstage, j);
+                    bh1[j] = *reinterpret_cast<const f16x8*>(st + b_off(j, 1));
+                    bl1[j] = *reinterpret_cast<const f16x8*>(st + b_off(j, 1) + D_B_BYTES);
                 }
-            }
-            RD_GSTAMP(4);
-            {
-                f16x8 bh[4], bl[4];
+                RD_GSTAMP(4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    bh[j] = *reinterpret_cast<const f16x8*>(st + b_off(j, 1));
-                    bl[j] = *reinterpret_cast<const f16x8*>(st + b_off(j, 1) + D_B_BYTES);
+                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1[j], acc1[j], 0, 0, 0);
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl1[j], acc2[j], 0, 0, 0);
+                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh1[j], acc2[j], 0, 0, 0);
+                    if constexpr (pf) { if (j < 2) issue_piece(kt + 2, pstage, 4 + j); }
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh[j], acc1[j], 0, 0, 0);
-                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl[j], acc2[j], 0, 0, 0);
-                    acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh[j], acc2[j], 0, 0, 0);
+            } else {
+                // both A fragments and the B fragments of k-step 0 are read up front, both splits done before the first MFMA; the B
+                // fragments of k-step 1 are read under the MFMAs of k-step 0 (all 16 up front do not fit 256 VGPRs next to 128 accumulators)
+                f32x4 xa[2][2];
+    #pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    xa[ks][0] = *reinterpret_cast<const f32x4*>(st + a_off(ks));
+                    xa[ks][1] = *reinterpret_cast<const f32x4*>(st + (a_off(ks) ^ 16));
+                }
+                f16x8 ah0, al0, ah1, al1;
+                {
+                    f16x8 bh[4], bl[4];
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bh[j] = *reinterpret_cast<const f16x8*>(st + b_off(j, 0));
+                        bl[j] = *reinterpret_cast<const f16x8*>(st + b_off(j, 0) + D_B_BYTES);
+                    }
+                    split8(xa[0][0], xa[0][1], ah0, al0);
+                    split8(xa[1][0], xa[1][1], ah1, al1);
+                    RD_GSTAMP(3);
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[j], acc1[j], 0, 0, 0);
+                        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[j], acc2[j], 0, 0, 0);
+                        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[j], acc2[j], 0, 0, 0);
+                    }
+                }
+                RD_GSTAMP(4);
+                {
+                    f16x8 bh[4], bl[4];
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bh[j] = *reinterpret_cast<const f16x8*>(st + b_off(j, 1));
+                        bl[j] = *reinterpret_cast<const f16x8*>(st + b_off(j, 1) + D_B_BYTES);
+                    }
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh[j], acc1[j], 0, 0, 0);
+                        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl[j], acc2[j], 0, 0, 0);
+                        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh[j], acc2[j], 0, 0, 0);
+                    }
                 }
             }
             RD_GSTAMP(5);
             if constexpr (TRACE) ++it;
             stage = stage == 2 ? 0 : stage + 1;
+        };
+        {
+            int kt = 0;
+            for (; kt + 2 < KT; ++kt) k_tile(kt, std::true_type{});
+            for (; kt < KT; ++kt) k_tile(kt, std::false_type{});
         }
         // every wavefront must be past its last LDS read before the next output tile's DMAs land in stages 0 / 1
         asm volatile("s_barrier" ::: "memory");
@@ -460,6 +524,15 @@ bool gemm_h3_dma_applies(const ConvParams& p) {
            p.out_mode == OUT_NHWC && !p.ascale && p.K % 4 == 0 && p.K >= 2 * DK && p.Ng >= 96 && p.M >= 2048 && (p.xld % 4) == 0;
 }
 
+// which of the two kernels launch_gemm_h3_dma runs for p (the per-op profile names it)
+bool gemm_h3_dma_uses16(const ConvParams& p) {
+    static const int force16 = [] { const char* e = getenv("RD_H3_DMA16"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    // the 8-wavefront kernel addresses its operands with 32-bit element offsets from p.x / p.wh
+    const bool fits32 = (unsigned long long)p.M * (unsigned long long)p.xld + (unsigned long long)p.K < (1ull << 32) &&
+                        (unsigned long long)p.Ng * (unsigned long long)((p.K + DK - 1) / DK * DK) < (1ull << 32);
+    return !fits32 || (force16 >= 0 ? force16 == 1 : (p.K <= 192 && p.act == ACT_GELU));
+}
+
 void launch_gemm_h3_dma(const ConvParams& p, hipStream_t s) {
     const int ntm = (p.M + DM - 1) / DM, ntn = (p.Ng + DN - 1) / DN, ntiles = ntm * ntn;
     static const int n_cu = [] {
@@ -472,15 +545,13 @@ void launch_gemm_h3_dma(const ConvParams& p, hipStream_t s) {
     static const int order_env = [] { const char* e = getenv("RD_GEMM_ORDER"); return e ? atoi(e) : 0; }();
     const int order = order_env;
     static unsigned long long lds_ok = 0, lds_ok16 = 0;
-    rd_allow_dynamic_lds((const void*)gemm_h3_dma_kernel<false>, sh, lds_ok);
-    // measured (TFLOP/s, 8 vs 16 wavefronts): K192 117 / 127, K384 162 / 172, K768 214 / 215, K2176 263 / 252, K4096 288 / 274:
-    // the K loop itself runs at the same ~1.8 us per K tile with two or four wavefronts per SIMD (it is not latency hiding
-    // inside a SIMD that is missing); the 16-wavefront tile only drains its prologue / epilogue faster, which shows for short K
-    static const int force16 = [] { const char* e = getenv("RD_H3_DMA16"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-    // the 8-wavefront kernel addresses its operands with 32-bit element offsets from p.x / p.wh
-    const bool fits32 = (unsigned long long)p.M * (unsigned long long)p.xld + (unsigned long long)p.K < (1ull << 32) &&
-                        (unsigned long long)p.Ng * (unsigned long long)((p.K + DK - 1) / DK * DK) < (1ull << 32);
-    const bool use16 = !fits32 || (force16 >= 0 ? force16 == 1 : p.K <= 384);
+    rd_allow_dynamic_lds((const void*)gemm_h3_dma_kernel<false, false>, sh, lds_ok);
+    // Which kernel (TFLOP/s-equivalent, 16 vs 8 wavefronts, same box, tools/mb_gemm_k16.py, round 4 - the 8-wavefront kernel with its DMA pieces
+    // between the MFMA groups): K384 N768 GELU M131072 199 / 207, M43056 221 / 232; K384 N384 240 / 277; K256 N512 184 / 198; K192 N192
+    // 113-124 / 128-136; K96 N96 100 / 112; only the short-K GELU layers keep the 16-wavefront tile: K192 N384 GELU 145 / 139, 183 / 169
+    // (their epilogue is a third of the tile's time and drains faster from 64 accumulator registers per wavefront).  Round 3 routed every
+    // K <= 384 to the 16-wavefront kernel on measurements at M = 26112-52224, where it led by 5 %.
+    const bool use16 = gemm_h3_dma_uses16(p);
     if (use16) {
         static const int dbg = [] { const char* e = getenv("RD_GEMM_DBG"); return e ? atoi(e) : 0; }();
 #define RD_DMA16(A)                                                                                                  \
@@ -507,8 +578,8 @@ void launch_gemm_h3_dma(const ConvParams& p, hipStream_t s) {
         static unsigned long long tok = 0;
         if (!tbuf) (void)hipMalloc(&tbuf, 1024 * sizeof(unsigned long long));
         (void)hipMemset(tbuf, 0, 1024 * sizeof(unsigned long long));
-        rd_allow_dynamic_lds((const void*)gemm_h3_dma_kernel<true>, sh + 16384, tok);
-        hipLaunchKernelGGL(gemm_h3_dma_kernel<true>, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), sh + 16384, s, p, ntn, ntiles, order, tbuf);
+        rd_allow_dynamic_lds((const void*)gemm_h3_dma_kernel<true, false>, sh + 16384, tok);
+        hipLaunchKernelGGL((gemm_h3_dma_kernel<true, false>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), sh + 16384, s, p, ntn, ntiles, order, tbuf);
         (void)hipStreamSynchronize(s);
         unsigned long long h[1024];
         (void)hipMemcpy(h, tbuf, sizeof(h), hipMemcpyDeviceToHost);
@@ -525,7 +596,14 @@ void launch_gemm_h3_dma(const ConvParams& p, hipStream_t s) {
         }
         return;
     }
-    hipLaunchKernelGGL(gemm_h3_dma_kernel<false>, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), sh, s, p, ntn, ntiles, order, (unsigned long long*)nullptr);
+    static const int il_env = [] { const char* e = getenv("RD_GEMM_IL"); return e ? atoi(e) : 1; }();
+    if (il_env) {
+        static unsigned long long ok_il = 0;
+        rd_allow_dynamic_lds((const void*)gemm_h3_dma_kernel<false, true>, sh, ok_il);
+        hipLaunchKernelGGL((gemm_h3_dma_kernel<false, true>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), sh, s, p, ntn, ntiles, order, (unsigned long long*)nullptr);
+        return;
+    }
+    hipLaunchKernelGGL((gemm_h3_dma_kernel<false, false>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), sh, s, p, ntn, ntiles, order, (unsigned long long*)nullptr);
 }
 
 }  // namespace rd

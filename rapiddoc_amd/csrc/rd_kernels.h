@@ -47,6 +47,7 @@ void launch_conv_igemm(const ConvParams& p, hipStream_t s);
 bool skinny_gemm_applies(int M, int K);   // true when launch_conv_igemm will take the small-M path that can fuse ln_g / ln_b
 // fp32-accurate variant on the fp16 matrix cores (3 MFMAs per product, see kernels_conv_h3.hip); needs p.wh / p.wl
 bool gemm_h3_dma_applies(const ConvParams& p);
+bool gemm_h3_dma_uses16(const ConvParams& p);   // the 16-wavefront kernel (short-K GELU layers, > 2^32-element tensors) or the 8-wavefront one
 void launch_gemm_h3_dma(const ConvParams& p, hipStream_t s);
 void launch_conv_igemm_h3(const ConvParams& p, hipStream_t s);
 // direct 2x2 / 3x3 stride-1 convolution for narrow outputs (kernels_conv_direct_h3.hip); launch_conv_igemm_h3 dispatches to it
