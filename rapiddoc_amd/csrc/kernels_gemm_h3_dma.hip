@@ -530,6 +530,8 @@ bool gemm_h3_dma_uses16(const ConvParams& p) {
     // the 8-wavefront kernel addresses its operands with 32-bit element offsets from p.x / p.wh
     const bool fits32 = (unsigned long long)p.M * (unsigned long long)p.xld + (unsigned long long)p.K < (1ull << 32) &&
                         (unsigned long long)p.Ng * (unsigned long long)((p.K + DK - 1) / DK * DK) < (1ull << 32);
+    static const bool old_route = [] { const char* e = getenv("RD_GEMM_ROUTE"); return e && e[0] == 'o'; }();      // A/B: round 3's K <= 384 rule
+    if (old_route && force16 < 0) return !fits32 || p.K <= 384;
     return !fits32 || (force16 >= 0 ? force16 == 1 : (p.K <= 192 && p.act == ACT_GELU));
 }
 

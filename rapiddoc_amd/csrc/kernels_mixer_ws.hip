@@ -477,6 +477,20 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
             ws_step_sync_pf<decltype(extra)::value, !(ABL & 16)>();
             issue_stage(t + 2);        // (no "no DMA" ablation here: the wait counts below rely on the pieces)
         };
+        // IL (ABL bit 7, round 4; what the engine dispatches): in the COMMON steps the six DMA pieces of stage t + 2 are issued between the
+        // MFMA units instead of in a clump behind the barrier.  A piece costs its wavefront 80-125 issue cycles (phase stamps of the DMA
+        // GEMM, tools/mb_gemm_trace.py) and both wavefronts of a SIMD paid all six with the matrix pipe idle; between units they issue
+        // while the pipe works.  Same pieces, same order relative to the re-fetch loads, so the counted waits are unchanged.
+        constexpr bool IL = (ABL & 128) != 0;
+        auto step_sync = [&](auto extra) { ws_step_sync_pf<decltype(extra)::value, !(ABL & 16)>(); };
+        auto issue_piece = [&](const unsigned char* src, unsigned char* dst, int u) {
+            int f = wave + u * WS_WAVES + rot;
+            f = f >= G::STAGE_FRAGS ? f - G::STAGE_FRAGS : f;
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 1024),
+                                             (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
         using E0 = std::integral_constant<int, 0>;
         using E12 = std::integral_constant<int, 12>;
         auto stage_of = [&]() { return lds + (t % WS_NSTAGE) * G::STAGE_BYTES; };
@@ -502,6 +516,8 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
         auto common_step = [&](int r, auto refetch) {
             const unsigned char* stage = stage_of();
             const int q = (t + NC - 1) % NC;
+            const unsigned char* il_src = wimg + (size_t)((t + 2 + NC - 1) % NC) * G::STAGE_BYTES + lane * 16;      // stage t + 2 (IL)
+            unsigned char* il_dst = lds + ((t + 2) % WS_NSTAGE) * G::STAGE_BYTES;
             f16x8 hh, hl;
 #pragma unroll
             for (int b = 0; b < 2; ++b) hn[b] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -515,6 +531,9 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
                 if (i < KS) unit_g1(i, i % 3);
                 else unit_g2(2 * (i - KS), i % 3, hh, hl);
                 pin_unit(i + 2 < NU);
+                if constexpr (IL) {
+                    if (i < G::PIECES) issue_piece(il_src, il_dst, i);
+                }
                 if constexpr (decltype(refetch)::value) {
                     if (i == KS - 1) {
                         __builtin_amdgcn_sched_barrier(0);
@@ -527,8 +546,13 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
         };
         bool after_switch = false;
         auto step_begin_rt = [&]() {                                           // allowance known at run time only (no load in flight)
-            if (!after_switch) step_begin(E0{});
-            else step_begin(E12{});
+            if constexpr (IL) {
+                if (!after_switch) step_sync(E0{});
+                else step_sync(E12{});
+            } else {
+                if (!after_switch) step_begin(E0{});
+                else step_begin(E12{});
+            }
             after_switch = false;
         };
         for (; t < T_total && (R == 0 || t < ph); ++t) step_begin(E0{});       // idle head (all of it for a wavefront without tiles)
@@ -547,7 +571,8 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
                     common_step(r, std::false_type{});
                     ++t;
                 }
-                step_begin(E0{});
+                if constexpr (IL) step_sync(E0{});
+                else step_begin(E0{});
                 common_step(r, std::true_type{});
                 ++t;
                 // switch step: residual into the accumulator, next tile requested, last chunk finished, epilogue, next tile split
@@ -797,6 +822,12 @@ void launch_mixer_fused_ws(const MixerParams& p, hipStream_t s) {
         return;
     }
     if (pf) {
+        static const bool il = [] { const char* e = getenv("RD_WS_IL"); return !(e && e[0] == '0'); }();     // A/B switch: RD_WS_IL=0 = the round-3 form
+        if (il) {
+            if (gated) launch_ws<192, true, false, 128, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s);
+            else launch_ws<192, false, false, 128, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s);
+            return;
+        }
         if (gated) launch_ws<192, true, false, 0, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s);
         else launch_ws<192, false, false, 0, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s);
         return;
