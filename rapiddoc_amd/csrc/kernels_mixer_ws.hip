@@ -546,14 +546,20 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
         };
         bool after_switch = false;
         auto step_begin_rt = [&]() {                                           // allowance known at run time only (no load in flight)
+            if (!after_switch) step_begin(E0{});
+            else step_begin(E12{});
+            after_switch = false;
+        };
+        // the same in front of a common step: under IL only the wait + barrier - common_step issues the pieces itself.  (NOT for the idle
+        // steps: an idle wavefront still owes its six fragments of every stage to the wavefronts that compute.)
+        auto step_begin_common_rt = [&]() {
             if constexpr (IL) {
                 if (!after_switch) step_sync(E0{});
                 else step_sync(E12{});
+                after_switch = false;
             } else {
-                if (!after_switch) step_begin(E0{});
-                else step_begin(E12{});
+                step_begin_rt();
             }
-            after_switch = false;
         };
         for (; t < T_total && (R == 0 || t < ph); ++t) step_begin(E0{});       // idle head (all of it for a wavefront without tiles)
         if (R > 0) {
@@ -567,7 +573,7 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
             ++t;
             for (int r = 0; r < R; ++r) {
                 for (int j = 1; j < NC - 1; ++j) {
-                    step_begin_rt();
+                    step_begin_common_rt();
                     common_step(r, std::false_type{});
                     ++t;
                 }

@@ -197,3 +197,63 @@ def test_strict_mode_falls_back_to_fp32_with_the_line_table(golden_dir):
     flat = [ln for r in b for ln in r.lines]
     check_lines_against_oracle(pipe, O.as_torch_state(states["ppocrv6_rec"]), flat, per_batch=4)
     assert [t for _q, t, _s in a[0].lines] == [t for _q, t, _s in b[0].lines]
+
+
+def test_page_uploader_streams_host_batches_and_run_batch_takes_host_pages(golden_dir):
+    """The reference hands host arrays to every batch (batch_analyze.py:108-111): `run_batch` on numpy pages == on the same pages already in
+    HBM; `PageUploader` (double-buffered, own copy stream) over a stream of four batches - pinned and pageable sources, buffers recycled -
+    gives every batch its own pages and the same results."""
+    from rapiddoc_amd.pages import synth_batch
+    from rapiddoc_amd.pipeline import PagePipeline, PageUploader, render_text_maps
+    states = {k: _state(golden_dir, k) for k in ("ppocrv6_det", "ppocrv6_rec")}
+    pipe = PagePipeline(states, n_rec_streams=2)
+    sets = [synth_batch(20 + k, 2) for k in range(4)]
+    det_hw = pipe.det_preprocess(torch.from_numpy(sets[0][0]).cuda()[:1])[1]
+    maps = [render_text_maps(b, p.shape[1:3], det_hw, torch.device("cuda", 0)) for p, b in sets]
+    strings = lambda res: [[(t, s) for _q, t, s in r.lines] for r in res]
+    want = [strings(pipe.run_batch(torch.from_numpy(p).cuda(), None, det_maps_override=m)) for (p, _b), m in zip(sets, maps)]
+    assert all(len(page) == 45 for w in want for page in w) and want[0] != want[1]
+    assert strings(pipe.run_batch(sets[1][0], None, det_maps_override=maps[1])) == want[1]                       # numpy pages
+    assert strings(pipe.run_batch(torch.from_numpy(sets[2][0]), None, det_maps_override=maps[2])) == want[2]     # CPU tensor
+    up = PageUploader(0, n_buffers=2)
+    host = []
+    for k, (p, _b) in enumerate(sets):
+        if k % 2 == 0:
+            t = PageUploader.pinned_like(p.shape)
+            t.copy_(torch.from_numpy(p))
+            host.append(t)
+        else:
+            host.append(p)                                    # pageable numpy: staged through the uploader's pinned buffer
+    got = []
+    nxt = up.submit(host[0])
+    for k in range(4):
+        cur, nxt = nxt, (up.submit(host[k + 1]) if k + 1 < 4 else None)
+        dev = up.wait(cur)
+        assert dev.is_cuda and tuple(dev.shape) == sets[k][0].shape
+        res = pipe.run_batch(dev, None, det_maps_override=maps[k])
+        up.release(cur)
+        got.append(strings(res))
+    torch.cuda.synchronize()
+    assert got == want and up.bytes_uploaded == sum(p.nbytes for p, _b in sets)
+
+
+def test_pipeline_pool_equals_single_pipeline_with_device_db_postprocess(golden_dir):
+    """PagePipelinePool(workers = 2): two pipelines on two host threads and streams, each with its OWN DB post-process workspaces
+    (a process-wide cache handed both threads the same union-find arrays).  Boxes come from the device post-process
+    (quads_per_page=None); both shards have the same (B, H, W) so they used to share a cache key.  Repeated: a race is not every run."""
+    from rapiddoc_amd.pages import synth_batch
+    from rapiddoc_amd.pipeline import PagePipeline, PagePipelinePool, render_text_maps
+    states = {k: _state(golden_dir, k) for k in ("ppocrv6_det", "ppocrv6_rec")}
+    kw = dict(rec_mode="throughput", rec_batch_num=1, n_rec_streams=2)      # one line per rec batch: a line's result does not depend on its shard
+    single = PagePipeline(states, **kw)
+    pool = PagePipelinePool(states, workers=2, **kw)
+    assert pool.pipes[0].db_ws is not pool.pipes[1].db_ws
+    pages_np, boxes = synth_batch(31, 4)
+    pages = torch.from_numpy(pages_np).cuda()
+    maps = render_text_maps(boxes, pages_np.shape[1:3], single.det_preprocess(pages[:1])[1], pages.device)
+    ref = single.run_batch(pages, None, det_maps_override=maps)
+    want = [[(q.round(2).tolist(), t, s) for q, t, s in r.lines] for r in ref]
+    assert [len(w) for w in want] == [45] * 4
+    for _ in range(6):
+        got = [[(q.round(2).tolist(), t, s) for q, t, s in r.lines] for r in pool.run_batch(pages, None, det_maps_override=maps)]
+        assert got == want
