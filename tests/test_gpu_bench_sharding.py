@@ -15,7 +15,7 @@ ROOT = Path(__file__).resolve().parents[1]
 # (--rec-mode throughput with one line per rec batch: a line's result then does not depend on which other lines its rank holds; in the
 #  default strict mode a line is padded like its chunk of six of the rank's pooled lines, exactly as the reference pools a page batch)
 COMMON = ["--rec-mode", "throughput", "--scaling", "strong", "--global-pages", "4", "--rec-chunking", "fixed", "--rec-batch", "1", "--rec-streams", "2", "--steps", "1",
-          "--warmup", "0", "--no-cpu-baseline"]
+          "--warmup", "0", "--setup-steps", "0", "--no-cpu-baseline"]
 
 
 def _last_json(out: str) -> dict:
@@ -46,7 +46,7 @@ def test_two_ranks_weak_scaling_cover_the_same_global_list():
     """--scaling weak: 2 pages per rank x 2 ranks = the same 4-page global list (rank r takes pages r, r + 2): same crc as the
     single-process run over 4 pages."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    base = ["--rec-mode", "throughput", "--rec-chunking", "fixed", "--rec-batch", "1", "--rec-streams", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    base = ["--rec-mode", "throughput", "--rec-chunking", "fixed", "--rec-batch", "1", "--rec-streams", "2", "--steps", "1", "--warmup", "0", "--setup-steps", "0", "--no-cpu-baseline"]
     one = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--scaling", "weak", "--pages", "4", *base], capture_output=True, text=True,
                          timeout=900, env=env, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-2000:]

@@ -257,3 +257,32 @@ def test_pipeline_pool_equals_single_pipeline_with_device_db_postprocess(golden_
     for _ in range(6):
         got = [[(q.round(2).tolist(), t, s) for q, t, s in r.lines] for r in pool.run_batch(pages, None, det_maps_override=maps)]
         assert got == want
+
+
+def test_bench_step_in_the_default_strict_mode_matches_the_oracle(golden_dir):
+    """One whole benchmark step as bench.py runs it by default (32 pages, 1440 lines, 8 rec streams, strict rec mode): every launch keeps the
+    reference's chunk widths (all 240 chunks of six), sampled lines of every launch against the oracle at their own width, the strings the
+    step returned are the decode of those, and two steps give the same result (what bench.py's result_crc32 hashes)."""
+    from rapiddoc_amd.pages import synth_pages
+    from rapiddoc_amd.pipeline import PagePipeline, render_text_maps
+    states = {k: _state(golden_dir, k) for k in ("ppocrv6_det", "ppocrv6_rec", "pphgnetv2_b4")}
+    pipe = PagePipeline(states, rec_width_multiple=32, n_rec_streams=8)
+    assert pipe.rec_mode == "strict"
+    pages_np, boxes = synth_pages(list(range(32)))
+    pages = torch.from_numpy(pages_np).cuda()
+    maps = render_text_maps(boxes, pages_np.shape[1:3], pipe.det_preprocess(pages[:1])[1], pages.device)
+    pipe.keep_rec_inputs = True
+    res = pipe.run_batch(pages, None, det_maps_override=maps)
+    assert [len(r.lines) for r in res] == [45] * 32
+    flat = [ln for r in res for ln in r.lines]
+    cw, ch, rot, keep = pipe.last_rec_crop_sizes
+    crop_hw = [(int(cw[i]), int(ch[i])) if rot[i] else (int(ch[i]), int(cw[i])) for i in range(len(flat))]
+    want_w = {i: w for idxs, w in _reference_rec_chunks(crop_hw) for i in idxs}
+    nb = len(pipe.last_rec_batches)
+    assert 8 <= nb <= 24 and sum(len(c) for c, *_ in pipe.last_rec_batches) == 1440
+    got_w = check_lines_against_oracle(pipe, O.as_torch_state(states["ppocrv6_rec"]), flat, per_batch=3)
+    assert got_w == want_w
+    pipe.keep_rec_inputs = False
+    pipe.last_rec_batches = []
+    again = pipe.run_batch(pages, None, det_maps_override=maps)
+    assert [[(t, s) for _q, t, s in r.lines] for r in again] == [[(t, s) for _q, t, s in r.lines] for r in res]
