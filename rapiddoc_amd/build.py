@@ -13,6 +13,15 @@ CSRC = PKG / "csrc"
 OUT = PKG / "librapiddoc_mi355.so"
 SOURCES = ["kernels_conv.hip", "kernels_conv_h3.hip", "kernels_conv_direct_h3.hip", "kernels_conv_stream_h3.hip", "kernels_gemm_h3_dma.hip", "kernels_misc.hip", "kernels_stem_fused.hip", "kernels_image.hip", "kernels_dbpost.hip", "kernels_attention_h3.hip", "kernels_ctc.hip", "kernels_mixer.hip", "kernels_mixer_h3.hip", "kernels_mixer_ws.hip", "kernels_mixer_res.hip", "formula_decoder.hip", "engine.cpp", "models.cpp", "api.cpp", "db_postprocess.cpp", "layout_postprocess.cpp", "polygon_ops.cpp", "rec_chunks.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-x", "hip"]
+# Per-file code-generation flags (tests/test_isa_resources.py and tools/isa_mix.py compile with the same ones: `extra_flags_for`).
+# kernels_mixer_ws.hip: hipcc -O3 SLP-packs adjacent scalar fp32 chains into v_pk_*_f32, and packed fp32 VALU does NOT issue under another
+# wavefront's MFMAs on gfx950 while plain VALU does (profiles/r4_probe_mfma_valu_wall.txt): the ws mixer's GELU is written scalar
+# (RD_GELU_SCALAR) and must stay scalar for its GELU-in-the-middle step order to pay.
+FILE_FLAGS = {"kernels_mixer_ws.hip": ["-fno-slp-vectorize", "-DRD_GELU_SCALAR"]}
+
+
+def extra_flags_for(src: str) -> list:
+    return list(FILE_FLAGS.get(Path(src).name, []))
 
 
 def _hipcc() -> str:
@@ -43,7 +52,7 @@ def build(force: bool = False, verbose: bool = True, extra_flags: tuple = (), ou
 
     def compile_one(src: str) -> Path:
         obj = objdir / (src + ".o")
-        cmd = [hipcc, *FLAGS, *extra_flags, "-c", str(CSRC / src), "-o", str(obj)]
+        cmd = [hipcc, *FLAGS, *extra_flags_for(src), *extra_flags, "-c", str(CSRC / src), "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -243,7 +243,11 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
     // round trip has two units (12 MFMAs) of cover, and a ring slot is rewritten a whole unit after its last reader (no
     // MFMA-source hazard nops).
     constexpr int NU = KS + NB / 2;
-    f16x8 fr[3][4] = {};
+#ifndef RD_WS_RING
+#define RD_WS_RING 4          // fragment ring depth of the common steps: reads three units ahead (round 4: +1-2 % over depth 3, -DRD_WS_RING=3; 216 VGPRs)
+#endif
+    constexpr int RG = RD_WS_RING;
+    f16x8 fr[RG > 3 ? RG : 3][4] = {};
     int frag_once = 0;
     auto unit_load = [&](const unsigned char* stage, int i, int slot) {
         if constexpr (ABL & 4) return;
@@ -521,26 +525,49 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
             f16x8 hh, hl;
 #pragma unroll
             for (int b = 0; b < 2; ++b) hn[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-            unit_load(stage, 0, 0);
-            unit_load(stage, 1, 1);
-            gelu_split(q, hh, hl);
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                if (i + 2 < NU) unit_load(stage, i + 2, (i + 2) % 3);
-                if (i < KS) unit_g1(i, i % 3);
-                else unit_g2(2 * (i - KS), i % 3, hh, hl);
-                pin_unit(i + 2 < NU);
-                if constexpr (IL) {
-                    if (i < G::PIECES) issue_piece(il_src, il_dst, i);
-                }
-                if constexpr (decltype(refetch)::value) {
-                    if (i == KS - 1) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        issue_raw(r);
-                        __builtin_amdgcn_sched_barrier(0);
+            for (int u = 0; u < RG - 1; ++u) unit_load(stage, u, u);
+            // units [lo, hi) of the step's MFMA pipeline (compile-time bounds: the loop is unrolled, the ring slots are constants)
+            auto units = [&](auto lo_c, auto hi_c) {          // (the ring reads ahead inside [lo, hi) only)
+                constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+#pragma unroll
+                for (int i = LO; i < HI; ++i) {
+                    if (i + RG - 1 < HI) unit_load(stage, i + RG - 1, (i + RG - 1) % RG);
+                    if (i < KS) unit_g1(i, i % RG);
+                    else unit_g2(2 * (i - KS), i % RG, hh, hl);
+                    pin_unit(i + RG - 1 < HI);
+                    if constexpr (IL) {
+                        if (i < G::PIECES) issue_piece(il_src, il_dst, i);
+                    }
+                    if constexpr (decltype(refetch)::value) {
+                        if (i == KS - 1) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue_raw(r);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 }
+            };
+            using U0 = std::integral_constant<int, 0>;
+            using UK = std::integral_constant<int, KS>;
+            using UN = std::integral_constant<int, NU>;
+            // GO (ABL bit 8, round 4): GEMM1 of the next chunk (which does not need this chunk's GELU) runs BEFORE the GELU, GEMM2 after it.
+            // With the GELU first, the two wavefronts of a SIMD - released together by the step's barrier - did their GELUs at the same
+            // time with the matrix pipe idle (ablation: GELU = 27 of 153 us).  With the GELU in the middle the wavefront that wins the
+            // matrix pipe (static s_setprio) reaches its GELU while the other still issues GEMM1, and starts GEMM2 while the other is in its
+            // GELU: one code path, the skew comes from the arbitration.
+            if constexpr ((ABL & 256) != 0) {
+                units(U0{}, UK{});
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < RG - 1; ++u) unit_load(stage, KS + u, (KS + u) % RG);      // GEMM2's first fragments land under the GELU
+                gelu_split(q, hh, hl);
+                __builtin_amdgcn_sched_barrier(0);
+                units(UK{}, UN{});
+            } else {
+                gelu_split(q, hh, hl);
+                __builtin_amdgcn_sched_barrier(0);
+                units(U0{}, UN{});
             }
             roll();
         };
@@ -829,6 +856,12 @@ void launch_mixer_fused_ws(const MixerParams& p, hipStream_t s) {
     }
     if (pf) {
         static const bool il = [] { const char* e = getenv("RD_WS_IL"); return !(e && e[0] == '0'); }();     // A/B switch: RD_WS_IL=0 = the round-3 form
+        static const bool go = [] { const char* e = getenv("RD_WS_GO"); return !(e && e[0] == '0'); }();    // A/B switch: RD_WS_GO=0 = GELU first (round 3)
+        if (il && go) {
+            if (gated) launch_ws<192, true, false, 384, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s);
+            else launch_ws<192, false, false, 384, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s);
+            return;
+        }
         if (il) {
             if (gated) launch_ws<192, true, false, 128, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s);
             else launch_ws<192, false, false, 128, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s);

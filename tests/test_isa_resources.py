@@ -35,7 +35,8 @@ def _hipcc():
 
 
 def _kernel_table(src: Path):
-    out = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "-S", "--cuda-device-only",
+    from rapiddoc_amd.build import extra_flags_for          # the per-file flags the library is built with
+    out = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", *extra_flags_for(src.name), "-x", "hip", "-S", "--cuda-device-only",
                           f"-I{CSRC}", str(src), "-o", "-"], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     rows = []
@@ -92,8 +93,9 @@ def test_inline_asm_register_loads_are_not_touched_in_flight():
     spec = importlib.util.spec_from_file_location("check_inflight", ROOT / "tools" / "check_inflight.py")
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    out = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "-S", "--cuda-device-only",
-                          f"-I{CSRC}", str(CSRC / "kernels_mixer_ws.hip"), "-o", "-"], capture_output=True, text=True)
+    from rapiddoc_amd.build import extra_flags_for
+    out = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", *extra_flags_for("kernels_mixer_ws.hip"), "-x", "hip", "-S",
+                          "--cuda-device-only", f"-I{CSRC}", str(CSRC / "kernels_mixer_ws.hip"), "-o", "-"], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.count("global_load_dwordx4") >= 48          # the PF instantiations are there
     hazards = mod.check(out.stdout, ["ELb1EEEvNS_11MixerParams"])      # <..., PF = true>: the instantiations with inline-asm loads

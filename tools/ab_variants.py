@@ -23,6 +23,20 @@ def main():
             B.build(force=True, verbose=True, extra_flags=tuple(f for f in flags.split(",") if f), out=VAR / f"lib.{tag}.so")
         return
     lib = ROOT / "rapiddoc_amd" / "librapiddoc_mi355.so"
+    if mode == "cmd":            # python tools/ab_variants.py cmd "<shell command>" tag ...: the command once per variant library
+        keep = lib.with_suffix(".so.keep")
+        shutil.copy2(lib, keep)
+        try:
+            for tag in specs[1:]:
+                shutil.copy2(keep if tag == "tree" else VAR / f"lib.{tag}.so", lib)
+                lib.touch()
+                r = subprocess.run(specs[0], shell=True, capture_output=True, text=True, cwd=ROOT)
+                for line in (r.stdout + r.stderr[-600:] * (r.returncode != 0)).splitlines():
+                    print(f"[{tag}] {line}")
+        finally:
+            shutil.copy2(keep, lib)
+            keep.unlink()
+        return
     keep = lib.with_suffix(".so.keep")
     shutil.copy2(lib, keep)
     extra = [a for a in specs if a.startswith("--")]

@@ -22,7 +22,7 @@ CSRC = ROOT / "rapiddoc_amd" / "csrc"
 
 # (label of the per-kernel table, source, regex over the mangled name of the dispatched instantiation)
 HOT = [
-    ("lc_mixer_ws_kernel<192> (prefetching form)", "kernels_mixer_ws.hip", r"lc_mixer_ws_kernelILi192ELb0ELb0ELi0ELb1E"),
+    ("lc_mixer_ws_kernel<192> (prefetching form)", "kernels_mixer_ws.hip", r"lc_mixer_ws_kernelILi192ELb0ELb0ELi384ELb1E"),
     ("gemm_h3_dma16_kernel", "kernels_gemm_h3_dma.hip", r"gemm_h3_dma16_kernelILi0E"),
     ("gemm_h3_dma_kernel", "kernels_gemm_h3_dma.hip", r"gemm_h3_dma_kernelILb0E"),
     ("dwconv3x3 (tiled, 8 wide)", "kernels_misc.hip", r"dwconv_tiled_kernelILi3ELi3ELi1ELi8ELi0E"),
@@ -47,7 +47,9 @@ def hipcc():
 
 
 def asm_of(src: str) -> str:
-    out = subprocess.run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "-S", "--cuda-device-only",
+    sys.path.insert(0, str(ROOT))
+    from rapiddoc_amd.build import extra_flags_for          # the per-file flags the library is built with
+    out = subprocess.run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", *extra_flags_for(src), "-x", "hip", "-S", "--cuda-device-only",
                           f"-I{CSRC}", str(CSRC / src), "-o", "-"], capture_output=True, text=True)
     if out.returncode != 0:
         sys.exit(out.stderr[-3000:])
