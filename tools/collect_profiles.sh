@@ -48,5 +48,7 @@ head -8 $O/${TAG}_rocprofv3_kernel_stats.csv | cut -c1-140
   bash $R/tools/prof_formula.sh 8 2>/dev/null | grep -E "skinny|dec_|layernorm"
 } > $O/${TAG}_formula_decode.txt
 cat $O/${TAG}_formula_decode.txt | cut -c1-160
+# phase stamps of the 8-wavefront DMA GEMM in its round-3 form (DMA pieces in a clump behind the barrier): DESIGN.md s3d
+timeout 100 python $R/tools/mb_gemm_trace.py 131072 768 384 0 2> $O/${TAG}_gemm_trace.txt > /dev/null
 # static instruction mix / issue budget of the hot loops (hipcc -S only: also runs without a GPU)
 python $R/tools/isa_mix.py > $O/${TAG}_isa_mix.txt 2>/dev/null || true
