@@ -9,7 +9,9 @@ ROOT = Path(__file__).resolve().parents[1]
 r = json.loads((ROOT / "profiles" / "r4_bench.json").read_text())
 res = json.loads((ROOT / "profiles" / "r4_bench_resident_one_set.json").read_text())
 c, roof, bb, f = r["config"], r["roofline"], r["backbone"], r["formula"]
-rows = list(csv.DictReader(open(ROOT / "profiles" / "r4_bench_per_kernel.csv")))[:9]
+lines = (ROOT / "profiles" / "r4_bench_per_kernel.csv").read_text().splitlines()
+keys = lines[0].split(",")
+rows = [dict(zip(keys, l.rsplit(",", len(keys) - 1))) for l in lines[1:10]]       # (kernel names may hold commas: split from the right)
 table = " · ".join("%s %.1f (%s)" % (x["kernel"].replace("_kernel", ""), float(x["total_ms"]),
                                      ("%.0f TFLOP/s" % float(x["TFLOPs"])) if float(x["TFLOPs"]) > 20 else ("%.1f TB/s" % (float(x["GBs"]) / 1e3)))
                    for x in rows)
