@@ -39,39 +39,6 @@ __device__ __forceinline__ void dma16(const void* src, unsigned lds_byte_offset,
                                      (__attribute__((address_space(3))) void*)(smem + lds_byte_offset), 16, 0, 0);
 }
 
-#ifdef RD_SPLIT_PLAIN
-// developer A/B: the same split written in PLAIN VALU instructions (inline asm: hipcc turns the C form into v_cvt_pk_f16_f32 / v_fma_mix /
-// v_pk_*_f32, all VOP3P - the class that does not issue under another wavefront's MFMAs, profiles/r4_probe_mfma_valu_wall.txt).  Six
-// instructions per element instead of about two: v_cvt_f16_f32 (upper half zeroed on gfx9), v_cvt_f32_f16, v_sub, v_mul by 2^11, v_cvt, and a
-// v_lshl_or_b32 per pair to pack.  Bit-identical: hi = fp16(v), lo = fp16((v - hi) * 2048) with an exact difference and scale.
-__device__ __forceinline__ void split2_plain(float v0, float v1, unsigned& hi2, unsigned& lo2) {
-    unsigned h0, h1, l0, l1;
-    asm volatile(
-        "v_cvt_f16_f32_e32 %0, %4\n\t"
-        "v_cvt_f16_f32_e32 %1, %5\n\t"
-        "v_cvt_f32_f16_e32 %2, %0\n\t"
-        "v_cvt_f32_f16_e32 %3, %1\n\t"
-        "v_sub_f32_e32 %2, %4, %2\n\t"
-        "v_sub_f32_e32 %3, %5, %3\n\t"
-        "v_mul_f32_e32 %2, 0x45000000, %2\n\t"
-        "v_mul_f32_e32 %3, 0x45000000, %3\n\t"
-        "v_cvt_f16_f32_e32 %2, %2\n\t"
-        "v_cvt_f16_f32_e32 %3, %3"
-        : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1)
-        : "v"(v0), "v"(v1));
-    asm volatile("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(hi2) : "v"(h1), "v"(h0));
-    asm volatile("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(lo2) : "v"(l1), "v"(l0));
-}
-__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
-    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-    split2_plain(a[0], a[1], h0, l0);
-    split2_plain(a[2], a[3], h1, l1);
-    split2_plain(b[0], b[1], h2, l2);
-    split2_plain(b[2], b[3], h3, l3);
-    hi = __builtin_bit_cast(f16x8, u32x4{h0, h1, h2, h3});
-    lo = __builtin_bit_cast(f16x8, u32x4{l0, l1, l2, l3});
-}
-#else
 __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -84,7 +51,6 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, f16x8& hi, 
         lo[4 + e] = l1;
     }
 }
-#endif
 
 // Epilogue of one 32x32 accumulator tile (16 rows of one output column per lane): combine the two accumulators, bias,
 // range guard, activation, residual, store.  The activation switch and the residual test sit OUTSIDE the 16-element loops
@@ -388,194 +354,6 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
 #undef RD_GSTAMP
 
 // ------------------------------------------------------------------------------------------------------------------
-// Ping-pong form of the 8-wavefront kernel (round 4).  The phase stamps of the kernel above say where a K tile's ~3000 cycles go:
-// the two wavefronts of a SIMD leave the barrier together, both read + split their fragments (200-450 cycles, matrix pipe idle), both
-// issue their 24 MFMAs (the pipe serialises them: 1536), both arrive at the barrier again.  Here wavefronts 0-3 (group A, one per SIMD)
-// and 4-7 (group B) run HALF an iteration apart: an iteration is R = {fragment reads, split} and M = {24 MFMAs with the DMA pieces of
-// later tiles between them}, a barrier in front of each, and group B is one barrier behind - so A's M runs against B's R and vice
-// versa, and the pipe goes from one wavefront's MFMAs straight to the other's.
-//   LDS: the activation stages are private to the wavefront that loaded them (a wavefront's 32 rows), three of them as before; the
-//   weight tile is read by everybody and loaded by everybody, and the other group needs it half an iteration EARLIER than the loader
-//   itself: weights are therefore requested THREE tiles ahead into FOUR stages (3 x 32 KB + 4 x 16 KB = 160 KB) and issued in front of
-//   the activation pieces of their M phase, so that one counted wait per iteration (everything but the youngest 6 pieces = those of
-//   the previous M phase) says "my A(kt) and my share of B(kt + 1) have landed" - which covers both groups.
-//   Barrier pairing per output tile (A | B): alpha_0 | extra, beta_kt | alpha_kt, alpha_kt+1 | beta_kt, ..., extra_end | beta_KT-1, sync | sync.
-//   RAW: a wavefront passes alpha_kt only after its own A(kt), and its share of B(kt + 1), have landed; the group-B wavefronts standing
-//   at beta_kt-1 when A leaves alpha_kt passed their alpha_kt-1 with their share of B(kt) landed.  WAR: activations are private (program
-//   order); a weight stage (kt + 3) % 4 = (kt - 1) % 4 is re-filled during M(kt), after every wavefront's R(kt - 1) (all fragment reads sit
-//   in R): group A enters M(kt) through beta_kt | alpha_kt, which B reaches after its M(kt - 1), hence after its R(kt - 1).
-static constexpr int PP_A_STAGES = 3, PP_B_STAGES = 4;
-static constexpr int PP_B_BASE = PP_A_STAGES * D_A_BYTES;                       // 96 KB
-static constexpr int PP_LDS = PP_B_BASE + PP_B_STAGES * 2 * D_B_BYTES;         // 160 KB
-template <int ABL>      // developer ablations (results garbage): 1 no DMA pieces in the K loop, 2 no MFMAs, 4 no fragment reads / split
-__global__ void __launch_bounds__(512) gemm_h3_pp_kernel(ConvParams p, int ntn, int ntiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool grp_b = wave >= 4;
-    const int wm = wave;
-    const int l31 = lane & 31, lhi = lane >> 5;
-    const int K = p.K, KT = (K + DK - 1) / DK, Kp = KT * DK;
-    const _Float16* wh = reinterpret_cast<const _Float16*>(p.wh);
-    const _Float16* wl = reinterpret_cast<const _Float16*>(p.wl);
-    int m0 = 0, n0 = 0;
-    unsigned aoff[4];
-    const int kc0 = 4 * ((lane & 7) ^ ((lane >> 4) & 7));
-    unsigned boff = 0;
-    auto setup_tile = [&](int v) {
-        const int w = gemm_tile_of(v, ntiles, 0);
-        const int tile_m = w / ntn;
-        m0 = tile_m * DM;
-        n0 = (w - tile_m * ntn) * DN;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int row = 32 * wave + 8 * jj + (lane >> 3);
-            aoff[jj] = (unsigned)min(m0 + row, p.M - 1) * (unsigned)p.xld;
-        }
-        const int brow = 16 * wave + (lane >> 2);
-        const int bc = (lane & 3) ^ ((brow >> 2) & 3);
-        boff = (unsigned)min(n0 + brow, p.Ng - 1) * (unsigned)Kp + 8u * bc;
-    };
-    // pieces: A(kt) = four 1-KB pieces into activation stage kt % 3, B(kt) = the two weight planes into weight stage kt % 4
-    auto issue_a = [&](int kt, int jj) {
-        const int k0 = kt * DK;
-        __builtin_amdgcn_sched_barrier(0);
-        dma16(p.x + (aoff[jj] + (unsigned)min(k0 + (kc0 ^ (16 * (jj & 1))), K - 4)), (unsigned)(kt % PP_A_STAGES) * D_A_BYTES + (unsigned)(4 * wave + jj) * 1024u, smem);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto issue_b = [&](int kt, int plane) {
-        __builtin_amdgcn_sched_barrier(0);
-        dma16((plane ? wl : wh) + (boff + (unsigned)(kt * DK)), (unsigned)PP_B_BASE + (unsigned)(kt % PP_B_STAGES) * (2 * D_B_BYTES) + (unsigned)plane * D_B_BYTES +
-                                                                  (unsigned)wave * 1024u, smem);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // Queue order: every M(kt) issues the weight pieces B(kt + 3) FIRST, then the activation pieces A(kt + 2); the prologue stands for
-    // M(-2) = [B1 A0] and M(-1) = [B2 A1] behind B0.  "Everything but the pieces of M(kt - 1)" then means A(kt) AND B(kt + 1) have landed.
-    auto prologue = [&]() {
-        issue_b(0, 0); issue_b(0, 1);
-        if (KT > 1) { issue_b(1, 0); issue_b(1, 1); }
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) issue_a(0, jj);
-        if (KT > 2) { issue_b(2, 0); issue_b(2, 1); }
-        if (KT > 1) {
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) issue_a(1, jj);
-        }
-    };
-    // the wait in front of alpha_kt: everything but the pieces of M(kt - 1) = [B(kt + 2), A(kt + 1)] has landed
-    auto wait_tile = [&](int kt, bool drained_first) {
-        const int allowed = (kt + 1 < KT ? 4 : 0) + (kt + 2 < KT ? 2 : 0);
-        if (drained_first || allowed == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (allowed == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    };
-    const int a_off0 = (wm * 32 + l31) * 128 + (((2 * lhi) ^ (((wm * 32 + l31) >> 1) & 7)) << 4);
-    const int b_off0 = l31 * 64 + ((lhi ^ ((l31 >> 2) & 3)) << 4);
-    auto a_off = [&](int ks) { return a_off0 ^ (ks << 6); };
-    auto b_off = [&](int j, int ks) { return (b_off0 ^ (ks << 5)) + j * 2048; };
-
-    unsigned emax = 0;
-    bool fresh = true;
-    int v = blockIdx.x;
-    if (v >= ntiles) return;
-    setup_tile(v);
-    prologue();
-    for (;;) {
-        f32x16 acc1[4], acc2[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[j][r] = acc2[j][r] = 0.f;
-        if (grp_b) {                                             // one barrier behind from here on (extra | alpha_0)
-            wait_tile(0, !fresh);
-            asm volatile("s_barrier" ::: "memory");
-        }
-        for (int kt = 0; kt < KT; ++kt) {
-            wait_tile(kt, kt == 0 && !fresh);                    // (after an epilogue: its stores share the counter and are not ordered against the pieces)
-            asm volatile("s_barrier" ::: "memory");              // alpha_kt
-            // ---- R: every fragment of the tile into registers, the activations split
-            const unsigned char* as = smem + (kt % PP_A_STAGES) * D_A_BYTES;
-            const unsigned char* bs = smem + PP_B_BASE + (kt % PP_B_STAGES) * (2 * D_B_BYTES);
-            f32x4 xa[2][2] = {};
-            f16x8 bh[2][4] = {}, bl[2][4] = {};
-            f16x8 ah[2] = {}, al[2] = {};
-            if constexpr (!(ABL & 4)) {
-                if constexpr (!(ABL & 16)) {          // (16: no LDS reads - registers keep whatever they hold)
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        xa[ks][0] = *reinterpret_cast<const f32x4*>(as + a_off(ks));
-                        xa[ks][1] = *reinterpret_cast<const f32x4*>(as + (a_off(ks) ^ 16));
-                    }
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            bh[ks][j] = *reinterpret_cast<const f16x8*>(bs + b_off(j, ks));
-                            bl[ks][j] = *reinterpret_cast<const f16x8*>(bs + b_off(j, ks) + D_B_BYTES);
-                        }
-                } else {
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        asm volatile("" : "+v"(xa[ks][0]), "+v"(xa[ks][1]));
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bh[ks][j]), "+v"(bl[ks][j]));
-                    }
-                }
-                if constexpr (!(ABL & 8)) {           // (8: no split - the raw bits stand in for the fragments)
-                    split8(xa[0][0], xa[0][1], ah[0], al[0]);
-                    split8(xa[1][0], xa[1][1], ah[1], al[1]);
-                } else {
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        ah[ks] = __builtin_bit_cast(f16x8, xa[ks][0]);
-                        al[ks] = __builtin_bit_cast(f16x8, xa[ks][1]);
-                    }
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // beta_kt (the fragments are in registers)
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- M: 24 MFMAs, the pieces of A(kt + 2) and B(kt + 3) between the groups
-            const bool pa = !(ABL & 1) && kt + 2 < KT, pb = !(ABL & 1) && kt + 3 < KT;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if constexpr (!(ABL & 2)) {
-                        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh[ks][j], acc1[j], 0, 0, 0);
-                        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl[ks][j], acc2[j], 0, 0, 0);
-                        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh[ks][j], acc2[j], 0, 0, 0);
-                    }
-                    // (weights first: the other group needs them half an iteration before this wavefront does)
-                    if (ks == 0 && j < 2) { if (pb) issue_b(kt + 3, j); }
-                    else if (ks == 0) { if (pa) issue_a(kt + 2, j - 2); }
-                    else if (j < 2) { if (pa) issue_a(kt + 2, j + 2); }
-                }
-        }
-        const int em0 = m0, en0 = n0;
-        const int vnext = v + (int)gridDim.x;
-        const bool has_next = vnext < ntiles;
-        // group A: extra_end | beta_KT-1 - from here every fragment read of this output tile is done, the next tile's pieces may land
-        if (!grp_b) asm volatile("s_barrier" ::: "memory");
-        if (has_next) {
-            setup_tile(vnext);
-            prologue();
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = en0 + j * 32 + l31;
-            if (n >= p.Ng) continue;
-            const float bv = p.bias ? p.bias[n] : 0.f;
-            dma_finish_tile(p, acc1[j], acc2[j], em0 + wm * 32 + 4 * lhi, n, bv, emax);
-        }
-        asm volatile("s_barrier" ::: "memory");                  // sync | sync: the groups are level again
-        if (!has_next) break;
-        v = vnext;
-        fresh = false;
-    }
-    if (emax >= 0x7f800000u && p.range_flag) atomicOr(p.range_flag, 1u);
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // 16-wavefront variant of the same pipeline: 256x128 tile, wavefronts as 8 x 2 with 32x64 each (64 accumulator registers
 // instead of 128), so FOUR wavefronts share a SIMD instead of two.  (Round 1 had them 4 x 4 with 64x32: every A row tile was
 // split - 2 VALU per element - by four wavefronts; VALU work does not run under another wavefront's MFMAs on this chip
@@ -818,30 +596,6 @@ void launch_gemm_h3_dma(const ConvParams& p, hipStream_t s) {
                             t[5] - t[4], (i + 1 < 60 && h[w * 512 + (i + 1) * 8]) ? h[w * 512 + (i + 1) * 8] - t[5] : 0ull, t[7] > t[6] ? t[7] - t[6] : 0ull);
                 }
         }
-        return;
-    }
-    static const bool pp_env = [] { const char* e = getenv("RD_GEMM_PP"); return e && e[0] == '1'; }();
-    if (pp_env && order == 0) {
-        static const int pp_abl = [] { const char* e = getenv("RD_GEMM_PP_ABL"); return e ? atoi(e) : 0; }();
-#define RD_PP(A)                                                                                                    \
-    do {                                                                                                            \
-        static unsigned long long ok_ = 0;                                                                          \
-        rd_allow_dynamic_lds((const void*)gemm_h3_pp_kernel<A>, (size_t)PP_LDS, ok_);                               \
-        hipLaunchKernelGGL(gemm_h3_pp_kernel<A>, dim3(ntiles < n_cu ? ntiles : n_cu), dim3(512), (size_t)PP_LDS, s, p, ntn, ntiles); \
-    } while (0)
-        switch (pp_abl) {
-            case 1: RD_PP(1); break;
-            case 2: RD_PP(2); break;
-            case 3: RD_PP(3); break;
-            case 5: RD_PP(5); break;
-            case 6: RD_PP(6); break;
-            case 7: RD_PP(7); break;
-            case 9: RD_PP(9); break;
-            case 17: RD_PP(17); break;
-            case 25: RD_PP(25); break;
-            default: RD_PP(0); break;
-        }
-#undef RD_PP
         return;
     }
     static const int il_env = [] { const char* e = getenv("RD_GEMM_IL"); return e ? atoi(e) : 1; }();
