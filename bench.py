@@ -253,7 +253,13 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    cores_per_rank = pin_rank_to_cores(local_rank, local_world) if world > 1 else None
+    if world > 1:
+        cores_per_rank = pin_rank_to_cores(local_rank, local_world)
+    else:           # one rank: no pinning, it may run on every core the process is allowed
+        try:
+            cores_per_rank = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            cores_per_rank = os.cpu_count()
     backend = os.environ.get("RD_BENCH_BACKEND", "nccl")
     dist = None
     if world > 1:
@@ -490,6 +496,11 @@ def main():
                 "algorithmic_bytes_per_launch": round(by / n), "launches_per_step": n,
                 "avg_launch_us": round(ms * 1e3 / n, 2), "avg_gflop_per_launch": round(fl / n / 1e9, 4),
                 "all_mfma_kernels_tflops": round(sum(v[0] for v in mfma.values()) / (sum(v[2] for v in mfma.values()) * 1e-3) / 1e12, 3),
+                # the other large MFMA kernels of the step, same accounting (each timed alone; split-fp16 kernels against 838.9, fp32-MFMA ones against 157.3)
+                "top_mfma_kernels": [{"kernel": k, "ms_per_step": round(v[2], 3), "launches": v[3], "tflops": round(v[0] / (v[2] * 1e-3) / 1e12, 1),
+                                      "frac": round(v[0] / (v[2] * 1e-3) / 1e12 /
+                                                    (F16_MFMA_PEAK_TFLOPS / 3.0 if ("_h3" in k or "_ws_" in k or "_res_" in k or "stem_fused" in k) else FP32_MFMA_PEAK_TFLOPS), 4)}
+                                     for k, v in sorted(mfma.items(), key=lambda kv: -kv[1][2])[:6]],
                 "step_kernel_ms": round(tot_ms, 2),
                 # summed over the concurrent streams (det / layout / 8 rec / tail): it exceeds ms_per_step when kernels overlap
                 "kernel_ms_overlapped": True}
