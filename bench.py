@@ -345,6 +345,8 @@ def main():
     def step():
         return gather_page_results(compute(0), dist)
 
+    step_wall_ms = []
+
     def run_steps(n):
         """n steps; with --inflight > 1 they are dealt round-robin to `inflight` host threads (one pipeline each) and the
         result collectives are issued from this thread in step order."""
@@ -362,6 +364,7 @@ def main():
                 if trace:
                     torch.cuda.synchronize()
                     print("step %.1f ms" % ((time.perf_counter() - ts) * 1e3), file=sys.stderr)
+                step_wall_ms.append((time.perf_counter() - ts) * 1e3)      # host clock only: no synchronise is added for it
             return out
         from concurrent.futures import ThreadPoolExecutor
         streams = [torch.cuda.Stream() for _ in pools]
@@ -572,6 +575,10 @@ def main():
                                          "stream, batch i + 1 under batch i; the first batch's copy is exposed)" % (pages_np.nbytes / 1e6)
                                          if upload else "HBM (resident, --resident-pages)",
                        "h2d_ms_per_batch_alone": None if h2d_ms is None else round(h2d_ms, 3),
+                       # this rank's host-clock time of each timed step (a step returns when its last line is decoded): the mean
+                       # is what `value` is made of, the median is the steady state, the maximum shows a stalled step
+                       "step_wall_ms": ({"median": round(float(np.median(step_wall_ms)), 2), "min": round(min(step_wall_ms), 2),
+                                         "max": round(max(step_wall_ms), 2), "first": round(step_wall_ms[0], 2)} if step_wall_ms else None),
                        "plan_cache_misses": int(plan_misses),     # per-shape plans built INSIDE the timed region (new rec / tail shapes of unseen page sets)
                        "hipgraph": {"captures": int(sum(p["graph_captures"] for p in plan_stats)), "replays": int(sum(p["graph_replays"] for p in plan_stats))},
                        "lines_per_step": n_lines, "host_stage_ms": host_stats,

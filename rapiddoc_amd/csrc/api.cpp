@@ -408,6 +408,32 @@ float rd_debug_conv(int N, int H, int W, int Cin, int Cout, int KH, int KW, int 
     return iters > 0 ? ms / iters : 0.f;
 }
 
+// developer entry: one depthwise convolution through launch_dwconv (x NHWC fp32 [N][H][W][C], w [KH*KW][C], bias [C] or null,
+// res NHWC or null, line_w int32 [N] valid widths or null, gap = [N][chunks][C] partial sums of the output or null).
+// *gap_chunks receives the chunk count the launcher uses for this geometry.  Returns ms per launch.
+float rd_debug_dwconv(int N, int H, int W, int C, int K, int SH, int act, int iters, float* x, float* w, float* bias, float* res, float* y,
+                      const int32_t* line_w, float* gap, int* gap_chunks) {
+    rd::DwParams p{};
+    p.x = x; p.xld = C; p.N = N; p.H = H; p.W = W; p.C = C; p.w = w; p.bias = bias; p.y = y; p.yld = C;
+    p.KH = p.KW = K; p.SH = SH; p.SW = 1; p.PT = p.PL = K / 2;
+    p.OH = (H + 2 * p.PT - K) / SH + 1; p.OW = W; p.act = act; p.res = res; p.rld = C;
+    const int chunks = rd::dwconv_gap_chunks(p);
+    if (gap_chunks) *gap_chunks = chunks;
+    p.gap_partial = chunks > 0 ? gap : nullptr; p.gap_chunks = chunks;
+    p.line_w = line_w; p.line_w_stride = 1;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    rd::launch_dwconv(p, nullptr);
+    (void)hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters; ++i) rd::launch_dwconv(p, nullptr);
+    (void)hipEventRecord(e1, nullptr);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return iters > 0 ? ms / iters : 0.f;
+}
+
 // developer timing of the fused CTC head on prepared weights: wp = W' [C][128] fp32 (bias in column K), wh / wl its fp16 split
 // (null: fp32 MFMA kernel); part = workspace of M * 64 * 4 floats.  Returns ms per launch; *nsplit_out = the split count used.
 float rd_debug_time_ctc(int M, int K, int Ccls, int iters, float* x, float* wp, void* wh, void* wl, float* part, int32_t* idx, float* prob,

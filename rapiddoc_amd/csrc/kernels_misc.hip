@@ -281,6 +281,7 @@ static inline int dw_tiled_tw(const DwParams& p) {
     return 0;
 }
 int dwconv_gap_chunks(const DwParams& p) {
+    if (dwconv_lds_applies(p)) return dwconv_lds_gap_chunks(p);
     if (dw_col_applies(p)) {
         int c4n, threads, gw, gpb, chunks;
         dw_col_geom(p, c4n, threads, gw, gpb, chunks);
@@ -300,6 +301,10 @@ void launch_dwconv(const DwParams& p_in, hipStream_t s) {
     if (p.tokinfo) {      // ragged rows: only the per-pixel kernel knows about line ends
         const long total = (long)p.N * p.OH * p.OW * (p.C >> 2);
         hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for(total)), dim3(256), 0, s, p);
+        return;
+    }
+    if (dwconv_lds_applies(p)) {
+        launch_dwconv_lds(p, s);
         return;
     }
     if (dw_col_applies(p)) {

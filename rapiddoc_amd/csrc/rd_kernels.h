@@ -116,6 +116,10 @@ void launch_dwconv(const DwParams& p, hipStream_t s);
 // number of per-image partial-sum chunks launch_dwconv writes to p.gap_partial for this geometry (0 = the fused
 // global-average-pool is not available for it)
 int dwconv_gap_chunks(const DwParams& p);
+// kernels_dw_lds.hip: the LDS-DMA-staged 3x3 / stride 1 for the recogniser's 3 / 6 / 12-row maps; launch_dwconv routes to it
+bool dwconv_lds_applies(const DwParams& p);
+int dwconv_lds_gap_chunks(const DwParams& p);
+void launch_dwconv_lds(const DwParams& p, hipStream_t s);
 
 // 2x2 stride-1 max-pool over an input zero-padded by one pixel on the right/bottom (stem branch b)
 void launch_maxpool2x2s1(const float* x, int xld, float* y, int yld, int N, int H, int W, int C, hipStream_t s);
