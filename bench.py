@@ -22,6 +22,8 @@ import time
 from collections import defaultdict
 from pathlib import Path
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # before the HIP runtime starts: one hardware queue per stream (rapiddoc_amd/__init__.py)
+
 import numpy as np
 import torch
 
@@ -226,6 +228,10 @@ def main():
                          "(one global argsort, chunks of 6, every line at the padded width int(48 * max ratio) of ITS chunk, "
                          "rapid_ocr.py:404-449) in GPU-sized launches (rd_rec_backbone_forward_lines); throughput = every line at its "
                          "launch's width.  The other mode is measured in a short post-pass and reported next to it")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="do not enqueue the next batch's det + layout forwards under this batch's recognition (A/B switch; default: "
+                         "a two-stage software pipeline over the batch stream - inside the timed region the first step's front is "
+                         "exposed and the last step runs nothing ahead, so exactly --steps batches of work are timed)")
     ap.add_argument("--vary-pages", type=int, default=8,
                     help="K different page sets, step i runs set i mod K: a document stream does not repeat a batch, so the steps keep "
                          "meeting new line widths / token counts (plan caches, hipGraph slots and the tail's bucketing are exercised, and "
@@ -321,10 +327,12 @@ def main():
     set_maps = [text_maps] + [render_text_maps(b, pages_np.shape[1:3], det_hw, pages.device) for _p, b in page_sets[1:]]
     quads = None
     step_no = [0]
+    prefetch_on = not args.no_prefetch and len(pools) == 1
 
-    def compute(k=0, ticket=None):
+    def compute(k=0, ticket=None, ahead=None):
         """One step on pool k.  `ticket`: (PageUploader ticket, set index) of pages already travelling; else the step's own set is taken
-        (resident, or - pinned host pages - uploaded by run_batch on the spot)."""
+        (resident, or - pinned host pages - uploaded by run_batch on the spot).  `ahead`: the NEXT step's ticket (or, resident, its
+        set index): its det + layout forwards are enqueued under this step's recognition (PagePipeline.run_batch `prefetch`)."""
         if ticket is None:
             si = step_no[0] % K_sets
             step_no[0] += 1
@@ -332,7 +340,10 @@ def main():
         else:
             tk, si = ticket
             pg = uploader.wait(tk)
-        res = pools[k].run_batch(pg, quads, det_maps_override=set_maps[si])
+        pf = None
+        if ahead is not None and prefetch_on:
+            pf = uploader.wait(ahead[0]) if upload else page_sets[ahead][0]
+        res = pools[k].run_batch(pg, quads, det_maps_override=set_maps[si], prefetch=pf)
         if ticket is not None:
             uploader.release(tk)
         return [(my_pages[i], [(t, s) for _, t, s in r.lines]) for i, r in enumerate(res)]
@@ -358,9 +369,9 @@ def main():
                 ts = time.perf_counter()
                 if upload:
                     cur, nxt = nxt, (next_ticket() if i + 1 < n else None)
-                    out = gather_page_results(compute(0, cur), dist)
+                    out = gather_page_results(compute(0, cur, nxt), dist)       # the last step has nothing to run ahead
                 else:
-                    out = step()
+                    out = gather_page_results(compute(0, None, (step_no[0] + 1) % K_sets if i + 1 < n else None), dist)
                 if trace:
                     torch.cuda.synchronize()
                     print("step %.1f ms" % ((time.perf_counter() - ts) * 1e3), file=sys.stderr)
@@ -409,6 +420,9 @@ def main():
     out = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
+    if os.environ.get("RD_BENCH_STOP_AFTER_TIMED") == "1":      # developer: a kernel trace whose tail is the timed steps (tools/trace_gaps.py)
+        print("timed region: %.2f ms per step" % (dt / args.steps * 1e3), file=sys.stderr)
+        return
     plan_stats = [e.plan_stats() for q in pools for e in q.engines]
     plan_misses = sum(p["plans_built"] for p in plan_stats) - plans_before
     h2d_ms = None
@@ -579,6 +593,8 @@ def main():
                        # is what `value` is made of, the median is the steady state, the maximum shows a stalled step
                        "step_wall_ms": ({"median": round(float(np.median(step_wall_ms)), 2), "min": round(min(step_wall_ms), 2),
                                          "max": round(max(step_wall_ms), 2), "first": round(step_wall_ms[0], 2)} if step_wall_ms else None),
+                       "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "front_prefetch": bool(prefetch_on),       # det + layout of batch i + 1 enqueued under the recognition of batch i
                        "plan_cache_misses": int(plan_misses),     # per-shape plans built INSIDE the timed region (new rec / tail shapes of unseen page sets)
                        "hipgraph": {"captures": int(sum(p["graph_captures"] for p in plan_stats)), "replays": int(sum(p["graph_replays"] for p in plan_stats))},
                        "lines_per_step": n_lines, "host_stage_ms": host_stats,

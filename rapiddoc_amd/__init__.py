@@ -1,0 +1,11 @@
+"""MI355X-native page-inference hot path of RapidDoc: HIP kernels + C-ABI library under `csrc/`, the host-side mirror
+of the reference's interfaces above it."""
+import os
+
+# One page batch keeps about fourteen HIP streams busy (eight recogniser streams, the neck + CTC tail, det, layout, the uploader's
+# copy stream, one per pool worker).  The ROCm runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues - four by default -
+# and work of streams that share a queue is dispatched in order: the next batch's layout backbone ended up in front of this batch's
+# DB post-process and the host waited 15 ms for a result that was ready ("front prefetch").  Sixteen queues give every
+# stream its own.  Only effective when set before the HIP runtime initialises, i.e. import this package (or set the variable) before
+# the first torch.cuda call; an explicit setting in the environment wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")

@@ -1216,7 +1216,7 @@ Engine::~Engine() {
     sweep_retired_graphs(true);
     for (auto ev : events_) (void)hipEventDestroy(ev);
     if (arena_) (void)hipFree(arena_);
-    if (range_flag_) (void)hipFree(range_flag_);
+    if (range_flag_host_) (void)hipHostFree(range_flag_host_);
 }
 
 void Engine::build(Builder& b, int B, int H, int W, int flags) {
@@ -1236,16 +1236,11 @@ void Engine::load_weights(const void* blob, size_t nbytes) {
     }
     Plan dummy;
     h3_prepared_ = precision_ == PREC_H3;
-    RD_HIP(hipMalloc((void**)&range_flag_, sizeof(unsigned)));
-    {   // a synchronous copy, not hipMemset: the fill kernel of a memset runs on the null stream and is not ordered against the
-        // non-blocking streams the forwards are launched on (a stale non-zero word would read as "range overflow")
-        const unsigned zero = 0;
-        RD_HIP(hipMemcpy(range_flag_, &zero, sizeof(zero), hipMemcpyHostToDevice));
-        RD_HIP(hipDeviceSynchronize());
-        unsigned back = 1;
-        RD_HIP(hipMemcpy(&back, range_flag_, sizeof(back), hipMemcpyDeviceToHost));
-        RD_CHECK(back == 0, "range flag did not initialise");
-    }
+    // the range flag: one word of pinned host memory mapped into the device's address space (rd_device.h rd_raise_flag) - reading
+    // it costs a stream synchronise and a host load, not a device-to-host copy that queues behind whatever shares its hardware queue
+    RD_HIP(hipHostMalloc((void**)&range_flag_host_, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    *range_flag_host_ = 0u;
+    RD_HIP(hipHostGetDevicePointer((void**)&range_flag_, (void*)range_flag_host_, 0));
     Builder b(Mode::PREPARE, &store_, &params_, &dummy, h3_prepared_, true);
     // smallest legal geometry; only weight names/shapes matter in PREPARE mode
     if (kind_ == "ppocrv6_rec") build(b, 1, 48, 64, 0), build(b, 1, 48, 64, REC_UNFUSED_CTC);
@@ -1261,15 +1256,11 @@ void Engine::set_precision(int p) {
 }
 
 int Engine::take_range_flag(hipStream_t s) {
-    if (!range_flag_) return 0;
+    if (!range_flag_host_) return 0;
     RD_HIP(hipSetDevice(device_));
-    unsigned v = 0;
-    RD_HIP(hipMemcpyAsync(&v, range_flag_, sizeof(v), hipMemcpyDeviceToHost, s));
-    RD_HIP(hipStreamSynchronize(s));
-    if (v) {
-        RD_HIP(hipMemsetAsync(range_flag_, 0, sizeof(unsigned), s));
-        RD_HIP(hipStreamSynchronize(s));
-    }
+    RD_HIP(hipStreamSynchronize(s));            // the forwards to be judged were launched on s, or s waits on their events
+    const unsigned v = __atomic_load_n(range_flag_host_, __ATOMIC_ACQUIRE);
+    if (v) __atomic_store_n(range_flag_host_, 0u, __ATOMIC_RELEASE);
     return v ? 1 : 0;
 }
 
@@ -1334,17 +1325,12 @@ void Engine::run(int B, int H, int W, int flags, const std::vector<void*>& ext, 
         if (range_trace && range_flag_) {
             for (const OpRecord& op : plan.ops) {
                 op.run(plan, ctx);
-                unsigned v = 0;
-                RD_HIP(hipMemcpyAsync(&v, range_flag_, sizeof(v), hipMemcpyDeviceToHost, s));
                 RD_HIP(hipStreamSynchronize(s));
+                unsigned v = __atomic_load_n(range_flag_host_, __ATOMIC_ACQUIRE);
                 if (v) {
                     fprintf(stderr, "[range] %s: op '%s' kind %s cfg %s shape %s raised the flag (B=%d H=%d W=%d flags=%d)\n", kind_.c_str(),
                             op.name.c_str(), op.kind.c_str(), op.cfg.c_str(), op.shape.c_str(), B, H, W, flags);
-                    RD_HIP(hipMemsetAsync(range_flag_, 0, sizeof(unsigned), s));
-                    v = 1;
-                    RD_HIP(hipMemcpyAsync(range_flag_, &v, sizeof(v), hipMemcpyHostToDevice, s));   // keep it raised for the caller
-                    RD_HIP(hipStreamSynchronize(s));
-                    break;
+                    break;                       // (the flag stays raised for the caller)
                 }
             }
             return;

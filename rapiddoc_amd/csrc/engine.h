@@ -275,7 +275,8 @@ class Engine {
     bool profiling_ = false;
     int precision_ = PREC_AUTO;
     bool h3_prepared_ = false;
-    unsigned* range_flag_ = nullptr;
+    unsigned* range_flag_ = nullptr;          // device address of ...
+    unsigned* range_flag_host_ = nullptr;     // ... this word of pinned, mapped host memory
     int n_classes_ = 0;
     int rec_token_dim_ = 0;
     ParamBlock params_;

@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(512) conv_direct_h3_kernel(ConvParams p, Direc
             }
         }
     }
-    if ((emax >= 0x7f800000u || !(amax < 65504.f)) && p.range_flag) atomicOr(p.range_flag, 1u);
+    if ((emax >= 0x7f800000u || !(amax < 65504.f)) && p.range_flag) rd_raise_flag(p.range_flag);
 }
 
 static bool direct_geom(const ConvParams& p, DirectGeom& g) {

@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 && BM * BN >= 128 *
     if (!has_next) break;
     v = vnext;
     }
-    if (emax >= 0x7f800000u && p.range_flag) atomicOr(p.range_flag, 1u);
+    if (emax >= 0x7f800000u && p.range_flag) rd_raise_flag(p.range_flag);
 }
 
 static inline int h3_pick_bn(const ConvParams& p) {

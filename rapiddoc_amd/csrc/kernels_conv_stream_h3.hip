@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256) conv_stream_h3_kernel(ConvParams p, Strea
             }
         }
     }
-    if ((emax >= 0x7f800000u || !(amax < 65504.f)) && p.range_flag) atomicOr(p.range_flag, 1u);
+    if ((emax >= 0x7f800000u || !(amax < 65504.f)) && p.range_flag) rd_raise_flag(p.range_flag);
 }
 
 static bool stream_geom(const ConvParams& p, StreamGeom& g) {

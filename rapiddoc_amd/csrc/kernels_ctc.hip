@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(512) ctc_head_h3_kernel(CtcParams p, int cls_p
     }
     if (late) stats(T{}, nit - 1);
 
-    if (!(amax < 65504.f) && p.range_flag) atomicOr(p.range_flag, 1u);
+    if (!(amax < 65504.f) && p.range_flag) rd_raise_flag(p.range_flag);
     i_run += c_begin + 4 * lhi;        // class code -> class
     const float om = __shfl_xor(m_run, 32, 64), os = __shfl_xor(s_run, 32, 64);
     const int oi = __shfl_xor(i_run, 32, 64);

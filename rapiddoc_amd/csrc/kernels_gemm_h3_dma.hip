@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(512) gemm_h3_dma_kernel(ConvParams p, int ntn,
         v = vnext;
         fresh = false;
     }
-    if (emax >= 0x7f800000u && p.range_flag) atomicOr(p.range_flag, 1u);
+    if (emax >= 0x7f800000u && p.range_flag) rd_raise_flag(p.range_flag);
     if constexpr (TRACE) {
         if (tr && lane == 0)
             for (int i = 0; i < 60 * 8; ++i) trace[(wave == 4 ? 512 : 0) + i] = trl[i];
@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
         v = vnext;
         fresh = false;
     }
-    if (emax >= 0x7f800000u && p.range_flag) atomicOr(p.range_flag, 1u);
+    if (emax >= 0x7f800000u && p.range_flag) rd_raise_flag(p.range_flag);
 }
 
 bool gemm_h3_dma_applies(const ConvParams& p) {

@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(256, C <= 96 ? 2 : 1) lc_mixer_h3_kernel(Mixer
             if (m < p.M) __builtin_nontemporal_store(o, &p.y[(size_t)m * p.yld + co]);
         }
     }
-    if (!(amax < 65504.f) && p.range_flag) atomicOr(p.range_flag, 1u);
+    if (!(amax < 65504.f) && p.range_flag) rd_raise_flag(p.range_flag);
 }
 
 

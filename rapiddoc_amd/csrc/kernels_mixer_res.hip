@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(1024) lc_mixer_res_kernel(MixerParams p, const
             }
         }
     }
-    if (!(amax < 65504.f) && p.range_flag) atomicOr(p.range_flag, 1u);   // (NaN: through the output check in the epilogue)
+    if (!(amax < 65504.f) && p.range_flag) rd_raise_flag(p.range_flag);   // (NaN: through the output check in the epilogue)
 }
 
 bool mixer_res_supported(int C) {

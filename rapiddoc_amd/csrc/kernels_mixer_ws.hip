@@ -705,7 +705,7 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
         for (int b = 0; b < 2; ++b) hc[b] = hn[b];
         hfac_cur = hfac;
     }
-    if ((bad || !(amax * WS_SH < 65504.f)) && p.range_flag) atomicOr(p.range_flag, 1u);   // NaN: `bad` (epilogue), not amax
+    if ((bad || !(amax * WS_SH < 65504.f)) && p.range_flag) rd_raise_flag(p.range_flag);   // NaN: `bad` (epilogue), not amax
 }
 
 // C = 96 builds and passes the same tests, but measures level with the round-1 kernel (99 vs 97 us at M = 211 200): the

@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
         }
         __syncthreads();        // e / a are free for the next tile
     }
-    if (emax >= 0x7f800000u && p.range_flag) atomicOr(p.range_flag, 1u);
+    if (emax >= 0x7f800000u && p.range_flag) rd_raise_flag(p.range_flag);
 }
 
 bool stem_fused_supported(int c1) { return c1 == 24 || c1 == 32 || c1 == 48; }

@@ -13,6 +13,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// Raise a handle's range flag.  The word lives in pinned, device-mapped HOST memory (engine.cpp load_weights): the host reads it
+// after synchronising on the forward's own events, with no device-to-host copy to queue behind other streams' kernels.  A plain
+// system-scope store (every raiser writes the same 1), not an atomic: PCIe atomics are not needed.
+__device__ __forceinline__ void rd_raise_flag(unsigned* flag) {
+    __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // GELU(x) = x/2 * (1 + erf(x/sqrt2)) as nn.GELU() (approximate='none'), erf by Abramowitz-Stegun 7.1.26
 // (|abs err| <= 1.5e-7, i.e. fp32 round-off class): 1 exp + 1 rcp + 7 FMAs instead of libm erff's ~60 instructions.
 // v_rcp_f32 (1 ulp) on purpose: `__frcp_rn` compiles to the 10-instruction IEEE division sequence.

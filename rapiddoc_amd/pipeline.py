@@ -167,6 +167,15 @@ class PagePipeline:
         self.rec_tail = RdEngine("ppocrv6_rec", device, guard="deferred").load_weights(states["ppocrv6_rec"])
         self.tail_stream = torch.cuda.Stream(device=self.tdev)
         self.layout_stream = torch.cuda.Stream(device=self.tdev)
+        # det runs on a stream of its own, so that the NEXT batch's det + layout forwards can be enqueued under this batch's
+        # recognition (`run_batch(..., prefetch=next_pages)`): `_front` / `_prefetched`
+        self.front_stream = torch.cuda.Stream(device=self.tdev)
+        self._prefetched: Optional[dict] = None
+        self._after_rec_enqueue = None    # one-shot hook of _rec_forward_sources_once: called with the backbones' events once they are all enqueued
+        # where in a batch's recognition the next batch's det forward may start: after this fraction of the rec launches (1.0 = when
+        # the last backbone is done, i.e. under the neck + CTC head, the decode and the step boundary, where the GPU runs under-filled;
+        # earlier, its small kernels only take CUs away from the persistent recognition kernels: measured slower)
+        self.prefetch_gate = float(os.environ.get("RD_PREFETCH_GATE", "1.0"))
         self.layout = RdEngine("pphgnetv2_b4", device, guard="deferred", reuse_outputs=True).load_weights(states["pphgnetv2_b4"]) if "pphgnetv2_b4" in states else None
         self._bufs: Dict[tuple, torch.Tensor] = {}
         ncls = self.rec.num_classes
@@ -436,6 +445,7 @@ class PagePipeline:
             ready.record(main)
             self.tail_stream.wait_event(ready)
         group_rows = {}
+        bb_events: List[torch.cuda.Event] = []        # per rec launch: its backbone (or whole network) is done
 
         def run_tail(gi):
             grp = groups[gi]
@@ -510,11 +520,16 @@ class PagePipeline:
                     idx, prob, _ = self.rec_engines[k].rec_forward(x)
                     rows, done = self._collapse_rows(idx, prob, nb, st)
                     outs.append((idx, prob, done, x.clone() if self.keep_rec_inputs else x, rows))
+            bb_events.append(outs[-1][2])
             pos += nb
             if two_stage and (bi + 1) % S == 0:
                 run_tail(bi // S)
         if two_stage and len(batches) % S:
             run_tail(len(groups) - 1)
+        hook, self._after_rec_enqueue = self._after_rec_enqueue, None
+        if hook is not None:
+            m = max(1, min(len(batches), int(np.ceil(self.prefetch_gate * len(batches)))))
+            hook(bb_events[max(0, m - S): m])          # streams run their launches in order: the last S up to m cover all before them
         self.stats["t_rec_enqueue_ms"] = (time.perf_counter() - t0) * 1e3 - self.stats["t_descs_ms"]
         # D2H per batch result (small) as soon as that batch is done, host CTC decode (rapidocr CTCLabelDecode)
         # overlaps the GPU work of the batches still in flight
@@ -634,25 +649,62 @@ class PagePipeline:
 
     # ---------------------------------------------------------------- whole batch
     def run_batch(self, pages: torch.Tensor, quads_per_page: Optional[Sequence[np.ndarray]] = None,
-                  det_maps_override: Optional[torch.Tensor] = None) -> List[PageResult]:
+                  det_maps_override: Optional[torch.Tensor] = None, prefetch: Optional[torch.Tensor] = None) -> List[PageResult]:
         """`_run_batch_once` plus the range guard of the split-fp16 kernels (include/rapiddoc_mi355.h, rd_range_status):
         an engine that met an operand outside the fp16 range is switched to native fp32 for good and the batch is
         repeated, so a result is never silently wrong.  `pages`: [P,H,W,3] uint8 RGB on the GPU, or host pages (numpy / CPU tensor,
         what the reference's caller holds: batch_analyze.py:108-111), which are uploaded first - a stream of batches should go through
-        `PageUploader` instead, whose copies run under the previous batch."""
+        `PageUploader` instead, whose copies run under the previous batch.
+
+        `prefetch`: the NEXT batch's pages, already on the GPU (valid on the current stream).  Their det and layout forwards are
+        enqueued as soon as this batch's det maps have been consumed, so they run under this batch's recognition instead of in
+        front of the next batch's; the next `run_batch` call on that very tensor picks them up.  Results are the same with or
+        without it (the same kernels on the same inputs); `last_det` then already belongs to the next batch when this call returns."""
         if isinstance(pages, np.ndarray) or not pages.is_cuda:
             src = torch.from_numpy(np.ascontiguousarray(pages)) if isinstance(pages, np.ndarray) else pages.contiguous()
             pages = src.to(self.tdev, non_blocking=src.is_pinned())
-        results = self._run_batch_once(pages, quads_per_page, det_maps_override)
+        results = self._run_batch_once(pages, quads_per_page, det_maps_override, prefetch)
         # det and the layout backbone (the rec engines are guarded inside rec_forward_lines)
         engines = [self.det] + ([self.layout] if self.layout is not None else [])
+        if os.environ.get("RD_DEV_SKIP_RANGE_CHECK") == "1":
+            engines = []
         if any([e.check_range_and_fallback() for e in engines]):
             self.stats["range_fallbacks"] = self.stats.get("range_fallbacks", 0) + 1
-            results = self._run_batch_once(pages, quads_per_page, det_maps_override)
+            self._prefetched = None        # made by the engine that has just been replaced: the next batch computes its own
+            results = self._run_batch_once(pages, quads_per_page, det_maps_override, prefetch)
         return results
 
+    @staticmethod
+    def _front_key(pages: torch.Tensor) -> tuple:
+        return (pages.data_ptr(), tuple(pages.shape))
+
+    def _front(self, pages: torch.Tensor, n_results: int, gate: Sequence[torch.cuda.Event] = ()) -> dict:
+        """Enqueue the batch's det forward (front stream) and, behind it, its layout backbone (layout stream).  The det forward starts
+        after everything enqueued on the current stream so far - the pages' upload, and the previous batch's use of the det maps,
+        whose buffer it overwrites - and after the `gate` events."""
+        cur = torch.cuda.current_stream()
+        h = {"key": self._front_key(pages), "feats": None, "layout_done": None}
+        self.front_stream.wait_stream(cur)
+        for ev in gate:
+            self.front_stream.wait_event(ev)
+        with torch.cuda.stream(self.front_stream):
+            h["prob_maps"], h["det_hw"] = self.det_forward(pages)
+            h["det_done"] = torch.cuda.Event()
+            h["det_done"].record(self.front_stream)
+        # the layout backbone keeps the GPU busy (on its own stream, so it also overlaps the recognition batches that follow)
+        # while the host turns the det maps into boxes
+        if self.layout is not None:
+            self.layout_stream.wait_event(h["det_done"])       # det first: it is on the batch's critical path, the layout features are not
+            with torch.cuda.stream(self.layout_stream):
+                feats = self.layout_forward(pages)
+                if self.keep_feats:                   # copies: the engine re-uses its output tensors on the next call of this shape
+                    h["feats"] = [[f[i].clone() for f in feats] for i in range(n_results)]
+                h["layout_done"] = torch.cuda.Event()
+                h["layout_done"].record(self.layout_stream)
+        return h
+
     def _run_batch_once(self, pages: torch.Tensor, quads_per_page: Optional[Sequence[np.ndarray]] = None,
-                        det_maps_override: Optional[torch.Tensor] = None) -> List[PageResult]:
+                        det_maps_override: Optional[torch.Tensor] = None, prefetch: Optional[torch.Tensor] = None) -> List[PageResult]:
         """pages: [P,H,W,3] uint8 RGB on the GPU.  Text-line quads come from the DB post-process of the det maps
         unless `quads_per_page` is given.  `det_maps_override` (benchmark / tests with random weights, whose maps carry
         no text): device maps [P,1,h,w] that replace the network's output as the post-process input - the det forward
@@ -660,28 +712,36 @@ class PagePipeline:
         assert pages.is_cuda and pages.dtype == torch.uint8 and pages.dim() == 4
         P, H, W, _ = pages.shape
         results = [PageResult() for _ in range(P)]
-        prob_maps, det_hw = self.det_forward(pages)
+        cur = torch.cuda.current_stream()
+        h, self._prefetched = self._prefetched, None
+        if h is None or h["key"] != self._front_key(pages):
+            h = self._front(pages, P)
+            self.stats["front_prefetched"] = 0.0
+        else:
+            self.stats["front_prefetched"] = 1.0
+        cur.wait_event(h["det_done"])
+        prob_maps, det_hw = h["prob_maps"], h["det_hw"]
         self.last_det = (prob_maps, det_hw)         # a VIEW of the engine's output buffer: valid until the next det forward of this shape
-        src = None
         if quads_per_page is None:
             src = det_maps_override if det_maps_override is not None else prob_maps
-        # the layout backbone keeps the GPU busy (on its own stream, so it also overlaps the recognition batches that follow)
-        # while the host turns the det maps into boxes
-        if self.layout is not None:
-            self.layout_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.layout_stream):
-                feats = self.layout_forward(pages)
-                if self.keep_feats:                   # copies: the engine re-uses its output tensors on the next call of this shape
-                    for i in range(P):
-                        results[i].layout_feats = [f[i].clone() for f in feats]
-        if quads_per_page is None:
             quads_per_page = self.boxes_from_maps_device(src.contiguous(), (H, W)) if self.device_db else self._boxes_via_host_maps(src, (H, W))
+        if prefetch is not None:
+            assert prefetch.is_cuda and prefetch.dtype == torch.uint8 and prefetch.dim() == 4
+
+            def front_next(gate):
+                self._prefetched = self._front(prefetch, prefetch.shape[0], gate)
+            self._after_rec_enqueue = front_next
         texts = self.rec_forward_lines(pages, quads_per_page)
-        if self.layout is not None:
-            torch.cuda.current_stream().wait_stream(self.layout_stream)
+        if self._after_rec_enqueue is not None:        # no line to recognise: the hook was not reached
+            self._after_rec_enqueue = None
+            front_next(())
+        if h["layout_done"] is not None:
+            cur.wait_event(h["layout_done"])
         for i in range(P):
             qs = np.asarray(quads_per_page[i], dtype=np.float32).reshape(-1, 4, 2)
             results[i].lines = [(qs[j], t, s) for j, (t, s) in enumerate(texts[i])]
+            if h["feats"] is not None:
+                results[i].layout_feats = h["feats"][i]
         return results
 
 
@@ -797,13 +857,17 @@ class PagePipelinePool:
         return out
 
     def run_batch(self, pages: torch.Tensor, quads_per_page: Optional[Sequence[np.ndarray]] = None,
-                  det_maps_override: Optional[torch.Tensor] = None) -> List[PageResult]:
+                  det_maps_override: Optional[torch.Tensor] = None, prefetch: Optional[torch.Tensor] = None) -> List[PageResult]:
+        """`prefetch`: the next batch's device pages (PagePipeline.run_batch) - every shard's pipeline enqueues its shard of them."""
         if isinstance(pages, np.ndarray) or not pages.is_cuda:      # host pages: one upload for all shards (see PagePipeline.run_batch)
             src = torch.from_numpy(np.ascontiguousarray(pages)) if isinstance(pages, np.ndarray) else pages.contiguous()
             pages = src.to(self.pipes[0].tdev, non_blocking=src.is_pinned())
         P = pages.shape[0]
         n = min(len(self.pipes), max(1, P))
         bounds = [P * k // n for k in range(n + 1)]
+        nb = None
+        if prefetch is not None and min(len(self.pipes), max(1, prefetch.shape[0])) == n:     # the next call will shard it the same way
+            nb = [prefetch.shape[0] * k // n for k in range(n + 1)]
         ready = torch.cuda.Event()
         ready.record()
 
@@ -814,7 +878,8 @@ class PagePipelinePool:
             with torch.cuda.stream(st):
                 st.wait_event(ready)
                 res = self.pipes[k].run_batch(pages[lo:hi], None if quads_per_page is None else quads_per_page[lo:hi],
-                                              None if det_maps_override is None else det_maps_override[lo:hi])
+                                              None if det_maps_override is None else det_maps_override[lo:hi],
+                                              None if nb is None else prefetch[nb[k]:nb[k + 1]])
                 done = torch.cuda.Event()
                 done.record(st)
             return res, done

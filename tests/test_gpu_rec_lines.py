@@ -286,3 +286,48 @@ def test_bench_step_in_the_default_strict_mode_matches_the_oracle(golden_dir):
     pipe.last_rec_batches = []
     again = pipe.run_batch(pages, None, det_maps_override=maps)
     assert [[(t, s) for _q, t, s in r.lines] for r in again] == [[(t, s) for _q, t, s in r.lines] for r in res]
+
+
+def test_prefetching_the_next_batch_changes_no_result(golden_dir):
+    """`run_batch(..., prefetch=next_pages)`: the next batch's det + layout forwards run under this batch's recognition and the next call
+    picks them up.  Over a stream of five batches (uploader buffers recycled, boxes from the det network's OWN maps for two of them, the
+    layout features kept) every page's lines and features equal the unprefetched run's; a call on a different tensor than the one that
+    was announced computes its own front; a pool of two shards prefetches per shard."""
+    from rapiddoc_amd.pages import synth_batch
+    from rapiddoc_amd.pipeline import PagePipeline, PagePipelinePool, PageUploader, render_text_maps
+    states = {k: _state(golden_dir, k) for k in ("ppocrv6_det", "ppocrv6_rec", "pphgnetv2_b4")}
+    pipe = PagePipeline(states, n_rec_streams=2, keep_feats=True)
+    sets = [synth_batch(50 + k, 2) for k in range(5)]
+    dev_sets = [torch.from_numpy(p).cuda() for p, _b in sets]
+    det_hw = pipe.det_preprocess(dev_sets[0][:1])[1]
+    maps = [render_text_maps(b, p.shape[1:3], det_hw, torch.device("cuda", 0)) if k % 2 == 0 else None for k, (p, b) in enumerate(sets)]
+
+    def digest(res):
+        torch.cuda.synchronize()
+        return [([(q.round(3).tolist(), t, s) for q, t, s in r.lines], [f.clone() for f in r.layout_feats]) for r in res]
+
+    def same(a, b):
+        return len(a) == len(b) and all(la == lb and len(fa) == len(fb) and all(torch.equal(x, y) for x, y in zip(fa, fb))
+                                        for (la, fa), (lb, fb) in zip(a, b))
+    want = [digest(pipe.run_batch(d, None, det_maps_override=m)) for d, m in zip(dev_sets, maps)]
+    assert pipe.stats["front_prefetched"] == 0.0 and any(len(page[0]) for page in want[0])
+    up = PageUploader(0, n_buffers=2)
+    nxt = up.submit(sets[0][0])
+    for k in range(5):
+        cur, nxt = nxt, (up.submit(sets[k + 1][0]) if k + 1 < 5 else None)
+        got = digest(pipe.run_batch(up.wait(cur), None, det_maps_override=maps[k], prefetch=up.wait(nxt) if nxt is not None else None))
+        up.release(cur)
+        assert pipe.stats["front_prefetched"] == (1.0 if k > 0 else 0.0)
+        assert same(got, want[k]), k
+    assert pipe._prefetched is None
+    # announced one batch, then asked for another: the stale front is dropped
+    pipe.run_batch(dev_sets[0], None, det_maps_override=maps[0], prefetch=dev_sets[1])
+    assert pipe._prefetched is not None
+    assert same(digest(pipe.run_batch(dev_sets[3], None, det_maps_override=maps[3])), want[3]) and pipe.stats["front_prefetched"] == 0.0
+    # pool of two shards (one page each)
+    pool = PagePipelinePool(states, workers=2, n_rec_streams=2, keep_feats=True)
+    ref = [digest(pool.run_batch(d, None, det_maps_override=m)) for d, m in zip(dev_sets[:3], maps[:3])]
+    for k in range(3):
+        got = digest(pool.run_batch(dev_sets[k], None, det_maps_override=maps[k], prefetch=dev_sets[k + 1] if k + 1 < 3 else None))
+        assert same(got, ref[k]), k
+        assert all(p.stats["front_prefetched"] == (1.0 if k > 0 else 0.0) for p in pool.pipes)

@@ -38,6 +38,25 @@ def main():
     print("window %.1f ms: %d kernels, GPU busy (union) %.2f ms = %.1f %%, sum of kernel durations %.2f ms (avg concurrency %.2f while busy)"
           % (wall, len(rows), busy, 100 * busy / wall, ssum, ssum / busy))
     print("time by number of co-running kernels (ms):", {k: round(v / 1e6, 2) for k, v in sorted(by_depth.items())})
+    # which kernels run ALONE (depth 1), and for how long: an under-filled kernel running alone is where a step's wall time hides
+    ev2 = []
+    for i, (s_, e_, _) in enumerate(rows):
+        ev2.append((s_, 1, i))
+        ev2.append((e_, -1, i))
+    ev2.sort()
+    live, prev_t, solo = set(), ev2[0][0], {}
+    for t, d, i in ev2:
+        if len(live) == 1:
+            k = rows[next(iter(live))][2].split("(")[0][:64]
+            solo[k] = solo.get(k, 0) + (t - prev_t)
+        prev_t = t
+        if d > 0:
+            live.add(i)
+        else:
+            live.discard(i)
+    print("kernels running alone (ms over the window):")
+    for k, v in sorted(solo.items(), key=lambda kv: -kv[1])[:14]:
+        print("  %8.2f  %s" % (v / 1e6, k))
     # gaps
     gaps = []
     cur_end, cur_name = rows[0][1], rows[0][2]
