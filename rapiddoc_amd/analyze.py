@@ -58,6 +58,23 @@ def _formulas_in_crop(formulas: Sequence[dict], useful: Sequence[int]):
         yield f, [x0, y0, x1, y1]
 
 
+def restore_poly(poly: Sequence[float], angle: str, orig_w: int, orig_h: int) -> List[float]:
+    """restore_poly (utils/boxbase.py:328-363): the axis-aligned box of a detection on the upright page -> the same box on the page as
+    it came in.  Only (xmin, ymin, xmax, ymax) = poly[0], poly[1], poly[2], poly[5] are read."""
+    xmin, ymin, xmax, ymax = poly[0], poly[1], poly[2], poly[5]
+    if angle == "0":
+        return poly
+    if angle == "90":
+        nx0, ny0, nx1, ny1 = orig_w - 1 - ymax, xmin, orig_w - 1 - ymin, xmax
+    elif angle == "270":
+        nx0, ny0, nx1, ny1 = ymin, orig_h - 1 - xmax, ymax, orig_h - 1 - xmin
+    elif angle == "180":
+        nx0, ny0, nx1, ny1 = orig_w - 1 - xmax, orig_h - 1 - ymax, orig_w - 1 - xmin, orig_h - 1 - ymin
+    else:
+        raise ValueError(f"unsupported angle: {angle}")
+    return [nx0, ny0, nx1, ny0, nx1, ny1, nx0, ny1]
+
+
 def _int_box(b, h: int, w: int) -> Optional[List[int]]:
     """normalize_to_int_bbox (utils/bbox_utils.py:6-55): floor / ceil, clip to the image, None if empty."""
     x0, y0 = int(np.floor(b[0])), int(np.floor(b[1]))
@@ -184,18 +201,22 @@ class RegionOcr:
 
     # ------------------------------------------------------------------ whole batch
     def __call__(self, pages: torch.Tensor, layout_dets_per_page: Sequence[Sequence[dict]], det_maps_fn=None,
-                 page_langs: Optional[Sequence[str]] = None) -> List[List[dict]]:
+                 page_langs: Optional[Sequence[str]] = None, mask_boxes_per_page: Optional[Sequence[Sequence[dict]]] = None) -> List[List[dict]]:
         """pages [P,H,W,3] u8 RGB (GPU); returns, per page, the layout detections followed by their OcrText spans
         (`layout_res` of the reference after both OCR stages).  `det_maps_fn(regions, (gh, gw), (dh, dw))` may supply the
         det maps of a size group (see `_detect_group`); regions = [(page, region dict, useful_list)].
         `page_langs[p]`: the language of page p (the `lang` of the reference's input tuples); regions are grouped by language first
-        and every language's lines are recognised by that language's pipeline in one pooled call."""
+        and every language's lines are recognised by that language's pipeline in one pooled call.
+        `mask_boxes_per_page[p]`: further {'bbox': ...} entries treated like the page's formulas - the reference's `checkbox_res`
+        (`single_page_mfdetrec_res + checkbox_res`, analyze_utils.py:133-136)."""
         assert pages.dtype == torch.uint8 and (pages.is_cuda or self.det_raw_fn is not None)
         P, H, W, _ = pages.shape
         out: List[List[dict]] = [list(d) for d in layout_dets_per_page]
         regions = []                                   # (page, region dict, useful_list, formula boxes in crop coords)
         for p, dets in enumerate(layout_dets_per_page):
             ocr_regions, _tables, formulas = layout_host.split_regions(dets)
+            if mask_boxes_per_page is not None:
+                formulas = list(formulas) + list(mask_boxes_per_page[p])
             for r in ocr_regions:
                 useful = layout_host.crop_geometry(r, PASTE, PASTE)
                 if useful[6] < 2 * PASTE or useful[7] < 2 * PASTE:        # inverted box: the reference's np.ones would raise
@@ -385,13 +406,17 @@ class TableOcr:
 
     def __call__(self, pages: torch.Tensor, layout_dets_per_page: Sequence[Sequence[dict]], table_model,
                  page_scales: Optional[Sequence[float]] = None, det_maps_fn=None, table_image_enable: bool = True,
-                 page_langs: Optional[Sequence[str]] = None) -> int:
+                 page_langs: Optional[Sequence[str]] = None, mask_boxes_per_page: Optional[Sequence[Sequence[dict]]] = None) -> int:
         """Writes `html` (and `formula_boxes` / `img_boxes`) into the table detections IN PLACE; returns the number of tables handed to
         the model.  `table_image_enable`: hand the images that lie inside a table (`layout_image_list`) to the model as
-        `fill_image_res` (extract_table_fill_image's layout branch)."""
+        `fill_image_res` (extract_table_fill_image's layout branch).  `mask_boxes_per_page[p]`: the page's `checkbox_res`, which the
+        reference appends to the formulas everywhere in this stage (analyze_utils.py:318-321,411-415); their `checkbox` text travels
+        to the table model like a formula's `latex`."""
         n = 0
         for p, dets in enumerate(layout_dets_per_page):
             _ocr, tables, formulas = layout_host.split_regions(dets)
+            if mask_boxes_per_page is not None:
+                formulas = list(formulas) + list(mask_boxes_per_page[p])
             scale = 1.0 if page_scales is None else page_scales[p]
             for t in tables:
                 rect = table_crop_rect(t)
@@ -407,6 +432,8 @@ class TableOcr:
                         a = {"bbox": box}
                         if f.get("latex"):
                             a["latex"] = f["latex"]
+                        if f.get("checkbox"):
+                            a["checkbox"] = f["checkbox"]
                         adjusted.append(a)
                 override = None
                 if det_maps_fn is not None and table.numel():      # (page, crop rectangle, det input size) -> maps [1,1,dh,dw]
@@ -482,15 +509,16 @@ class PageAnalyzer:
 
     Every page is processed independently (`pages[p]` only feeds `out[p]`); the result is the reference's
     `images_layout_res`: per page the filtered layout detections, formula `latex` fields filled in place, followed by the
-    OcrText spans, then (7.) `text` written into the seal regions (`_run_seal_ocr`).  Not built (reference sub-stages outside SURVEY 8):
-    orientation classification (off by default: USE_DOC_ORIENTATION_CLASSIFY), checkbox detection (off by default), the 'txt' det mode
-    (PDF text layer)."""
+    OcrText spans, then (7.) `text` written into the seal regions (`_run_seal_ocr`).  Page orientation (0., off by
+    default: USE_DOC_ORIENTATION_CLASSIFY) and checkbox detection (off by default) are seams for caller-supplied models, sequenced as
+    in the reference.  Not built: the 'txt' det mode (PDF text layer)."""
 
     def __init__(self, layout_model, pipeline, formula_model=None, table_model=None, custom_ocr=None, layout_batch_size: int = 1,
                  formula_level: int = 0, box_thresh: float = 0.3, unclip_ratio: float = 1.8, formula_batch_size: int = 1,
                  formula_expand_px: int = 2, det_batch_num: Optional[int] = None, det_raw_fn=None, lang: str = "ch",
                  table_det_raw_fn=None, table_rec_fn=None, table_image_enable: bool = True, table_use_word_box: bool = True,
-                 seal_model=None, seal_enable: bool = True):
+                 seal_model=None, seal_enable: bool = True, checkbox_fn=None, checkbox_enable: bool = False,
+                 orientation_model=None, use_doc_orientation_classify: bool = False):
         """Batch sizes default to the reference's (layout_config['batch_num'] / formula_config['batch_num'] = 1,
         batch_analyze.py:66-71); `det_batch_num` / `det_raw_fn`: see RegionOcr."""
         self.layout_model, self.pipe = layout_model, pipeline
@@ -505,12 +533,39 @@ class PageAnalyzer:
         #    the reference obtains with get_atom_model(OCR, is_seal=True) - `.ocr(bgr crop, det=True, rec=True) -> [[(box, (text, score)), ...]]`.
         #    Its seal detector is ONNX-only (not built): pages WITH a seal region and no model to read it fail loudly.
         self.seal_model, self.seal_enable = seal_model, seal_enable
+        # checkbox detection (checkbox_config["checkbox_enable"], default False, batch_analyze.py:51,207-219): `checkbox_fn(bgr page) ->
+        # [{'bbox': [x0, y0, x1, y1], 'text': ...}]` = utils/checkbox_det_cls.py checkbox_predict (OpenCV morphology on the host; not
+        # built - a caller that enables the stage supplies it).  Every hit becomes a CheckBox detection of the page and masks the OCR
+        # detector's input like a formula box.
+        self.checkbox_fn, self.checkbox_enable = checkbox_fn, checkbox_enable
+        if checkbox_enable and checkbox_fn is None:
+            raise ValueError("checkbox_enable needs a checkbox_fn (the reference's checkbox_predict is host OpenCV code, not part of this build)")
+        # page orientation (USE_DOC_ORIENTATION_CLASSIFY, default off, batch_analyze.py:66-67,113-125,153-161): `orientation_model.predict(
+        # rgb page) -> "0" | "90" | "180" | "270"` (the ONNX-only ImgOrientationCls model); pages labelled 90 / 270 are turned upright
+        # before the layout model sees them and every detection's `poly` is mapped back afterwards
+        self.orientation_model, self.use_doc_orientation_classify = orientation_model, use_doc_orientation_classify
+        if use_doc_orientation_classify and orientation_model is None:
+            raise ValueError("use_doc_orientation_classify needs an orientation_model (ONNX-only in the reference, not part of this build)")
+        self.last_rotate_labels: List[str] = []
 
     def __call__(self, pages: torch.Tensor, det_maps_fn=None, page_scales: Optional[Sequence[float]] = None,
                  table_det_maps_fn=None, page_langs: Optional[Sequence[str]] = None) -> List[List[dict]]:
         """`page_scales[p]`: the render scale the reference carries with every page (the `scale` of its input tuples); only the
         `formula_boxes` written next to a table's `html` use it (analyze_utils.py:405-418).  Default 1."""
         assert pages.dtype == torch.uint8 and pages.dim() == 4 and (pages.is_cuda or self.ocr.det_raw_fn is not None)
+        # 0. page orientation (off by default): classify every page, turn the 90 / 270 ones upright (get_rotate_image, utils/boxbase.py:
+        #    312-326: "270" -> cv2.ROTATE_90_CLOCKWISE, "90" -> counter-clockwise; 0 and 180 are left as they are)
+        orig_hw_label = []
+        if self.use_doc_orientation_classify:
+            labels = [self.orientation_model.predict(pages[i].cpu().numpy()) for i in range(pages.shape[0])]
+            turned = [lb in ("90", "270") for lb in labels]
+            if any(turned) and not all(turned):
+                raise NotImplementedError("a batch that mixes upright and sideways pages: the page tensor is one [P,H,W,3] array - "
+                                          "hand the two groups over as separate batches")
+            orig_hw_label = [(int(pages.shape[1]), int(pages.shape[2]), lb) for lb in labels]
+            if all(turned) and labels:
+                pages = torch.stack([torch.rot90(pages[i], 1 if lb == "90" else -1, dims=(0, 1)) for i, lb in enumerate(labels)]).contiguous()
+            self.last_rotate_labels = list(labels)
         P, H, W, _ = pages.shape
         use_custom = self.custom_ocr is not None
         # 1. layout (+ overlap filter, formula level)
@@ -521,9 +576,19 @@ class PageAnalyzer:
             dets = [[d for d in page if d["category_id"] != inline] for page in dets]
         # 2. region collection: writes the integer `bbox` into the formula detections before anything else touches them, so that the
         #    fields of a detection also appear in the reference's ORDER (bbox, then latex) when the result is serialised
+        checkbox_res: Optional[List[List[dict]]] = None
         for p, page in enumerate(dets):
             layout_host.split_regions(page)
             attach_table_images(pages, p, page)
+            if self.checkbox_enable:          # after the regions were collected: a checkbox is never an OCR region itself
+                if checkbox_res is None:
+                    checkbox_res = []
+                found = list(self.checkbox_fn(np.ascontiguousarray(pages[p].cpu().numpy()[:, :, ::-1])))
+                checkbox_res.append(found)
+                for res in found:
+                    b = res["bbox"]
+                    page.append({"bbox": b, "poly": [b[0], b[1], b[2], b[1], b[2], b[3], b[0], b[3]],
+                                 "category_id": layout_host.CHECKBOX_CATEGORY_ID, "checkbox": res["text"], "score": 0.9})
         # 3. formulas
         if self.formula_model is not None:
             recognise_formulas(pages, dets, self.formula_model, self.formula_expand_px, self.formula_batch_size)
@@ -547,7 +612,7 @@ class PageAnalyzer:
                                "vl_ocr": True, "original_label": r.get("original_label"), "original_order": r.get("original_order"),
                                "polygon_points": r.get("polygon_points")})
         else:
-            out = self.ocr(pages, dets, det_maps_fn=det_maps_fn, page_langs=page_langs)
+            out = self.ocr(pages, dets, det_maps_fn=det_maps_fn, page_langs=page_langs, mask_boxes_per_page=checkbox_res)
         # 5. tables: one pooled `batch_predict` of a CustomBaseModel-shaped model (seam S1, batch_analyze.py:359-379) or, for a
         #    `predict`-shaped one (RapidTableModel, seam S3), the reference's own table stage with the table OCR on the GPU
         if self.table_model is not None and hasattr(self.table_model, "batch_predict"):
@@ -569,9 +634,16 @@ class PageAnalyzer:
                         t["html"] = html
         elif self.table_model is not None:
             self.table_ocr(pages, dets, self.table_model, page_scales, det_maps_fn=table_det_maps_fn, table_image_enable=self.table_image_enable,
-                           page_langs=page_langs)
+                           page_langs=page_langs, mask_boxes_per_page=checkbox_res)
         if self.seal_enable:
             self._run_seal_ocr(pages, out)
+        # back to the coordinates of the pages as they came in (restore_poly, utils/boxbase.py:328-363; batch_analyze.py:153-161:
+        # every detection gets `rotate_label`, only 90 / 270 pages have their `poly` mapped - a 180 page keeps its coordinates)
+        for p, (h, w, label) in enumerate(orig_hw_label):
+            for d in out[p]:
+                d["rotate_label"] = label
+                if label in ("90", "270"):
+                    d["poly"] = restore_poly(d["poly"], label, w, h)
         return out
 
     def _run_seal_ocr(self, pages: torch.Tensor, out: List[List[dict]]) -> int:

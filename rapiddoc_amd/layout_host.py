@@ -138,6 +138,7 @@ class LayoutPostProcess:
 _EXCLUSIVE_LABELS = {"image", "seal", "chart"}          # never dropped against a box of another label
 OCR_CATEGORY_IDS = (0, 1, 2, 4, 6, 7, 9)                 # model_utils.py:177
 TABLE_CATEGORY_ID = 5
+CHECKBOX_CATEGORY_ID = 200                          # utils/enum_class.py:106 CategoryId.CheckBox
 FORMULA_CATEGORY_IDS = (8, 13, 14)
 IMAGE_CATEGORY_IDS = (3,)
 

@@ -26,6 +26,7 @@ import importlib.abc
 import importlib.machinery
 import importlib.util
 import json
+import os
 import sys
 import types
 import zlib
@@ -91,6 +92,9 @@ def _fake_cv2():
             layout_polygon.fill_poly(img, np.asarray(p_).reshape(-1, 2), int(color))
         return img
     cv2.fillPoly = fill_poly
+    # get_rotate_image (utils/boxbase.py:312-326): the two quarter turns, as numpy does them (seeds 8 / 9)
+    cv2.ROTATE_90_CLOCKWISE, cv2.ROTATE_90_COUNTERCLOCKWISE = 0, 2
+    cv2.rotate = lambda img, code: np.ascontiguousarray(np.rot90(img, -1 if code == 0 else 1))
 
     def _missing(name):
         raise AttributeError(f"cv2.{name} is not stood in for: the traced path must not reach it")
@@ -258,16 +262,44 @@ def main():
     # seeds 0-4 were cut with ocr_config["seal_enable"] = False; 5 and 6 run the reference's DEFAULT (the key absent -> True,
     # batch_analyze.py:62): 5 = the pages and layout of seed 0 (no seal region: the seal stage must leave the output alone), 6 = two seal
     # regions (one with a polygon) -> _run_seal_ocr (batch_analyze.py:415-470) with a recording seal OCR model
+    # 7: checkbox detection on (checkbox_config["checkbox_enable"], batch_analyze.py:51,207-219) with a stand-in checkbox_predict - its
+    #    hits become CheckBox detections and mask the OCR detector's input next to the formulas;
+    # 8 / 9: USE_DOC_ORIENTATION_CLASSIFY=true (batch_analyze.py:66-67,113-125,153-161) with a recording ImgOrientationCls stand-in:
+    #    8 = both pages sideways ("90", "270": turned upright before the layout model, polys mapped back), 9 = "0" and "180" (left alone)
     for seed, (n_pages, formula_enable, formula_level, polygons, langs, seal) in enumerate([
             (3, True, 0, False, None, None), (2, False, 0, False, None, None), (2, True, 1, False, None, None), (2, True, 0, True, None, None),
             (3, True, 0, False, ["ch", "en", "ch"], None),              # pages of two languages in one batch
-            (3, True, 0, False, None, "default"), (2, True, 0, False, None, "regions")]):
+            (3, True, 0, False, None, "default"), (2, True, 0, False, None, "regions"),
+            (2, True, 0, False, None, "default"), (2, True, 0, False, None, "default"), (2, True, 0, False, None, "default")]):
         rng = np.random.default_rng(7000 + (0 if seed == 5 else seed))
         trace = {"det_calls": [], "rec_calls": [], "formula_calls": [], "layout_calls": []}
         page_ids = [int(rng.integers(0, 1000)) for _ in range(n_pages)]
         pages = [synth_page(i)[0] for i in page_ids]
         H, W = pages[0].shape[:2]
+        rotate_labels = {8: ["90", "270"], 9: ["0", "180"]}.get(seed)
+        sideways = seed == 8
         dets = [layout_for_page(rng, H, W, polygons) for _ in range(n_pages)]
+        if sideways:                          # the pages come in lying on their side (one quarter turn); either label stands them up as H x W
+            pages = [np.ascontiguousarray(np.rot90(p_, 1)) for p_ in pages]
+        os.environ["USE_DOC_ORIENTATION_CLASSIFY"] = "true" if rotate_labels else "false"
+
+        class OrientationCls:                # get_atom_model(ImgOrientationCls).predict(rgb page) -> "0" | "90" | "180" | "270"
+            def predict(self, img):
+                img = np.asarray(img)
+                k = len(trace.setdefault("orientation_calls", []))
+                trace["orientation_calls"].append({"shape": list(img.shape), "crc32": zlib.crc32(np.ascontiguousarray(img).tobytes())})
+                return rotate_labels[k]
+
+        def checkbox_predict(bgr):           # utils/checkbox_det_cls.py checkbox_predict(bgr page) -> [{'bbox', 'text', ...}]
+            bgr = np.asarray(bgr)
+            k = len(trace.setdefault("checkbox_calls", []))
+            trace["checkbox_calls"].append({"shape": list(bgr.shape), "crc32": zlib.crc32(np.ascontiguousarray(bgr).tobytes())})
+            # one hit inside the first text region of the page (it masks that region's det input), one far outside every region
+            first = next(d for d in dets[k] if d["category_id"] in (0, 1, 2, 4, 6, 7, 9))
+            x0, y0 = int(first["poly"][0]) + 12, int(first["poly"][1]) + 6
+            return [{"bbox": [x0, y0, x0 + 14, y0 + 14], "text": "checked" if k == 0 else "unchecked", "score": 0.97},
+                    {"bbox": [3, 3, 15, 15], "text": "unchecked", "score": 0.5}]
+        ba.checkbox_predict = checkbox_predict
         if seal == "regions":
             def seal_det(x0, y0, x1, y1, pts, order):
                 return {"category_id": 3, "original_label": "seal", "original_order": order, "poly": [x0, y0, x1, y0, x1, y1, x0, y1],
@@ -292,6 +324,9 @@ def main():
 
         class Registry:                      # rapid_doc/backend/pipeline/model_init.py:57-88 AtomModelSingleton
             def get_atom_model(self, atom_model_name, **kw):
+                if atom_model_name == AtomicModel.ImgOrientationCls:
+                    assert rotate_labels and not kw
+                    return OrientationCls()
                 assert atom_model_name == AtomicModel.OCR, atom_model_name
                 if kw.get("is_seal"):
                     assert set(kw) == {"is_seal"}
@@ -318,11 +353,15 @@ def main():
             del ocr_cfg["seal_enable"]       # the reference's default: True
         analyzer = ba.BatchAnalyze(Manager(), batch_ratio=1, formula_enable=formula_enable, table_enable=False,
                                    layout_config={"batch_num": 2}, ocr_config=ocr_cfg,
-                                   formula_config={"formula_level": formula_level, "batch_num": 4, "bbox_expand_px": 2})
+                                   formula_config={"formula_level": formula_level, "batch_num": 4, "bbox_expand_px": 2},
+                                   checkbox_config={"checkbox_enable": True} if seed == 7 else None)
         ba.clean_vram = lambda *a, **k: None
         from PIL import Image
         inputs = [(Image.fromarray(p), 2.0, True, (langs[i] if langs else "ch"), {}) for i, p in enumerate(pages)]
         out = analyzer(inputs)
+        os.environ.pop("USE_DOC_ORIENTATION_CLASSIFY", None)
+        if rotate_labels:
+            assert [pd.get("rotate_label") for *_x, pd in inputs] == rotate_labels
 
         def clean(o):
             if isinstance(o, dict):
@@ -334,6 +373,7 @@ def main():
             return o
         fixture = {"seed": seed, "page_langs": langs, "page_ids": page_ids, "page_hw": [H, W], "formula_enable": formula_enable, "formula_level": formula_level,
                    "ocr_config": ocr_cfg, "layout_batch_num": 2, "formula_batch_num": 4, "layout_dets": dets,
+                   "checkbox_enable": seed == 7, "rotate_labels": rotate_labels, "input_rot90": 1 if sideways else 0,
                    "trace": clean(trace), "output": clean(out)}
         (HERE / f"analyze_trace_seed{seed}.json").write_text(json.dumps(fixture))
         n_spans = [sum(1 for d in page if d["category_id"] in (15, 16)) for page in fixture["output"]]

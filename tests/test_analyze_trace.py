@@ -90,17 +90,23 @@ class ReplayPipe:
         return out
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2, 3, 5, 6])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 5, 6, 7, 8, 9])
 def test_page_analyzer_replays_the_reference_trace(golden_dir, seed):
     """Seeds 0-3: traces cut with ocr_config["seal_enable"] = False.  5 and 6: the reference's DEFAULT (seal OCR on, batch_analyze.py:62) -
     5 = seed 0's pages (no seal region: same output), 6 = three seal regions, one with a polygon, one nothing is read in: the crops
-    handed to the seal OCR model byte for byte, the `text` lists written into the regions."""
+    handed to the seal OCR model byte for byte, the `text` lists written into the regions.  7: checkbox detection on (batch_analyze.py:
+    207-219) - the BGR pages handed to checkbox_predict, its hits as CheckBox detections in front of the OCR spans and whited out of the
+    det canvases next to the formulas.  8 / 9: USE_DOC_ORIENTATION_CLASSIFY (batch_analyze.py:113-125,153-161) - the pages handed to
+    the orientation model; 8: both pages sideways ("90", "270") -> turned upright before the layout model (its logged input shapes),
+    every `poly` mapped back, `rotate_label` on every detection; 9: "0" and "180" -> pages untouched, labels only."""
     fx = json.loads((golden_dir / f"analyze_trace_seed{seed}.json").read_text())
     tr = fx["trace"]
     seal_on = fx["ocr_config"].get("seal_enable", True)
     assert seal_on == (seed >= 5)
     pages = torch.from_numpy(np.stack([synth_page(i)[0] for i in fx["page_ids"]]))      # CPU tensor: the networks are stood in for
     assert list(pages.shape[1:3]) == fx["page_hw"]
+    if fx.get("input_rot90"):          # seed 8: the pages come in lying on their side
+        pages = torch.from_numpy(np.stack([np.ascontiguousarray(np.rot90(p_, fx["input_rot90"])) for p_ in pages.numpy()]))
     log = {"layout": [], "formula": [], "det": [], "rec": []}
     det_calls = iter(tr["det_calls"])
 
@@ -121,13 +127,37 @@ def test_page_analyzer_replays_the_reference_trace(golden_dir, seed):
             box = [[1.0, 2.0], [30.0, 2.0], [30.0, 12.0], [1.0, 12.0]]
             return [[[box, (f"seal {k} line a {img.shape[0]}x{img.shape[1]}", 0.91)], None, [box], [box, ()], [box, ("", 0.4)], [box, ("line b", 0.2)]]]
 
+    class ReplayOrientation:          # == make_golden_analyze.OrientationCls
+        def predict(self, img):
+            k = len(log.setdefault("orientation", []))
+            log["orientation"].append({"shape": list(img.shape), "crc32": zlib.crc32(np.ascontiguousarray(img).tobytes())})
+            return fx["rotate_labels"][k]
+
+    def checkbox_fn(bgr):             # == make_golden_analyze.checkbox_predict
+        k = len(log.setdefault("checkbox", []))
+        log["checkbox"].append({"shape": list(bgr.shape), "crc32": zlib.crc32(np.ascontiguousarray(bgr).tobytes())})
+        first = next(d for d in fx["layout_dets"][k] if d["category_id"] in (0, 1, 2, 4, 6, 7, 9))
+        x0, y0 = int(first["poly"][0]) + 12, int(first["poly"][1]) + 6
+        return [{"bbox": [x0, y0, x0 + 14, y0 + 14], "text": "checked" if k == 0 else "unchecked", "score": 0.97},
+                {"bbox": [3, 3, 15, 15], "text": "unchecked", "score": 0.5}]
+
     formula_model = ReplayFormula(log["formula"]) if fx["formula_enable"] else None
+    extra = {}
+    if fx.get("checkbox_enable"):
+        extra.update(checkbox_fn=checkbox_fn, checkbox_enable=True)
+    if fx.get("rotate_labels"):
+        extra.update(orientation_model=ReplayOrientation(), use_doc_orientation_classify=True)
     pa = analyze.PageAnalyzer(ReplayLayout(fx["layout_dets"], log["layout"]), ReplayPipe(log["rec"]), formula_model=formula_model,
                               layout_batch_size=fx["layout_batch_num"], formula_level=fx["formula_level"],
                               formula_batch_size=fx["formula_batch_num"], det_batch_num=fx["ocr_config"]["Det.rec_batch_num"],
-                              det_raw_fn=det_raw_fn, seal_model=ReplaySeal() if seed == 6 else None, seal_enable=seal_on)
+                              det_raw_fn=det_raw_fn, seal_model=ReplaySeal() if seed == 6 else None, seal_enable=seal_on, **extra)
     out = pa(pages)
     assert log.get("seal", []) == tr.get("seal_calls", [])
+    assert log.get("checkbox", []) == tr.get("checkbox_calls", []) and log.get("orientation", []) == tr.get("orientation_calls", [])
+    if seed == 7:
+        assert len(log["checkbox"]) == 2 and sum(1 for page in out for d in page if d["category_id"] == 200) == 4
+    if seed in (8, 9):
+        assert pa.last_rotate_labels == fx["rotate_labels"] and all(d["rotate_label"] == fx["rotate_labels"][p] for p, page in enumerate(out) for d in page)
     if seed == 6:
         assert len(log["seal"]) == 3 and sum(1 for page in out for d in page if d.get("original_label") == "seal" and "text" in d) == 2
     if seed == 5:
@@ -366,3 +396,40 @@ def test_a_language_without_a_pipeline_fails_loudly():
     ocr = analyze.RegionOcr({"ch": object()})
     with pytest.raises(KeyError):
         ocr._pipe_for("en")
+
+
+def test_optional_stages_without_their_models_fail_loudly(golden_dir):
+    """checkbox detection / page orientation are seams for caller-supplied models: switching one on without its model is an error at
+    construction, and a batch that mixes upright and sideways pages (one [P,H,W,3] tensor cannot hold both) says so."""
+    fx = json.loads((golden_dir / "analyze_trace_seed9.json").read_text())
+    with pytest.raises(ValueError, match="checkbox_fn"):
+        analyze.PageAnalyzer(ReplayLayout([], []), ReplayPipe([]), checkbox_enable=True)
+    with pytest.raises(ValueError, match="orientation_model"):
+        analyze.PageAnalyzer(ReplayLayout([], []), ReplayPipe([]), use_doc_orientation_classify=True)
+
+    class Mixed:
+        def __init__(self):
+            self.k = 0
+
+        def predict(self, img):
+            self.k += 1
+            return ["0", "90"][self.k - 1]
+    pages = torch.from_numpy(np.stack([synth_page(i)[0] for i in fx["page_ids"]]))
+    pa = analyze.PageAnalyzer(ReplayLayout(fx["layout_dets"], []), ReplayPipe([]), det_raw_fn=lambda c, b: [], seal_enable=False,
+                              orientation_model=Mixed(), use_doc_orientation_classify=True)
+    with pytest.raises(NotImplementedError, match="mixes upright and sideways"):
+        pa(pages)
+
+
+def test_restore_poly_matches_the_quarter_turns():
+    """restore_poly (utils/boxbase.py:328-363) against the geometry it stands for: a pixel's box on the turned page maps back onto the
+    pixel's box on the page as it came in (get_rotate_image: "270" = clockwise quarter turn, "90" = counter-clockwise)."""
+    h, w = 7, 11
+    img = np.arange(h * w).reshape(h, w)
+    for label, k in (("90", 1), ("270", -1)):
+        turned = np.rot90(img, k)
+        for y in range(turned.shape[0]):
+            for x in range(turned.shape[1]):
+                x0, y0, x1, _, _, y1, _, _ = analyze.restore_poly([x, y, x, y, x, y, x, y], label, w, h)
+                assert (x0, y0) == (x1, y1) and img[y0, x0] == turned[y, x]
+    assert analyze.restore_poly([1, 2, 3, 2, 3, 4, 1, 4], "180", w, h) == [w - 1 - 3, h - 1 - 4, w - 1 - 1, h - 1 - 4, w - 1 - 1, h - 1 - 2, w - 1 - 3, h - 1 - 2]
