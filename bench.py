@@ -376,6 +376,10 @@ def main():
                     torch.cuda.synchronize()
                     print("step %.1f ms" % ((time.perf_counter() - ts) * 1e3), file=sys.stderr)
                 step_wall_ms.append((time.perf_counter() - ts) * 1e3)      # host clock only: no synchronise is added for it
+                if os.environ.get("RD_BENCH_STEP_LOG") == "1":           # developer: what each step built (no synchronise)
+                    ps = [e.plan_stats() for q in pools for e in q.engines]
+                    print("step %2d  %.1f ms  plans %d  captures %d  stats %s" % (i, step_wall_ms[-1], sum(p_["plans_built"] for p_ in ps),
+                          sum(p_["graph_captures"] for p_ in ps), {k_: round(v_, 1) for k_, v_ in pool.stats.items() if k_.startswith("t_")}), file=sys.stderr)
             return out
         from concurrent.futures import ThreadPoolExecutor
         streams = [torch.cuda.Stream() for _ in pools]
@@ -502,7 +506,11 @@ def main():
         tf = ROOT / "profiles" / "pmc_traffic.json"
         if tf.exists():
             tj = json.loads(tf.read_text())
-            traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
+            row = tj.get(dom)
+            if row is None:          # the counter file names instantiations in full (gemm_h3_dma_kernel<false,true>): match on the kernel name
+                cands = [k for k in tj if not k.startswith("_") and k.split("<")[0] == dom.split("<")[0] and ("<" not in dom)]
+                row = tj[cands[0]] if len(cands) == 1 else None
+            traffic = (row or {}).get("hbm_bytes_per_launch")
             if traffic is not None:
                 traffic_source = "profiles/pmc_traffic.json (%s)" % tj.get("_collected", "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes")
         # a split-fp16 kernel issues 3 fp16 MFMAs per fp32 product: its ceiling in algorithmic (fp32) FLOPs is the dense

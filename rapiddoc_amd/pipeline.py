@@ -526,11 +526,13 @@ class PagePipeline:
                 run_tail(bi // S)
         if two_stage and len(batches) % S:
             run_tail(len(groups) - 1)
+        self.stats["t_rec_enqueue_ms"] = (time.perf_counter() - t0) * 1e3 - self.stats["t_descs_ms"]
         hook, self._after_rec_enqueue = self._after_rec_enqueue, None
         if hook is not None:
+            t_h = time.perf_counter()
             m = max(1, min(len(batches), int(np.ceil(self.prefetch_gate * len(batches)))))
             hook(bb_events[max(0, m - S): m])          # streams run their launches in order: the last S up to m cover all before them
-        self.stats["t_rec_enqueue_ms"] = (time.perf_counter() - t0) * 1e3 - self.stats["t_descs_ms"]
+            self.stats["t_front_next_ms"] = (time.perf_counter() - t_h) * 1e3
         # D2H per batch result (small) as soon as that batch is done, host CTC decode (rapidocr CTCLabelDecode)
         # overlaps the GPU work of the batches still in flight
         t_dec = 0.0
