@@ -150,6 +150,140 @@ __global__ void __launch_bounds__(128) dec_attention_kernel(AttnDecParams p) {
     if (tid < 32) p.out[(size_t)b * p.ldo + h * HD + tid] = (red[tid] + red[32 + tid]) * inv;
 }
 
+// Round 4: the projection that feeds an attention call, fused into it.  One decode step was 52 dependent launches of 5-15 us (the loop
+// is a latency chain, profiles/r3_formula_decode.txt); q|k|v (self) and q (cross) were skinny GEMMs of ~9 us each whose only consumer is
+// the attention launch behind them.  Here the (sequence, head) workgroup computes ITS 32 (x 3) outputs itself: LayerNorm of the row
+// (two-pass, as layernorm_kernel), then a 512-long dot product per output - eight lanes per output, each reading every eighth float4 of
+// the weight row so that a load instruction covers 128 contiguous bytes per row - and goes straight on to the scores.  The weight slab
+// of a head (64 KB per matrix) is read by the B workgroups of that head: from HBM once, from L2 after that.  52 -> 40 launches per
+// token.  Used for B <= 32 (beyond that a real GEMM reads the weights once instead of B times).
+struct AttnFusedParams {
+    const float* x;                           // [B][D] the layer's input row (before its LayerNorm)
+    const float* ln_g; const float* ln_b;
+    const float* w; const float* bias;        // SELF: q | k | v rows [3 D][D] (q pre-scaled); cross: q rows [D][D]
+    const float* kc; const float* vc; int ldkv; long long seq_stride;
+    float* kw; float* vw;                     // SELF: where this step's k, v are appended
+    const DecState* st; int fixed_T;
+    float* out; int ldo;
+};
+template <bool SELF>
+__global__ void __launch_bounds__(256) dec_attn_fused_kernel(AttnFusedParams p) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    float* xn = smf;                   // [512] normalised row
+    float* qs = smf + D;               // [32] q | [32] k | [32] v of this step
+    float* red = qs + 3 * HD;          // [256]
+    float* sc = red + 256;             // [T] scores
+    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    static_assert(D == 512 && HD == 32, "two values per thread, eight float4 per head row");
+    // ---- LayerNorm of row b
+    {
+        const float v0 = p.x[(size_t)b * D + tid], v1 = p.x[(size_t)b * D + 256 + tid];
+        float s = wsum(v0 + v1);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        const float mean = (red[0] + red[1] + red[2] + red[3]) / D;
+        const float d0 = v0 - mean, d1 = v1 - mean;
+        float q = wsum(d0 * d0 + d1 * d1);
+        if (lane == 0) red[4 + wave] = q;
+        __syncthreads();
+        const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / D + 1e-5f);
+        xn[tid] = d0 * rstd * p.ln_g[tid] + p.ln_b[tid];
+        xn[256 + tid] = d1 * rstd * p.ln_g[256 + tid] + p.ln_b[256 + tid];
+    }
+    __syncthreads();
+    // ---- this head's projections: output o = tid / 8, its eight lanes take float4 number 8 i + part of the row
+    const int Tc = SELF ? p.st->step : p.fixed_T;
+    {
+        const int o = tid >> 3, part = tid & 7;
+        f4 xr[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xr[i] = reinterpret_cast<const f4*>(xn)[8 * i + part];
+#pragma unroll
+        for (int m = 0; m < (SELF ? 3 : 1); ++m) {
+            const int row = m * D + h * HD + o;
+            const f4* wr = reinterpret_cast<const f4*>(p.w + (size_t)row * D);
+            f4 wv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) wv[i] = wr[8 * i + part];
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = fmaf(xr[i][e], wv[i][e], acc);
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 4, 64);
+            if (part == 0) {
+                const float v = acc + p.bias[row];
+                qs[m * HD + o] = v;
+                if (SELF && m == 1) p.kw[(size_t)b * p.seq_stride + (size_t)Tc * p.ldkv + h * HD + o] = v;
+                if (SELF && m == 2) p.vw[(size_t)b * p.seq_stride + (size_t)Tc * p.ldkv + h * HD + o] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- single-query attention (dec_attention_kernel with 256 threads; this step's k, v come from LDS)
+    const int T = Tc + (SELF ? 1 : 0);
+    f4 q[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) q[d] = reinterpret_cast<const f4*>(qs)[d];
+    auto krow = [&](int j) -> const float* { return (!SELF || j < Tc) ? p.kc + (size_t)b * p.seq_stride + (size_t)j * p.ldkv + h * HD : qs + HD; };
+    auto vrow = [&](int j) -> const float* { return (!SELF || j < Tc) ? p.vc + (size_t)b * p.seq_stride + (size_t)j * p.ldkv + h * HD : qs + 2 * HD; };
+    float mx = -INFINITY;
+    for (int j = tid; j < T; j += 256) {
+        const f4* kr = reinterpret_cast<const f4*>(krow(j));
+        f4 k[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) k[d] = kr[d];
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = fmaf(q[d][e], k[d][e], s);
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = tid; j < T; j += 256) {
+        const float e = __expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+    sum = wsum(sum);
+    __syncthreads();                       // (red[0..3] read by everybody; sc[] complete)
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+    // output: thread (g = tid / 8: one of 32 key groups, dq = tid % 8: dims 4 dq .. + 3), four rows in flight
+    const int dq = tid & 7, g = tid >> 3;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    int j = g;
+    for (; j + 96 < T; j += 128) {
+        const f4 v0 = reinterpret_cast<const f4*>(vrow(j))[dq], v1 = reinterpret_cast<const f4*>(vrow(j + 32))[dq];
+        const f4 v2 = reinterpret_cast<const f4*>(vrow(j + 64))[dq], v3 = reinterpret_cast<const f4*>(vrow(j + 96))[dq];
+        acc += v0 * sc[j];
+        acc += v1 * sc[j + 32];
+        acc += v2 * sc[j + 64];
+        acc += v3 * sc[j + 96];
+    }
+    for (; j < T; j += 32) acc += reinterpret_cast<const f4*>(vrow(j))[dq] * sc[j];
+    __syncthreads();                       // red[] is reused below
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+    }
+    if (lane < 8) *reinterpret_cast<f4*>(&red[wave * 32 + 4 * lane]) = acc;
+    __syncthreads();
+    if (tid < 32) p.out[(size_t)b * p.ldo + h * HD + tid] = (red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid]) * inv;
+}
+
 // next token: argmax of the logits row (forced EOS at the length limit), pad for finished sequences, append.  The last
 // block to finish advances the step counter (arrival ticket), so no separate launch is needed.
 __global__ void __launch_bounds__(1024) dec_select_kernel(const float* logits, int V, long long* ids, int ids_ld, int* unfinished,
@@ -395,6 +529,10 @@ int FormulaDecoder::decode(const float* enc, int B, int S, int max_new, long lon
         gemm(enc_d, B * S, D, "l" + std::to_string(l) + ".ckv", 2 * D, ckv + (size_t)l * B * S * 2 * D, ACT_NONE, nullptr, s);
 
     const size_t attn_sh_self = (size_t)(((Tmax + 3) & ~3) + 128) * f, attn_sh_cross = (size_t)(((S + 3) & ~3) + 128) * f;
+    // fused projection + attention launches (dec_attn_fused_kernel): RD_DEC_FUSED=0 keeps the round-3 form (A/B, parity tests)
+    static const bool fused_env = [] { const char* e = getenv("RD_DEC_FUSED"); return !(e && e[0] == '0'); }();
+    const bool fused = fused_env && B <= 32;
+    const size_t fsh_self = (size_t)(D + 3 * HD + 256 + ((Tmax + 3) & ~3)) * f, fsh_cross = (size_t)(D + 3 * HD + 256 + ((S + 3) & ~3)) * f;
     // One decode step = ~70 dependent launches whose arguments never change (the step index lives in device memory), so
     // the step is captured once into a hipGraph and replayed: the host cost per step drops from ~70 launches to one.
     auto enqueue_step = [&]() {
@@ -404,6 +542,29 @@ int FormulaDecoder::decode(const float* enc, int B, int S, int max_new, long lon
         float* nxt = x2;
         for (int l = 0; l < n_layers_; ++l) {
             const std::string K = "l" + std::to_string(l) + ".";
+            if (fused) {
+                AttnFusedParams sp{};
+                sp.x = cur; sp.ln_g = params_.ptr(K + "ln1.weight"); sp.ln_b = params_.ptr(K + "ln1.bias");
+                sp.w = params_.ptr(K + "qkv#w"); sp.bias = params_.ptr(K + "qkv#b");
+                sp.kc = kc + (size_t)l * B * Tmax * D; sp.vc = vc + (size_t)l * B * Tmax * D; sp.ldkv = D; sp.seq_stride = (long long)Tmax * D;
+                sp.kw = kc + (size_t)l * B * Tmax * D; sp.vw = vc + (size_t)l * B * Tmax * D;
+                sp.st = st; sp.fixed_T = 0; sp.out = a; sp.ldo = D;
+                hipLaunchKernelGGL((dec_attn_fused_kernel<true>), dim3(B, HEADS), dim3(256), fsh_self, s, sp);
+                gemm(a, B, D, K + "so", D, nxt, ACT_NONE, cur, s);
+                std::swap(cur, nxt);
+                AttnFusedParams xp{};
+                xp.x = cur; xp.ln_g = params_.ptr(K + "ln2.weight"); xp.ln_b = params_.ptr(K + "ln2.bias");
+                xp.w = params_.ptr(K + "cq#w"); xp.bias = params_.ptr(K + "cq#b");
+                xp.kc = ckv + (size_t)l * B * S * 2 * D; xp.vc = xp.kc + D; xp.ldkv = 2 * D; xp.seq_stride = (long long)S * 2 * D;
+                xp.st = st; xp.fixed_T = S; xp.out = a; xp.ldo = D;
+                hipLaunchKernelGGL((dec_attn_fused_kernel<false>), dim3(B, HEADS), dim3(256), fsh_cross, s, xp);
+                gemm(a, B, D, K + "co", D, nxt, ACT_NONE, cur, s);
+                std::swap(cur, nxt);
+                gemm(cur, B, D, K + "fc1", FFN, ff, ACT_GELU, nullptr, s, K + "ln3", h);
+                gemm(ff, B, FFN, K + "fc2", D, nxt, ACT_NONE, cur, s);
+                std::swap(cur, nxt);
+                continue;
+            }
             // self-attention
             gemm(cur, B, D, K + "qkv", 3 * D, qkv, ACT_NONE, nullptr, s, K + "ln1", h);
             AttnDecParams ap{};
