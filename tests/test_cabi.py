@@ -1,6 +1,7 @@
 """CPU: the C-ABI library builds, loads and exports every symbol include/rapiddoc_mi355.h declares; the
 product path fails loudly (no CPU fallback) when there is no GPU."""
 import ctypes as C
+import os
 import re
 from pathlib import Path
 
@@ -56,3 +57,16 @@ def test_product_package_never_imports_oracle():
     for py in (ROOT / "rapiddoc_amd").rglob("*.py"):
         src = py.read_text()
         assert "import oracle" not in src and "from oracle" not in src, py
+
+
+def test_importing_the_package_defaults_the_hardware_queue_count_and_respects_an_explicit_one():
+    """`import rapiddoc_amd` gives every HIP stream its own hardware queue unless the environment says otherwise (with
+    the runtime's default of four, streams that share a queue serialise - 7-15 % of a step)."""
+    import subprocess
+    import sys
+    root = str(Path(__file__).resolve().parents[1])
+    code = "import os, sys; sys.path.insert(0, %r); import rapiddoc_amd; print(os.environ['GPU_MAX_HW_QUEUES'])" % root
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "16"
+    env["GPU_MAX_HW_QUEUES"] = "4"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "4"

@@ -82,6 +82,17 @@ def test_known_register_budgets(tables):
     k16 = next(v for n, v in rows.items() if "gemm_h3_dma16_kernelILi0E" in n)
     assert k8[0] <= 256 and k8[1:] == (0, 0)
     assert k16[0] <= 128 and k16[1:] == (0, 0)
+    # the LDS-DMA-staged depthwise 3x3 lives on occupancy (nothing persistent: one workgroup's DMA under another's arithmetic): four
+    # workgroups per CU need <= 128 registers, five <= 96 (left alone the compiler sank every FMA behind the loop: 138, three per SIMD)
+    dw = {n: (v, s_, p_) for n, v, s_, p_ in tables["kernels_dw_lds.hip"]}
+    assert len(dw) == 3
+    for n, (v, s_, p_) in dw.items():
+        assert v <= 104 and (s_, p_) == (0, 0), (n, v, s_, p_)
+    assert next(v for n, v in dw.items() if "ILi16ELi6E" in n)[0] <= 96
+    # the fused projection + attention launches of the formula decode: 256 threads, no spill
+    fd = {n: (v, s_, p_) for n, v, s_, p_ in tables["formula_decoder.hip"]}
+    fused = [v for n, v in fd.items() if "dec_attn_fused_kernel" in n]
+    assert len(fused) == 2 and all(v[0] <= 160 and v[1:] == (0, 0) for v in fused), fused
 
 
 def test_inline_asm_register_loads_are_not_touched_in_flight():
