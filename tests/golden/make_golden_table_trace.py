@@ -135,7 +135,9 @@ def main():
     ro.TextRecInput = lambda img, return_word_box=False: types.SimpleNamespace(img=img, return_word_box=return_word_box)   # rapidocr dataclasses
     ro.TextRecOutput = lambda imgs, txts, scores, words, elapse: types.SimpleNamespace(txts=list(txts), scores=list(scores), word_results=words)
 
-    kinds = ("traditional", "custom", "custom_ocr", "traditional_words")
+    # "traditional_checkbox": checkbox detection on (batch_analyze.py:207-219) - a hit inside the first table is whited out of the table
+    # detector's input and travels to the table model with its `checkbox` text, every hit is listed in `formula_boxes`
+    kinds = ("traditional", "custom", "custom_ocr", "traditional_words", "traditional_checkbox")
     for kind in kinds:
         rng = np.random.default_rng(8000 + kinds.index(kind))
         trace = {"det_calls": [], "rec_calls": [], "formula_calls": [], "layout_calls": [], "table_det_calls": [], "table_calls": []}
@@ -146,6 +148,16 @@ def main():
         if kind == "custom_ocr":              # one page with polygons on every box (crop_img's mask), one without
             dets[0] = MGA.layout_for_page(rng, H, W, polygons=True)
         ocr = MGA.RecordingOcr(trace)
+
+        def checkbox_predict(bgr):           # utils/checkbox_det_cls.py checkbox_predict(bgr page) -> [{'bbox', 'text', ...}]
+            bgr = np.asarray(bgr)
+            k = len(trace.setdefault("checkbox_calls", []))
+            trace["checkbox_calls"].append({"shape": list(bgr.shape), "crc32": zlib.crc32(np.ascontiguousarray(bgr).tobytes())})
+            tb = next(d for d in dets[k] if d["category_id"] == 5)
+            x0, y0 = int(tb["poly"][0]) + 30, int(tb["poly"][1]) + 20
+            return [{"bbox": [x0, y0, x0 + 16, y0 + 16], "text": "checked" if k == 0 else "unchecked", "score": 0.9},
+                    {"bbox": [5, 5, 17, 17], "text": "unchecked", "score": 0.6}]
+        ba.checkbox_predict = checkbox_predict
 
         def text_detector(img):
             img = np.asarray(img)
@@ -176,7 +188,7 @@ def main():
                     "boxes": [np.asarray(b, dtype=np.float64).tolist() for b in boxes], "texts": list(texts), "scores": [float(s) for s in scores],
                     "fill_image_res": fill_summary(fill_image_res), "mfd_res": json.loads(json.dumps(mfd_res)),
                     "flags": [bool(skip_text_in_image), bool(use_img2table), bool(skip_table_orientation)]})
-                if len(texts) % 2 == 0:       # an answer without a table in it: the reference leaves the region without `html`
+                if len(texts) % 2 == 0 and kind != "traditional_checkbox":       # an answer without a table in it: the reference leaves the region without `html`
                     return "<html><body>nothing found</body></html>"
                 return f"<html><body><table><tr><td>{len(texts)} lines</td></tr></table></body></html>"
 
@@ -223,9 +235,11 @@ def main():
         ocr_cfg = {"use_det_mode": "ocr", "Det.rec_batch_num": 3, "seal_enable": False}
         # table_image_enable stays at its default, True; "traditional_words" runs the reference's DEFAULT table config (use_word_box True)
         table_cfg = {} if kind == "traditional_words" else {"use_word_box": False}
+        fixture_extra = {"checkbox_enable": kind == "traditional_checkbox"}
         analyzer = ba.BatchAnalyze(Manager(), batch_ratio=1, formula_enable=True, table_enable=(kind != "custom_ocr"), layout_config={"batch_num": 2},
                                    ocr_config=ocr_cfg, table_config=table_cfg,
-                                   formula_config={"formula_level": 0, "batch_num": 4, "bbox_expand_px": 2})
+                                   formula_config={"formula_level": 0, "batch_num": 4, "bbox_expand_px": 2},
+                                   checkbox_config={"checkbox_enable": True} if kind == "traditional_checkbox" else None)
         ba.clean_vram = lambda *a, **k: None
         from PIL import Image
         out = analyzer([(Image.fromarray(p), 2.0, True, "ch", {"blocks": [], "ori_image_list": []}) for p in pages])
@@ -240,7 +254,7 @@ def main():
             return o
         fixture = {"kind": kind, "page_ids": page_ids, "page_hw": [H, W], "page_scale": 2.0, "formula_enable": True, "formula_level": 0,
                    "ocr_config": ocr_cfg, "table_config": table_cfg, "layout_batch_num": 2, "formula_batch_num": 4, "layout_dets": dets,
-                   "trace": clean(trace), "output": clean(out)}
+                   "trace": clean(trace), "output": clean(out), **fixture_extra}
         (HERE / f"analyze_trace_table_{kind}.json").write_text(json.dumps(fixture))
         print(f"{kind}: table det calls {[c['shape'][:2] for c in trace['table_det_calls']]}, table calls {len(trace['table_calls'])}, "
               f"html fields {sum(1 for p in fixture['output'] for d in p if 'html' in d)}")

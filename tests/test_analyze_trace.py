@@ -211,7 +211,7 @@ def table_words_for(h, w, dt_box):       # == make_golden_table_trace.table_word
     return words
 
 
-@pytest.mark.parametrize("kind", ["traditional", "custom", "traditional_words"])
+@pytest.mark.parametrize("kind", ["traditional", "custom", "traditional_words", "traditional_checkbox"])
 def test_table_stage_replays_the_reference_trace(golden_dir, kind):
     """`traditional`: a `predict`-shaped table model - per table the reference crops (box snapped outwards to multiples of 5 px), whites the
     page's formulas out of the detector's copy, detects (0.5 / 1.6, sorted, cut around formulas, NOT merged), recognises every line
@@ -219,7 +219,9 @@ def test_table_stage_replays_the_reference_trace(golden_dir, kind):
     with latex, True, False, skip_table_orientation=True); the answer's <table> part and the page's formula boxes / scale land on the
     region; a picture lying inside a table (>= 0.8 of its area) reaches the model as `fill_image_res` (page box, corners in crop
     coordinates, the PIL crop) and its box / scale lands in `img_boxes`.  Demanded back: the detector canvases and the table images
-    byte for byte, every argument of every predict call, the output dicts.  `custom`: ONE batch_predict over the tables of all pages with the same crops and fill_image_res_list."""
+    byte for byte, every argument of every predict call, the output dicts.  `custom`: ONE batch_predict over the tables of all pages with the same crops and fill_image_res_list.
+    `traditional_checkbox`: checkbox detection on - a hit inside a table is whited out of the table detector's copy and handed to the
+    table model next to the formulas (analyze_utils.py:318-321), every hit of the page is listed in `formula_boxes` (:411-418)."""
     fx = json.loads((golden_dir / f"analyze_trace_table_{kind}.json").read_text())
     tr = fx["trace"]
     pages = torch.from_numpy(np.stack([synth_page(i)[0] for i in fx["page_ids"]]))
@@ -265,9 +267,17 @@ def test_table_stage_replays_the_reference_trace(golden_dir, kind):
                                  "boxes": [np.asarray(b, dtype=np.float64).tolist() for b in boxes], "texts": list(texts),
                                  "scores": [float(s) for s in scores], "fill_image_res": fill_summary(fill_image_res), "mfd_res": mfd_res,
                                  "flags": [bool(skip_text_in_image), bool(use_img2table), bool(skip_table_orientation)]})
-            if len(texts) % 2 == 0:
+            if len(texts) % 2 == 0 and kind != "traditional_checkbox":
                 return "<html><body>nothing found</body></html>"
             return f"<html><body><table><tr><td>{len(texts)} lines</td></tr></table></body></html>"
+
+    def checkbox_fn(bgr):             # == make_golden_table_trace.checkbox_predict
+        k = len(log.setdefault("checkbox", []))
+        log["checkbox"].append({"shape": list(bgr.shape), "crc32": zlib.crc32(np.ascontiguousarray(bgr).tobytes())})
+        tb = next(d for d in fx["layout_dets"][k] if d["category_id"] == 5)
+        x0, y0 = int(tb["poly"][0]) + 30, int(tb["poly"][1]) + 20
+        return [{"bbox": [x0, y0, x0 + 16, y0 + 16], "text": "checked" if k == 0 else "unchecked", "score": 0.9},
+                {"bbox": [5, 5, 17, 17], "text": "unchecked", "score": 0.6}]
 
     class ReplayCustomTable:
         def batch_predict(self, image_list, **kwargs):
@@ -280,8 +290,14 @@ def test_table_stage_replays_the_reference_trace(golden_dir, kind):
                               table_model=ReplayCustomTable() if kind == "custom" else ReplayTable(),
                               layout_batch_size=fx["layout_batch_num"], formula_level=fx["formula_level"],
                               formula_batch_size=fx["formula_batch_num"], det_batch_num=fx["ocr_config"]["Det.rec_batch_num"],
-                              det_raw_fn=det_raw_fn, table_det_raw_fn=table_det_raw_fn, table_rec_fn=table_rec_fn, table_use_word_box=word_box)
+                              det_raw_fn=det_raw_fn, table_det_raw_fn=table_det_raw_fn, table_rec_fn=table_rec_fn, table_use_word_box=word_box,
+                              seal_enable=fx["ocr_config"].get("seal_enable", True),
+                              **(dict(checkbox_fn=checkbox_fn, checkbox_enable=True) if fx.get("checkbox_enable") else {}))
     out = pa(pages, page_scales=[fx["page_scale"]] * len(pages))
+    assert log.get("checkbox", []) == tr.get("checkbox_calls", [])
+    if kind == "traditional_checkbox":
+        assert len(log["checkbox"]) == 2 and any({"bbox": [31, 22, 47, 38]} in c["mfd_res"] for c in tr["table_calls"])
+        assert all([2, 2, 8, 8] in d["formula_boxes"] for page in out for d in page if d["category_id"] == 5)
     if word_box:       # the crops and boxes rapidocr's cal_rec_boxes was called with, and the reference's zip quirk was exercised
         assert log["table_words"] == tr["table_word_calls"]
         n_lines = sum(len(c["shapes"]) for c in tr["table_word_calls"])
