@@ -34,10 +34,11 @@ __device__ __forceinline__ void dw_dma16(const void* src, unsigned lds_byte_offs
 }
 
 // CS = float4 channel lanes per workgroup (16: 64 channels, 8: 32 channels); RT = output rows per thread.  256 threads =
-// CS channel lanes x 16 columns x RH row groups, the map height is RT * RH.
-template <int CS, int RT>
+// CS channel lanes x 16 columns x RH row groups; the OUTPUT map is RT * RH rows high, the input SH times that (SH = 2: the
+// stride-(2, 1) depthwise conv in front of a stage's first block, pad 1: output row r reads input rows 2 r - 1 .. 2 r + 1).
+template <int CS, int RT, int SH = 1>
 __global__ void __launch_bounds__(256) dwconv3x3_lds_kernel(DwParams p, int ct_n, int ns, int ntiles, int per_xcd) {
-    constexpr int PX = 256 / CS, RH = PX / kDwTileCols, HH = RT * RH;
+    constexpr int PX = 256 / CS, RH = PX / kDwTileCols, HO = RT * RH, HH = SH * HO;
     constexpr int TCOL = kDwTileCols + 2;
     constexpr int NPIX = HH * TCOL;
     constexpr int PPC = 64 / CS;                          // pixels per DMA instruction of one wavefront
@@ -89,21 +90,23 @@ __global__ void __launch_bounds__(256) dwconv3x3_lds_kernel(DwParams p, int ct_n
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int r0 = rh * RT;
+    const int r0 = RH == 1 ? 0 : rh * RT;          // (one row group: a compile-time zero, so that the row tests below fold)
     f32x4 acc[RT];
 #pragma unroll
     for (int t = 0; t < RT; ++t) acc[t] = bias;
     const f32x4* tilep = reinterpret_cast<const f32x4*>(smem) + c4;
+    constexpr int NROW = SH * (RT - 1) + 3;               // input rows under this thread's RT outputs
 #pragma unroll
-    for (int j = 0; j < RT + 2; ++j) {
-        const int ir = r0 - 1 + j;
-        if (RH == 1 ? (j == 0 || j == RT + 1) : ((unsigned)ir >= (unsigned)HH)) continue;     // the conv's zero rows
+    for (int j = 0; j < NROW; ++j) {
+        const int ir = SH * r0 - 1 + j;
+        if (RH == 1 ? (j == 0 || ir >= HH) : ((unsigned)ir >= (unsigned)HH)) continue;     // the conv's zero rows
         const f32x4* rp = tilep + (size_t)(ir * TCOL + col) * CS;
         const f32x4 v0 = rp[0], v1 = rp[CS], v2 = rp[2 * CS];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
-            const int t = j - kh;
-            if (t < 0 || t >= RT) continue;
+            if ((j - kh) % SH != 0) continue;
+            const int t = (j - kh) / SH;
+            if (j - kh < 0 || t >= RT) continue;
             acc[t] += v0 * wv[kh * 3 + 0];
             acc[t] += v1 * wv[kh * 3 + 1];
             acc[t] += v2 * wv[kh * 3 + 2];
@@ -116,7 +119,7 @@ __global__ void __launch_bounds__(256) dwconv3x3_lds_kernel(DwParams p, int ct_n
 
     f32x4 gsum = zero4;
     if (gx < p.OW) {
-        const size_t pix0 = ((size_t)n * HH + r0) * p.OW + gx;
+        const size_t pix0 = ((size_t)n * HO + r0) * p.OW + gx;
         if (p.act != ACT_NONE) {            // the switch once, not once per value
 #pragma unroll
             for (int t = 0; t < RT; ++t) acc[t] = act4v(acc[t], p.act);
@@ -149,7 +152,14 @@ __global__ void __launch_bounds__(256) dwconv3x3_lds_kernel(DwParams p, int ct_n
 static inline int dw_lds_variant(const DwParams& p) {
     static const bool off = std::getenv("RD_DW_LDS") && std::string(std::getenv("RD_DW_LDS")) == "0";
     if (off || p.tokinfo) return 0;
-    if (!(p.KH == 3 && p.KW == 3 && p.SH == 1 && p.SW == 1 && p.PT == 1 && p.PL == 1 && p.OH == p.H && p.OW == p.W)) return 0;
+    if (!(p.KH == 3 && p.KW == 3 && p.SW == 1 && p.PT == 1 && p.PL == 1 && p.OW == p.W)) return 0;
+    if (p.SH == 2) {                                      // the stride-(2, 1) layer in front of a stage (H even: OH = H / 2)
+        if (p.OH * 2 != p.H || p.C % 4 != 0) return 0;
+        if (p.H == 12 && p.C % 32 == 0) return 4;         // <8, 3, 2>
+        if (p.H == 6 && p.C % 64 == 0) return 5;          // <16, 3, 2>
+        return 0;
+    }
+    if (p.SH != 1 || p.OH != p.H) return 0;
     // geometry only - no pointer or leading dimension may enter: the planner asks with an unbound DwParams (dwconv_gap_chunks)
     // and must get the answer the launch gets.  The SE partial buffer is one value per 16 x H outputs, ~1 % of the map.
     if (p.H == 6 && p.C % 64 == 0) return 1;              // <16, 6>
@@ -163,7 +173,7 @@ int dwconv_lds_gap_chunks(const DwParams& p) { return (p.W + kDwTileCols - 1) / 
 void launch_dwconv_lds(const DwParams& p, hipStream_t s) {
     const int v = dw_lds_variant(p);
     const int ct_n = (p.W + kDwTileCols - 1) / kDwTileCols;
-    const int ns = p.C / (v == 2 ? 32 : 64);
+    const int ns = p.C / ((v == 2 || v == 4) ? 32 : 64);
     const int ntiles = p.N * ct_n * ns;
     const int per_xcd = (ntiles + 7) / 8;
     dim3 grid(per_xcd * 8), block(256);
@@ -171,6 +181,8 @@ void launch_dwconv_lds(const DwParams& p, hipStream_t s) {
         case 1: hipLaunchKernelGGL((dwconv3x3_lds_kernel<16, 6>), grid, block, 0, s, p, ct_n, ns, ntiles, per_xcd); break;
         case 2: hipLaunchKernelGGL((dwconv3x3_lds_kernel<8, 6>), grid, block, 0, s, p, ct_n, ns, ntiles, per_xcd); break;
         case 3: hipLaunchKernelGGL((dwconv3x3_lds_kernel<16, 3>), grid, block, 0, s, p, ct_n, ns, ntiles, per_xcd); break;
+        case 4: hipLaunchKernelGGL((dwconv3x3_lds_kernel<8, 3, 2>), grid, block, 0, s, p, ct_n, ns, ntiles, per_xcd); break;
+        case 5: hipLaunchKernelGGL((dwconv3x3_lds_kernel<16, 3, 2>), grid, block, 0, s, p, ct_n, ns, ntiles, per_xcd); break;
         default: throw std::runtime_error("launch_dwconv_lds: geometry not supported");
     }
 }

@@ -660,7 +660,8 @@ class PagePipeline:
 
         `prefetch`: the NEXT batch's pages, already on the GPU (valid on the current stream).  Their det and layout forwards are
         enqueued as soon as this batch's det maps have been consumed, so they run under this batch's recognition instead of in
-        front of the next batch's; the next `run_batch` call on that very tensor picks them up.  Results are the same with or
+        front of the next batch's; the next `run_batch` call on that very tensor picks them up (any other call drops them).  The
+        tensor is recognised by address and shape: its CONTENTS must not change between the two calls.  Results are the same with or
         without it (the same kernels on the same inputs); `last_det` then already belongs to the next batch when this call returns."""
         if isinstance(pages, np.ndarray) or not pages.is_cuda:
             src = torch.from_numpy(np.ascontiguousarray(pages)) if isinstance(pages, np.ndarray) else pages.contiguous()
@@ -733,7 +734,11 @@ class PagePipeline:
             def front_next(gate):
                 self._prefetched = self._front(prefetch, prefetch.shape[0], gate)
             self._after_rec_enqueue = front_next
-        texts = self.rec_forward_lines(pages, quads_per_page)
+        try:
+            texts = self.rec_forward_lines(pages, quads_per_page)
+        except BaseException:
+            self._after_rec_enqueue = None             # a failed batch must not leave its hook to the next one
+            raise
         if self._after_rec_enqueue is not None:        # no line to recognise: the hook was not reached
             self._after_rec_enqueue = None
             front_next(())

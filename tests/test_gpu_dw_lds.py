@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ACT_NONE, ACT_RELU = 0, 1
 
 
-def _run(N, H, W, Cn, act=ACT_NONE, res=False, widths=None, bias=True, seed=0, K=3):
+def _run(N, H, W, Cn, act=ACT_NONE, res=False, widths=None, bias=True, seed=0, K=3, SH=1):
     from rapiddoc_amd import _lib
     lib = _lib.load()
     lib.rd_debug_dwconv.restype = C.c_float
@@ -21,12 +21,13 @@ def _run(N, H, W, Cn, act=ACT_NONE, res=False, widths=None, bias=True, seed=0, K
     x = torch.rand((N, H, W, Cn), device="cuda", generator=g) - 0.5
     w = torch.rand((K * K, Cn), device="cuda", generator=g) - 0.5
     b = (torch.rand((Cn,), device="cuda", generator=g) - 0.5) if bias else None
-    r = (torch.rand((N, H, W, Cn), device="cuda", generator=g) - 0.5) if res else None
-    y = torch.full((N, H, W, Cn), float("nan"), device="cuda")
+    OH = (H + 2 * (K // 2) - K) // SH + 1
+    r = (torch.rand((N, OH, W, Cn), device="cuda", generator=g) - 0.5) if res else None
+    y = torch.full((N, OH, W, Cn), float("nan"), device="cuda")
     lw = torch.tensor(widths, dtype=torch.int32, device="cuda") if widths is not None else None
     gap = torch.full((N * ((W + 3) // 4 + 8) * H * Cn,), float("nan"), device="cuda")
     chunks = C.c_int(-1)
-    lib.rd_debug_dwconv(N, H, W, Cn, K, 1, act, 0, x.data_ptr(), w.data_ptr(), b.data_ptr() if bias else None,
+    lib.rd_debug_dwconv(N, H, W, Cn, K, SH, act, 0, x.data_ptr(), w.data_ptr(), b.data_ptr() if bias else None,
                         r.data_ptr() if res else None, y.data_ptr(), lw.data_ptr() if lw is not None else None, gap.data_ptr(),
                         C.byref(chunks))
     torch.cuda.synchronize()
@@ -35,7 +36,7 @@ def _run(N, H, W, Cn, act=ACT_NONE, res=False, widths=None, bias=True, seed=0, K
         for n, wl in enumerate(widths):
             xd[n, :, wl:, :] = 0
     ref = torch.nn.functional.conv2d(xd.permute(0, 3, 1, 2), w.double().t().reshape(Cn, 1, K, K), b.double() if bias else None,
-                                     padding=K // 2, groups=Cn).permute(0, 2, 3, 1)
+                                     padding=K // 2, stride=(SH, 1), groups=Cn).permute(0, 2, 3, 1)
     if act == ACT_RELU:
         ref = ref.clamp_min(0)
     if res:
@@ -73,3 +74,20 @@ def test_other_geometries_keep_the_register_kernel():
     assert float((y.double() - ref).abs().max()) < 2e-6
     y, ref, gap, chunks = _run(2, 8, 40, 192)
     assert float((y.double() - ref).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(5, 12, 67, 96), (3, 6, 50, 192), (2, 12, 16, 32), (1, 6, 1, 64), (7, 12, 130, 96)])
+@pytest.mark.parametrize("epi", ["plain", "relu_res"])
+def test_dw_lds_stride_2_rows(shape, epi):
+    """The stride-(2, 1) depthwise conv in front of a stage's first block (rec_lcnetv4.py: `token_conv` of the down-sampling blocks):
+    12 -> 6 and 6 -> 3 rows from the same full-height strips."""
+    N, H, W, Cn = shape
+    widths = [W, 1, 17, W - 1, 16][:N] + [W] * max(0, N - 5) if N > 1 else None
+    y, ref, gap, chunks = _run(N, H, W, Cn, act=ACT_RELU if epi == "relu_res" else ACT_NONE, res=epi == "relu_res", SH=2, widths=widths, seed=5)
+    assert y.shape[1] == H // 2 and chunks == (W + 15) // 16, "the staged kernel did not take this geometry"
+    assert torch.isfinite(y).all()
+    assert float((y.double() - ref).abs().max()) < 2e-6
+    part = gap[: N * chunks * Cn].view(N, chunks, Cn).double().sum(1)
+    wl = widths if widths is not None else [W] * N
+    want = torch.stack([ref[n, :, :wl[n], :].sum((0, 1)) for n in range(N)])
+    assert float((part - want).abs().max()) < 1e-3 * max(1.0, H * W / 100.0)
