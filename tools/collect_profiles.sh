@@ -16,9 +16,9 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$TAG
 cp /tmp/rp_$TAG/s_kernel_stats.csv $O/${TAG}_rocprofv3_kernel_stats.csv
 # same workload with the recognition batches on ONE stream: per-kernel durations without co-running kernels (these are
 # the durations bench.py's roofline pass measures with HIP events, so the two must agree)
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rq_$TAG -o s -- python $R/bench.py --no-cpu-baseline --no-extra-passes --rec-streams 1 $ONE > /tmp/rq.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rq_$TAG -o s -- python $R/bench.py --no-cpu-baseline --no-extra-passes --rec-streams 1 --no-prefetch $ONE > /tmp/rq.log 2>&1
 cp /tmp/rq_$TAG/s_kernel_stats.csv $O/${TAG}_rocprofv3_kernel_stats_1stream.csv
-B="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra-passes --rec-streams 1 $ONE"
+B="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra-passes --rec-streams 1 --no-prefetch $ONE"
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d /tmp/p1_$TAG -o a -- $B > /tmp/p1.log 2>&1
 python $R/tools/pmc_summary.py $(find /tmp/p1_$TAG -name "*counter_collection.csv" | head -1) $O/${TAG}_pmc_sq.csv > /dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
