@@ -421,6 +421,7 @@ float rd_debug_dwconv(int N, int H, int W, int C, int K, int SH, int act, int it
     if (gap_chunks) *gap_chunks = chunks;
     p.gap_partial = chunks > 0 ? gap : nullptr; p.gap_chunks = chunks;
     p.line_w = line_w; p.line_w_stride = 1;
+    if (gap_chunks && rd::dwconv_kxk_lds_applies(p)) *gap_chunks = -1;      // (tests: the one-channel-per-lane 5x5 / 7x7 kernel takes this call)
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     rd::launch_dwconv(p, nullptr);

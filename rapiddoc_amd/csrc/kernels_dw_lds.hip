@@ -148,6 +148,120 @@ __global__ void __launch_bounds__(256) dwconv3x3_lds_kernel(DwParams p, int ct_n
     }
 }
 
+// --------------------------------------------------------------------------------------------------------------------------------
+// Depthwise 5x5 / 7x7, stride 1 (PPHGNetV2's light blocks, rec_pphgnetv2.py:945-953; the RepLK neck of the detector, db_fpn.py:315-323)
+// on the same staging scheme.  The register-tiled kernel keeps float4 channel vectors per thread, so its 25 / 49 weight vectors (100 /
+// 196 registers) cannot stay in registers: they are re-read per kernel row, four outputs per thread at 7x7 (260 VGPRs for eight), and the
+// kernel runs at 2.0 / 1.3 TB/s.  Here a lane owns ONE channel: the K x K weights are 25 / 49 scalar registers, a thread computes a 4 x 4
+// patch of outputs of its channel from a (4 + K - 1)^2 window of ds_read_b32 (a wavefront = 32 channels x 2 patches: two 128-byte rows of
+// LDS per read), and a workgroup = 32 channels x (4 x 2 patches) = a 16 x 8 output tile whose (16 + K - 1) x (8 + K - 1) x 32-channel input
+// tile arrives by LDS-DMA (addresses clamped at the borders, the zero padding applied by a select per value read).  Nothing persistent:
+// 31 / 39 KB of LDS, four to five workgroups per CU.
+template <int K>
+__global__ void __launch_bounds__(256) dwconv_kxk_lds_kernel(DwParams p, int tx_n, int ty_n, int ns, int ntiles, int per_xcd) {
+    constexpr int R = K / 2, TW = 4, TH = 4, OWT = 16, OHT = 8;
+    constexpr int IW = OWT + K - 1, IH = OHT + K - 1, NPIX = IW * IH;
+    constexpr int NCHUNK = (NPIX + 7) / 8;                 // one DMA instruction of a wavefront = 8 pixels x 32 channels
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NCHUNK * 1024];
+    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= ntiles) return;
+    const int sl = tile % ns;
+    const int tx = (tile / ns) % tx_n;
+    const int ty = (tile / (ns * tx_n)) % ty_n;
+    const int n = tile / (ns * tx_n * ty_n);
+    const int x0 = tx * OWT, y0 = ty * OHT, c0 = sl * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        const float* xb = p.x + (size_t)n * p.H * p.W * p.xld + c0 + (lane & 7) * 4;
+#pragma unroll
+        for (int k0 = 0; k0 < NCHUNK; k0 += 4) {
+            const int k = k0 + wave;
+            if (k < NCHUNK) {
+                const int pi = min(k * 8 + (lane >> 3), NPIX - 1);
+                const int row = pi / IW, col = pi - row * IW;
+                const int gy = min(max(y0 - R + row, 0), p.H - 1), gx = min(max(x0 - R + col, 0), p.W - 1);
+                dw_dma16(xb + ((size_t)gy * p.W + gx) * p.xld, (unsigned)k * 1024u, smem);
+            }
+        }
+    }
+    const int ch = tid & 31, pl = tid >> 5, plx = pl & 3, ply = pl >> 2;
+    const int c = c0 + ch;
+    float wr[K * K];
+#pragma unroll
+    for (int k = 0; k < K * K; ++k) wr[k] = p.w[(size_t)k * p.C + c];
+    const float bias = p.bias ? p.bias[c] : 0.f;
+    unsigned colok = 0;                                    // bit i: input column i of this thread's window lies inside the image
+#pragma unroll
+    for (int i = 0; i < TW + K - 1; ++i) colok |= ((unsigned)(x0 + plx * TW - R + i) < (unsigned)p.W) ? (1u << i) : 0u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const bool interior = x0 >= R && x0 + OWT + R <= p.W && y0 >= R && y0 + OHT + R <= p.H;
+    float acc[TH][TW];
+#pragma unroll
+    for (int t = 0; t < TH; ++t)
+#pragma unroll
+        for (int q = 0; q < TW; ++q) acc[t][q] = bias;
+    const float* win = reinterpret_cast<const float*>(smem) + (size_t)((ply * TH) * IW + plx * TW) * 32 + ch;
+#pragma unroll
+    for (int j = 0; j < TH + K - 1; ++j) {
+        const bool rowok = (unsigned)(y0 + ply * TH - R + j) < (unsigned)p.H;
+        float v[TW + K - 1];
+#pragma unroll
+        for (int i = 0; i < TW + K - 1; ++i) v[i] = win[(j * IW + i) * 32];
+        if (!interior) {                 // (workgroup-uniform: most tiles of a large map lie inside it and skip the selects)
+#pragma unroll
+            for (int i = 0; i < TW + K - 1; ++i) v[i] = (rowok && ((colok >> i) & 1u)) ? v[i] : 0.f;
+        }
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            const int t = j - kh;
+            if (t < 0 || t >= TH) continue;
+#pragma unroll
+            for (int q = 0; q < TW; ++q)
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) acc[t][q] = fmaf(v[q + kw], wr[kh * K + kw], acc[t][q]);
+        }
+#pragma unroll
+        for (int t = 0; t < TH; ++t)
+#pragma unroll
+            for (int q = 0; q < TW; ++q) asm volatile("" : "+v"(acc[t][q]));     // (keeps the FMAs here: see the 3x3 kernel)
+    }
+#pragma unroll
+    for (int t = 0; t < TH; ++t) {
+        const int oy = y0 + ply * TH + t;
+#pragma unroll
+        for (int q = 0; q < TW; ++q) {
+            const int ox = x0 + plx * TW + q;
+            if (oy < p.OH && ox < p.OW) {
+                const size_t pix = ((size_t)n * p.OH + oy) * p.OW + ox;
+                float o = rd_act(acc[t][q], p.act);
+                if (p.res) o += p.res[pix * p.rld + c];
+                p.y[pix * p.yld + c] = o;
+            }
+        }
+    }
+}
+
+static inline int dw_kxk_lds_k(const DwParams& p) {
+    static const bool off = std::getenv("RD_DW_LDS") && std::string(std::getenv("RD_DW_LDS")) == "0";
+    if (off || p.tokinfo || p.line_w || p.gap_partial) return 0;       // (gap_partial: the planner sized its buffer for the register kernel)
+    if (p.KH != p.KW || (p.KH != 5 && p.KH != 7) || p.SH != 1 || p.SW != 1 || p.PT != p.KH / 2 || p.PL != p.KH / 2) return 0;
+    if (p.OH != p.H || p.OW != p.W || p.C % 32 != 0 || p.xld % 4 != 0) return 0;
+    return p.KH;
+}
+bool dwconv_kxk_lds_applies(const DwParams& p) { return dw_kxk_lds_k(p) != 0; }
+void launch_dwconv_kxk_lds(const DwParams& p, hipStream_t s) {
+    const int k = dw_kxk_lds_k(p);
+    const int tx_n = (p.W + 15) / 16, ty_n = (p.H + 7) / 8, ns = p.C / 32;
+    const int ntiles = p.N * ty_n * tx_n * ns, per_xcd = (ntiles + 7) / 8;
+    dim3 grid(per_xcd * 8), block(256);
+    if (k == 5) hipLaunchKernelGGL((dwconv_kxk_lds_kernel<5>), grid, block, 0, s, p, tx_n, ty_n, ns, ntiles, per_xcd);
+    else if (k == 7) hipLaunchKernelGGL((dwconv_kxk_lds_kernel<7>), grid, block, 0, s, p, tx_n, ty_n, ns, ntiles, per_xcd);
+    else throw std::runtime_error("launch_dwconv_kxk_lds: geometry not supported");
+}
+
 // which instantiation serves this geometry: 0 = none
 static inline int dw_lds_variant(const DwParams& p) {
     static const bool off = std::getenv("RD_DW_LDS") && std::string(std::getenv("RD_DW_LDS")) == "0";

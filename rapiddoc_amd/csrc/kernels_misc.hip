@@ -307,6 +307,10 @@ void launch_dwconv(const DwParams& p_in, hipStream_t s) {
         launch_dwconv_lds(p, s);
         return;
     }
+    if (dwconv_kxk_lds_applies(p)) {
+        launch_dwconv_kxk_lds(p, s);
+        return;
+    }
     if (dw_col_applies(p)) {
         int c4n, threads, gw, gpb, chunks;
         dw_col_geom(p, c4n, threads, gw, gpb, chunks);

@@ -120,6 +120,9 @@ int dwconv_gap_chunks(const DwParams& p);
 bool dwconv_lds_applies(const DwParams& p);
 int dwconv_lds_gap_chunks(const DwParams& p);
 void launch_dwconv_lds(const DwParams& p, hipStream_t s);
+// ... and the 5x5 / 7x7 stride-1 kernel with one channel per lane (needs gap_partial == nullptr: checked at the launch, not by the planner)
+bool dwconv_kxk_lds_applies(const DwParams& p);
+void launch_dwconv_kxk_lds(const DwParams& p, hipStream_t s);
 
 // 2x2 stride-1 max-pool over an input zero-padded by one pixel on the right/bottom (stem branch b)
 void launch_maxpool2x2s1(const float* x, int xld, float* y, int yld, int N, int H, int W, int C, hipStream_t s);

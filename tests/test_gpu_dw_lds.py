@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ACT_NONE, ACT_RELU = 0, 1
 
 
-def _run(N, H, W, Cn, act=ACT_NONE, res=False, widths=None, bias=True, seed=0, K=3, SH=1):
+def _run(N, H, W, Cn, act=ACT_NONE, res=False, widths=None, bias=True, seed=0, K=3, SH=1, use_gap=True):
     from rapiddoc_amd import _lib
     lib = _lib.load()
     lib.rd_debug_dwconv.restype = C.c_float
@@ -28,7 +28,7 @@ def _run(N, H, W, Cn, act=ACT_NONE, res=False, widths=None, bias=True, seed=0, K
     gap = torch.full((N * ((W + 3) // 4 + 8) * H * Cn,), float("nan"), device="cuda")
     chunks = C.c_int(-1)
     lib.rd_debug_dwconv(N, H, W, Cn, K, SH, act, 0, x.data_ptr(), w.data_ptr(), b.data_ptr() if bias else None,
-                        r.data_ptr() if res else None, y.data_ptr(), lw.data_ptr() if lw is not None else None, gap.data_ptr(),
+                        r.data_ptr() if res else None, y.data_ptr(), lw.data_ptr() if lw is not None else None, gap.data_ptr() if use_gap else None,
                         C.byref(chunks))
     torch.cuda.synchronize()
     xd = x.double().clone()
@@ -91,3 +91,23 @@ def test_dw_lds_stride_2_rows(shape, epi):
     wl = widths if widths is not None else [W] * N
     want = torch.stack([ref[n, :, :wl[n], :].sum((0, 1)) for n in range(N)])
     assert float((part - want).abs().max()) < 1e-3 * max(1.0, H * W / 100.0)
+
+
+@pytest.mark.parametrize("K", [5, 7])
+@pytest.mark.parametrize("shape", [(2, 50, 50, 192), (3, 25, 25, 384), (1, 40, 44, 96), (2, 8, 16, 32), (1, 1, 1, 32), (1, 9, 17, 64), (2, 33, 5, 96)])
+@pytest.mark.parametrize("epi", ["plain", "relu_res"])
+def test_dw_kxk_lds_matches_fp64(K, shape, epi):
+    """5x5 / 7x7 stride-1 depthwise convs (PPHGNetV2's light blocks, the detector's RepLK neck) on the one-channel-per-lane staged kernel:
+    maps smaller than a tile, tiles cut by the right / bottom border, 32 / 64 / 96 / 192 / 384 channels."""
+    N, H, W, Cn = shape
+    y, ref, _gap, chunks = _run(N, H, W, Cn, act=ACT_RELU if epi == "relu_res" else ACT_NONE, res=epi == "relu_res", K=K, use_gap=False, seed=7)
+    assert chunks == -1, "the staged k x k kernel did not take this geometry"
+    assert torch.isfinite(y).all()
+    assert float((y.double() - ref).abs().max()) < 5e-6
+
+
+def test_dw_kxk_with_se_sums_stays_on_the_register_kernel():
+    y, ref, gap, chunks = _run(2, 20, 24, 64, K=5, use_gap=True)
+    assert chunks > 0 and float((y.double() - ref).abs().max()) < 5e-6
+    part = gap[: 2 * chunks * 64].view(2, chunks, 64).double().sum(1)
+    assert float((part - ref.sum((1, 2))).abs().max()) < 1e-3

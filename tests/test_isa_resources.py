@@ -84,8 +84,10 @@ def test_known_register_budgets(tables):
     assert k16[0] <= 128 and k16[1:] == (0, 0)
     # the LDS-DMA-staged depthwise 3x3 lives on occupancy (nothing persistent: one workgroup's DMA under another's arithmetic): four
     # workgroups per CU need <= 128 registers, five <= 96 (left alone the compiler sank every FMA behind the loop: 138, three per SIMD)
-    dw = {n: (v, s_, p_) for n, v, s_, p_ in tables["kernels_dw_lds.hip"]}
-    assert len(dw) == 5
+    dw_all = {n: (v, s_, p_) for n, v, s_, p_ in tables["kernels_dw_lds.hip"]}
+    dw = {n: v for n, v in dw_all.items() if "dwconv3x3_lds_kernel" in n}
+    kxk = {n: v for n, v in dw_all.items() if "dwconv_kxk_lds_kernel" in n}
+    assert len(dw) == 5 and len(kxk) == 2 and all(v[0] <= 104 and v[1:] == (0, 0) for v in kxk.values()), kxk
     for n, (v, s_, p_) in dw.items():
         assert v <= 104 and (s_, p_) == (0, 0), (n, v, s_, p_)
     assert next(v for n, v in dw.items() if "ILi16ELi6E" in n)[0] <= 96

@@ -27,3 +27,14 @@ for (N, H, W, Cn, gap_on) in ((128, 6, 132, 192, True), (128, 6, 132, 192, False
                              gap.data_ptr() if gap_on else None, C.byref(ch))
     by = 8.0 * N * H * W * Cn
     print(f"RD_DW_LDS={os.environ.get('RD_DW_LDS', '1')} dw3x3 N={N} H={H} W={W} C={Cn} gap={int(gap_on)} chunks={ch.value}: {ms*1e3:7.1f} us  {by/ms/1e9:7.2f} TB/s", flush=True)
+
+# 5x5 / 7x7 (PPHGNetV2 light blocks 32 x 50 x 50 x 192 and 32 x 25 x 25 x 384; the detector's RepLK neck 32 x 240 x 176 x 96 ...)
+for (N, H, W, Cn, K) in ((32, 50, 50, 192, 5), (32, 25, 25, 384, 5), (32, 240, 176, 96, 7), (32, 120, 88, 96, 7), (32, 60, 44, 96, 7)):
+    x = torch.rand((N, H, W, Cn), device="cuda") - 0.5
+    w = torch.rand((K * K, Cn), device="cuda") - 0.5
+    b = torch.rand((Cn,), device="cuda")
+    y = torch.empty_like(x)
+    ch = C.c_int(0)
+    ms = lib.rd_debug_dwconv(N, H, W, Cn, K, 1, 0, 30, x.data_ptr(), w.data_ptr(), b.data_ptr(), None, y.data_ptr(), None, None, C.byref(ch))
+    by = 8.0 * N * H * W * Cn
+    print(f"RD_DW_LDS={os.environ.get('RD_DW_LDS', '1')} dw{K}x{K} N={N} H={H} W={W} C={Cn} staged={int(ch.value == -1)}: {ms*1e3:7.1f} us  {by/ms/1e9:7.2f} TB/s", flush=True)
