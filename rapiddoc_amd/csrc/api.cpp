@@ -352,12 +352,26 @@ float rd_debug_time_mixer(int C, int M, int variant, int iters, float* x, float*
     for (void* b : hbuf) if (b) (void)hipFree(b);
     return ms / iters;
 }
+// h1 image of device weights w [N][K] (single-accumulator split GEMM, kernels_gemm_h1.hip): uploaded into fresh device buffers
+static bool debug_h1_image(const float* w_dev, int N, int K, void** img_dev, float* inv) {
+    if (!rd::gemm_h1_shape_ok(K, N)) return false;
+    std::vector<float> hw((size_t)N * K);
+    if (hipMemcpy(hw.data(), w_dev, hw.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    std::vector<uint16_t> img;
+    *inv = rd::prepare_gemm_h1_weights(hw.data(), N, K, img);
+    if (hipMalloc(img_dev, img.size() * 2) != hipSuccess) return false;
+    (void)hipMemcpy(*img_dev, img.data(), img.size() * 2, hipMemcpyHostToDevice);
+    return true;
+}
 float rd_debug_time_gemm(int M, int K, int N, int act, int iters, float* x, float* w, float* b, float* y, void* wh, void* wl) {
     rd::ConvParams p{};
     p.wh = (const uint16_t*)wh; p.wl = (const uint16_t*)wl;
     p.x = x; p.xld = K; p.N = 1; p.H = 1; p.W = M; p.Cin = K; p.w = w; p.bias = b; p.y = y; p.yld = N;
     p.OH = 1; p.OW = M; p.Cout = N; p.KH = p.KW = p.SH = p.SW = 1; p.act = act; p.out_mode = rd::OUT_NHWC;
     p.M = M; p.K = K; p.Ng = N;
+    void* img = nullptr;
+    float inv = 0.f;
+    if (wh && debug_h1_image(w, N, K, &img, &inv)) { p.w1 = (const uint16_t*)img; p.w1_inv = inv; }   // as the engine prepares it
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     auto go = [&] { if (wh) rd::launch_conv_igemm_h3(p, nullptr); else rd::launch_conv_igemm(p, nullptr); };
@@ -369,7 +383,45 @@ float rd_debug_time_gemm(int M, int K, int N, int act, int iters, float* x, floa
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (img) (void)hipFree(img);
     return ms / iters;
+}
+// developer entry: the single-accumulator split GEMM alone, with strides, residual and the range flag:
+// y[M][yld] = act(x[M][xld(K used)] * w[N][K]^T + b) + res[M][rld].  Returns ms per launch, or -1 when the kernel does not take the shape.
+// *range_out (optional) receives 1 when the kernel raised its range flag.
+float rd_debug_gemm_h1(int M, int K, int N, int act, int iters, float* x, int xld, float* w, float* b, float* res, int rld, float* y, int yld,
+                       int* range_out) {
+    rd::ConvParams p{};
+    p.x = x; p.xld = xld; p.N = 1; p.H = 1; p.W = M; p.Cin = K; p.w = w; p.bias = b; p.y = y; p.yld = yld;
+    p.OH = 1; p.OW = M; p.Cout = N; p.KH = p.KW = p.SH = p.SW = 1; p.act = act; p.out_mode = rd::OUT_NHWC;
+    p.res = res; p.rld = rld;
+    p.M = M; p.K = K; p.Ng = N;
+    void* img = nullptr;
+    float inv = 0.f;
+    if (!debug_h1_image(w, N, K, &img, &inv)) return -1.f;
+    p.w1 = (const uint16_t*)img; p.w1_inv = inv;
+    unsigned* flag = nullptr;
+    (void)hipHostMalloc((void**)&flag, sizeof(unsigned), hipHostMallocMapped);
+    *flag = 0;
+    p.range_flag = flag;
+    float ms = -1.f;
+    if (rd::gemm_h1_applies(p)) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        rd::launch_gemm_h1(p, nullptr);
+        (void)hipEventRecord(e0, nullptr);
+        for (int i = 0; i < iters; ++i) rd::launch_gemm_h1(p, nullptr);
+        (void)hipEventRecord(e1, nullptr);
+        (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        ms = iters > 0 ? ms / iters : 0.f;
+    }
+    (void)hipDeviceSynchronize();
+    if (range_out) *range_out = (int)*flag;
+    (void)hipHostFree(flag);
+    (void)hipFree(img);
+    return ms;
 }
 
 // developer entry: one dense convolution on prepared operands (x NHWC fp32 [N][H][W][Cin]; w folded [Cout][K], k = (kh*KW+kw)*Cin+ci;

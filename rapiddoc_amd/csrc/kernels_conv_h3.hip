@@ -376,7 +376,11 @@ void launch_conv_igemm_h3(const ConvParams& p, hipStream_t s) {
         launch_conv_direct_h3(p, s);
         return;
     }
-    if (gemm_h3_dma_applies(p)) {   // pointwise, K % 32 == 0, wide: the LDS-DMA pipeline (kernels_gemm_h3_dma.hip)
+    if (gemm_h1_applies(p)) {       // pointwise, K % 32 == 0, wide: single-accumulator split, two workgroups per CU (kernels_gemm_h1.hip)
+        launch_gemm_h1(p, s);
+        return;
+    }
+    if (gemm_h3_dma_applies(p)) {   // pointwise, other K: the round-3 LDS-DMA pipeline (kernels_gemm_h3_dma.hip)
         launch_gemm_h3_dma(p, s);
         return;
     }

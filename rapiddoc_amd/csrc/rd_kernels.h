@@ -42,6 +42,10 @@ struct ConvParams {
     int act, out_mode;
     int M, K, Ng;
     unsigned* range_flag = nullptr;   // split-fp16 kernels: raised when an activation leaves the fp16 range
+    // single-accumulator split GEMM (kernels_gemm_h1.hip): fragment-ordered image of the power-of-two pre-scaled weights and the
+    // inverse of that scale (prepare_gemm_h1_weights), or nullptr / 0
+    const uint16_t* w1 = nullptr;
+    float w1_inv = 0.f;
 };
 void launch_conv_igemm(const ConvParams& p, hipStream_t s);
 bool skinny_gemm_applies(int M, int K);   // true when launch_conv_igemm will take the small-M path that can fuse ln_g / ln_b
@@ -49,6 +53,11 @@ bool skinny_gemm_applies(int M, int K);   // true when launch_conv_igemm will ta
 bool gemm_h3_dma_applies(const ConvParams& p);
 bool gemm_h3_dma_uses16(const ConvParams& p);   // the 16-wavefront kernel (short-K GELU layers, > 2^32-element tensors) or the 8-wavefront one
 void launch_gemm_h3_dma(const ConvParams& p, hipStream_t s);
+// single-accumulator split GEMM, 64 x 128 per wavefront, two 4-wavefront workgroups per CU (kernels_gemm_h1.hip); needs p.w1 / p.w1s
+bool gemm_h1_shape_ok(int K, int cout);       // host-side: which layers get a weight image
+bool gemm_h1_applies(const ConvParams& p);
+void launch_gemm_h1(const ConvParams& p, hipStream_t s);
+float prepare_gemm_h1_weights(const float* w, int N, int K, std::vector<uint16_t>& img);   // returns the inverse scale
 void launch_conv_igemm_h3(const ConvParams& p, hipStream_t s);
 // direct 2x2 / 3x3 stride-1 convolution for narrow outputs (kernels_conv_direct_h3.hip); launch_conv_igemm_h3 dispatches to it
 bool conv_direct_h3_supported(const ConvParams& p);   // geometry

@@ -20,6 +20,9 @@ ALLOWED = {
     r"lc_mixer_ws_kernelILi192ELb[01]ELb[01]ELi(1|2|4|8|12|13|16|17|25|27|28|29|64|72|88)ELb[01]E": "ablation instantiations of the ws mixer (tools/microbench.py)",
     r"gemm_h3_dma16_kernelILi(1|2|4|8|10)E": "ablation instantiations of the 16-wavefront GEMM (tools/mb_gemm_abl.py, RD_GEMM_DBG)",
     r"dwconv_tiled_kernelILi3ELi3ELi1ELi8ELi[1-7]E": "ablation instantiations of the depthwise 3x3 (RD_DW_DBG)",
+    r"gemm_h1_kernelILi(1|2|8|16)E": "ablation instantiations of the single-accumulator GEMM (tools/mb_gemm_h1.py, RD_GEMM1_DBG)",
+    r"gemm_h1_kernelILi0ELb1E": "the single-accumulator GEMM with its DMA pieces between the MFMA groups (RD_GEMM1_IL=1, A/B only): 8 spilled "
+                                "registers at the tile switch",
     r"lc_mixer_h3_kernel.*Li192E": "round-1 C = 192 mixer: superseded by the ws kernel, kept for A/B (RD_MIXER_WS=0)",
     r"db_(regions|finish)_kernel": "no spill: local arrays (4-corner boxes, hull scratch) of the geometry code shared with the host path "
                                    "(csrc/db_geom.h), indexed at run time; one thread per text-line candidate, ~50 candidates per page",
@@ -82,6 +85,10 @@ def test_known_register_budgets(tables):
     k16 = next(v for n, v in rows.items() if "gemm_h3_dma16_kernelILi0E" in n)
     assert k8[0] <= 256 and k8[1:] == (0, 0)
     assert k16[0] <= 128 and k16[1:] == (0, 0)
+    # the single-accumulator GEMM lives on TWO workgroups of four wavefronts per CU: 256 registers, nothing spilled
+    h1 = {n: (v, s, p) for n, v, s, p in tables["kernels_gemm_h1.hip"]}
+    k1 = next(v for n, v in h1.items() if "gemm_h1_kernelILi0ELb0E" in n)
+    assert k1[0] <= 256 and k1[1:] == (0, 0)
     # the LDS-DMA-staged depthwise 3x3 lives on occupancy (nothing persistent: one workgroup's DMA under another's arithmetic): four
     # workgroups per CU need <= 128 registers, five <= 96 (left alone the compiler sank every FMA behind the loop: 138, three per SIMD)
     dw_all = {n: (v, s_, p_) for n, v, s_, p_ in tables["kernels_dw_lds.hip"]}
@@ -176,7 +183,8 @@ def test_isa_mix_finds_the_inner_loops_of_the_dominant_kernels():
     spec.loader.exec_module(mix)
     _hipcc()
     for src, pat, shape, n_mfma in (("kernels_mixer_ws.hip", r"lc_mixer_ws_kernelILi192ELb0ELb0ELi0ELb1E", "f32_16x16x32_f16", 72),
-                                    ("kernels_gemm_h3_dma.hip", r"gemm_h3_dma16_kernelILi0E", "f32_32x32x16_f16", 12)):
+                                    ("kernels_gemm_h3_dma.hip", r"gemm_h3_dma16_kernelILi0E", "f32_32x32x16_f16", 12),
+                                    ("kernels_gemm_h1.hip", r"gemm_h1_kernelILi0ELb0E", "f32_32x32x16_f16", 48)):
         bodies, _meta = mix.kernel_bodies(mix.asm_of(src))
         name = min((n for n in bodies if re.search(pat, n)), key=len)
         loops = mix.innermost_mfma_loops(bodies[name])
