@@ -328,6 +328,14 @@ def main():
     quads = None
     step_no = [0]
     prefetch_on = not args.no_prefetch and len(pools) == 1
+    # strict rec batching over N ranks: the reference pools the lines of the WHOLE page batch before it sorts and chunks them, so every
+    # rank takes its lines' padded widths from the global list (one more small all-gather per step; the strings do not depend on N)
+    width_sync = None
+    if dist is not None and args.rec_mode == "strict" and args.workers == 1 and os.environ.get("RD_BENCH_WIDTH_SYNC", "1") != "0":
+        from rapiddoc_amd.dist import GlobalLineWidths
+        width_sync = GlobalLineWidths(dist)
+        for pl in pools:
+            pl.pipes[0].rec_width_sync = width_sync
 
     def compute(k=0, ticket=None, ahead=None):
         """One step on pool k.  `ticket`: (PageUploader ticket, set index) of pages already travelling; else the step's own set is taken
@@ -343,7 +351,7 @@ def main():
         pf = None
         if ahead is not None and prefetch_on:
             pf = uploader.wait(ahead[0]) if upload else page_sets[ahead][0]
-        res = pools[k].run_batch(pg, quads, det_maps_override=set_maps[si], prefetch=pf)
+        res = pools[k].run_batch(pg, quads, det_maps_override=set_maps[si], prefetch=pf, page_keys=my_pages if width_sync else None)
         if ticket is not None:
             uploader.release(tk)
         return [(my_pages[i], [(t, s) for _, t, s in r.lines]) for i, r in enumerate(res)]
@@ -593,8 +601,11 @@ def main():
                                     if pipe.det.precision == "auto" else pipe.det.precision,
                        "rec_batching": "strict: " + _strict_rule(n_lines) if args.rec_mode == "strict" else
                                        "throughput (%s; the reference's own batching is timed in strict_rec_batching)" % _throughput_rule(args),
+                       "rec_mode": args.rec_mode,
                        "rec_launch_batches": int(pool.stats.get("rec_batches", 0)),
                        "pages_per_gpu": P, "global_pages": n_global, "pages_gathered": len(out), "result_crc32": result_crc,
+                       "rec_width_sync": (None if width_sync is None else {"collective_calls": width_sync.calls,
+                                          "what": "global argsort / chunks of 6 over the lines of all ranks (dist.GlobalLineWidths)"}),
                        "page_sets_cycled": K_sets, "setup_steps": max(0, args.setup_steps),
                        "pages_start_in": "pinned host memory: every step's %.0f MB are uploaded inside the timed region (PageUploader: copy "
                                          "stream, batch i + 1 under batch i; the first batch's copy is exposed)" % (pages_np.nbytes / 1e6)

@@ -376,7 +376,11 @@ class TableOcr:
         if not boxes:
             return []
         quads = np.asarray(boxes, dtype=np.float32).reshape(-1, 4, 2)
-        if self.use_word_box:
+        # word boxes come from the strict two-stage recogniser (per-line kept time steps); a pipeline built in another batching mode
+        # serves the table model line-level entries (the reference's use_word_box=False shape) instead of failing in the table stage
+        pipe = self.det._pipe_for(lang or self.det.lang)
+        words_ok = self.rec_fn is not None or (getattr(pipe, "rec_mode", None) == "strict" and getattr(pipe, "rec_two_stage", False))
+        if self.use_word_box and words_ok:
             return self._word_level(canvas, quads, h, w, lang)
         if self.rec_fn is not None:
             lines = self.rec_fn(canvas, quads)
@@ -392,10 +396,15 @@ class TableOcr:
         else:
             raw = self.det._pipe_for(lang or self.det.lang).rec_forward_sources([(canvas.contiguous(), [quads])], image_keys=[[0]],
                                                                                 want_words=True)[0][0]
-            infos = [WB.decode_word_info(t, ws["cols"], ws["confs"], ws["n_steps"], ws["wh_ratio"], ws["max_wh_ratio"]) if ws else WB.WordInfo()
-                     for t, _s, ws in raw]
-            crop_hw = [ws["crop_hw"] if ws else (1, 1) for _t, _s, ws in raw]
-            word_lines = WB.cal_rec_boxes(crop_hw, [q for q in quads], [t for t, _s, _w in raw], infos)
+            # lines the recogniser marked degenerate (no homography: `ws` None) or read nothing in carry no words: they never reach the
+            # box arithmetic (whose inverse rotation would divide by a zero side / solve a singular system) and drop out below
+            good = [i for i, (t, _s, ws) in enumerate(raw) if ws and t]
+            infos = [WB.decode_word_info(raw[i][0], raw[i][2]["cols"], raw[i][2]["confs"], raw[i][2]["n_steps"], raw[i][2]["wh_ratio"],
+                                         raw[i][2]["max_wh_ratio"]) for i in good]
+            word_good = WB.cal_rec_boxes([raw[i][2]["crop_hw"] for i in good], [quads[i] for i in good], [raw[i][0] for i in good], infos)
+            word_lines: List[list] = [[] for _ in raw]
+            for i, wl in zip(good, word_good):
+                word_lines[i] = wl
             lines = [(t, s, wl) for (t, s, _w), wl in zip(raw, word_lines)]
         origin = WB.calc_word_boxes([wl for _t, _s, wl in lines], h, w)     # (lines without words drop out: rapid_ocr.py:325-326)
         rec_res = list(zip([t for t, _s, _w in lines], [s for _t, s, _w in lines], origin))      # rapid_ocr.py:295 - zip, as it is
@@ -574,6 +583,9 @@ class PageAnalyzer:
         if self.formula_model is None or self.formula_level == 1:
             inline = layout_host.CATEGORY_ID["InlineEquation"]
             dets = [[d for d in page if d["category_id"] != inline] for page in dets]
+        # a seal region nobody can read must stop the batch HERE, not after the formula / OCR / table stages have run for nothing
+        if self.seal_enable and not self._can_read_seals() and any(d.get("original_label") == "seal" for page in dets for d in page):
+            raise RuntimeError(self._NO_SEAL_MODEL)
         # 2. region collection: writes the integer `bbox` into the formula detections before anything else touches them, so that the
         #    fields of a detection also appear in the reference's ORDER (bbox, then latex) when the result is serialised
         checkbox_res: Optional[List[List[dict]]] = None
@@ -646,6 +658,15 @@ class PageAnalyzer:
                     d["poly"] = restore_poly(d["poly"], label, w, h)
         return out
 
+    _NO_SEAL_MODEL = ("the page holds a seal region and seal OCR is enabled (the reference's default), but no seal_model was "
+                      "given: the seal detector / recogniser are ONNX-only and not part of this build - pass a "
+                      "RapidOcrModel-shaped `seal_model` or seal_enable=False")
+
+    def _can_read_seals(self) -> bool:
+        import inspect
+        return self.seal_model is not None or (self.custom_ocr is not None and
+                                               "is_seal" in inspect.signature(self.custom_ocr.batch_predict).parameters)
+
     def _run_seal_ocr(self, pages: torch.Tensor, out: List[List[dict]]) -> int:
         """`BatchAnalyze._run_seal_ocr` (batch_analyze.py:415-470): every region the layout model labelled `seal` is cropped (crop_img, no
         margin, polygon whited out), handed over as BGR and gets `text` = the LIST of the lines read in it - from the custom OCR model when
@@ -666,9 +687,7 @@ class PageAnalyzer:
                 texts = self.custom_ocr.batch_predict([crop_bgr], is_seal=True)[0].split("\n")
             else:
                 if self.seal_model is None:
-                    raise RuntimeError("the page holds a seal region and seal OCR is enabled (the reference's default), but no seal_model was "
-                                       "given: the seal detector / recogniser are ONNX-only and not part of this build - pass a "
-                                       "RapidOcrModel-shaped `seal_model` or seal_enable=False")
+                    raise RuntimeError(self._NO_SEAL_MODEL)
                 res = self.seal_model.ocr(crop_bgr, det=True, rec=True)[0]
                 if not res:
                     continue

