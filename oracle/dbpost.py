@@ -56,7 +56,7 @@ def _score(pred, box):
     return float(pred[y0:y1 + 1, x0:x1 + 1][inside].mean()) if inside.any() else 0.0
 
 
-def db_postprocess(pred: np.ndarray, src_hw, thresh=0.3, box_thresh=0.5, unclip_ratio=1.6, use_dilation=True, min_size=3):
+def db_postprocess(pred: np.ndarray, src_hw, thresh=0.3, box_thresh=0.5, unclip_ratio=1.6, use_dilation=True, min_size=3, max_candidates=1000):
     H, W = pred.shape
     src_h, src_w = src_hw
     bm = pred > thresh
@@ -88,6 +88,7 @@ def db_postprocess(pred: np.ndarray, src_hw, thresh=0.3, box_thresh=0.5, unclip_
         o = np.lexsort((hx, hy))[0]
         point_sets.append(((int(hy[o]), int(hx[o]) - 1), np.stack([xs, ys], 1)))
     point_sets.sort(key=lambda t: t[0])            # raster order of the contours' start pixels
+    point_sets = point_sets[:max_candidates]       # DBPostProcess looks at the first max_candidates contours only
     out = []
     for start, pts in point_sets:
         r = _min_area_rect(pts)

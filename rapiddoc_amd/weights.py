@@ -93,7 +93,7 @@ def to_safetensors_bytes(state: Dict[str, np.ndarray], skip_int: bool = False) -
     chunks = []
     off = 0
     for name, arr in state.items():
-        arr = np.ascontiguousarray(arr)
+        arr = np.asarray(arr, order="C")          # (np.ascontiguousarray would turn a 0-d tensor - num_batches_tracked - into shape [1])
         if skip_int and arr.dtype.kind in "iu":
             continue
         raw = arr.tobytes()

@@ -100,3 +100,28 @@ def test_hole_borders_are_contours_like_retr_list():
     assert 140 <= hole[:, 0].min() and hole[:, 0].max() <= 170 and 50 <= hole[:, 1].min() and hole[:, 1].max() <= 80
     ring_mean = (0.9 * 19 + 0.05 * 81) / 100.0
     assert abs(scores[1] - ring_mean) < 1e-6
+
+
+@pytest.mark.parametrize("kind", ["lines", "blobs", "holes", "empty", "full", "speckle"])
+def test_host_path_against_the_oracle_on_the_maps_of_the_device_test(kind):
+    """The six map kinds of tests/test_gpu_image_ops.py::test_device_db_postprocess_equals_host_path (where the device chain must equal
+    the host C++ box for box), here host C++ vs oracle/dbpost.py on the CPU: same boxes, same order, same count (also past
+    max_candidates); coordinates equal except for the float32 / float64 effects that test's comment states (<= 3 px, <= 0.5 %)."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("gpu_image_ops_maps", Path(__file__).with_name("test_gpu_image_ops.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    m, box_thresh, B = mod._db_test_map(kind)
+    hw = [(640, 896)] * B
+    host = H.db_postprocess(m, hw, thresh=0.3, box_thresh=box_thresh, unclip_ratio=1.8)
+    n_coord = n_diff = 0
+    for b in range(B):
+        ob, osc = OD.db_postprocess(m[b], hw[b], thresh=0.3, box_thresh=box_thresh, unclip_ratio=1.8)
+        assert len(ob) == len(host[b][0])
+        for x, y, so, sh in zip(ob, host[b][0], osc, host[b][1]):
+            d = np.abs(np.asarray(x) - y)
+            assert d.max() <= 3 and abs(so - sh) < 1e-5
+            n_coord += d.size
+            n_diff += int((d > 0).sum())
+    assert n_diff <= max(2, 0.005 * n_coord)

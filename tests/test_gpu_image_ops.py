@@ -228,16 +228,8 @@ def test_page_analyzer_runs_the_reference_stage_order(golden_dir):
         assert all(isinstance(s["text"], str) and s["score"] == float(f"{s['score']:.3f}") for s in spans)
 
 
-@pytest.mark.parametrize("kind", ["lines", "blobs", "holes", "empty", "full", "speckle"])
-def test_device_db_postprocess_equals_host_path(kind):
-    """rd_db_boxes_device (everything on the GPU: raster-ordered runs, union-find regions, hulls of the row extremes, min-area
-    rectangles, scores, unclip, filter) == rd_db_postprocess (flood fill on the host), box for box and in the same order:
-    text-line maps, irregular blobs (touching the borders, diagonal 8-connections, holes), a map built around hole borders
-    (cv2.findContours RETR_LIST returns them as contours: rings, a hole with an island with a hole, one-pixel holes, holes that
-    touch only diagonally = two holes, notches that reach the image frame = no hole; scored with a box_thresh low enough to keep
-    them), an empty and a full map, and a speckled map with more than max_candidates regions (only the first 1000 contours in
-    raster order count)."""
-    from rapiddoc_amd import ocr_host
+def _db_test_map(kind):
+    """The DB probability maps of test_device_db_postprocess_equals_host_path (also read by tests/test_db_postprocess.py on the CPU)."""
     rng = np.random.default_rng(5)
     B, H, W = 3, 320, 448
     m = np.full((B, H, W), 0.02, np.float32)
@@ -292,6 +284,20 @@ def test_device_db_postprocess_equals_host_path(kind):
         m[:, 280:300, 40:400] = 0.85                           # a text line BEHIND the first 1000 regions of page 0 / 1 ...
         m[2, :250] = 0.02                                      # ... and in front of them on page 2
         m[2, 20:40, 40:400] = 0.85
+    return m, box_thresh, B
+
+
+@pytest.mark.parametrize("kind", ["lines", "blobs", "holes", "empty", "full", "speckle"])
+def test_device_db_postprocess_equals_host_path(kind):
+    """rd_db_boxes_device (everything on the GPU: raster-ordered runs, union-find regions, hulls of the row extremes, min-area
+    rectangles, scores, unclip, filter) == rd_db_postprocess (flood fill on the host), box for box and in the same order:
+    text-line maps, irregular blobs (touching the borders, diagonal 8-connections, holes), a map built around hole borders
+    (cv2.findContours RETR_LIST returns them as contours: rings, a hole with an island with a hole, one-pixel holes, holes that
+    touch only diagonally = two holes, notches that reach the image frame = no hole; scored with a box_thresh low enough to keep
+    them), an empty and a full map, and a speckled map with more than max_candidates regions (only the first 1000 contours in
+    raster order count)."""
+    from rapiddoc_amd import ocr_host
+    m, box_thresh, B = _db_test_map(kind)
     hw = [(640, 896)] * B
     host = ocr_host.db_postprocess(m, hw, thresh=0.3, box_thresh=box_thresh, unclip_ratio=1.8)
     dev = ocr_host.db_postprocess_device(torch.from_numpy(m).cuda(), hw, thresh=0.3, box_thresh=box_thresh, unclip_ratio=1.8)
@@ -299,14 +305,26 @@ def test_device_db_postprocess_equals_host_path(kind):
     for (hb, hs), (db, ds) in zip(host, dev):
         assert hb.shape == db.shape and np.array_equal(hb, db)
         assert np.allclose(hs, ds, rtol=0, atol=1e-6)
+    # ... and against the independent restatement (oracle/dbpost.py: scipy labelling / hulls, float64), every kind:
+    # the same boxes in the same order.  Corner coordinates are equal except where the two arithmetic classes part: the C++ / device
+    # chain carries the minimum-area rectangle in float32, the oracle in float64, so (a) a scaled corner within float32 rounding of
+    # k + 0.5 rounds to the other integer (1 px) and (b) when two edge orientations of the truncated box give minimum-area rectangles of
+    # equal area to float32 precision, either may be picked (<= 3 px).  Measured on these maps: 12 of 5992 coordinates.
+    from oracle import dbpost as OD
     if kind == "holes":
-        from oracle import dbpost as OD
         assert len(host[0][0]) == 9 and len(host[1][0]) == 1 + 12 + 3 and len(host[2][0]) > 100
-        for b in range(B):
-            ob, osc = OD.db_postprocess(m[b], hw[b], thresh=0.3, box_thresh=box_thresh, unclip_ratio=1.8)
-            assert len(ob) == len(dev[b][0])
-            for x, y in zip(ob, dev[b][0]):
-                assert np.abs(np.asarray(x) - y).max() <= 1
+    n_coord = n_diff = 0
+    for b in range(B):
+        ob, osc = OD.db_postprocess(m[b], hw[b], thresh=0.3, box_thresh=box_thresh, unclip_ratio=1.8)
+        assert len(ob) == len(dev[b][0]), (kind, b)
+        for x, y, so, sd in zip(ob, dev[b][0], osc, dev[b][1]):
+            d = np.abs(np.asarray(x) - y)
+            assert d.max() <= 3 and abs(so - sd) < 1e-5
+            n_coord += d.size
+            n_diff += int((d > 0).sum())
+    assert n_diff <= max(2, 0.005 * n_coord), (kind, n_diff, n_coord)
+    if kind in ("lines", "full", "speckle"):
+        assert n_diff == 0
     if kind == "speckle":
         assert [len(b) for b, _ in dev] == [0, 0, 1] or [len(b) for b, _ in dev][2] >= 1
     if kind == "lines":

@@ -1,0 +1,104 @@
+"""GPU: the S2 drop-in seam as such (VERDICT r4 missing #4).  The reference's OCR sessions are callables
+`session(np.ndarray NCHW float32) -> np.ndarray` built from a cfg with `model_path` (rapid_doc/model/ocr/torch.py:171-198):
+det returns the DB maps, rec the softmax over classes [B, T, C].  `rapiddoc_amd.session.Mi355DetSession / Mi355RecSession` are
+those objects on the C-ABI; here they are built the way rapidocr builds them (`from_cfg` on a written .safetensors file whose keys
+carry the reference's `model.` prefix), called with numpy, compared with the oracle (oracle/nets.py, pinned to the reference's
+BaseModel), and the reference's chunk-of-6 recogniser loop (rapid_ocr.py:404-449) is run THROUGH the session and decoded on the
+host - it must give the strings of the strict fast path on the same crops."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets as O
+from rapiddoc_amd import ocr_host
+from rapiddoc_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _state(golden_dir, kind):
+    return W.synth_state_dict(W.load_manifest(golden_dir / f"manifest_{kind}.json"), 0)
+
+
+def _write(tmp_path, kind, state):
+    p = tmp_path / f"ch_PP-OCRv6_{'det' if 'det' in kind else 'rec'}_small.safetensors"
+    p.write_bytes(W.to_safetensors_bytes({"model." + k: v for k, v in state.items()}))     # the prefix torch.py:105-110 strips
+    return p
+
+
+def test_det_session_from_cfg_returns_the_reference_maps(tmp_path, golden_dir):
+    from rapiddoc_amd.session import Mi355DetSession
+    st = _state(golden_dir, "ppocrv6_det")
+    sess = Mi355DetSession.from_cfg({"model_path": str(_write(tmp_path, "ppocrv6_det", st)), "engine_cfg": {"gpu_id": 0}})
+    assert sess.have_key() is False and sess.get_character_list() == []
+    x = np.random.default_rng(0).standard_normal((2, 3, 96, 160)).astype(np.float32)
+    got = sess(x)
+    assert isinstance(got, np.ndarray) and got.dtype == np.float32 and got.shape == (2, 1, 96, 160)
+    with torch.no_grad():
+        ref = O.det_forward(O.as_torch_state(st), torch.from_numpy(x)).numpy()
+    assert float(np.abs(got - ref).max()) < TOL
+
+
+@pytest.mark.parametrize("width", [320, 481])
+def test_rec_session_from_cfg_returns_the_reference_softmax(tmp_path, golden_dir, width):
+    from rapiddoc_amd.session import Mi355RecSession
+    st = _state(golden_dir, "ppocrv6_rec")
+    sess = Mi355RecSession.from_cfg({"model_path": str(_write(tmp_path, "ppocrv6_rec", st))})
+    x = np.random.default_rng(width).uniform(-1, 1, (6, 3, 48, width)).astype(np.float32)       # a chunk of six, as rapid_ocr.py:443 hands it over
+    got = sess(x)
+    with torch.no_grad():
+        ref = torch.softmax(O.rec_forward(O.as_torch_state(st), torch.from_numpy(x)), dim=2).numpy()
+    assert isinstance(got, np.ndarray) and got.dtype == np.float32 and got.shape == ref.shape and got.shape[0] == 6
+    assert got.shape[1] == ocr_host.rec_seq_len(width)
+    assert float(np.abs(got - ref).max()) < TOL
+    assert float(np.abs(got.sum(axis=2) - 1.0).max()) < 1e-4                                    # a softmax
+
+
+def test_the_reference_chunk_loop_through_the_session_gives_the_fast_path_strings(tmp_path, golden_dir):
+    """rapid_ocr.py:404-449 with the MI355X session in the place of `self.text_recognizer.session`: sort by aspect ratio, chunks of
+    six, every chunk padded to int(48 * max ratio), `preds = session(norm_img_batch)` (numpy in, softmax numpy out), argmax / max on
+    the host (CTCLabelDecode) - against the strings and scores PagePipeline's strict mode returns for the same crops."""
+    from rapiddoc_amd.pages import synth_batch
+    from rapiddoc_amd.pipeline import PagePipeline, render_text_maps
+    from rapiddoc_amd.session import Mi355RecSession
+    states = {k: _state(golden_dir, k) for k in ("ppocrv6_det", "ppocrv6_rec")}
+    pipe = PagePipeline(states, n_rec_streams=2)
+    pipe.keep_rec_inputs = True
+    pages_np, boxes = synth_batch(11, 1)
+    pages = torch.from_numpy(pages_np).cuda()
+    maps = render_text_maps(boxes, pages_np.shape[1:3], pipe.det_preprocess(pages[:1])[1], pages.device)
+    res = pipe.run_batch(pages, None, det_maps_override=maps)
+    flat = [ln for r in res for ln in r.lines]
+    n = len(flat)
+    assert n >= 30
+    # the normalised line images the fast path recognised (zero padded beyond each line's own width) and their crop sizes
+    line_x, line_w = {}, {}
+    for chunk, x, lw, _i, _p in pipe.last_rec_batches:
+        for j, i in enumerate(chunk.tolist()):
+            line_x[int(i)], line_w[int(i)] = x[j].cpu().numpy(), int(lw[j])
+    cw, ch, rot, _keep = pipe.last_rec_crop_sizes
+    crop_hw = [(int(cw[i]), int(ch[i])) if rot[i] else (int(ch[i]), int(cw[i])) for i in range(n)]
+    sess = Mi355RecSession.from_cfg({"model_path": str(_write(tmp_path, "ppocrv6_rec", states["ppocrv6_rec"]))})
+    # the reference's loop
+    ratios = np.array([w / float(h) for h, w in crop_hw])
+    indices = np.argsort(ratios)
+    out = [None] * n
+    n_calls = 0
+    for beg in range(0, n, 6):
+        idxs = [int(i) for i in indices[beg: beg + 6]]
+        img_w = int(48 * max(320 / 48, max(ratios[i] for i in idxs)))
+        assert all(line_w[i] == img_w for i in idxs)                       # the fast path gave each line its chunk's width
+        batch = np.zeros((len(idxs), 3, 48, img_w), np.float32)
+        for r, i in enumerate(idxs):
+            src = line_x[i]
+            assert src.shape[2] >= img_w and float(np.abs(src[:, :, img_w:]).max(initial=0.0)) == 0.0
+            batch[r] = src[:, :, :img_w]
+        preds = sess(batch)                                                # numpy [B, T, C] softmax, as torch.py:186-192 returns it
+        n_calls += 1
+        assert preds.shape[:2] == (len(idxs), ocr_host.rec_seq_len(img_w))
+        for r, (t, s) in enumerate(ocr_host.ctc_decode(preds.argmax(axis=2), preds.max(axis=2), pipe.characters)):
+            out[idxs[r]] = (t, s)
+    assert n_calls == -(-n // 6)
+    assert [t for t, _s in out] == [t for _q, t, _s in flat]
+    assert max(abs(ocr_host.format_score(s) - fs) for (_t, s), (_q, _t2, fs) in zip(out, flat)) <= 1e-3

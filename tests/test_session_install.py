@@ -50,3 +50,24 @@ def test_install_without_rapidocr_fails_loudly(monkeypatch):
         monkeypatch.delitem(sys.modules, k)
     with pytest.raises(ModuleNotFoundError):
         S.install_into_rapidocr()
+
+
+def test_safetensors_writer_and_reader_agree_with_the_safetensors_package(golden_dir):
+    """The byte image the tests write for `from_cfg` (weights.to_safetensors_bytes) is what the installed `safetensors` package - the
+    one the reference loads its weights with (torch.py:93-103) - reads and writes: same tensors both ways."""
+    import numpy as np
+    safetensors_numpy = __import__("pytest").importorskip("safetensors.numpy")
+    from rapiddoc_amd import weights as W
+    state = W.synth_state_dict(W.load_manifest(golden_dir / "manifest_ppocrv6_det.json"), 0)
+    state = {"model." + k: v for k, v in list(state.items())[:40]}
+    state["i64"] = np.arange(5, dtype=np.int64)
+    state["f16"] = np.linspace(-1, 1, 7).astype(np.float16)
+    blob = W.to_safetensors_bytes(state)
+    theirs = safetensors_numpy.load(blob)
+    assert set(theirs) == set(state)
+    for k, v in state.items():
+        assert theirs[k].dtype == v.dtype and theirs[k].shape == v.shape and np.array_equal(theirs[k], v), k
+    ours = W.from_safetensors_bytes(safetensors_numpy.save(state))
+    assert set(ours) == set(state)
+    for k, v in state.items():
+        assert ours[k].dtype == v.dtype and np.array_equal(ours[k], v), k
