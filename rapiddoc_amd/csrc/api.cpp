@@ -302,7 +302,9 @@ float rd_debug_time_mixer(int C, int M, int variant, int iters, float* x, float*
         (void)hipMemcpy(hw1.data(), w1, hw1.size() * 4, hipMemcpyDeviceToHost);
         (void)hipMemcpy(hw2.data(), w2, hw2.size() * 4, hipMemcpyDeviceToHost);
         std::vector<uint16_t> img;
-        rd::prepare_mixer_weights_res(hw1.data(), hw2.data(), C, img);
+        float inv[2];
+        rd::prepare_mixer_weights_res(hw1.data(), hw2.data(), C, img, inv);
+        p.ws_inv1 = inv[0]; p.ws_inv2 = inv[1];
         (void)hipMalloc(&hbuf[0], img.size() * 2);
         (void)hipMemcpy(hbuf[0], img.data(), img.size() * 2, hipMemcpyHostToDevice);
         p.w1h = (const uint16_t*)hbuf[0];

@@ -451,8 +451,10 @@ TView Builder::mixer_fused(const std::string& prefix, const TView& x, const TVie
         }
         if (!pb_->has(hkey + ".res") && fits && mixer_res_supported(C)) {   // fragment image of the resident-weights kernel
             std::vector<uint16_t> img;
-            prepare_mixer_weights_res(f1, f2, C, img);
+            float inv[2];
+            prepare_mixer_weights_res(f1, f2, C, img, inv);
             pb_->add_u16(hkey + ".res", img);
+            pb_->add(hkey + ".resinv", std::vector<float>{inv[0], inv[1]});
         }
         if (!pb_->has(hkey + ".ws") && fits && mixer_ws_preferred(C)) {   // weight stream image of the ws kernel
             std::vector<uint16_t> img;
@@ -470,6 +472,8 @@ TView Builder::mixer_fused(const std::string& prefix, const TView& x, const TVie
     MixerParams p{};
     if (res_k) {
         p.w1h = reinterpret_cast<const uint16_t*>(pb_->ptr(hkey + ".res"));
+        p.ws_inv1 = pb_->host_ptr(hkey + ".resinv")[0];
+        p.ws_inv2 = pb_->host_ptr(hkey + ".resinv")[1];
         p.range_flag = range_flag_;
     } else if (ws) {
         p.w1h = reinterpret_cast<const uint16_t*>(pb_->ptr(hkey + ".ws"));

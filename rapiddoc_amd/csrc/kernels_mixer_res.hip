@@ -1,6 +1,6 @@
 // Fused PPLCNetV4 channel mixer (rec_lcnetv4.py:226-236: y = xg + W2 * GELU(W1 * xg + b1) + b2, xg = x * SE gate) for the NARROW
-// blocks (C = 96; any multiple of 32 whose weights fit in LDS) - split-fp16 arithmetic as in kernels_mixer_h3.hip (x = hi + lo * 2^-11, three MFMAs per product, two fp32
-// accumulators).
+// blocks (C = 96; any multiple of 32 whose weights fit in LDS) - split-fp16 arithmetic (three MFMAs per product; rounds 2-4:
+// x = hi + lo * 2^-11 into two fp32 accumulators as in kernels_mixer_h3.hip - round 5: one accumulator, see RS below).
 //
 // At C = 96 a mixer is HBM-bound: 8 M C^2 = 7.7 GFLOP against 80 MB of activations (M = 104 448): ~12 us of MFMA issue, ~16 us of
 // VALU (GELU) and 20 us of HBM at 4 TB/s.  The round-1 kernel (one wavefront per SIMD, phases separated by barriers) and the
@@ -12,6 +12,16 @@
 //     C/D registers ARE the next B fragment (W2's columns are permuted to match), Y^T's C/D registers are four consecutive output
 //     channels of the lane's pixel: residual and store are float4 at the addresses the tile was loaded from;
 //   * four wavefronts per SIMD (<= 128 VGPRs) hide the tile loads and the LDS fragment reads of one another.
+// Round 5 (RS): the tile is read ONCE.  W1's input channels are permuted in the image so that the 8 k-slots a lane feeds to k-step ks
+// of GEMM1 are the 2 x 4 channels it owns in the C/D layout of Y^T (blocks 2 ks, 2 ks + 1: channels 16 ob + 4 kg .. + 4, the ws
+// kernel's arrangement): the tile load uses the epilogue's float4 addresses and the residual is re-formed from the split fragments
+// already in registers, x = hi + lo * 2^-11 (exact sum, 2^-24 |x| from x) instead of a second fetch of the tile and the gate
+// (counters, round 4: 361 MB moved per launch against 255 MB algorithmic).  The fragments must stay live through the hidden loop for
+// that, which the two accumulator sets of the round-2 arithmetic leave no room for at 128 registers (four wavefronts per SIMD) - so
+// the kernel moves to the ONE-accumulator split of kernels_gemm_h1.hip / kernels_mixer_ws.hip: low planes unscaled (x = hi + lo;
+// gfx950's fp16 matrix cores keep subnormal inputs), weights pre-scaled per matrix by a power of two (max |w| in [2^13, 2^14)), the
+// sums multiplied by the exact inverse scales (p.ws_inv1 / ws_inv2) where they leave the accumulators.
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -20,6 +30,13 @@
 namespace rd {
 
 static constexpr int MR_WAVES = 16;
+
+// x = hi + lo, hi = fp16(x), lo = fp16(x - hi): the difference is exact, the second rounding keeps 11 more bits (or stops at the
+// fp16 subnormal spacing: absolute error 2^-25)
+__device__ __forceinline__ void mr_split(float v, float neg1, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)__builtin_fmaf((float)hi, neg1, v);       // neg1: -1 in a register the compiler cannot fold (keeps it one v_fma_mix)
+}
 
 template <int C>
 struct ResGeom {
@@ -35,7 +52,7 @@ struct ResGeom {
 };
 
 // image layout: [W1 hi: F1 fragments][W1 lo][W2 hi: F2][W2 lo]; W1 fragment (hb, ks), W2 fragment (ob, q)
-template <int C, bool GATED>
+template <int C, bool GATED, bool RS>
 __global__ void __launch_bounds__(1024) lc_mixer_res_kernel(MixerParams p, const unsigned char* __restrict__ wimg, int n_tiles) {
     using G = ResGeom<C>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -58,35 +75,39 @@ __global__ void __launch_bounds__(1024) lc_mixer_res_kernel(MixerParams p, const
     const int px = lane & 15, kg = lane >> 4;
     const unsigned lo16 = (unsigned)lane * 16u;
     float amax = 0.f;
+    float neg1 = -1.f;
+    asm volatile("" : "+s"(neg1));
+    const float inv1 = p.ws_inv1, inv2 = p.ws_inv2;
 
     for (int tile = (int)blockIdx.x * MR_WAVES + wave; tile < n_tiles; tile += (int)gridDim.x * MR_WAVES) {
         const int mm = tile * 16 + px;
         const int m = min(mm, p.M - 1);                 // rows past M re-read the last row and are never stored
-        const float* xp = p.x + (size_t)m * p.xld + 8 * kg;
-        const float* gp = GATED ? p.gate + (size_t)(m / p.HW) * C + 8 * kg : nullptr;
-        // ---- X^T as B fragments: k-step ks, lane (px, kg) = channels 32 ks + 8 kg .. + 8
+        const float* xp = p.x + (size_t)m * p.xld + 4 * kg;
+        const float* gp = GATED ? p.gate + (size_t)(m / p.HW) * C + 4 * kg : nullptr;
+        // ---- X^T as B fragments: k-step ks, lane (px, kg) = channels 16 (2 ks) + 4 kg .. + 4 and 16 (2 ks + 1) + 4 kg .. + 4 (W1's
+        // columns are permuted to this order in the image): the lane's own channels of output blocks 2 ks and 2 ks + 1
         f16x8 xh[G::KS1], xl[G::KS1];
 #pragma unroll
         for (int ks = 0; ks < G::KS1; ++ks) {
             f32x4 v0 = *reinterpret_cast<const f32x4*>(xp + 32 * ks);
-            f32x4 v1 = *reinterpret_cast<const f32x4*>(xp + 32 * ks + 4);
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(xp + 32 * ks + 16);
             if (GATED) {
                 v0 *= *reinterpret_cast<const f32x4*>(gp + 32 * ks);
-                v1 *= *reinterpret_cast<const f32x4*>(gp + 32 * ks + 4);
+                v1 *= *reinterpret_cast<const f32x4*>(gp + 32 * ks + 16);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 _Float16 h0, l0, h1, l1;
-                rd_split(v0[e], h0, l0);
-                rd_split(v1[e], h1, l1);
+                mr_split(v0[e], neg1, h0, l0);
+                mr_split(v1[e], neg1, h1, l1);
                 xh[ks][e] = h0; xh[ks][4 + e] = h1;
                 xl[ks][e] = l0; xl[ks][4 + e] = l1;
                 amax = fmaxf(amax, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
             }
         }
-        f32x4 y1[G::OB], y2[G::OB];
+        f32x4 y1[G::OB];
 #pragma unroll
-        for (int ob = 0; ob < G::OB; ++ob) y1[ob] = y2[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ob = 0; ob < G::OB; ++ob) y1[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll 1
         for (int q = 0; q < G::NQ; ++q) {
@@ -94,7 +115,7 @@ __global__ void __launch_bounds__(1024) lc_mixer_res_kernel(MixerParams p, const
             f16x8 hh, hl;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+                f32x4 a1 = {0.f, 0.f, 0.f, 0.f};
                 const int hb = 2 * q + b;
 #pragma unroll
                 for (int ks = 0; ks < G::KS1; ++ks) {
@@ -102,18 +123,18 @@ __global__ void __launch_bounds__(1024) lc_mixer_res_kernel(MixerParams p, const
                     const f16x8 wh = *reinterpret_cast<const f16x8*>(W1h + fo);
                     const f16x8 wl = *reinterpret_cast<const f16x8*>(W1l + fo);
                     a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[ks], a1, 0, 0, 0);
-                    a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[ks], a2, 0, 0, 0);
-                    a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[ks], a2, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[ks], a1, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[ks], a1, 0, 0, 0);
                 }
                 // bias, GELU, split: C/D rows 4 kg + r of block hb = hidden 16 hb + 4 kg + r -> B slot 4 b + r of k-step q
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(&B1s[16 * hb + 4 * kg]);
 #pragma unroll
                 for (int r = 0; r < 4; r += 2) {
-                    const f32x2 v = rd_gelu2(f32x2{fmaf(a2[r], 1.f / 2048.f, a1[r]) + bv[r], fmaf(a2[r + 1], 1.f / 2048.f, a1[r + 1]) + bv[r + 1]});
+                    const f32x2 v = rd_gelu2(f32x2{fmaf(a1[r], inv1, bv[r]), fmaf(a1[r + 1], inv1, bv[r + 1])});
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         _Float16 h, l;
-                        rd_split(v[u], h, l);
+                        mr_split(v[u], neg1, h, l);
                         hh[4 * b + r + u] = h;
                         hl[4 * b + r + u] = l;
                         amax = fmaxf(amax, fabsf(v[u]));
@@ -127,8 +148,8 @@ __global__ void __launch_bounds__(1024) lc_mixer_res_kernel(MixerParams p, const
                 const f16x8 wh = *reinterpret_cast<const f16x8*>(W2h + fo);
                 const f16x8 wl = *reinterpret_cast<const f16x8*>(W2l + fo);
                 y1[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hh, y1[ob], 0, 0, 0);
-                y2[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hl, y2[ob], 0, 0, 0);
-                y2[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, hh, y2[ob], 0, 0, 0);
+                y1[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hl, y1[ob], 0, 0, 0);
+                y1[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, hh, y1[ob], 0, 0, 0);
             }
         }
         // ---- epilogue: C/D rows 4 kg + r of output block ob = channels 16 ob + 4 kg .. + 4 of pixel px: + b2 + gated x, float4 store
@@ -138,12 +159,19 @@ __global__ void __launch_bounds__(1024) lc_mixer_res_kernel(MixerParams p, const
             float* yp = p.y + (size_t)m * p.yld + 4 * kg;
 #pragma unroll
             for (int ob = 0; ob < G::OB; ++ob) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(xr + 16 * ob);
-                if (GATED) v *= *reinterpret_cast<const f32x4*>(gr + 16 * ob);
+                f32x4 v;
+                if constexpr (RS) {          // the gated tile, re-formed from its split fragments
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = (float)xl[ob >> 1][(ob & 1) * 4 + e] + (float)xh[ob >> 1][(ob & 1) * 4 + e];
+                } else {
+                    v = *reinterpret_cast<const f32x4*>(xr + 16 * ob);
+                    if (GATED) v *= *reinterpret_cast<const f32x4*>(gr + 16 * ob);
+                }
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(&B2s[16 * ob + 4 * kg]);
                 f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = fmaf(y2[ob][e], 1.f / 2048.f, y1[ob][e]) + bv[e] + v[e];
+                for (int e = 0; e < 4; ++e) o[e] = fmaf(y1[ob][e], inv2, bv[e]) + v[e];
                 // a NaN operand is invisible to the fmaxf chains (they return the non-NaN operand) but reaches the output
                 if (!(fabsf(o[0]) + fabsf(o[1]) + fabsf(o[2]) + fabsf(o[3]) < INFINITY)) amax = INFINITY;
                 __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(yp + 16 * ob));
@@ -161,13 +189,28 @@ bool mixer_res_supported(int C) {
 // w1 [2C][C], w2 [C][2C] (BN folded) -> fragment image (layout above).  A fragment of v_mfma_f32_16x16x32_f16: lane l holds row
 // l % 16, k = 8 (l / 16) + e.  W2's k-slot e of k-step q is hidden unit 16 (2q + e / 4) + 4 (l / 16) + e % 4 (the C/D registers of
 // the two hidden blocks, see the kernel).
-void prepare_mixer_weights_res(const float* w1, const float* w2, int C, std::vector<uint16_t>& img) {
+// Each matrix is pre-scaled by a power of two (max |w| * s in [2^13, 2^14)) and split into hi = fp16(w s), lo = fp16(w s - hi);
+// inv[0] = 1 / s(W1), inv[1] = 1 / s(W2): what the kernel multiplies its sums by (MixerParams ws_inv1 / ws_inv2).
+void prepare_mixer_weights_res(const float* w1, const float* w2, int C, std::vector<uint16_t>& img, float inv[2]) {
     const int H2 = 2 * C, KS1 = C / 32, HB = H2 / 16, NQ = H2 / 32, OB = C / 16;
     const int F1 = HB * KS1, F2 = OB * NQ;
     img.assign((size_t)2 * (F1 + F2) * 512, 0);
-    auto put = [](float v, uint16_t& hb, uint16_t& lb) {
-        const _Float16 h = (_Float16)v;
-        const _Float16 l = (_Float16)((v - (float)h) * 2048.f);
+    auto scale_of = [](const float* w, size_t n) {
+        float mx = 0.f;
+        for (size_t i = 0; i < n; ++i) mx = std::fmax(mx, std::fabs(w[i]));
+        if (!(mx > 0.f) || !(mx < INFINITY)) return 1.f;
+        int e = 0;
+        (void)std::frexp(mx, &e);
+        return std::ldexp(1.f, 14 - e);
+    };
+    const float s1 = scale_of(w1, (size_t)H2 * C), s2 = scale_of(w2, (size_t)H2 * C);
+    inv[0] = 1.f / s1;
+    inv[1] = 1.f / s2;
+    float sc = s1;
+    auto put = [&sc](float v, uint16_t& hb, uint16_t& lb) {
+        const float vs = v * sc;
+        const _Float16 h = (_Float16)vs;
+        const _Float16 l = (_Float16)(vs - (float)h);
         __builtin_memcpy(&hb, &h, 2);
         __builtin_memcpy(&lb, &l, 2);
     };
@@ -179,10 +222,12 @@ void prepare_mixer_weights_res(const float* w1, const float* w2, int C, std::vec
         for (int ks = 0; ks < KS1; ++ks)
             for (int l = 0; l < 64; ++l)
                 for (int e = 0; e < 8; ++e) {
-                    const int row = 16 * hb + (l & 15), k = 32 * ks + 8 * (l >> 4) + e;
+                    // k-slot e of lane group g = l / 16: channel 16 (2 ks + e / 4) + 4 g + e % 4 (see the kernel's tile load)
+                    const int row = 16 * hb + (l & 15), k = 16 * (2 * ks + (e >> 2)) + 4 * (l >> 4) + (e & 3);
                     const size_t o = ((size_t)(hb * KS1 + ks) * 64 + l) * 8 + e;
                     put(w1[(size_t)row * C + k], w1h[o], w1l[o]);
                 }
+    sc = s2;
     for (int ob = 0; ob < OB; ++ob)
         for (int q = 0; q < NQ; ++q)
             for (int l = 0; l < 64; ++l)
@@ -207,13 +252,20 @@ static void launch_res(const MixerParams& p, hipStream_t s) {
     const int n_wg = (n_tiles + MR_WAVES - 1) / MR_WAVES;
     const int grid = n_wg < n_cu ? n_wg : n_cu;
     const unsigned char* img = reinterpret_cast<const unsigned char*>(p.w1h);
-    static unsigned long long ok0 = 0, ok1 = 0;
-    if (p.gate) {
-        rd_allow_dynamic_lds((const void*)lc_mixer_res_kernel<C, true>, G::LDS_BYTES, ok1);
-        hipLaunchKernelGGL((lc_mixer_res_kernel<C, true>), dim3(grid), dim3(1024), G::LDS_BYTES, s, p, img, n_tiles);
+    static unsigned long long ok0 = 0, ok1 = 0, ok2 = 0, ok3 = 0;
+    static const bool rs = [] { const char* e = getenv("RD_RES_RS"); return !(e && e[0] == '0'); }();     // A/B switch: RD_RES_RS=0 = residual re-read (round 2-4)
+    if (p.gate && rs) {
+        rd_allow_dynamic_lds((const void*)lc_mixer_res_kernel<C, true, true>, G::LDS_BYTES, ok3);
+        hipLaunchKernelGGL((lc_mixer_res_kernel<C, true, true>), dim3(grid), dim3(1024), G::LDS_BYTES, s, p, img, n_tiles);
+    } else if (rs) {
+        rd_allow_dynamic_lds((const void*)lc_mixer_res_kernel<C, false, true>, G::LDS_BYTES, ok2);
+        hipLaunchKernelGGL((lc_mixer_res_kernel<C, false, true>), dim3(grid), dim3(1024), G::LDS_BYTES, s, p, img, n_tiles);
+    } else if (p.gate) {
+        rd_allow_dynamic_lds((const void*)lc_mixer_res_kernel<C, true, false>, G::LDS_BYTES, ok1);
+        hipLaunchKernelGGL((lc_mixer_res_kernel<C, true, false>), dim3(grid), dim3(1024), G::LDS_BYTES, s, p, img, n_tiles);
     } else {
-        rd_allow_dynamic_lds((const void*)lc_mixer_res_kernel<C, false>, G::LDS_BYTES, ok0);
-        hipLaunchKernelGGL((lc_mixer_res_kernel<C, false>), dim3(grid), dim3(1024), G::LDS_BYTES, s, p, img, n_tiles);
+        rd_allow_dynamic_lds((const void*)lc_mixer_res_kernel<C, false, false>, G::LDS_BYTES, ok0);
+        hipLaunchKernelGGL((lc_mixer_res_kernel<C, false, false>), dim3(grid), dim3(1024), G::LDS_BYTES, s, p, img, n_tiles);
     }
 }
 

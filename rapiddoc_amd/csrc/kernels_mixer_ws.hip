@@ -370,6 +370,9 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
             else if constexpr (N == 12)
                 asm volatile("s_waitcnt vmcnt(12)" : "+v"(xh[0]), "+v"(xl[0]), "+v"(xh[1]), "+v"(xl[1]), "+v"(xh[2]), "+v"(xl[2]), "+v"(xh[3]),
                              "+v"(xl[3]), "+v"(xh[4]), "+v"(xl[4]), "+v"(xh[5]), "+v"(xl[5]));
+            else if constexpr (N == 18)
+                asm volatile("s_waitcnt vmcnt(18)" : "+v"(xh[0]), "+v"(xl[0]), "+v"(xh[1]), "+v"(xl[1]), "+v"(xh[2]), "+v"(xl[2]), "+v"(xh[3]),
+                             "+v"(xl[3]), "+v"(xh[4]), "+v"(xl[4]), "+v"(xh[5]), "+v"(xl[5]));
             else
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(xh[0]), "+v"(xl[0]), "+v"(xh[1]), "+v"(xl[1]), "+v"(xh[2]), "+v"(xl[2]), "+v"(xh[3]),
                              "+v"(xl[3]), "+v"(xh[4]), "+v"(xl[4]), "+v"(xh[5]), "+v"(xl[5]));
@@ -387,6 +390,27 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
                 if (GATED) v *= gate_block(r, n);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[n][e] = fmaf(v[e], s2h, y[n][e]);
+            }
+        };
+        // RS (ABL bit 9, round 5): the residual WITHOUT a second read of the tile.  The X registers still hold x' * sx as (hi, lo): hi + lo is
+        // exact in fp32 and equals x' * sx to 2^-24 relative (lo is normal for every channel within 2^-17 of the pixel's largest; the
+        // pixel's smaller channels keep an absolute error of 2^-39 of that largest), so  Y^T += (hi + lo) * (s2h / sx)  - exact powers of
+        // two - puts the residual into the accumulator with an error of <= 2^-24 |x'| per element, the size of one fp32 rounding.
+        // The counters said what the re-read cost: 370 MB fetched + written per launch against 249 MB algorithmic (1.49x, VERDICT r4
+        // weak #9).  It runs right behind the last reader of the fragments (GEMM1 of the tile's last chunk); the NEXT tile is then
+        // requested into the freed registers a whole step earlier than before.
+        constexpr bool RS = (ABL & 512) != 0;
+        auto fold_split = [&]() {
+            const float f = hfac * (1.f / inv1) * s2h;          // (1 / sx) * scale(W2) * WS_SH
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                const f16x8& h = xh[n >> 1];
+                const f16x8& l = xl[n >> 1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = (float)h[(n & 1) * 4 + e] + (float)l[(n & 1) * 4 + e];
+                    y[n][e] = fmaf(v, f, y[n][e]);
+                }
             }
         };
         // raw tile r in the X registers -> (gate) -> per-pixel scale -> split, in place (load_x without the loads)
@@ -542,7 +566,13 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
                     if constexpr (decltype(refetch)::value) {
                         if (i == KS - 1) {
                             __builtin_amdgcn_sched_barrier(0);
-                            issue_raw(r);
+                            if constexpr (RS) {
+                                fold_split();              // residual from the fragments GEMM1 has just read for the last time ...
+                                __builtin_amdgcn_sched_barrier(0);
+                                issue_raw(r + 1);          // ... whose registers then receive the NEXT tile
+                            } else {
+                                issue_raw(r);
+                            }
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -613,11 +643,13 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
                 {
                     const unsigned char* stage = stage_of();
                     const int q = (t + NC - 1) % NC;
-                    raw_landed(std::integral_constant<int, 6>{});             // younger: this step's six DMA pieces
-                    fold_raw(r);
-                    __builtin_amdgcn_sched_barrier(0);
-                    issue_raw(r + 1);
-                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (!RS) {
+                        raw_landed(std::integral_constant<int, 6>{});             // younger: this step's six DMA pieces
+                        fold_raw(r);
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_raw(r + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     f16x8 hh, hl;
                     unit_load(stage, KS, 0);
                     unit_load(stage, KS + 1, 1);
@@ -631,7 +663,8 @@ __global__ void __launch_bounds__(512, 2) lc_mixer_ws_kernel(MixerParams p, cons
                     }
                     epilogue_pf(r);
                     __builtin_amdgcn_sched_barrier(0);
-                    raw_landed(E12{});                // younger: the twelve stores (a tile wholly past M: see split_raw)
+                    if constexpr (RS) raw_landed(std::integral_constant<int, 18>{});     // younger: this step's six DMA pieces + the twelve stores
+                    else raw_landed(E12{});           // younger: the twelve stores (a tile wholly past M: see split_raw)
                     split_raw(r + 1);
                     gemm1_only(stage);
                     roll();
@@ -857,6 +890,12 @@ void launch_mixer_fused_ws(const MixerParams& p, hipStream_t s) {
     if (pf) {
         static const bool il = [] { const char* e = getenv("RD_WS_IL"); return !(e && e[0] == '0'); }();     // A/B switch: RD_WS_IL=0 = the round-3 form
         static const bool go = [] { const char* e = getenv("RD_WS_GO"); return !(e && e[0] == '0'); }();    // A/B switch: RD_WS_GO=0 = GELU first (round 3)
+        static const bool rs = [] { const char* e = getenv("RD_WS_RS"); return !(e && e[0] == '0'); }();    // A/B switch: RD_WS_RS=0 = residual re-read (rounds 3-4)
+        if (il && go && rs) {
+            if (gated) launch_ws<192, true, false, 896, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s);
+            else launch_ws<192, false, false, 896, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s);
+            return;
+        }
         if (il && go) {
             if (gated) launch_ws<192, true, false, 384, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s);
             else launch_ws<192, false, false, 384, true>(p, img, n_tiles, grid, ph_mul, ph_unit, s);

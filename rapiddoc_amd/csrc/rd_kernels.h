@@ -300,6 +300,6 @@ void launch_mixer_debug(const MixerParams& p, int variant, hipStream_t s);
 // resident-weights variant for the narrow blocks (kernels_mixer_res.hip; C = 96): all split weights in LDS, 16 independent
 // wavefronts per CU.  p.w1h carries the fragment image built by prepare_mixer_weights_res.
 bool mixer_res_supported(int C);
-void prepare_mixer_weights_res(const float* w1, const float* w2, int C, std::vector<uint16_t>& img);
+void prepare_mixer_weights_res(const float* w1, const float* w2, int C, std::vector<uint16_t>& img, float inv[2]);   // inv -> ws_inv1 / ws_inv2
 void launch_mixer_fused_res(const MixerParams& p, hipStream_t s);
 }  // namespace rd

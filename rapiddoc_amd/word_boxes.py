@@ -36,7 +36,7 @@ class WordInfo:                      # rapidocr/ch_ppocr_rec/typings.py
 
 
 def has_chinese_char(text: str) -> bool:
-    return any("一" <= ch <= "鿿" for ch in text)
+    return bool(_cjk_mask(text).any())
 
 
 def quads_to_rect_bbox(bbox: np.ndarray) -> Tuple[float, float, float, float]:
@@ -52,84 +52,65 @@ def quads_to_rect_bbox(bbox: np.ndarray) -> Tuple[float, float, float, float]:
 # ---------------------------------------------------------------------------------------------------------------------
 # RapidDoc's patched methods (pinned)
 # ---------------------------------------------------------------------------------------------------------------------
+def _cjk_mask(text: str) -> np.ndarray:
+    return np.fromiter(("\u4e00" <= ch <= "\u9fff" for ch in text), dtype=bool, count=len(text))
+
+
 def get_word_info(text: str, kept_cols: Sequence[int]) -> WordInfo:
-    """ocr_patch.py:333-389 (`selection` there is the boolean mask whose True positions are `kept_cols`): characters grouped into
-    words - a space is a word of its own, a run breaks when the script changes (CJK / other) or when two kept time steps are more than
-    5 apart."""
-    valid_col = np.asarray(kept_cols, dtype=np.int64)
-    if len(valid_col) <= 0:
+    """What RapidDoc's replacement of `CTCLabelDecode.get_word_info` computes (ocr_patch.py:333-389; its `selection` mask is True at
+    `kept_cols`): the line's characters cut into words.  Character i sits at time step kept_cols[i].  A word boundary falls in front of
+    character i when it or its predecessor is white space (a space is a word of its own, typed "en&num"), when the script changes
+    between two neighbours (CJK / everything else), or when their time steps are more than 5 apart.  Stated here as ONE boundary mask
+    over the line and a split at its set positions."""
+    steps = np.asarray(kept_cols, dtype=np.int64).reshape(-1)
+    n = min(len(text), steps.size)           # (character i is paired with kept step i; a dictionary entry that decodes to nothing
+    if n == 0:                               #  leaves more steps than characters - the surplus steps at the end stay unused)
         return WordInfo()
-    col_width = np.zeros(valid_col.shape)
-    col_width[1:] = valid_col[1:] - valid_col[:-1]
-    col_width[0] = min(3 if has_chinese_char(text[0]) else 2, int(valid_col[0]))
-    words, cols, types_ = [], [], []
-    cur_w: List[str] = []
-    cur_c: List[int] = []
-    state: Optional[str] = None
-
-    def flush():
-        nonlocal cur_w, cur_c
-        if cur_w:
-            words.append(cur_w)
-            cols.append(cur_c)
-            types_.append(state)
-            cur_w, cur_c = [], []
-    for c_i, ch in enumerate(text):
-        if ch.isspace():
-            flush()
-            words.append([ch])
-            cols.append([int(valid_col[c_i])])
-            types_.append(EN_NUM)
-            state = None
-            continue
-        c_state = CN if has_chinese_char(ch) else EN_NUM
-        if state is None:
-            state = c_state
-        if state != c_state or col_width[c_i] > 5:
-            flush()
-            state = c_state
-        cur_w.append(ch)
-        cur_c.append(int(valid_col[c_i]))
-    flush()
-    return WordInfo(words=words, word_cols=cols, word_types=types_)
-
-
-def _word_conf(word_col: Sequence[int], col_confs: dict) -> float:
-    confs = [col_confs[c] for c in word_col if c in col_confs]
-    return round(float(np.mean(confs)), 5) if confs else 0.0
+    chars, steps = text[:n], steps[:n]
+    blank = np.fromiter((ch.isspace() for ch in chars), dtype=bool, count=n)
+    cjk = _cjk_mask(chars)
+    far = np.zeros(n, dtype=bool)
+    far[1:] = np.diff(steps) > 5             # (the first character's nominal width, min(3 | 2, step 0), never exceeds 5)
+    cut = np.ones(n, dtype=bool)
+    cut[1:] = blank[1:] | blank[:-1] | (cjk[1:] != cjk[:-1]) | far[1:]
+    starts = np.flatnonzero(cut)
+    stops = np.append(starts[1:], n)
+    words = [list(chars[a:e]) for a, e in zip(starts, stops)]
+    cols = [steps[a:e].tolist() for a, e in zip(starts, stops)]
+    kinds = [EN_NUM if blank[a] or not cjk[a] else CN for a in starts]
+    return WordInfo(words=words, word_cols=cols, word_types=kinds)
 
 
 def cal_ocr_word_box(rec_txt: str, bbox: np.ndarray, word_info: WordInfo, return_single_char_box: bool = False, helpers=None):
-    """ocr_patch.py:264-329: (word contents, word boxes, confidences).  All-latin lines get one box per word, any CJK gives one box per
-    character.  `helpers`: an object with rapidocr's calc_* methods (tests pin the flow with recording stand-ins); default = this module's
-    restatements."""
-    h = helpers if helpers is not None else _Helpers
+    """What RapidDoc's replacement of `CalRecBoxes.cal_ocr_word_box` returns (ocr_patch.py:264-329): (contents, boxes, confidences) - one
+    entry per WORD when the whole line is latin / digits (and single-character boxes were not asked for), else one per CHARACTER.  A
+    cell of the line is (box width) / line_txt_len wide; every word of two or more characters contributes one estimate of the
+    character width, their pooled average places the boxes; an entry's confidence is the mean of its time steps' probabilities, rounded
+    to five places (steps without a probability do not count, none at all gives 0).  `helpers`: an object with rapidocr's calc_*
+    methods (the tests pin the call flow with recording stand-ins); default = this module's restatements."""
+    geo = helpers if helpers is not None else _Helpers
     if not rec_txt or word_info.line_txt_len == 0:
         return [], [], []
-    bbox_points = quads_to_rect_bbox(bbox[None, ...])
-    avg_col_width = (bbox_points[2] - bbox_points[0]) / word_info.line_txt_len
-    is_all_en_num = all(v == EN_NUM for v in word_info.word_types)
-    all_cols = [c for wc in word_info.word_cols for c in wc]
-    col_confs = dict(zip(all_cols, word_info.confs))
-    line_cols, char_widths, word_contents, content_confs = [], [], [], []
-    for word, word_col in zip(word_info.words, word_info.word_cols):
-        if is_all_en_num and not return_single_char_box:
-            line_cols.append(word_col)
-            word_contents.append("".join(word))
-            content_confs.append(_word_conf(word_col, col_confs))
-        else:
-            line_cols.extend(word_col)
-            word_contents.extend(word)
-            content_confs.extend(_word_conf([c], col_confs) for c in word_col)
-        if len(word_col) == 1:
-            continue
-        char_widths.append(h.calc_avg_char_width(word_col, avg_col_width))
-    avg_char_width = h.calc_all_char_avg_width(char_widths, bbox_points[0], bbox_points[2], len(rec_txt))
-    if is_all_en_num and not return_single_char_box:
-        word_boxes = h.calc_en_num_box(line_cols, avg_char_width, avg_col_width, bbox_points)
+    rect = quads_to_rect_bbox(bbox[None, ...])
+    cell = (rect[2] - rect[0]) / word_info.line_txt_len
+    by_word = not return_single_char_box and all(k == EN_NUM for k in word_info.word_types)
+    prob_at = dict(zip((c for wc in word_info.word_cols for c in wc), word_info.confs))
+
+    def mean_prob(steps) -> float:
+        got = [prob_at[c] for c in steps if c in prob_at]
+        return round(float(np.mean(got)), 5) if got else 0.0
+    widths = [geo.calc_avg_char_width(wc, cell) for wc in word_info.word_cols if len(wc) != 1]
+    if by_word:
+        contents = ["".join(w) for w in word_info.words]
+        groups = [wc for wc in word_info.word_cols]
+        confs = [mean_prob(wc) for wc in word_info.word_cols]
     else:
-        word_boxes = h.calc_box(line_cols, avg_char_width, avg_col_width, bbox_points)
-    return word_contents, word_boxes, content_confs
+        contents = [ch for w in word_info.words for ch in w]
+        groups = [c for wc in word_info.word_cols for c in wc]
+        confs = [mean_prob((c,)) for c in groups]
+    char_w = geo.calc_all_char_avg_width(widths, rect[0], rect[2], len(rec_txt))
+    place = geo.calc_en_num_box if by_word else geo.calc_box
+    return contents, place(groups, char_w, cell, rect), confs
 
 
 def map_boxes_to_original(dt_boxes: np.ndarray, op_record: dict, ori_h: int, ori_w: int) -> np.ndarray:

@@ -25,16 +25,28 @@ def _last_json(out: str) -> dict:
     return json.loads(lines[-1])
 
 
+def _run(cmd, env, timeout=420):
+    """subprocess.run with the child in a process group of its own that is killed as a whole on a timeout: a hung multi-rank run
+    (a collective one rank never joins) must not leave its ranks behind on the GPU and the host cores of the tests that follow."""
+    import signal
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        out, err = p.communicate()
+        raise AssertionError("timed out after %d s: %s\n%s" % (timeout, " ".join(cmd[-12:]), err[-1500:]))
+    assert p.returncode == 0, err[-2000:]
+    return out
+
+
 def _one_and_two(extra, port, env_two=None):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    one = subprocess.run([sys.executable, str(ROOT / "bench.py"), *COMMON, *extra], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert one.returncode == 0, one.stderr[-2000:]
+    one = _run([sys.executable, str(ROOT / "bench.py"), *COMMON, *extra], env)
     env2 = dict(env, RD_BENCH_BACKEND="gloo", **(env_two or {}))
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", *COMMON, *extra],
-                         capture_output=True, text=True, timeout=900, env=env2, cwd=ROOT)
-    assert two.returncode == 0, two.stderr[-2000:]
-    return _last_json(one.stdout), _last_json(two.stdout)
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", *COMMON, *extra], env2)
+    return _last_json(one), _last_json(two)
 
 
 def test_two_ranks_on_one_gpu_equal_one_rank_in_the_default_strict_mode():
@@ -67,15 +79,10 @@ def test_two_ranks_weak_scaling_cover_the_same_global_list():
     single-process run over 4 pages."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     base = ["--rec-streams", "2", "--steps", "1", "--warmup", "0", "--setup-steps", "0", "--no-cpu-baseline", "--no-extra-passes", "--vary-pages", "1"]
-    one = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--scaling", "weak", "--pages", "4", *base], capture_output=True, text=True,
-                         timeout=900, env=env, cwd=ROOT)
-    assert one.returncode == 0, one.stderr[-2000:]
-    a = _last_json(one.stdout)
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29743", str(ROOT / "bench.py"), "--gpus", "2", "--scaling", "weak", "--pages", "2", *base],
-                         capture_output=True, text=True, timeout=900, env=dict(env, RD_BENCH_BACKEND="gloo"), cwd=ROOT)
-    assert two.returncode == 0, two.stderr[-2000:]
-    b = _last_json(two.stdout)
+    a = _last_json(_run([sys.executable, str(ROOT / "bench.py"), "--scaling", "weak", "--pages", "4", *base], env))
+    b = _last_json(_run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29743", str(ROOT / "bench.py"), "--gpus", "2", "--scaling", "weak", "--pages", "2", *base],
+                        dict(env, RD_BENCH_BACKEND="gloo")))
     assert b["n_gpus"] == 2 and b["scaling"] == "weak" and b["config"]["pages_per_gpu"] == 2
     assert a["config"]["pages_gathered"] == b["config"]["pages_gathered"] == 4
     assert a["config"]["result_crc32"] == b["config"]["result_crc32"]
