@@ -199,8 +199,16 @@ def measure_s2_dropin(states, pipe, pages, text_maps, device):
         out_bytes = step()
     torch.cuda.synchronize()
     sec = (time.perf_counter() - t0) / steps
+    # the same with the sessions handing out views of their pinned staging buffers (`copy_out = False`: no host memcpy of the softmax)
+    det_s.copy_out = rec_s.copy_out = False
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    sec_view = time.perf_counter() - t0
     in_bytes = sum(b.nbytes for b in det_batches) + sum(b.nbytes for b in rec_batches)
     return {"pages_s": round(P / sec, 3), "ms_per_step": round(sec * 1e3, 3), "steps": steps, "warmup": "1 det + 8 rec calls",
+            "pages_s_pinned_views": round(P / sec_view, 3), "ms_per_step_pinned_views": round(sec_view * 1e3, 3),
             "det_session_calls": len(det_batches), "rec_session_calls": len(rec_batches), "lines": n,
             "h2d_mb_per_step": round(in_bytes / 1e6, 1), "d2h_mb_per_step": round(out_bytes / 1e6, 1),
             "what": "numpy -> session -> numpy exactly as rapid_ocr.py:443,528 call it (det batches of <= 8 pages, rec chunks of 6 returning "
@@ -509,6 +517,17 @@ def main():
     out = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
+    # the product's gather of whole per-page results (dist.gather_page_dets, wire format v2 - what PageAnalyzer's List[List[dict]] travels
+    # in): one call on this step's lines as OcrText-span dicts, every rank, outside the timed region (the timed
+    # region gathers the flat (text, score) format v1)
+    from rapiddoc_amd.dist import gather_page_dets
+    last_local = [(i, [{"category_id": 15, "poly": [float(k) for k in range(8)], "score": s_, "text": t_} for t_, s_ in lines])
+                  for i, lines in out if i in set(my_pages)]
+    fence()
+    tg = time.perf_counter()
+    v2 = gather_page_dets(last_local, dist)
+    gather_v2_ms = (time.perf_counter() - tg) * 1e3
+    assert [i for i, _ in v2] == [i for i, _ in out]
     if os.environ.get("RD_BENCH_STOP_AFTER_TIMED") == "1":      # developer: a kernel trace whose tail is the timed steps (tools/trace_gaps.py)
         print("timed region: %.2f ms per step" % (dt / args.steps * 1e3), file=sys.stderr)
         return
@@ -703,6 +722,7 @@ def main():
                        "rec_mode": args.rec_mode,
                        "rec_launch_batches": int(pool.stats.get("rec_batches", 0)),
                        "pages_per_gpu": P, "global_pages": n_global, "pages_gathered": len(out), "result_crc32": result_crc,
+                       "gather_page_dets_v2_ms": round(gather_v2_ms, 2),      # one gather of this step's results as per-page dict lists (wire format v2), all ranks
                        "rec_width_sync": (None if width_sync is None else {"collective_calls": width_sync.calls,
                                           "what": "global argsort / chunks of 6 over the lines of all ranks (dist.GlobalLineWidths)"}),
                        "page_sets_cycled": K_sets, "setup_steps": max(0, args.setup_steps),

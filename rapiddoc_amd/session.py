@@ -42,18 +42,27 @@ class _BaseSession:
         x = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32))
         return x.to(self.device, non_blocking=True)
 
+    # `copy_out = False`: __call__ returns a VIEW of one of the session's two pinned staging buffers instead of a fresh array - valid
+    # until the session has been called twice more.  rapidocr's callers consume a result (DB post-process, CTC argmax) before they
+    # call the session again, so the view is safe there and saves a host memcpy of the whole softmax tensor per call; the default
+    # keeps the reference's contract (a fresh array per call).
+    copy_out = True
+
     def _to_host(self, t: torch.Tensor) -> np.ndarray:
-        """Device tensor -> a fresh numpy array, through a pinned staging buffer of the session (grown on demand): the copy off the
-        device then runs at the link's rate instead of the pageable-memory path of `.cpu()` (the rec session hands back tens of MB per
+        """Device tensor -> numpy through pinned staging buffers of the session (two, used in turn, grown on demand): the copy off the
+        device runs at the link's rate instead of the pageable-memory path of `.cpu()` (the rec session hands back tens of MB per
         call: softmax [6, T, 18710])."""
         t = t.contiguous()
         n = t.numel()
-        if getattr(self, "_pin", None) is None or self._pin.numel() < n or self._pin.dtype != t.dtype:
-            self._pin = torch.empty(int(n * 1.25) + 1024, dtype=t.dtype, pin_memory=True)
-        stage = self._pin[:n].view(t.shape)
+        if not hasattr(self, "_pins"):
+            self._pins, self._pin_i = [None, None], 0
+        k = self._pin_i = self._pin_i ^ 1
+        if self._pins[k] is None or self._pins[k].numel() < n or self._pins[k].dtype != t.dtype:
+            self._pins[k] = torch.empty(int(n * 1.25) + 1024, dtype=t.dtype, pin_memory=True)
+        stage = self._pins[k][:n].view(t.shape)
         stage.copy_(t, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
-        return stage.numpy().copy()
+        return stage.numpy().copy() if self.copy_out else stage.numpy()
 
     # rapidocr InferSession protocol (ocr/torch.py:194-198)
     def have_key(self, key: str = "character") -> bool:
