@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include "rd_device.h"
 
@@ -132,7 +133,7 @@ __device__ __forceinline__ void h1_finish_block(const ConvParams& p, const f32x1
 // even K tile (a plain 4-byte load per row whose result is never used, so that the memory side sees 256 contiguous bytes per row): 1-7 %
 // slower at every shape, also with the MFMAs switched off - the activation stream is not bound by DRAM page locality.
 template <int ABL, bool IL>
-__global__ void __launch_bounds__(256, 2) gemm_h1_kernel(ConvParams p, int ntn, int ntiles) {
+__global__ void __launch_bounds__(256, 2) gemm_h1_kernel(ConvParams p, int ntn, int ntiles, unsigned long long* trace) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..3: rows 64 * wave .. + 63 of the tile
@@ -180,6 +181,16 @@ __global__ void __launch_bounds__(256, 2) gemm_h1_kernel(ConvParams p, int ntn, 
     asm volatile("" : "+s"(neg1));
 
     unsigned emax = 0;
+    // TRACE (ABL bit 5, developer: RD_GEMM1_DBG=32, tools/mb_gemm_h1.py trace): wavefront 0 of every workgroup sums, in shader cycles
+    // (s_memtime), what it spends in the two wait + barrier points of a K tile, in the epilogue and in total; written out once at the end
+    constexpr bool TRACE = (ABL & 32) != 0;
+    unsigned long long tw0 = 0, tw1 = 0, tep = 0, tstart = 0, tmark = 0;
+    auto now = [&]() {
+        unsigned long long t_;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+        return t_;
+    };
+    if constexpr (TRACE) tstart = now();
     int v = blockIdx.x;
     if (v >= ntiles) return;
     int ab = 0;                      // activation buffer of the current K tile (runs on across output tiles)
@@ -215,7 +226,9 @@ __global__ void __launch_bounds__(256, 2) gemm_h1_kernel(ConvParams p, int ntn, 
             const int tA = last ? 0 : t + 1, sB = last ? 0 : 2 * t + 2;
             const unsigned char* sa = smem + ab * H_A;
             // ---------------- step (t, 0)
+            if constexpr (TRACE) tmark = now();
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (TRACE) tw0 += now() - tmark;
             // the k-step-0 activations are read and split first; the k-step-1 reads reuse their registers
             f16x8 ah[2], al[2];
             f16x8 bh[4], bl[4];
@@ -285,7 +298,9 @@ __global__ void __launch_bounds__(256, 2) gemm_h1_kernel(ConvParams p, int ntn, 
                 if (g == 3) h1_split8(x1[1][0], x1[1][1], neg1, ah1[1], al1[1]);
             });
             // ---------------- step (t, 1)
+            if constexpr (TRACE) tmark = now();
             asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            if constexpr (TRACE) tw1 += now() - tmark;
             f16x8 ch[4], cl[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -296,6 +311,7 @@ __global__ void __launch_bounds__(256, 2) gemm_h1_kernel(ConvParams p, int ntn, 
             ab ^= 1;
         }
         // ---- epilogue (the next tile's first pieces are in flight)
+        if constexpr (TRACE) tmark = now();
         if constexpr ((ABL & 8) != 0) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -318,10 +334,20 @@ __global__ void __launch_bounds__(256, 2) gemm_h1_kernel(ConvParams p, int ntn, 
                 }
             }
         }
+        if constexpr (TRACE) {
+            asm volatile("s_nop 0" ::: "memory");
+            tep += now() - tmark;
+        }
         if (!has_next) break;
         v = vnext;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the last tile's re-read pieces)
+    if constexpr (TRACE) {
+        if (trace && wave == 0 && lane == 0) {
+            unsigned long long* o = trace + (size_t)blockIdx.x * 4;
+            o[0] = now() - tstart; o[1] = tw0; o[2] = tw1; o[3] = tep;
+        }
+    }
     if (emax >= 0x7f800000u && p.range_flag) rd_raise_flag(p.range_flag);
 }
 
@@ -393,7 +419,7 @@ void launch_gemm_h1(const ConvParams& p, hipStream_t s) {
     do {                                                                                                              \
         static unsigned long long ok_ = 0;                                                                            \
         rd_allow_dynamic_lds((const void*)gemm_h1_kernel<A, I>, H_LDS, ok_);                                          \
-        hipLaunchKernelGGL((gemm_h1_kernel<A, I>), dim3(grid), dim3(256), H_LDS, s, p, ntn, ntiles);                  \
+        hipLaunchKernelGGL((gemm_h1_kernel<A, I>), dim3(grid), dim3(256), H_LDS, s, p, ntn, ntiles, (unsigned long long*)nullptr); \
     } while (0)
     if (dbg == 0 && il) { RD_H1(0, true); return; }
     if (dbg == 0) { RD_H1(0, false); return; }
@@ -402,6 +428,36 @@ void launch_gemm_h1(const ConvParams& p, hipStream_t s) {
         case 2: RD_H1(2, false); break;
         case 8: RD_H1(8, false); break;
         case 16: RD_H1(16, false); break;
+        case 32: case 34: {      // phase cycles of every workgroup's wavefront 0 (one synchronous launch per call; stderr)
+            static unsigned long long* tbuf = nullptr;
+            if (!tbuf) (void)hipMalloc(&tbuf, 4096 * 4 * sizeof(unsigned long long));
+            (void)hipMemsetAsync(tbuf, 0, 4096 * 4 * sizeof(unsigned long long), s);
+            static unsigned long long ok32 = 0, ok34 = 0;
+            if (dbg == 32) {
+                rd_allow_dynamic_lds((const void*)gemm_h1_kernel<32, false>, H_LDS, ok32);
+                hipLaunchKernelGGL((gemm_h1_kernel<32, false>), dim3(grid), dim3(256), H_LDS, s, p, ntn, ntiles, tbuf);
+            } else {
+                rd_allow_dynamic_lds((const void*)gemm_h1_kernel<34, false>, H_LDS, ok34);
+                hipLaunchKernelGGL((gemm_h1_kernel<34, false>), dim3(grid), dim3(256), H_LDS, s, p, ntn, ntiles, tbuf);
+            }
+            static int printed = 0;
+            if (printed < 24 && (++printed % 3) == 0) {      // every third launch of a shape list, warmed up
+                (void)hipStreamSynchronize(s);
+                std::vector<unsigned long long> h((size_t)grid * 4);
+                (void)hipMemcpy(h.data(), tbuf, h.size() * 8, hipMemcpyDeviceToHost);
+                double sum[4] = {0, 0, 0, 0}, mx = 0;
+                for (int b = 0; b < grid; ++b) {
+                    for (int k = 0; k < 4; ++k) sum[k] += (double)h[(size_t)b * 4 + k];
+                    mx = std::fmax(mx, (double)h[(size_t)b * 4]);
+                }
+                const double tiles_per_wg = (double)ntiles / grid, kt = p.K / HK;
+                fprintf(stderr, "h1 trace M=%d K=%d N=%d dbg=%d: per workgroup (mean of %d, shader cycles): total %.0f (max %.0f) = %.1f tiles x [ %d K tiles x "
+                        "( wait A+B %.0f + wait B %.0f + rest %.0f ) + epilogue %.0f ]\n", p.M, p.K, p.Ng, dbg, grid, sum[0] / grid, mx, tiles_per_wg, (int)kt,
+                        sum[1] / grid / tiles_per_wg / kt, sum[2] / grid / tiles_per_wg / kt,
+                        (sum[0] - sum[1] - sum[2] - sum[3]) / grid / tiles_per_wg / kt, sum[3] / grid / tiles_per_wg);
+            }
+            break;
+        }
         default: RD_H1(0, false); break;
     }
 #undef RD_H1

@@ -105,6 +105,12 @@ def perf_child(tag):
         g = torch.Generator(device="cuda").manual_seed(0)
         x = torch.rand((M, K), device="cuda", generator=g) - 0.5
         w = (torch.rand((N, K), device="cuda", generator=g) - 0.5) * 0.1
+        if os.environ.get("MB_ZEROS") == "1":       # zero operands: same instruction stream, far fewer toggling bits - what the power budget costs
+            x.zero_()
+            w.zero_()
+        if os.environ.get("MB_ZEROS") == "2":       # small integers: hi planes busy, lo planes all zero
+            x = torch.randint(-8, 9, (M, K), device="cuda", generator=g).float()
+            w = torch.randint(-8, 9, (N, K), device="cuda", generator=g).float()
         b = torch.zeros(N, device="cuda")
         y = torch.empty((M, N), device="cuda")
         Kp = (K + 31) // 32 * 32
@@ -136,5 +142,8 @@ if __name__ == "__main__":
                 env[k] = v
         r = subprocess.run([sys.executable, __file__, "child", cfg or "default"], env=env, capture_output=True, text=True)
         print(r.stdout, end="", flush=True)
+        for ln in r.stderr.splitlines():
+            if ln.startswith("h1 trace"):          # RD_GEMM1_DBG=32 / 34: the library's cycle accounting
+                print(ln, flush=True)
         if r.returncode != 0:
             print(r.stderr[-2000:])
