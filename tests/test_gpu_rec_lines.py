@@ -176,7 +176,9 @@ def test_strict_mode_gives_every_line_its_reference_width_in_gpu_sized_launches(
     res1 = pipe.run_batch(pages, None, det_maps_override=maps)
     for a, b in zip(res, res1):
         assert [t for _q, t, _s in a.lines] == [t for _q, t, _s in b.lines]
-        assert max(abs(sa - sb) for (_q, _t, sa), (_q2, _t2, sb) in zip(a.lines, b.lines)) <= 1e-3
+        # scores are printed to three places (analyze_utils.py:280): the two launch forms may sit on either side of a rounding boundary,
+        # i.e. differ by ONE unit of the third place (0.001 up to its own float rounding), never more
+        assert max(abs(sa - sb) for (_q, _t, sa), (_q2, _t2, sb) in zip(a.lines, b.lines)) <= 1e-3 + 1e-9
 
 
 def test_strict_mode_falls_back_to_fp32_with_the_line_table(golden_dir):

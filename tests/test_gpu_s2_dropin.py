@@ -101,4 +101,5 @@ def test_the_reference_chunk_loop_through_the_session_gives_the_fast_path_string
             out[idxs[r]] = (t, s)
     assert n_calls == -(-n // 6)
     assert [t for t, _s in out] == [t for _q, t, _s in flat]
-    assert max(abs(ocr_host.format_score(s) - fs) for (_t, s), (_q, _t2, fs) in zip(out, flat)) <= 1e-3
+    # (scores printed to three places: at most one unit of the third place apart)
+    assert max(abs(ocr_host.format_score(s) - fs) for (_t, s), (_q, _t2, fs) in zip(out, flat)) <= 1e-3 + 1e-9

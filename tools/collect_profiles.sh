@@ -43,7 +43,7 @@ head -8 $O/${TAG}_rocprofv3_kernel_stats.csv | cut -c1-140
 } > $O/${TAG}_microbench_dw.txt
 (cd /tmp && RD_BENCH_STOP_AFTER_TIMED=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tg_$TAG -o t -- python $R/bench.py --steps 6 --warmup 5 --no-cpu-baseline --no-extra-passes > /tmp/tg.log 2>&1
  python $R/tools/trace_gaps.py $(find /tmp/tg_$TAG -name "*kernel_trace.csv" | head -1) 330 > $O/${TAG}_trace_gaps.txt 2>&1)
-{
+[ "${SKIP_AB:-0}" = "1" ] || {
   echo "# python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-passes <flags>: pages/s, ms/step, per-step wall (median / min / max / first), t_wait_maps"
   for f in "default" "--no-prefetch" "Q4" "Q4 --no-prefetch"; do
     q=16; a="$f"; case "$f" in default) a="";; Q4*) q=4; a="${f#Q4}";; esac
@@ -51,7 +51,7 @@ head -8 $O/${TAG}_rocprofv3_kernel_stats.csv | cut -c1-140
     python -c "import json; r=json.load(open('/tmp/ab.json')); print('GPU_MAX_HW_QUEUES=$q $a:', r['value'], r['ms_per_step'], r['config']['step_wall_ms'], r['config']['host_stage_ms']['t_wait_maps_ms'])"
   done
 } > $O/${TAG}_ab_prefetch_queues.txt
-cat $O/${TAG}_microbench_dw.txt $O/${TAG}_ab_prefetch_queues.txt; head -20 $O/${TAG}_trace_gaps.txt
+cat $O/${TAG}_microbench_dw.txt; [ -f $O/${TAG}_ab_prefetch_queues.txt ] && cat $O/${TAG}_ab_prefetch_queues.txt; head -20 $O/${TAG}_trace_gaps.txt
 if [ "${LIGHT:-0}" = "1" ]; then python $R/tools/isa_mix.py > $O/${TAG}_isa_mix.txt 2>/dev/null || true; exit 0; fi
 # microbenchmarks behind DESIGN.md s3c: the ws mixer (round-2 form 200 vs prefetching form 400) and its ablations, each in its own process
 {

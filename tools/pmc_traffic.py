@@ -37,6 +37,9 @@ def canon(name):
         return "lc_mixer_ws_kernel<%s>" % m.group(1)
     if name.startswith("gemm_h1_kernel<"):
         return "gemm_h1_kernel"
+    m = re.match(r"lc_mixer_res_kernel<(\d+),", name)
+    if m:
+        return "lc_mixer_res_kernel<%s>" % m.group(1)
     m = re.match(r"lc_mixer_kernel<(\d+),0>", name)
     if m:
         return "lc_mixer_kernel<%s>" % m.group(1)
