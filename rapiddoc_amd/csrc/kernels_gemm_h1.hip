@@ -319,6 +319,86 @@ __global__ void __launch_bounds__(256, 2) gemm_h1_kernel(ConvParams p, int ntn, 
                 for (int j = 0; j < 4; ++j) emax = max(emax, __float_as_uint(acc[i][j][0] + acc[i][j][7]) & 0x7fffffffu);
         } else {
             const float sinv = p.w1_inv;
+            const bool interior = em0 + HM <= p.M && en0 + HN <= p.Ng;        // (wave-uniform)
+            if (interior) {
+                // Interior tile (all but the last row / column of tiles): no bounds test, and every load / store is "uniform row base
+                // (SGPR pair) + this lane's 32-bit offset + immediate column block": the general path below spends a 64-bit multiply-add,
+                // a 64-bit shift-add, a compare and an EXEC save / branch on each of its 128 four-byte stores.
+                // (buffer addressing: descriptor at the tile's first row, lane offset in the vector operand, row offset in the scalar one,
+                //  column block as immediate - zero vector instructions per access; aux 2 = nt, like the general path's stores)
+                const unsigned yoff = ((unsigned)(4 * lhi) * (unsigned)p.yld + (unsigned)(en0 + l31)) * 4u;
+                const unsigned roff = ((unsigned)(4 * lhi) * (unsigned)p.rld + (unsigned)(en0 + l31)) * 4u;
+                const h1_rsrc ry = h1_make_rsrc(p.y + (size_t)(em0 + 64 * wave) * p.yld);
+                const h1_rsrc rr = h1_make_rsrc((p.res ? p.res : p.y) + (size_t)(em0 + 64 * wave) * (p.res ? p.rld : p.yld));
+                float bv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[j] = p.bias ? p.bias[en0 + 32 * j + l31] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 16; r4 += 4) {          // four rows (consecutive pixels) x four column blocks at a time
+                        float o[4][4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[q][j] = fmaf(acc[i][j][r4 + q], sinv, bv[j]);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) emax = max(emax, __float_as_uint(o[q][0]) & 0x7fffffffu);       // column block 0 carries the range check
+                        if constexpr ((ABL & 4) != 0) {
+                        } else if (p.act == ACT_GELU) {
+                            if constexpr ((ABL & 64) != 0) {          // A/B (RD_GEMM1_DBG=64, valid results): two GELUs per packed-fp32 instruction
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                                    for (int j = 0; j < 4; j += 2) {
+                                        const f32x2 g = rd_gelu2(f32x2{o[q][j], o[q][j + 1]});
+                                        o[q][j] = g[0];
+                                        o[q][j + 1] = g[1];
+                                    }
+                            } else {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) o[q][j] = rd_gelu(o[q][j]);
+                            }
+                        } else if (p.act == ACT_RELU) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) o[q][j] = fmaxf(o[q][j], 0.f);
+                        } else if (p.act != ACT_NONE) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) o[q][j] = rd_act(o[q][j], p.act);
+                        }
+                        const int row0 = 32 * i + 8 * (r4 >> 2);       // + q: wave-uniform row inside the wavefront's 64 (lhi sits in the lane offsets)
+                        if (p.res && !(ABL & 4)) {
+                            float rs[4][4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const unsigned so = (unsigned)(row0 + q) * (unsigned)p.rld * 4u;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    rs[q][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, (int)(roff + 128u * j), (int)so, 0));
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) o[q][j] += rs[q][j];
+                        }
+                        if (!((ABL & 1) && o[0][0] != 12345.678f)) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const unsigned so = (unsigned)(row0 + q) * (unsigned)p.yld * 4u;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[q][j]), ry, (int)(yoff + 128u * j), (int)so, 2);
+                            }
+                        }
+                    }
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = en0 + j * 32 + l31;
@@ -332,6 +412,7 @@ __global__ void __launch_bounds__(256, 2) gemm_h1_kernel(ConvParams p, int ntn, 
                     if (j == 0) h1_finish_block<ABL, true>(p, acc[i][j], mb, nn, sinv, bv, emax);
                     else h1_finish_block<ABL, false>(p, acc[i][j], mb, nn, sinv, bv, emax);
                 }
+            }
             }
         }
         if constexpr (TRACE) {
@@ -428,6 +509,7 @@ void launch_gemm_h1(const ConvParams& p, hipStream_t s) {
         case 2: RD_H1(2, false); break;
         case 8: RD_H1(8, false); break;
         case 16: RD_H1(16, false); break;
+        case 64: RD_H1(64, false); break;
         case 32: case 34: {      // phase cycles of every workgroup's wavefront 0 (one synchronous launch per call; stderr)
             static unsigned long long* tbuf = nullptr;
             if (!tbuf) (void)hipMalloc(&tbuf, 4096 * 4 * sizeof(unsigned long long));

@@ -20,7 +20,7 @@ ALLOWED = {
     r"lc_mixer_ws_kernelILi192ELb[01]ELb[01]ELi(1|2|4|8|12|13|16|17|25|27|28|29|64|72|88)ELb[01]E": "ablation instantiations of the ws mixer (tools/microbench.py)",
     r"gemm_h3_dma16_kernelILi(1|2|4|8|10)E": "ablation instantiations of the 16-wavefront GEMM (tools/mb_gemm_abl.py, RD_GEMM_DBG)",
     r"dwconv_tiled_kernelILi3ELi3ELi1ELi8ELi[1-7]E": "ablation instantiations of the depthwise 3x3 (RD_DW_DBG)",
-    r"gemm_h1_kernelILi(1|2|8|16|32|34)E": "ablation instantiations of the single-accumulator GEMM (tools/mb_gemm_h1.py, RD_GEMM1_DBG)",
+    r"gemm_h1_kernelILi(1|2|8|16|32|34|64)E": "ablation instantiations of the single-accumulator GEMM (tools/mb_gemm_h1.py, RD_GEMM1_DBG)",
     r"gemm_h1_kernelILi0ELb1E": "the single-accumulator GEMM with its DMA pieces between the MFMA groups (RD_GEMM1_IL=1, A/B only): 8 spilled "
                                 "registers at the tile switch",
     r"lc_mixer_h3_kernel.*Li192E": "round-1 C = 192 mixer: superseded by the ws kernel, kept for A/B (RD_MIXER_WS=0)",
