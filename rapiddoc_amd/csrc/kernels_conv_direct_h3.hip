@@ -243,6 +243,52 @@ __global__ void __launch_bounds__(512) conv_direct_h3_kernel(ConvParams p, Direc
 
         // ---- epilogue: lane = output channel, registers = 16 of this wavefront's 32 pixels
         const int oh = oh0 + wr;
+        // Interior wavefront tile (its 32 pixels all inside the row - every tile but a row's last): no per-pixel bounds test, and every
+        // load / store is a buffer access - descriptor at the row's first pixel, the lane's (pixel group, channel) offset in the vector
+        // operand, the pixel in the scalar one: one instruction per 4-byte store.  The general path below spends a 64-bit multiply-add,
+        // a compare and an EXEC save / branch on each (round 5; same change as the interior epilogue of kernels_gemm_h1.hip).
+        const bool interior = oh < p.OH && ow0 + wc0 + 32 <= p.OW;
+        if (interior) {
+            typedef __amdgpu_buffer_rsrc_t rsrc_t;
+            const size_t pix0 = ((size_t)img * p.OH + oh) * p.OW + ow0 + wc0;
+            const rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y + pix0 * p.yld, 0, 0x7fffffff, 0x00020000);
+            const rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res + pix0 * p.rld : p.y), 0, 0x7fffffff, 0x00020000);
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));                 // (keeps the offsets below out of the registers that live through the tap loops)
+            const int l31e = lane_e & 31, lhie = lane_e >> 5;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int n = nb * 32 + l31e;
+                if (n >= p.Ng) continue;
+                const float bv = p.bias ? p.bias[n] : 0.f;
+                const unsigned yoff = ((unsigned)(4 * lhie) * (unsigned)p.yld + (unsigned)n) * 4u;
+                const unsigned roff = ((unsigned)(4 * lhie) * (unsigned)p.rld + (unsigned)n) * 4u;
+                float o[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    o[r] = fmaf(acc2[nb][r], 1.f / 2048.f, acc1[nb][r]) + bv;
+                    emax = max(emax, __float_as_uint(o[r]) & 0x7fffffffu);
+                }
+                if (p.act == ACT_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] = fmaxf(o[r], 0.f);
+                } else if (p.act != ACT_NONE) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] = rd_act(o[r], p.act);
+                }
+                if (p.res) {
+                    float rs[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        rs[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, (int)roff, (int)((unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.rld * 4u), 0));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] += rs[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[r]), ry, (int)yoff, (int)((unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.yld * 4u), 2);
+            }
+        } else {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int n = nb * 32 + l31;
@@ -271,6 +317,7 @@ __global__ void __launch_bounds__(512) conv_direct_h3_kernel(ConvParams p, Direc
                     __builtin_nontemporal_store(vv, &p.y[(row0 + ow) * p.yld + n]);
                 }
             }
+        }
         }
     }
     if ((emax >= 0x7f800000u || !(amax < 65504.f)) && p.range_flag) rd_raise_flag(p.range_flag);

@@ -326,29 +326,34 @@ __global__ void __launch_bounds__(256, 2) gemm_h1_kernel(ConvParams p, int ntn, 
                 // a 64-bit shift-add, a compare and an EXEC save / branch on each of its 128 four-byte stores.
                 // (buffer addressing: descriptor at the tile's first row, lane offset in the vector operand, row offset in the scalar one,
                 //  column block as immediate - zero vector instructions per access; aux 2 = nt, like the general path's stores)
-                const unsigned yoff = ((unsigned)(4 * lhi) * (unsigned)p.yld + (unsigned)(en0 + l31)) * 4u;
-                const unsigned roff = ((unsigned)(4 * lhi) * (unsigned)p.rld + (unsigned)(en0 + l31)) * 4u;
+                // (the lane's offsets are re-derived here on purpose: computed from an opaque copy of the lane id they cannot be hoisted out
+                //  of the tile loop, where they would sit in registers through the K loop - the kernel has none to spare)
+                int lane_e = lane;
+                asm volatile("" : "+v"(lane_e));
+                const int l31e = lane_e & 31, lhie = lane_e >> 5;
+                const unsigned yoff = ((unsigned)(4 * lhie) * (unsigned)p.yld + (unsigned)(en0 + l31e)) * 4u;
+                const unsigned roff = ((unsigned)(4 * lhie) * (unsigned)p.rld + (unsigned)(en0 + l31e)) * 4u;
                 const h1_rsrc ry = h1_make_rsrc(p.y + (size_t)(em0 + 64 * wave) * p.yld);
                 const h1_rsrc rr = h1_make_rsrc((p.res ? p.res : p.y) + (size_t)(em0 + 64 * wave) * (p.res ? p.rld : p.yld));
                 float bv[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bv[j] = p.bias ? p.bias[en0 + 32 * j + l31] : 0.f;
+                for (int j = 0; j < 4; ++j) bv[j] = p.bias ? p.bias[en0 + 32 * j + l31e] : 0.f;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
 #pragma unroll
-                    for (int r4 = 0; r4 < 16; r4 += 4) {          // four rows (consecutive pixels) x four column blocks at a time
-                        float o[4][4];
+                    for (int r4 = 0; r4 < 16; r4 += 2) {          // two rows x four column blocks at a time (four rows: two spilled registers)
+                        float o[2][4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
+                        for (int q = 0; q < 2; ++q)
 #pragma unroll
                             for (int j = 0; j < 4; ++j) o[q][j] = fmaf(acc[i][j][r4 + q], sinv, bv[j]);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) emax = max(emax, __float_as_uint(o[q][0]) & 0x7fffffffu);       // column block 0 carries the range check
+                        for (int q = 0; q < 2; ++q) emax = max(emax, __float_as_uint(o[q][0]) & 0x7fffffffu);       // column block 0 carries the range check
                         if constexpr ((ABL & 4) != 0) {
                         } else if (p.act == ACT_GELU) {
                             if constexpr ((ABL & 64) != 0) {          // A/B (RD_GEMM1_DBG=64, valid results): two GELUs per packed-fp32 instruction
 #pragma unroll
-                                for (int q = 0; q < 4; ++q)
+                                for (int q = 0; q < 2; ++q)
 #pragma unroll
                                     for (int j = 0; j < 4; j += 2) {
                                         const f32x2 g = rd_gelu2(f32x2{o[q][j], o[q][j + 1]});
@@ -357,39 +362,39 @@ __global__ void __launch_bounds__(256, 2) gemm_h1_kernel(ConvParams p, int ntn, 
                                     }
                             } else {
 #pragma unroll
-                                for (int q = 0; q < 4; ++q)
+                                for (int q = 0; q < 2; ++q)
 #pragma unroll
                                     for (int j = 0; j < 4; ++j) o[q][j] = rd_gelu(o[q][j]);
                             }
                         } else if (p.act == ACT_RELU) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q)
+                            for (int q = 0; q < 2; ++q)
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) o[q][j] = fmaxf(o[q][j], 0.f);
                         } else if (p.act != ACT_NONE) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q)
+                            for (int q = 0; q < 2; ++q)
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) o[q][j] = rd_act(o[q][j], p.act);
                         }
-                        const int row0 = 32 * i + 8 * (r4 >> 2);       // + q: wave-uniform row inside the wavefront's 64 (lhi sits in the lane offsets)
+                        const int row0 = 32 * i + 8 * (r4 >> 2) + (r4 & 3);       // + q: wave-uniform row inside the wavefront's 64 (lhi sits in the lane offsets)
                         if (p.res && !(ABL & 4)) {
-                            float rs[4][4];
+                            float rs[2][4];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
+                            for (int q = 0; q < 2; ++q) {
                                 const unsigned so = (unsigned)(row0 + q) * (unsigned)p.rld * 4u;
 #pragma unroll
                                 for (int j = 0; j < 4; ++j)
                                     rs[q][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, (int)(roff + 128u * j), (int)so, 0));
                             }
 #pragma unroll
-                            for (int q = 0; q < 4; ++q)
+                            for (int q = 0; q < 2; ++q)
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) o[q][j] += rs[q][j];
                         }
                         if (!((ABL & 1) && o[0][0] != 12345.678f)) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
+                            for (int q = 0; q < 2; ++q) {
                                 const unsigned so = (unsigned)(row0 + q) * (unsigned)p.yld * 4u;
 #pragma unroll
                                 for (int j = 0; j < 4; ++j)
