@@ -28,6 +28,7 @@ struct DirectGeom {
     int TR, TC, WPR;     // tile rows / cols, wavefronts per tile row
     int tiles_r, tiles_c;
     int N32;             // weight rows in LDS (Cout rounded up to 32)
+    int fast_epi;        // interior wavefront tiles store through buffer accesses (round 5; RD_DIRECT_FAST_EPI=0: A/B switch)
 };
 
 template <int NB, int KS>
@@ -247,7 +248,7 @@ __global__ void __launch_bounds__(512) conv_direct_h3_kernel(ConvParams p, Direc
         // load / store is a buffer access - descriptor at the row's first pixel, the lane's (pixel group, channel) offset in the vector
         // operand, the pixel in the scalar one: one instruction per 4-byte store.  The general path below spends a 64-bit multiply-add,
         // a compare and an EXEC save / branch on each (round 5; same change as the interior epilogue of kernels_gemm_h1.hip).
-        const bool interior = oh < p.OH && ow0 + wc0 + 32 <= p.OW;
+        const bool interior = g.fast_epi && oh < p.OH && ow0 + wc0 + 32 <= p.OW;
         if (interior) {
             typedef __amdgpu_buffer_rsrc_t rsrc_t;
             const size_t pix0 = ((size_t)img * p.OH + oh) * p.OW + ow0 + wc0;
@@ -390,6 +391,8 @@ void launch_conv_direct_h3(const ConvParams& p, hipStream_t s) {
         (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n > 0 ? n : 256;
     }();
+    static const int fast_epi = [] { const char* e = getenv("RD_DIRECT_FAST_EPI"); return e && e[0] == '0' ? 0 : 1; }();
+    g.fast_epi = fast_epi;
     const long ntiles = (long)p.N * g.tiles_r * g.tiles_c;
     // persistent workgroups: as many as fit the chip at once (two per CU when LDS and the 128-VGPR single-block kernels allow)
     const int per_cu = (nb == 1 && lds <= 80 * 1024 - 256) ? 2 : 1;

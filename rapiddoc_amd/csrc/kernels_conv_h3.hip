@@ -254,6 +254,10 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 && BM * BN >= 128 *
     // K loop (tracking max |a| there cost 35 % of the kernel's throughput).  Non-finite results that fp32 would also
     // produce only cost the caller a redundant fp32 re-run.
     const int ohw = p.OH * p.OW;
+    // (only the persistent 256 x 64 tile: the 256 x 128 one sits at the register limit, and the 4-wavefront tiles live on occupancy -
+    //  the second epilogue cost them 29 registers, i.e. a wavefront per SIMD)
+    constexpr bool FAST_OK = BM == 256 && BN == 64;
+    const bool interior_m = FAST_OK && p.fast_epi && em0 + BM <= p.M;      // (workgroup-uniform)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = en0 + (wn * TN + j) * 32 + l31;
@@ -269,6 +273,52 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 && BM * BN >= 128 *
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mb = em0 + (wm * TM + i) * 32 + 4 * lhi;
+            if constexpr (FAST_OK) if (p.out_mode == OUT_NHWC && interior_m) {
+                // Interior row tile (round 5, as in kernels_gemm_h1.hip): no bounds test, every load / store a buffer access (descriptor at
+                // the wavefront block's first row, lane offset in the vector operand, row in the scalar one): one instruction per store
+                typedef __amdgpu_buffer_rsrc_t rsrc_t;
+                const int wrow = __builtin_amdgcn_readfirstlane(em0 + (wm * TM + i) * 32);
+                const rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)wrow * p.yld, 0, 0x7fffffff, 0x00020000);
+                const rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res + (size_t)wrow * p.rld : p.y), 0, 0x7fffffff, 0x00020000);
+                const unsigned yoff = ((unsigned)(4 * lhi) * (unsigned)p.yld + (unsigned)co) * 4u;
+                const unsigned roff = ((unsigned)(4 * lhi) * (unsigned)p.rld + (unsigned)co) * 4u;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = half * 8 + e;
+                        o[e] = fmaf(acc2[i][j][r], 1.f / 2048.f, acc1[i][j][r]) + bv;
+                        emax = max(emax, __float_as_uint(o[e]) & 0x7fffffffu);
+                    }
+                    if (p.act == ACT_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = rd_gelu(o[e]);
+                    } else if (p.act == ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = fmaxf(o[e], 0.f);
+                    } else if (p.act != ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = rd_act(o[e], p.act);
+                    }
+                    if (p.res) {
+                        float rs[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int r = half * 8 + e;
+                            rs[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, (int)roff, (int)((unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.rld * 4u), 0));
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] += rs[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = half * 8 + e;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[e]), ry, (int)yoff, (int)((unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.yld * 4u), 0);
+                    }
+                }
+                continue;
+            }
             if (p.out_mode == OUT_NHWC) {
                 // eight values at a time: the activation switch and the residual test stay outside the element loops and
                 // the residual loads are unconditional (clamped row) and batched ahead of the stores - a load issued behind
@@ -349,7 +399,10 @@ static inline bool h3_is_1x1(const ConvParams& p) {
     return p.KH == 1 && p.KW == 1 && p.SH == 1 && p.SW == 1 && p.PT == 0 && p.PL == 0 && p.OH == p.H && p.OW == p.W;
 }
 template <int BM, int BN, int WM, int WN>
-static void h3_launch_cfg(const ConvParams& p, hipStream_t s) {
+static void h3_launch_cfg(const ConvParams& p_in, hipStream_t s) {
+    static const int fast_epi = [] { const char* e = getenv("RD_CONV_FAST_EPI"); return e && e[0] == '0' ? 0 : 1; }();
+    ConvParams p = p_in;
+    p.fast_epi = fast_epi;
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.Ng + BN - 1) / BN, ntiles = ntm * ntn;
     // 8-wavefront tiles: persistent workgroups, one per CU (their two LDS stages leave room for one only)
     static const int n_cu = [] {

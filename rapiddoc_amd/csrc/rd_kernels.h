@@ -46,6 +46,7 @@ struct ConvParams {
     // inverse of that scale (prepare_gemm_h1_weights), or nullptr / 0
     const uint16_t* w1 = nullptr;
     float w1_inv = 0.f;
+    int fast_epi = 1;               // interior tiles of the split implicit-GEMM kernels store through buffer accesses (round 5; RD_CONV_FAST_EPI=0: A/B)
 };
 void launch_conv_igemm(const ConvParams& p, hipStream_t s);
 bool skinny_gemm_applies(int M, int K);   // true when launch_conv_igemm will take the small-M path that can fuse ln_g / ln_b
