@@ -201,16 +201,27 @@ class RegionOcr:
 
     # ------------------------------------------------------------------ whole batch
     def __call__(self, pages: torch.Tensor, layout_dets_per_page: Sequence[Sequence[dict]], det_maps_fn=None,
-                 page_langs: Optional[Sequence[str]] = None, mask_boxes_per_page: Optional[Sequence[Sequence[dict]]] = None) -> List[List[dict]]:
+                 page_langs: Optional[Sequence[str]] = None, mask_boxes_per_page: Optional[Sequence[Sequence[dict]]] = None,
+                 page_keys: Optional[Sequence[int]] = None, all_langs: Optional[Sequence[str]] = None) -> List[List[dict]]:
         """pages [P,H,W,3] u8 RGB (GPU); returns, per page, the layout detections followed by their OcrText spans
         (`layout_res` of the reference after both OCR stages).  `det_maps_fn(regions, (gh, gw), (dh, dw))` may supply the
         det maps of a size group (see `_detect_group`); regions = [(page, region dict, useful_list)].
         `page_langs[p]`: the language of page p (the `lang` of the reference's input tuples); regions are grouped by language first
         and every language's lines are recognised by that language's pipeline in one pooled call.
         `mask_boxes_per_page[p]`: further {'bbox': ...} entries treated like the page's formulas - the reference's `checkbox_res`
-        (`single_page_mfdetrec_res + checkbox_res`, analyze_utils.py:133-136)."""
+        (`single_page_mfdetrec_res + checkbox_res`, analyze_utils.py:133-136).
+        Page-sharded runs (the pipeline's `rec_width_sync` set, rapiddoc_amd.dist.GlobalLineWidths): `page_keys[p]` = page p's
+        position in the GLOBAL page list - the pooling key of the recogniser's width exchange, which makes the strings and scores
+        those of the unsharded batch; `all_langs` = every language of the global batch in one agreed order (default: this
+        object's language) - each rank makes one pooled recogniser call per language, also for a language it holds no region of,
+        so the exchanges pair up across ranks."""
         assert pages.dtype == torch.uint8 and (pages.is_cuda or self.det_raw_fn is not None)
         P, H, W, _ = pages.shape
+        assert page_keys is None or len(page_keys) == P
+        pipes = list(self.pipe.values()) if isinstance(self.pipe, dict) else [self.pipe]
+        synced = any(getattr(pp, "rec_width_sync", None) is not None for pp in pipes)
+        if synced and page_keys is None:
+            raise ValueError("rec_width_sync is set on the OCR pipeline: hand over page_keys (the pages' positions in the global page list)")
         out: List[List[dict]] = [list(d) for d in layout_dets_per_page]
         regions = []                                   # (page, region dict, useful_list, formula boxes in crop coords)
         for p, dets in enumerate(layout_dets_per_page):
@@ -222,7 +233,7 @@ class RegionOcr:
                 if useful[6] < 2 * PASTE or useful[7] < 2 * PASTE:        # inverted box: the reference's np.ones would raise
                     continue
                 regions.append((p, r, useful, _formula_boxes_in_crop(formulas, useful)))
-        if not regions:
+        if not regions and not synced:
             return out
         langs = [self.lang if page_langs is None else page_langs[p] for p, _r, _u, _f in regions]
         groups = ocr_host.det_buckets([(u[7], u[6]) for _, _, u, _ in regions], langs, det_batch_num=len(regions))
@@ -285,14 +296,22 @@ class RegionOcr:
                 spans_per_img.append(spans)
                 quads_per_img.append(np.asarray(quads, dtype=np.float32).reshape(-1, 4, 2))
             pending.append((canv, quads_per_img, spans_per_img, [regions[ridx][0] for ridx in members], _lang))
-        if not pending:
+        if not pending and not synced:
             return out
         # rec: every line of the page batch - per language - in ONE pooled call (analyze_utils.py:216-252), ordered page by page
         texts_all: List = [None] * len(pending)
-        for lang in dict.fromkeys(e[4] for e in pending):
+        key_of = (lambda p: p) if page_keys is None else (lambda p: int(page_keys[p]))
+        rec_langs = list(dict.fromkeys(e[4] for e in pending))
+        if synced:                                     # the agreed language list: every rank makes the same pooled calls
+            agreed = list(all_langs) if all_langs is not None else [self.lang]
+            missing = [lg for lg in rec_langs if lg not in agreed]
+            if missing:
+                raise ValueError(f"languages {missing} are not in all_langs {agreed}: a page-sharded run needs the global list")
+            rec_langs = agreed
+        for lang in rec_langs:
             idx = [i for i, e in enumerate(pending) if e[4] == lang]
             res = self._pipe_for(lang).rec_forward_sources([(pending[i][0], pending[i][1]) for i in idx],
-                                                           image_keys=[pending[i][3] for i in idx])
+                                                           image_keys=[[key_of(p) for p in pending[i][3]] for i in idx])
             for i, r in zip(idx, res):
                 texts_all[i] = r
         for (canv, _q, spans_per_img, pages_of, _lg), texts in zip(pending, texts_all):
@@ -385,7 +404,7 @@ class TableOcr:
         if self.rec_fn is not None:
             lines = self.rec_fn(canvas, quads)
         else:
-            lines = self.det._pipe_for(lang or self.det.lang).rec_forward_sources([(canvas.contiguous(), [quads])], image_keys=[[0]])[0][0]
+            lines = self.det._pipe_for(lang or self.det.lang).rec_forward_sources([(canvas.contiguous(), [quads])], image_keys=[[0]], pooled=False)[0][0]
         return [[q for q in quads], [table_host.normalize_table_ocr_text(t) for t, _s in lines], [s for _t, s in lines]]
 
     def _word_level(self, canvas: torch.Tensor, quads: np.ndarray, h: int, w: int, lang: Optional[str]) -> list:
@@ -395,7 +414,7 @@ class TableOcr:
             lines = self.rec_fn(canvas, quads)                     # [(text, score, [(word, conf, box)])]
         else:
             raw = self.det._pipe_for(lang or self.det.lang).rec_forward_sources([(canvas.contiguous(), [quads])], image_keys=[[0]],
-                                                                                want_words=True)[0][0]
+                                                                                want_words=True, pooled=False)[0][0]
             # lines the recogniser marked degenerate (no homography: `ws` None) or read nothing in carry no words: they never reach the
             # box arithmetic (whose inverse rotation would divide by a zero side / solve a singular system) and drop out below
             good = [i for i, (t, _s, ws) in enumerate(raw) if ws and t]
@@ -494,7 +513,7 @@ class RegionTextModel:
             quads = [np.asarray([q for q in b if q[2][0] - q[0][0] >= MIN_WIDTH], dtype=np.float32).reshape(-1, 4, 2) for b in boxes]
             pending.append((canv, quads, ids))
         if pending:
-            lines_all = pipe.rec_forward_sources([(c, q) for c, q, _i in pending], image_keys=[ids for _c, _q, ids in pending])
+            lines_all = pipe.rec_forward_sources([(c, q) for c, q, _i in pending], image_keys=[ids for _c, _q, ids in pending], pooled=False)
             for (_c, _q, ids), lines in zip(pending, lines_all):
                 for k, i in enumerate(ids):
                     texts[i] = "\n".join(t for t, s in lines[k] if s >= MIN_CONFIDENCE and t)
@@ -558,8 +577,11 @@ class PageAnalyzer:
         self.last_rotate_labels: List[str] = []
 
     def __call__(self, pages: torch.Tensor, det_maps_fn=None, page_scales: Optional[Sequence[float]] = None,
-                 table_det_maps_fn=None, page_langs: Optional[Sequence[str]] = None) -> List[List[dict]]:
-        """`page_scales[p]`: the render scale the reference carries with every page (the `scale` of its input tuples); only the
+                 table_det_maps_fn=None, page_langs: Optional[Sequence[str]] = None,
+                 page_keys: Optional[Sequence[int]] = None, all_langs: Optional[Sequence[str]] = None) -> List[List[dict]]:
+        """`page_keys` / `all_langs`: page-sharded runs, see RegionOcr.__call__ (the OCR stage's pooled recogniser call is the one step
+        of the batch whose result depends on the other pages; tables, formulas and layout are per region / per page).
+        `page_scales[p]`: the render scale the reference carries with every page (the `scale` of its input tuples); only the
         `formula_boxes` written next to a table's `html` use it (analyze_utils.py:405-418).  Default 1."""
         assert pages.dtype == torch.uint8 and pages.dim() == 4 and (pages.is_cuda or self.ocr.det_raw_fn is not None)
         # 0. page orientation (off by default): classify every page, turn the 90 / 270 ones upright (get_rotate_image, utils/boxbase.py:
@@ -624,7 +646,8 @@ class PageAnalyzer:
                                "vl_ocr": True, "original_label": r.get("original_label"), "original_order": r.get("original_order"),
                                "polygon_points": r.get("polygon_points")})
         else:
-            out = self.ocr(pages, dets, det_maps_fn=det_maps_fn, page_langs=page_langs, mask_boxes_per_page=checkbox_res)
+            out = self.ocr(pages, dets, det_maps_fn=det_maps_fn, page_langs=page_langs, mask_boxes_per_page=checkbox_res,
+                           page_keys=page_keys, all_langs=all_langs)
         # 5. tables: one pooled `batch_predict` of a CustomBaseModel-shaped model (seam S1, batch_analyze.py:359-379) or, for a
         #    `predict`-shaped one (RapidTableModel, seam S3), the reference's own table stage with the table OCR on the GPU
         if self.table_model is not None and hasattr(self.table_model, "batch_predict"):

@@ -242,7 +242,8 @@ class PagePipeline:
         return self.rec_forward_sources([(pages, quads_per_page)])[0]
 
     def rec_forward_sources(self, sources: Sequence[Tuple[torch.Tensor, Sequence[np.ndarray]]],
-                            image_keys: Optional[Sequence[Sequence[int]]] = None, want_words: bool = False):
+                            image_keys: Optional[Sequence[Sequence[int]]] = None, want_words: bool = False,
+                            pooled: bool = True):
         """`sources`: [(images [P,H,W,3] u8 on the GPU, text-line quads per image)] - image arrays of DIFFERENT sizes whose
         lines are recognised TOGETHER, the way the reference pools every line of a page batch per language before it sorts
         and chunks them (analyze_utils.py:216-252 -> rapid_ocr.py:404-472).  Returns, per source, per image, [(text, score)]
@@ -252,7 +253,11 @@ class PagePipeline:
         analyze.RegionOcr, RegionTextModel - gets it): a tripped engine is switched to native fp32 and the lines are
         recognised again.  `want_words` (strict two-stage mode only): every line comes back as (text, score, words) with
         words = {cols, confs, n_steps, wh_ratio, max_wh_ratio, crop_hw} - the kept characters' time steps and probabilities and the
-        numbers rapidocr's CTCLabelDecode / cal_rec_boxes turn into word boxes (rapiddoc_amd/word_boxes.py; table OCR, analyze_utils.py:308)."""
+        numbers rapidocr's CTCLabelDecode / cal_rec_boxes turn into word boxes (rapiddoc_amd/word_boxes.py; table OCR, analyze_utils.py:308).
+        `pooled=False`: a call whose lines the reference does NOT pool across pages (one table's OCR, analyze_utils.py:478-540: one
+        recogniser call per table) - its widths depend on its own lines only, so a page-sharded run needs no exchange for it and
+        `rec_width_sync` is not consulted (ranks hold different numbers of tables: a collective here would not pair up)."""
+        self._sync_this_call = bool(pooled)
         if not self._in_run_batch:          # a call of its own: a new round of the width collective (run_batch opens one per batch)
             self._width_sync_epoch += 1
         out = self._rec_forward_sources_once(sources, image_keys, want_words)
@@ -326,6 +331,10 @@ class PagePipeline:
 
     def _rec_forward_sources_once(self, sources, image_keys=None, want_words=False):
         t0 = time.perf_counter()
+        if not sources:                 # nothing to read on this rank: it still takes part in the batch's width exchange
+            if self.rec_width_sync is not None and self.rec_mode == "strict" and self.rec_two_stage and getattr(self, "_sync_this_call", True):
+                self._synced_widths(self.rec_width_sync, np.zeros(0, np.int64), np.zeros(0))
+            return []
         dev = sources[0][0].device
         # flat line list in source-major, image-major order (the reference's pooled order: pages, then a page's spans)
         src_of, page_of, quad_list, n_img = [], [], [], []
@@ -339,7 +348,7 @@ class PagePipeline:
                     src_of.append(np.full(len(q), si, np.int32))
                     page_of.append(np.full(len(q), pi, np.int32))
         empty = [[[] for _ in range(k)] for k in n_img]
-        sync = self.rec_width_sync if (self.rec_mode == "strict" and self.rec_two_stage) else None
+        sync = self.rec_width_sync if (self.rec_mode == "strict" and self.rec_two_stage and getattr(self, "_sync_this_call", True)) else None
         if not quad_list:
             if sync is not None:
                 self._synced_widths(sync, np.zeros(0, np.int64), np.zeros(0))       # every rank makes the same calls

@@ -333,3 +333,78 @@ def test_prefetching_the_next_batch_changes_no_result(golden_dir):
         got = digest(pool.run_batch(dev_sets[k], None, det_maps_override=maps[k], prefetch=dev_sets[k + 1] if k + 1 < 3 else None))
         assert same(got, ref[k]), k
         assert all(p.stats["front_prefetched"] == (1.0 if k > 0 else 0.0) for p in pool.pipes)
+
+
+def test_region_ocr_of_a_page_shard_reads_what_the_whole_batch_reads(golden_dir):
+    """analyze.RegionOcr under page sharding: with `rec_width_sync` set and the pages' GLOBAL positions handed over as `page_keys`, the
+    shard's lines are recognised at the widths the reference gives them inside the pooled list of the WHOLE batch
+    (analyze_utils.py:216-252 -> rapid_ocr.py:404-449) - strings and scores of the unsharded call.  The exchange is played by a
+    two-round stand-in (round one records every shard's (key, ratio) contribution, round two answers from the union: what
+    dist.GlobalLineWidths computes from its all-gather, covered by tests/test_rec_width_sync_gloo.py)."""
+    from rapiddoc_amd import ocr_host
+    from rapiddoc_amd.analyze import RegionOcr
+    from rapiddoc_amd.pages import synth_batch
+    from rapiddoc_amd.pipeline import PagePipeline, render_text_maps
+    from rapiddoc_amd import weights as W
+    states = {k: W.synth_state_dict(W.load_manifest(golden_dir / f"manifest_{k}.json"), 0) for k in ("ppocrv6_det", "ppocrv6_rec")}
+    pipe = PagePipeline(states, rec_mode="strict", n_rec_streams=2)
+    pages_np, boxes = synth_batch(3, 3)
+    pages = torch.from_numpy(pages_np).cuda()
+
+    def region(x0, y0, x1, y1, order):
+        return {"category_id": 1, "original_label": "text", "original_order": order,
+                "poly": [x0, y0, x1, y0, x1, y1, x0, y1], "score": 0.9}
+    dets = [[region(60, 50, 1140, 985, 0), region(60, 990, 645, 1420, 1)] for _ in range(3)]
+
+    def maps_fn_for(first_page):
+        def maps_fn(regs, ghw, dhw):
+            per_img = []
+            for p, r, useful in regs:
+                px, py, x0, y0 = useful[0], useful[1], useful[2], useful[3]
+                bb = np.asarray(boxes[first_page + p], dtype=np.float64).reshape(-1, 4)
+                x1, y1 = r["poly"][4], r["poly"][5]
+                inside = bb[(bb[:, 0] >= x0) & (bb[:, 2] <= x1) & (bb[:, 1] >= y0) & (bb[:, 3] <= y1)]
+                per_img.append(inside - [x0 - px, y0 - py, x0 - px, y0 - py])
+            return render_text_maps(per_img, ghw, dhw, pages.device)
+        return maps_fn
+
+    def spans_of(out):
+        return [[(d["text"], d["score"], d["category_id"]) for d in page if d["category_id"] in (15, 16)] for page in out]
+    ocr = RegionOcr(pipe)
+    whole = spans_of(ocr(pages, [list(d) for d in dets], det_maps_fn=maps_fn_for(0)))
+    assert all(len(s) > 5 for s in whole)
+    shards = [(0, 2), (2, 3)]                          # rank 0: pages 0-1, rank 1: page 2
+
+    class Exchange:
+        def __init__(self):
+            self.contrib, self.rank, self.answer = {}, 0, False
+
+        def __call__(self, keys, ratios):
+            if not self.answer:                        # round one: record, answer with the local rule
+                self.contrib[self.rank] = (np.array(keys), np.array(ratios))
+                return ocr_host.rec_reference_widths(list(ratios))
+            ks = np.concatenate([self.contrib[r][0] for r in sorted(self.contrib)])
+            rs = np.concatenate([self.contrib[r][1] for r in sorted(self.contrib)])
+            rk = np.concatenate([np.full(len(self.contrib[r][0]), r) for r in sorted(self.contrib)])
+            assert np.array_equal(self.contrib[self.rank][0], keys) and np.array_equal(self.contrib[self.rank][1], ratios)
+            order = np.argsort(ks, kind="stable")      # pooled page by page (lines of one page live on one rank, in its order)
+            w, r = ocr_host.rec_reference_widths(rs[order].tolist())
+            mine = rk[order] == self.rank
+            return w[mine], r[mine]
+    ex = Exchange()
+    pipe.rec_width_sync = ex
+    with pytest.raises(ValueError, match="page_keys"):
+        ocr(pages[:1], [list(dets[0])], det_maps_fn=maps_fn_for(0))
+    local = {}
+    for ex.answer in (False, True):
+        for ex.rank, (a, b) in enumerate(shards):
+            local[ex.rank] = spans_of(ocr(pages[a:b].contiguous(), [list(d) for d in dets[a:b]], det_maps_fn=maps_fn_for(a),
+                                          page_keys=list(range(a, b))))
+    assert sorted(set(ex.contrib[0][0].tolist())) == [0, 1] and sorted(set(ex.contrib[1][0].tolist())) == [2]      # GLOBAL page keys
+    assert local[0] + local[1] == whole
+    # a rank without a single region still takes part in the exchange (its peers' collective would not pair up otherwise)
+    n_before = len(ex.contrib)
+    ex.rank, ex.answer = 7, False
+    assert ocr(pages[:1], [[]], page_keys=[9]) == [[]]
+    assert len(ex.contrib) == n_before + 1 and len(ex.contrib[7][0]) == 0
+    pipe.rec_width_sync = None
