@@ -18,7 +18,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # wavefront's MFMAs on gfx950 while plain VALU does (profiles/r4_probe_mfma_valu_wall.txt): the ws mixer's GELU is written scalar
 # (RD_GELU_SCALAR) and must stay scalar for its GELU-in-the-middle step order to pay.
 # kernels_gemm_h1.hip: the activation split next to the MFMAs must stay on plain VALU (v_cvt_pk_f16_f32 + v_fma_mix), same reason.
-FILE_FLAGS = {"kernels_mixer_ws.hip": ["-fno-slp-vectorize", "-DRD_GELU_SCALAR"], "kernels_gemm_h1.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"kernels_mixer_ws.hip": ["-fno-slp-vectorize", "-DRD_GELU_SCALAR"], "kernels_gemm_h1.hip": ["-fno-slp-vectorize"],
+              "kernels_stem_fused.hip": ["-fno-slp-vectorize"]}
 
 
 def extra_flags_for(src: str) -> list:

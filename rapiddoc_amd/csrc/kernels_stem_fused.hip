@@ -13,8 +13,11 @@
 // fragment reads conflict-free).  stem1's K = 27 is laid out as 3 k-steps of 16 slots (one kernel row each: 9 taps x channels
 // contiguous in the channel-interleaved patch, 7 zero-weight slots).  Halo recompute: 1.33x for stem1, 1.16x for stem2a.
 // HBM traffic per tile: the patch + the cat tile.  Persistent workgroups; the next tile's patch is prefetched into registers.
-// Arithmetic: the split-fp16 scheme of kernels_conv_h3.hip (x = hi + lo 2^-11, three MFMAs per product, fp32 accumulate); the
-// `fp32` precision mode keeps the four separate fp32 kernels.
+// Arithmetic (round 5): the split of kernels_gemm_h1.hip - x = hi + lo with the low plane UNSCALED (gfx950's matrix cores keep fp16
+// subnormals), each weight matrix pre-scaled by a power of two so that its low plane is a normal fp16 number (max |w| s in [2^13, 2^14)),
+// the inverse scale applied in the epilogue; three MFMAs per product, fp32 accumulate.  1.5 VALU operations per split element instead
+// of the 3.5 the scaled form compiled to here.  The `fp32` precision mode keeps the four separate fp32 kernels.
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -41,6 +44,7 @@ struct SfGeom {
     // weight image (halfs): [w1 hi | w1 lo | w2a hi | w2a lo | w2b hi | w2b lo], rows = output channels
     static constexpr int W1_H = C1 * R1, W2A_H = NA * R2A, W2B_H = C1 * R2B;
     static constexpr int W_HALFS = 2 * (W1_H + W2A_H + W2B_H);
+    static constexpr int IMG_HALFS = W_HALFS + 16;               // + six floats: the inverse scales and the scales of w1 / w2a / w2b
     static constexpr int BIAS_FLOATS = C1 + NA + C1;
     static constexpr int E_FLOATS = SF_EH * SF_EW * SE;
     static constexpr int A_FLOATS_RAW = SF_AH * SF_AW * SA;
@@ -63,14 +67,23 @@ struct StemFusedParams {
     int dbg;                                    // developer: RD_STEM_DBG ablation bits (results garbage): 1 no stem1, 2 no stem2a, 4 no pool, 8 no stem2b, 16 no patch traffic
 };
 
-__device__ __forceinline__ void sf_split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
+// x = hi + lo, hi = fp16(x), lo = fp16(x - hi) (kernels_gemm_h1.hip h1_split8): one packed conversion per pair whose halves are the f16
+// sources of two v_fma_mix{lo,hi}_f16; `neg1` = -1.0f in a scalar register the compiler cannot see through (a literal folds the fused
+// multiply-add into cvt-back + subtract + cvt)
+typedef _Float16 sf_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sf_split8(const f32x4 a, const f32x4 b, float neg1, f16x8& hi, f16x8& lo) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        _Float16 h0, l0, h1, l1;
-        rd_split(a[e], h0, l0);
-        rd_split(b[e], h1, l1);
-        hi[e] = h0; hi[4 + e] = h1;
-        lo[e] = l0; lo[4 + e] = l1;
+    for (int e = 0; e < 4; e += 2) {
+        const sf_f16x2 ha = __builtin_convertvector(f32x2{a[e], a[e + 1]}, sf_f16x2);
+        const sf_f16x2 hb = __builtin_convertvector(f32x2{b[e], b[e + 1]}, sf_f16x2);
+        hi[e] = ha[0];
+        hi[e + 1] = ha[1];
+        hi[4 + e] = hb[0];
+        hi[4 + e + 1] = hb[1];
+        lo[e] = (_Float16)__builtin_fmaf((float)ha[0], neg1, a[e]);
+        lo[e + 1] = (_Float16)__builtin_fmaf((float)ha[1], neg1, a[e + 1]);
+        lo[4 + e] = (_Float16)__builtin_fmaf((float)hb[0], neg1, b[e]);
+        lo[4 + e + 1] = (_Float16)__builtin_fmaf((float)hb[1], neg1, b[e + 1]);
     }
 }
 
@@ -95,6 +108,10 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
+    const float* scl = reinterpret_cast<const float*>(p.wimg + G::W_HALFS);       // [inv1, inv2a, inv2b, s1, s2a, s2b] (powers of two)
+    const float inv1 = scl[0], inv2a = scl[1], inv2b = scl[2], sc1 = scl[3], sc2a = scl[4], sc2b = scl[5];
+    float neg1 = -1.f;
+    asm volatile("" : "+s"(neg1));
 
     // weights + biases -> LDS, once per (persistent) workgroup
     for (int i = tid; i < G::W_HALFS / 8; i += SF_NT)
@@ -175,32 +192,46 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
             f32x16 acc1[G::NB1], acc2[G::NB1];
 #pragma unroll
             for (int nb = 0; nb < G::NB1; ++nb) {
-                const float bv = b1[min(nb * 32 + l31, C1 - 1)];
+                const float bv = b1[min(nb * 32 + l31, C1 - 1)] * sc1;       // (the accumulators hold sums of x (w s1))
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { acc1[nb][r] = bv; acc2[nb][r] = 0.f; }
             }
             const float* src0 = As + 2 * ey * SF_PROW + 2 * ex * 3 + 8 * lhi;
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
+            // Software pipeline (round 5): the fragments of kernel row kh + 1 are requested BEFORE the matrix instructions of row kh
+            // are issued (the compiler's own order was load -> wait -> split -> MFMA per step: every step paid the LDS latency with
+            // two wavefronts per SIMD to hide it).  sched_barrier keeps the requests where they are written.
+            f32x2 q[4];
+            f16x8 wh[G::NB1], wl[G::NB1];
+            auto fetch1 = [&](int kh) {
                 const float* src = src0 + kh * SF_PROW;
-                f32x4 v0, v1;
-                {
-                    const f32x2 q0 = *reinterpret_cast<const f32x2*>(src), q1 = *reinterpret_cast<const f32x2*>(src + 2);
-                    const f32x2 q2 = *reinterpret_cast<const f32x2*>(src + 4), q3 = *reinterpret_cast<const f32x2*>(src + 6);
-                    v0 = f32x4{q0[0], q0[1], q1[0], q1[1]};
-                    v1 = f32x4{q2[0], q2[1], q3[0], q3[1]};
-                }
-                f16x8 ah, al;
-                sf_split8(v0, v1, ah, al);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q[i] = *reinterpret_cast<const f32x2*>(src + 2 * i);
 #pragma unroll
                 for (int nb = 0; nb < G::NB1; ++nb) {
                     const _Float16* wb = W1h + min(nb * 32 + l31, C1 - 1) * G::R1 + 8 * lhi + kh * 16;
-                    const f16x8 bh = *reinterpret_cast<const f16x8*>(wb);
-                    const f16x8 bl = *reinterpret_cast<const f16x8*>(wb + G::W1_H);
-                    acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[nb], 0, 0, 0);
-                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[nb], 0, 0, 0);
-                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[nb], 0, 0, 0);
+                    wh[nb] = *reinterpret_cast<const f16x8*>(wb);
+                    wl[nb] = *reinterpret_cast<const f16x8*>(wb + G::W1_H);
                 }
+            };
+            fetch1(0);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const f32x4 v0 = f32x4{q[0][0], q[0][1], q[1][0], q[1][1]}, v1 = f32x4{q[2][0], q[2][1], q[3][0], q[3][1]};
+                f16x8 bh[G::NB1], bl[G::NB1];
+#pragma unroll
+                for (int nb = 0; nb < G::NB1; ++nb) { bh[nb] = wh[nb]; bl[nb] = wl[nb]; }
+                f16x8 ah, al;
+                sf_split8(v0, v1, neg1, ah, al);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kh + 1 < 3) fetch1(kh + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nb = 0; nb < G::NB1; ++nb) {
+                    acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nb], acc1[nb], 0, 0, 0);
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[nb], acc2[nb], 0, 0, 0);
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[nb], acc2[nb], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int nb = 0; nb < G::NB1; ++nb) {
@@ -209,7 +240,7 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
                 if (inner && mb + 1 < G::MB1 && (C1 % 32 == 0 || nb + 1 < G::NB1)) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        dst[((r & 3) + 8 * (r >> 2)) * G::SE] = fmaxf(fmaf(acc2[nb][r], 1.f / 2048.f, acc1[nb][r]), 0.f);
+                        dst[((r & 3) + 8 * (r >> 2)) * G::SE] = fmaxf((acc1[nb][r] + acc2[nb][r]) * inv1, 0.f);
                 } else {
                     const int mr0 = mb * 32 + 4 * lhi;
                     const int ry = mr0 / SF_EW, rx = mr0 - ry * SF_EW;      // row / column of element r = 0; the others by carry
@@ -218,7 +249,7 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
                         const int off = (r & 3) + 8 * (r >> 2);
                         int cx = rx + off, cy = ry;
                         if (cx >= SF_EW) { cx -= SF_EW; cy += 1; }
-                        float v = fmaxf(fmaf(acc2[nb][r], 1.f / 2048.f, acc1[nb][r]), 0.f);
+                        float v = fmaxf((acc1[nb][r] + acc2[nb][r]) * inv1, 0.f);
                         if (ty0 + cy >= p.H2 || tx0 + cx >= W2n) v = 0.f;        // beyond the map: the zero padding of stem2a / the pool
                         if (mr0 + off < SF_EH * SF_EW && nn < C1) dst[off * G::SE] = v;
                     }
@@ -233,27 +264,39 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
             const int m = min(mb * 32 + l31, SF_AH * SF_AW - 1);
             const int ay = m / SF_AW, ax = m - ay * SF_AW;
             const int nrow = min(l31, G::NA - 1);
-            const float bv = b2a[nrow];
+            const float bv = b2a[nrow] * sc2a;
             f32x16 acc1, acc2;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc1[r] = bv; acc2[r] = 0.f; }
             const float* src0 = Es + (ay * SF_EW + ax) * G::SE;
             const _Float16* wb = W2Ah + nrow * G::R2A + 8 * lhi;
-#pragma unroll
-            for (int j = 0; j < G::K2A / 16; ++j) {
+            f32x4 nv0, nv1;
+            f16x8 nbh, nbl;
+            auto fetch2a = [&](int j) {
                 // k0 = 16 j + 8 lhi -> (tap, channel): both halves resolved at compile time, one select per k-step
                 constexpr int CAc = G::CA;
                 const int t0 = (16 * j) / CAc, c0 = (16 * j) % CAc, t1 = (16 * j + 8) / CAc, c1 = (16 * j + 8) % CAc;
                 const int o0 = ((t0 >> 1) * SF_EW + (t0 & 1)) * G::SE + c0, o1 = ((t1 >> 1) * SF_EW + (t1 & 1)) * G::SE + c1;
                 const float* src = src0 + (lhi ? o1 : o0);
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+                nv0 = *reinterpret_cast<const f32x4*>(src);
+                nv1 = *reinterpret_cast<const f32x4*>(src + 4);
+                nbh = *reinterpret_cast<const f16x8*>(wb + 16 * j);
+                nbl = *reinterpret_cast<const f16x8*>(wb + G::W2A_H + 16 * j);
+            };
+            fetch2a(0);
+#pragma unroll
+            for (int j = 0; j < G::K2A / 16; ++j) {        // (pipelined like stem1: step j + 1's fragments travel under step j's MFMAs)
+                const f32x4 v0 = nv0, v1 = nv1;
+                const f16x8 bh = nbh, bl = nbl;
                 f16x8 ah, al;
-                sf_split8(v0, v1, ah, al);
-                const f16x8 bh = *reinterpret_cast<const f16x8*>(wb + 16 * j);
-                const f16x8 bl = *reinterpret_cast<const f16x8*>(wb + G::W2A_H + 16 * j);
+                sf_split8(v0, v1, neg1, ah, al);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 1 < G::K2A / 16) fetch2a(j + 1);
+                __builtin_amdgcn_sched_barrier(0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             float* dst = As + (mb * 32 + 4 * lhi) * G::SA + l31;
             const bool lane_on = l31 < G::CB;               // channels NA .. CB - 1 are the zero padding of the a tile
@@ -261,7 +304,7 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
             if (inner && mb + 1 < G::MB2) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = fmaf(acc2[r], 1.f / 2048.f, acc1[r]);
+                    const float v = (acc1[r] + acc2[r]) * inv2a;
                     if (lane_on) dst[((r & 3) + 8 * (r >> 2)) * G::SA] = real ? fmaxf(v, 0.f) : 0.f;
                 }
             } else {
@@ -272,7 +315,7 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
                     const int off = (r & 3) + 8 * (r >> 2);
                     int cx = rx + off, cy = ry;
                     if (cx >= SF_AW) { cx -= SF_AW; cy += 1; }
-                    float v = fmaxf(fmaf(acc2[r], 1.f / 2048.f, acc1[r]), 0.f);
+                    float v = fmaxf((acc1[r] + acc2[r]) * inv2a, 0.f);
                     if (ty0 + cy >= p.H2 || tx0 + cx >= W2n || !real) v = 0.f;   // padding of stem2b; zero pad channels
                     if (mr0 + off < SF_AH * SF_AW && lane_on) dst[off * G::SA] = v;
                 }
@@ -312,29 +355,46 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
             f32x16 acc1[G::NB3], acc2[G::NB3];
 #pragma unroll
             for (int nb = 0; nb < G::NB3; ++nb) {
-                const float bv = b2b[min(nb * 32 + l31, C1 - 1)];
+                const float bv = b2b[min(nb * 32 + l31, C1 - 1)] * sc2b;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { acc1[nb][r] = bv; acc2[nb][r] = 0.f; }
             }
             const float* src0 = As + (by * SF_AW + bx) * G::SA;
-#pragma unroll
-            for (int j = 0; j < G::K2B / 16; ++j) {
+            f32x4 nv0, nv1;
+            f16x8 nwh[G::NB3], nwl[G::NB3];
+            auto fetch2b = [&](int j) {
                 constexpr int CBc = G::CB;
                 const int t0 = (16 * j) / CBc, c0 = (16 * j) % CBc, t1 = (16 * j + 8) / CBc, c1 = (16 * j + 8) % CBc;
                 const int o0 = ((t0 >> 1) * SF_AW + (t0 & 1)) * G::SA + c0, o1 = ((t1 >> 1) * SF_AW + (t1 & 1)) * G::SA + c1;
                 const float* src = src0 + (lhi ? o1 : o0);
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
-                f16x8 ah, al;
-                sf_split8(v0, v1, ah, al);
+                nv0 = *reinterpret_cast<const f32x4*>(src);
+                nv1 = *reinterpret_cast<const f32x4*>(src + 4);
 #pragma unroll
                 for (int nb = 0; nb < G::NB3; ++nb) {
                     const int nrow = min(nb * 32 + l31, C1 - 1);
-                    const f16x8 bh = *reinterpret_cast<const f16x8*>(W2Bh + nrow * G::R2B + 16 * j + 8 * lhi);
-                    const f16x8 bl = *reinterpret_cast<const f16x8*>(W2Bl + nrow * G::R2B + 16 * j + 8 * lhi);
-                    acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[nb], 0, 0, 0);
-                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[nb], 0, 0, 0);
-                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[nb], 0, 0, 0);
+                    nwh[nb] = *reinterpret_cast<const f16x8*>(W2Bh + nrow * G::R2B + 16 * j + 8 * lhi);
+                    nwl[nb] = *reinterpret_cast<const f16x8*>(W2Bl + nrow * G::R2B + 16 * j + 8 * lhi);
                 }
+            };
+            fetch2b(0);
+#pragma unroll
+            for (int j = 0; j < G::K2B / 16; ++j) {        // (pipelined like stem1)
+                const f32x4 v0 = nv0, v1 = nv1;
+                f16x8 bh[G::NB3], bl[G::NB3];
+#pragma unroll
+                for (int nb = 0; nb < G::NB3; ++nb) { bh[nb] = nwh[nb]; bl[nb] = nwl[nb]; }
+                f16x8 ah, al;
+                sf_split8(v0, v1, neg1, ah, al);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 1 < G::K2B / 16) fetch2b(j + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nb = 0; nb < G::NB3; ++nb) {
+                    acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nb], acc1[nb], 0, 0, 0);
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[nb], acc2[nb], 0, 0, 0);
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[nb], acc2[nb], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             // The next tile's patch (requested above, before these MFMAs) must have landed BEFORE the stores below are issued: loads
             // and stores retire in issue order, and the compiler's wait for `pre` at the top of the next tile would otherwise be a
@@ -349,7 +409,7 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
                 if (inner && (C1 % 32 == 0 || nb + 1 < G::NB3)) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float v = fmaf(acc2[nb][r], 1.f / 2048.f, acc1[nb][r]);
+                        const float v = (acc1[nb][r] + acc2[nb][r]) * inv2b;
                         emax = max(emax, __float_as_uint(v) & 0x7fffffffu);
                         __builtin_nontemporal_store(fmaxf(v, 0.f), &yrow[(size_t)((r & 3) + 8 * (r >> 2)) * p.yld + nn]);
                     }
@@ -357,7 +417,7 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int off = (r & 3) + 8 * (r >> 2);
-                        const float v = fmaf(acc2[nb][r], 1.f / 2048.f, acc1[nb][r]);
+                        const float v = (acc1[nb][r] + acc2[nb][r]) * inv2b;
                         emax = max(emax, __float_as_uint(v) & 0x7fffffffu);
                         if (gy < p.H2 && tx0 + 4 * lhi + off < p.W2 && nn < C1)
                             yrow[(size_t)off * p.yld + nn] = tx0 + 4 * lhi + off < W2n ? fmaxf(v, 0.f) : 0.f;   // (zero beyond a line's own width)
@@ -372,13 +432,26 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
 
 bool stem_fused_supported(int c1) { return c1 == 24 || c1 == 32 || c1 == 48; }
 
+// power-of-two scale of one weight matrix: max |w| s in [2^13, 2^14) (prepare_gemm_h1_weights) -> exponent
+static int sf_scale_exp(const float* w, size_t n) {
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) mx = std::fmax(mx, std::fabs(w[i]));
+    if (!(mx > 0.f) || !std::isfinite(mx)) return 0;
+    int x = 0;
+    (void)std::frexp(mx, &x);
+    const int ex = 14 - x;
+    return ex > 100 ? 100 : ex < -100 ? -100 : ex;
+}
+
 template <int C1>
 static void sf_prepare(const float* w1, const float* w2a, const float* w2b, std::vector<uint16_t>& img) {
     using G = SfGeom<C1>;
-    img.assign(G::W_HALFS, 0);
-    auto put = [&](size_t hi_at, size_t lo_at, float v) {
-        const _Float16 h = (_Float16)v;
-        const _Float16 l = (_Float16)((v - (float)h) * 2048.f);
+    img.assign(G::IMG_HALFS, 0);
+    const int ex[3] = {sf_scale_exp(w1, (size_t)27 * C1), sf_scale_exp(w2a, (size_t)G::NA * G::K2A), sf_scale_exp(w2b, (size_t)C1 * 4 * G::NA)};
+    auto put = [&](size_t hi_at, size_t lo_at, float v, int e) {
+        const float vs = std::ldexp(v, e);
+        const _Float16 h = (_Float16)vs;
+        const _Float16 l = (_Float16)(vs - (float)h);
         __builtin_memcpy(&img[hi_at], &h, 2);
         __builtin_memcpy(&img[lo_at], &l, 2);
     };
@@ -386,19 +459,22 @@ static void sf_prepare(const float* w1, const float* w2a, const float* w2b, std:
     for (int co = 0; co < C1; ++co)
         for (int kh = 0; kh < 3; ++kh)
             for (int j = 0; j < 9; ++j)
-                put((size_t)co * G::R1 + kh * 16 + j, (size_t)G::W1_H + (size_t)co * G::R1 + kh * 16 + j, w1[(size_t)(kh * 9 + j) * C1 + co]);
+                put((size_t)co * G::R1 + kh * 16 + j, (size_t)G::W1_H + (size_t)co * G::R1 + kh * 16 + j, w1[(size_t)(kh * 9 + j) * C1 + co], ex[0]);
     // stem2a: folded [NA][4 * C1] with k = tap * C1 + c (tap = dy * 2 + dx): same order
     const size_t o2a = 2 * (size_t)G::W1_H;
     for (int n = 0; n < G::NA; ++n)
         for (int k = 0; k < G::K2A; ++k)
-            put(o2a + (size_t)n * G::R2A + k, o2a + G::W2A_H + (size_t)n * G::R2A + k, w2a[(size_t)n * G::K2A + k]);
+            put(o2a + (size_t)n * G::R2A + k, o2a + G::W2A_H + (size_t)n * G::R2A + k, w2a[(size_t)n * G::K2A + k], ex[1]);
     // stem2b: folded [C1][4 * NA] with k = tap * NA + c  ->  tap * CB + c (channels padded to a multiple of 8 per tap)
     const size_t o2b = o2a + 2 * (size_t)G::W2A_H;
     for (int n = 0; n < C1; ++n)
         for (int tap = 0; tap < 4; ++tap)
             for (int c = 0; c < G::NA; ++c)
                 put(o2b + (size_t)n * G::R2B + tap * G::CB + c, o2b + G::W2B_H + (size_t)n * G::R2B + tap * G::CB + c,
-                    w2b[(size_t)n * 4 * G::NA + tap * G::NA + c]);
+                    w2b[(size_t)n * 4 * G::NA + tap * G::NA + c], ex[2]);
+    float scl[6];
+    for (int k = 0; k < 3; ++k) { scl[k] = std::ldexp(1.f, -ex[k]); scl[3 + k] = std::ldexp(1.f, ex[k]); }
+    __builtin_memcpy(&img[G::W_HALFS], scl, sizeof(scl));
 }
 // w1: the stem layout [27][C1] (kh, kw, ci major; co fastest), w2a / w2b: folded [Cout][kh * kw * Cin] (ci fastest), BN folded
 void prepare_stem_fused_weights(int c1, const float* w1, const float* w2a, const float* w2b, std::vector<uint16_t>& img) {
