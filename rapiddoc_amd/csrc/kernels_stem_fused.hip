@@ -46,8 +46,10 @@ struct SfGeom {
     static constexpr int W_HALFS = 2 * (W1_H + W2A_H + W2B_H);
     static constexpr int IMG_HALFS = W_HALFS + 16;               // + six floats: the inverse scales and the scales of w1 / w2a / w2b
     static constexpr int BIAS_FLOATS = C1 + NA + C1;
-    static constexpr int E_FLOATS = SF_EH * SF_EW * SE;
-    static constexpr int A_FLOATS_RAW = SF_AH * SF_AW * SA;
+    // (both tiles are padded to whole 32-pixel MFMA blocks: the last block's rows beyond the tile land in the pad, so that every
+    //  block stores through the same unconditional epilogue)
+    static constexpr int E_FLOATS = (SF_EH * SF_EW + 31) / 32 * 32 * SE;
+    static constexpr int A_FLOATS_RAW = (SF_AH * SF_AW + 31) / 32 * 32 * SA;
     static constexpr int A_FLOATS = A_FLOATS_RAW > SF_PATCH_FLOATS ? A_FLOATS_RAW : SF_PATCH_FLOATS;   // the patch shares this region
     static constexpr size_t LDS_BYTES = (size_t)W_HALFS * 2 + (size_t)(BIAS_FLOATS + E_FLOATS + A_FLOATS) * 4 + 64;
     static constexpr int MB1 = (SF_EH * SF_EW + 31) / 32, NB1 = (C1 + 31) / 32;
@@ -233,30 +235,34 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // One epilogue for every block (round 5): the bounds of the map are NOT tested per element here - an edge tile zeroes what
+            // lies beyond the map in one pass behind the barrier (below).  Before, the last block of every tile, the second channel
+            // block of C1 = 48 (16 of 32 lanes) and every block of an edge tile (a third of the recogniser's tiles: 24 rows = three
+            // tile rows, the last one cut) went through ~10 VALU operations of index arithmetic per element.
 #pragma unroll
             for (int nb = 0; nb < G::NB1; ++nb) {
                 const int nn = nb * 32 + l31;
                 float* dst = Es + (mb * 32 + 4 * lhi) * G::SE + nn;
-                if (inner && mb + 1 < G::MB1 && (C1 % 32 == 0 || nb + 1 < G::NB1)) {
+                if (nn < C1) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         dst[((r & 3) + 8 * (r >> 2)) * G::SE] = fmaxf((acc1[nb][r] + acc2[nb][r]) * inv1, 0.f);
-                } else {
-                    const int mr0 = mb * 32 + 4 * lhi;
-                    const int ry = mr0 / SF_EW, rx = mr0 - ry * SF_EW;      // row / column of element r = 0; the others by carry
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int off = (r & 3) + 8 * (r >> 2);
-                        int cx = rx + off, cy = ry;
-                        if (cx >= SF_EW) { cx -= SF_EW; cy += 1; }
-                        float v = fmaxf((acc1[nb][r] + acc2[nb][r]) * inv1, 0.f);
-                        if (ty0 + cy >= p.H2 || tx0 + cx >= W2n) v = 0.f;        // beyond the map: the zero padding of stem2a / the pool
-                        if (mr0 + off < SF_EH * SF_EW && nn < C1) dst[off * G::SE] = v;
-                    }
                 }
             }
         }
         __syncthreads();
+        // rows / columns of the tile that lie inside the map (the line's own width under a line table); beyond them e and a are the
+        // zero padding of stem2a / the pool / stem2b
+        const int vh = p.H2 - ty0, vw = W2n - tx0;
+        if (!inner) {
+            constexpr int C4 = C1 / 4;
+            for (int i = tid; i < SF_EH * SF_EW * C4; i += SF_NT) {
+                const int pix = i / C4, cg = i - pix * C4;
+                const int cy = pix / SF_EW, cx = pix - cy * SF_EW;
+                if (cy >= vh || cx >= vw) *reinterpret_cast<f32x4*>(Es + pix * G::SE + 4 * cg) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            __syncthreads();
+        }
 
         // ---------------- stem2a: a = ReLU(conv2x2 (e)), K = 4 taps x C1 channels.  Ten 32-pixel blocks on eight wavefronts: the
         // six wavefronts without a second block do the max-pool in the meantime (it only needs e)
@@ -301,23 +307,11 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
             float* dst = As + (mb * 32 + 4 * lhi) * G::SA + l31;
             const bool lane_on = l31 < G::CB;               // channels NA .. CB - 1 are the zero padding of the a tile
             const bool real = l31 < G::NA;
-            if (inner && mb + 1 < G::MB2) {
+            if (lane_on) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = (acc1[r] + acc2[r]) * inv2a;
-                    if (lane_on) dst[((r & 3) + 8 * (r >> 2)) * G::SA] = real ? fmaxf(v, 0.f) : 0.f;
-                }
-            } else {
-                const int mr0 = mb * 32 + 4 * lhi;
-                int ry = mr0 / SF_AW, rx = mr0 - ry * SF_AW;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int off = (r & 3) + 8 * (r >> 2);
-                    int cx = rx + off, cy = ry;
-                    if (cx >= SF_AW) { cx -= SF_AW; cy += 1; }
-                    float v = fmaxf((acc1[r] + acc2[r]) * inv2a, 0.f);
-                    if (ty0 + cy >= p.H2 || tx0 + cx >= W2n || !real) v = 0.f;   // padding of stem2b; zero pad channels
-                    if (mr0 + off < SF_AH * SF_AW && lane_on) dst[off * G::SA] = v;
+                    dst[((r & 3) + 8 * (r >> 2)) * G::SA] = real ? fmaxf(v, 0.f) : 0.f;
                 }
             }
         }
@@ -344,6 +338,15 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
             }
         }
         __syncthreads();
+        if (!inner) {            // a beyond the map: the zero padding of stem2b
+            constexpr int B4 = G::CB / 4;
+            for (int i = tid; i < SF_AH * SF_AW * B4; i += SF_NT) {
+                const int pix = i / B4, cg = i - pix * B4;
+                const int ay = pix / SF_AW, ax = pix - ay * SF_AW;
+                if (ay >= vh || ax >= vw) *reinterpret_cast<f32x4*>(As + pix * G::SA + 4 * cg) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            __syncthreads();
+        }
 
         // the next tile's patch travels while stem2b runs
         const int tn = t + (int)gridDim.x;
@@ -406,12 +409,14 @@ __global__ void __launch_bounds__(SF_NT, 2) stem_fused_kernel(StemFusedParams p)
 #pragma unroll
             for (int nb = 0; nb < G::NB3; ++nb) {
                 const int nn = nb * 32 + l31;
-                if (inner && (C1 % 32 == 0 || nb + 1 < G::NB3)) {
+                if (inner) {
+                    if (nn < C1) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = (acc1[nb][r] + acc2[nb][r]) * inv2b;
-                        emax = max(emax, __float_as_uint(v) & 0x7fffffffu);
-                        __builtin_nontemporal_store(fmaxf(v, 0.f), &yrow[(size_t)((r & 3) + 8 * (r >> 2)) * p.yld + nn]);
+                        for (int r = 0; r < 16; ++r) {
+                            const float v = (acc1[nb][r] + acc2[nb][r]) * inv2b;
+                            emax = max(emax, __float_as_uint(v) & 0x7fffffffu);
+                            __builtin_nontemporal_store(fmaxf(v, 0.f), &yrow[(size_t)((r & 3) + 8 * (r >> 2)) * p.yld + nn]);
+                        }
                     }
                 } else {
 #pragma unroll
