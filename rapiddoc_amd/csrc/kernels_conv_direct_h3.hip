@@ -137,14 +137,9 @@ __global__ void __launch_bounds__(512) conv_direct_h3_kernel(ConvParams p, Direc
                 for (int j = 0; j < 2; ++j) {
                     if (tid + 512 * j >= row_slots) continue;
                     f16x4 hi, lo;
+                    rd_split4(v[rr][j], hi, lo);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        _Float16 h, l;
-                        rd_split(v[rr][j][e], h, l);
-                        hi[e] = h;
-                        lo[e] = l;
-                        amax = fmaxf(amax, fabsf(v[rr][j][e]));
-                    }
+                    for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(v[rr][j][e]));
                     const size_t o = (size_t)((r0 + rr) * PW + s_col[j]) * S + s_g[j] * 8;
                     *reinterpret_cast<f16x4*>(Ph + o) = hi;
                     *reinterpret_cast<f16x4*>(Pl + o) = lo;

@@ -22,15 +22,7 @@ namespace rd {
 static constexpr int HBK = 32;    // K tile (fp32 elements)
 static constexpr int HLD = 40;    // LDS row stride in halfs (64 B data + 16 B pad: conflict-free ds_read_b128)
 
-__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        _Float16 h, l;
-        rd_split(v[i], h, l);
-        hi[i] = h;
-        lo[i] = l;
-    }
-}
+__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) { rd_split4(v, hi, lo); }
 
 template <int BM, int BN, int WM, int WN, bool IS1X1>
 __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 && BM * BN >= 128 * 128) ? 2 : 1) conv_igemm_h3_kernel(ConvParams p, int ntn, int ntiles) {

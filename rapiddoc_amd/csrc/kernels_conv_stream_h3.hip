@@ -109,15 +109,15 @@ __global__ void __launch_bounds__(256) conv_stream_h3_kernel(ConvParams p, Strea
             x1 = *reinterpret_cast<const f32x4*>(xp + o1);
         }
         f16x8 ah, al;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            _Float16 h0, l0, h1, l1;
-            rd_split(c0[e], h0, l0);
-            rd_split(c1[e], h1, l1);
-            ah[e] = h0; ah[4 + e] = h1;
-            al[e] = l0; al[4 + e] = l1;
-            amax = fmaxf(amax, fmaxf(fabsf(c0[e]), fabsf(c1[e])));
+        {
+            f16x4 h0, l0, h1, l1;
+            rd_split4(c0, h0, l0);
+            rd_split4(c1, h1, l1);
+            ah = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+            al = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(c0[e]), fabsf(c1[e])));
         const unsigned bo = b_lane + (unsigned)(tap * g.C16 + ks * 16) * 2u;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {

@@ -218,12 +218,12 @@ __global__ void __launch_bounds__(512) ctc_head_h3_kernel(CtcParams p, int cls_p
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (k < p.K) v = *reinterpret_cast<const f32x4*>(xr + k);
                 else if (k == p.K) v[0] = 1.f;
+                f16x4 h4, l4;
+                rd_split4(v, h4, l4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    _Float16 h, l;
-                    rd_split(v[e], h, l);
-                    xh[ks][4 * hq + e] = h;
-                    xl[ks][4 * hq + e] = l;
+                    xh[ks][4 * hq + e] = h4[e];
+                    xl[ks][4 * hq + e] = l4[e];
                     amax = (v[e] != v[e]) ? INFINITY : fmaxf(amax, fabsf(v[e]));   // fmaxf alone would drop a NaN token
                 }
             }

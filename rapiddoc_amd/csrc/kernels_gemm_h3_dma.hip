@@ -40,16 +40,11 @@ __device__ __forceinline__ void dma16(const void* src, unsigned lds_byte_offset,
 }
 
 __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        _Float16 h0, l0, h1, l1;
-        rd_split(a[e], h0, l0);
-        rd_split(b[e], h1, l1);
-        hi[e] = h0;
-        hi[4 + e] = h1;
-        lo[e] = l0;
-        lo[4 + e] = l1;
-    }
+    f16x4 h0, l0, h1, l1;
+    rd_split4(a, h0, l0);
+    rd_split4(b, h1, l1);
+    hi = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    lo = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
 }
 
 // Epilogue of one 32x32 accumulator tile (16 rows of one output column per lane): combine the two accumulators, bias,

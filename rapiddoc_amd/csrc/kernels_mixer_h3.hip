@@ -80,14 +80,9 @@ __global__ void __launch_bounds__(256, C <= 96 ? 2 : 1) lc_mixer_h3_kernel(Mixer
                 f32x4 v = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.xld + 4 * q);
                 if (decltype(gated)::value) v *= *reinterpret_cast<const f32x4*>(p.gate + (size_t)(m / p.HW) * C + 4 * q);
                 f16x4 hi, lo;
+                rd_split4(v, hi, lo);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    _Float16 a, b;
-                    rd_split(v[e], a, b);
-                    hi[e] = a;
-                    lo[e] = b;
-                    amax = fmaxf(amax, fabsf(v[e]));
-                }
+                for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(v[e]));
                 *reinterpret_cast<f16x4*>(&Xh[r * XS + 4 * q]) = hi;
                 *reinterpret_cast<f16x4*>(&Xl[r * XS + 4 * q]) = lo;
             }
@@ -102,14 +97,9 @@ __global__ void __launch_bounds__(256, C <= 96 ? 2 : 1) lc_mixer_h3_kernel(Mixer
                 f32x4 v = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.xld + 4 * q);
                 if (p.gate) v *= *reinterpret_cast<const f32x4*>(p.gate + (size_t)(m / p.HW) * C + 4 * q);
                 f16x4 hi, lo;
+                rd_split4(v, hi, lo);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    _Float16 a, b;
-                    rd_split(v[e], a, b);
-                    hi[e] = a;
-                    lo[e] = b;
-                    amax = fmaxf(amax, fabsf(v[e]));
-                }
+                for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(v[e]));
                 *reinterpret_cast<f16x4*>(&Xh[r * XS + 4 * q]) = hi;
                 *reinterpret_cast<f16x4*>(&Xl[r * XS + 4 * q]) = lo;
             }
