@@ -197,6 +197,7 @@ class PagePipeline:
         # page-sharded runs (dist.GlobalLineWidths): callable (pooling keys int64 [n], aspect ratios float64 [n]) -> (reference width, max_wh_ratio)
         # per line, decided over the lines of EVERY rank; None = this process holds the whole page batch
         self.rec_width_sync = None
+        self._sync_this_call = True       # False inside a rec_forward_sources(pooled=False) call: its widths are its own lines'
         self._width_sync_cache = None
         self._width_sync_epoch, self._in_run_batch = 0, False
         self.keep_rec_inputs = False      # tests: keep every rec batch's input tensor and raw (idx, prob) in last_rec_batches
@@ -332,7 +333,7 @@ class PagePipeline:
     def _rec_forward_sources_once(self, sources, image_keys=None, want_words=False):
         t0 = time.perf_counter()
         if not sources:                 # nothing to read on this rank: it still takes part in the batch's width exchange
-            if self.rec_width_sync is not None and self.rec_mode == "strict" and self.rec_two_stage and getattr(self, "_sync_this_call", True):
+            if self.rec_width_sync is not None and self.rec_mode == "strict" and self.rec_two_stage and self._sync_this_call:
                 self._synced_widths(self.rec_width_sync, np.zeros(0, np.int64), np.zeros(0))
             return []
         dev = sources[0][0].device
@@ -348,7 +349,7 @@ class PagePipeline:
                     src_of.append(np.full(len(q), si, np.int32))
                     page_of.append(np.full(len(q), pi, np.int32))
         empty = [[[] for _ in range(k)] for k in n_img]
-        sync = self.rec_width_sync if (self.rec_mode == "strict" and self.rec_two_stage and getattr(self, "_sync_this_call", True)) else None
+        sync = self.rec_width_sync if (self.rec_mode == "strict" and self.rec_two_stage and self._sync_this_call) else None
         if not quad_list:
             if sync is not None:
                 self._synced_widths(sync, np.zeros(0, np.int64), np.zeros(0))       # every rank makes the same calls

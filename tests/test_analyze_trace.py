@@ -449,3 +449,57 @@ def test_restore_poly_matches_the_quarter_turns():
                 x0, y0, x1, _, _, y1, _, _ = analyze.restore_poly([x, y, x, y, x, y, x, y], label, w, h)
                 assert (x0, y0) == (x1, y1) and img[y0, x0] == turned[y, x]
     assert analyze.restore_poly([1, 2, 3, 2, 3, 4, 1, 4], "180", w, h) == [w - 1 - 3, h - 1 - 4, w - 1 - 1, h - 1 - 4, w - 1 - 1, h - 1 - 2, w - 1 - 3, h - 1 - 2]
+
+
+def test_page_sharded_analyzer_hands_global_page_keys_to_one_pooled_call_per_agreed_language(golden_dir):
+    """Page-sharded runs (`rec_width_sync` set on the pipelines, rapiddoc_amd.dist.GlobalLineWidths): the OCR stage's pooled recogniser
+    call - the one step of `BatchAnalyze.__call__` whose result depends on the OTHER pages of the batch (analyze_utils.py:216-252) - gets
+    the pages' GLOBAL positions as pooling keys and is made once per language of the agreed list, in that order, on every rank (also a
+    rank that holds no region of a language, or no region at all: the width exchange inside must pair up across ranks).  The output is
+    the fixture's: keys and call order do not change what is read."""
+    fx = json.loads((golden_dir / "analyze_trace_seed4.json").read_text())
+    tr, langs = fx["trace"], fx["page_langs"]
+    pages = torch.from_numpy(np.stack([synth_page(i)[0] for i in fx["page_ids"]]))
+    order = []
+
+    class ShardPipe(ReplayPipe):
+        rec_width_sync = staticmethod(lambda keys, ratios: None)        # (only its presence matters to the analyzer)
+
+        def __init__(self, lang):
+            super().__init__([])
+            self.lang, self.keys = lang, []
+
+        def rec_forward_sources(self, sources, image_keys=None):
+            order.append(self.lang)
+            self.keys.append(image_keys)
+            return super().rec_forward_sources(sources, image_keys) if sources else []
+    det_calls = iter(tr["det_calls"])
+
+    def det_raw_fn(canvases, batch_size):
+        return [np.asarray(b, dtype=np.float32).reshape(-1, 4, 2) for b in next(det_calls)["boxes"]]
+    pipes = {lg: ShardPipe(lg) for lg in ("ch", "en")}
+    pa = analyze.PageAnalyzer(ReplayLayout(fx["layout_dets"], []), pipes, formula_model=ReplayFormula([]),
+                              layout_batch_size=fx["layout_batch_num"], formula_level=fx["formula_level"], formula_batch_size=fx["formula_batch_num"],
+                              det_batch_num=fx["ocr_config"]["Det.rec_batch_num"], det_raw_fn=det_raw_fn)
+    with pytest.raises(ValueError, match="page_keys"):
+        pa(pages, page_langs=langs)
+    det_calls = iter(tr["det_calls"])
+    agreed = sorted(set(langs), reverse=True)                            # an order of its own: not the order of first appearance
+    keys = [40 + 3 * i for i in range(len(langs))]
+    out = pa(pages, page_langs=langs, page_keys=keys, all_langs=agreed)
+    assert order == agreed
+    for lg in agreed:
+        seen = sorted({k for per_src in pipes[lg].keys[0] for k in per_src})
+        assert seen == sorted(k for k, l in zip(keys, langs) if l == lg)              # the pages of that language, by their GLOBAL key
+    for mine, theirs in zip(out, fx["output"]):
+        assert mine == theirs
+    # a language outside the agreed list cannot be exchanged
+    det_calls = iter(tr["det_calls"])
+    with pytest.raises(ValueError, match="all_langs"):
+        pa(pages, page_langs=langs, page_keys=keys, all_langs=[agreed[0]])
+    # a rank without a single region: one (empty) pooled call per agreed language all the same
+    order.clear()
+    pa_empty = analyze.PageAnalyzer(ReplayLayout([[] for _ in langs], []), pipes, formula_model=ReplayFormula([]), layout_batch_size=2,
+                                    formula_batch_size=4, det_batch_num=3, det_raw_fn=lambda c, b: [])
+    assert pa_empty(pages, page_langs=langs, page_keys=keys, all_langs=agreed) == [[] for _ in langs]
+    assert order == agreed
