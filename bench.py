@@ -334,14 +334,34 @@ def main():
     ap.add_argument("--no-extra-passes", action="store_true", help="skip the post-passes (other rec mode, fp32 precision, backbone alone)")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    backend = os.environ.get("RD_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    # --gpus N is the job size.  One process per GPU: with the RCCL backend N ranks need N devices - fewer is an error, never a
+    # silent N = 1 number.  RD_BENCH_BACKEND=gloo (ranks share the devices that exist) exists only to exercise the multi-process
+    # code path on a single-GPU box.
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if backend == "nccl" and args.gpus > n_dev:
+        raise SystemExit("bench.py: --gpus %d asked for, %d device(s) visible: one rank per GPU over RCCL needs %d devices"
+                         % (args.gpus, n_dev, args.gpus))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a bare `python bench.py --gpus N`: start the N ranks ourselves, exactly as the driver's torchrun line does
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    # one process per GPU; RD_BENCH_BACKEND=gloo (+ fewer GPUs than ranks) exists only to exercise the multi-process code
-    # path on a single-GPU box
-    dev_index = local_rank % torch.cuda.device_count()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if world > 1:
@@ -351,7 +371,6 @@ def main():
             cores_per_rank = len(os.sched_getaffinity(0))
         except (AttributeError, OSError):
             cores_per_rank = os.cpu_count()
-    backend = os.environ.get("RD_BENCH_BACKEND", "nccl")
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -361,6 +380,20 @@ def main():
         else:
             dist_mod.init_process_group(backend)
         dist = dist_mod
+    # what the process group itself reports: its backend, its size, and the device every rank computes on (uuid all-gathered over the
+    # group - over RCCL the eight must be distinct; the gloo test mode on a 1-GPU box shows one uuid N times)
+    props = torch.cuda.get_device_properties(dev_index)
+    my_dev = "%s/%s" % (getattr(props, "uuid", None) or "index%d" % dev_index, props.name)
+    group_info = {"backend": None, "world_size": 1, "rccl_ranks_seen": 1, "devices": [my_dev], "distinct_devices": 1}
+    if dist:
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, my_dev))
+        assert sorted(r for r, _ in seen) == list(range(world)), seen
+        devs = [d for _, d in sorted(seen)]
+        group_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_ranks_seen": len(seen),
+                      "devices": devs, "distinct_devices": len(set(devs))}
+        if backend == "nccl" and len(set(devs)) != world:
+            raise SystemExit("bench.py: %d ranks over RCCL share %d device(s): %s" % (world, len(set(devs)), devs))
 
     # rank 0 (re)builds the library if it is missing or stale; EVERY rank then passes the same barrier, so no rank can
     # dlopen a half-linked file or pair its first collective with rank 0's barrier (build() links to a temporary name
@@ -416,7 +449,9 @@ def main():
     # strict rec batching over N ranks: the reference pools the lines of the WHOLE page batch before it sorts and chunks them, so every
     # rank takes its lines' padded widths from the global list (one more small all-gather per step; the strings do not depend on N)
     width_sync = None
-    if dist is not None and args.rec_mode == "strict" and args.workers == 1 and os.environ.get("RD_BENCH_WIDTH_SYNC", "1") != "0":
+    # (one pipeline per rank only: with --inflight > 1 every lane would issue the collective from its own host thread, in no fixed order)
+    if (dist is not None and args.rec_mode == "strict" and args.workers == 1 and len(pools) == 1
+            and os.environ.get("RD_BENCH_WIDTH_SYNC", "1") != "0"):
         from rapiddoc_amd.dist import GlobalLineWidths
         width_sync = GlobalLineWidths(dist)
         for pl in pools:
@@ -742,6 +777,9 @@ def main():
                        "host_ms_per_step_max_over_ranks": round(host_ms_max, 2), "cores_per_rank": cores_per_rank,
                        "range_fallbacks": int(sum(e.range_fallbacks for q in pools for e in q.engines)),   # engines that left the split-fp16 mode (0 = the dtype claim holds)
                        "parallelism": "page-sharded dp%d; %d page batch(es) in flight per GPU" % (world, len(pools)),
+                       "backend": group_info["backend"], "world_size": group_info["world_size"],
+                       "rccl_ranks_seen": group_info["rccl_ranks_seen"], "distinct_devices": group_info["distinct_devices"],
+                       "devices": group_info["devices"],
                        "layout_head": "absent (ONNX-only in the reference; backbone only)",
                        "det_postprocess": "DB post-process runs on maps rendered from the generator's line boxes "
                                           "(random-weight det output has no text); its boxes drive crop+rec"},
