@@ -361,7 +361,8 @@ TView Builder::conv(const std::string& wname, const std::string& bname, const st
     const TView xv = x, yv = y;
     const bool has_res = res != nullptr, has_as = ascale != nullptr;
     const TView rv = res ? *res : TView{}, av = ascale ? *ascale : TView{};
-    const bool h3 = (h3_ || (mixer_h3_ && !ascale && p.M >= 2048 && auto_split_conv(kh, kw, K, cout))) &&
+    // (routed by LAYER - kernel size, K, N - never by the row count M: an image's bits must not depend on the launch it rides in)
+    const bool h3 = (h3_ || (mixer_h3_ && !ascale && auto_split_conv(kh, kw, K, cout))) &&
                     pb_->has(key + "#wh");
     if (h3) {
         p.wh = reinterpret_cast<const uint16_t*>(pb_->ptr(key + "#wh"));

@@ -478,6 +478,7 @@ void FormulaDecoder::gemm(const float* x, int M, int K, const std::string& key, 
     p.res = res; p.rld = N;
     p.act = act; p.out_mode = OUT_NHWC;
     p.M = M; p.K = K; p.Ng = N;
+    p.allow_skinny = 1;      // M is the decode batch
     launch_conv_igemm(p, s);
 }
 

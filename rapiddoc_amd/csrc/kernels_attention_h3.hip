@@ -14,6 +14,7 @@
 // planes, staged once per (line, head) by the whole workgroup; Q stays in registers.  Arithmetic as in kernels_conv_h3.hip
 // (x = hi + lo 2^-11, hi.hi into one accumulator, hi.lo + lo.hi into a second one, fp32 accumulate); exp / max / sums in fp32.
 // Lines longer than ATT_MAX_T tokens (a text line wider than ~6000 px at height 48) keep the VALU kernel.
+#include <algorithm>
 #include <cstdlib>
 
 #include "rd_device.h"
@@ -42,7 +43,9 @@ __global__ void __launch_bounds__(256) attention_h3_kernel(const float* __restri
         tok0 = (size_t)seg[2 * b];
         T = seg[2 * b + 1];
     }
-    if (T <= 0) return;                                     // (an empty line of a ragged batch: nothing to attend over, nothing to write)
+    // (an empty line of a ragged batch: nothing to attend over, nothing to write; a line beyond ATT_MAX_T is the VALU kernel's - launch_attention
+    //  runs it over the same line table: the kernel that serves a line follows from the LINE's length, never from its launch's longest)
+    if (T <= 0 || T > ATT_MAX_T) return;
     const int tpad = (T + 31) & ~31, nkt = tpad >> 5;
     const int vrow = att_vrow_halfs(tpad_max);              // (the launcher sized the allocation with tpad_max)
     _Float16* Kh = reinterpret_cast<_Float16*>(sm);
@@ -152,11 +155,12 @@ __global__ void __launch_bounds__(256) attention_h3_kernel(const float* __restri
 
 bool attention_h3_applies(int T, int hd) {
     static const bool off = [] { const char* e = getenv("RD_ATTN_MFMA"); return e && e[0] == '0'; }();
-    return !off && (hd == 15 || hd == 16) && T >= 32 && T <= ATT_MAX_T;
+    return !off && (hd == 15 || hd == 16) && T >= 1 && T <= ATT_MAX_T;
 }
+int attention_h3_max_t() { return ATT_MAX_T; }
 
 void launch_attention_h3(const float* qkv, float* o, int B, int T, int heads, int hd, float scale, hipStream_t s, const int32_t* seg) {
-    const int tpad = (T + 31) & ~31;
+    const int tpad = std::min((T + 31) & ~31, ATT_MAX_T);       // (ragged launches: longer lines are skipped by the kernel)
     const size_t sh = (size_t)2 * tpad * ATT_KROW * 2 + (size_t)2 * 16 * att_vrow_halfs(tpad) * 2;
     static unsigned long long ok15 = 0, ok16 = 0;
     if (hd == 15) {

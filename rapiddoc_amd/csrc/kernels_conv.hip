@@ -491,7 +491,7 @@ bool skinny_gemm_applies(int M, int K) { return M <= 32 && K % 4 == 0 && K >= 64
 
 void launch_conv_igemm(const ConvParams& p, hipStream_t s) {
     if (p.M <= 0) return;
-    if (p.M <= 32 && p.out_mode == OUT_NHWC && is_1x1(p) && p.K % 4 == 0 && p.K >= 64 && (!p.ln_g || p.K <= 512)) {
+    if (p.allow_skinny && p.M <= 32 && p.out_mode == OUT_NHWC && is_1x1(p) && p.K % 4 == 0 && p.K >= 64 && (!p.ln_g || p.K <= 512)) {
         launch_skinny(p, s);
         return;
     }

@@ -370,7 +370,7 @@ bool conv_direct_h3_supported(const ConvParams& p) {
 // the implicit GEMM (58 / 62 vs 54 / 63 us) and stay there (RD_CONV_DIRECT=2 routes them here too, =0 nothing).
 bool conv_direct_h3_applies(const ConvParams& p) {
     static const int mode = [] { const char* e = getenv("RD_CONV_DIRECT"); return e ? atoi(e) : 1; }();
-    if (mode == 0 || p.M < 4096) return false;
+    if (mode == 0) return false;
     if (p.KH * p.KW < 9 && mode != 2) return false;
     return conv_direct_h3_supported(p);
 }

@@ -182,7 +182,7 @@ bool conv_stream_h3_supported(const ConvParams& p) {
 // routing policy (launch_conv_igemm_h3): every layer it supports, unless RD_CONV_STREAM=0
 bool conv_stream_h3_applies(const ConvParams& p) {
     static const bool off = [] { const char* e = getenv("RD_CONV_STREAM"); return e && e[0] == '0'; }();
-    return !off && p.M >= 4096 && conv_stream_h3_supported(p);
+    return !off && conv_stream_h3_supported(p);
 }
 
 void launch_conv_stream_h3(const ConvParams& p, hipStream_t s) {

@@ -343,25 +343,21 @@ __global__ void __launch_bounds__(256) ctc_merge_kernel(const float* part, int M
     prob[tok] = 1.f / sum;
 }
 
-// class splits: one block = (split, token tile); blocks run one per CU, so a launch costs rounds x (steps per block + a
-// fixed part for the token tile and the first class tile).  Pick the split count that minimises it; every split must own at
-// least one class (classes per split are rounded up to a multiple of 4).
-static int ctc_pick_nsplit(int M, int C, int tok_per_block, int cls_per_step, int fixed_steps) {
-    const int tiles = (M + tok_per_block - 1) / tok_per_block;
-    int best = 1;
-    long best_cost = -1;
-    for (int ns = 1; ns <= 64; ++ns) {
-        const int cps = ((C + ns - 1) / ns + 3) / 4 * 4;
-        if (ns > 1 && (long)cps * (ns - 1) >= C) continue;
-        const long rounds = ((long)tiles * ns + 255) / 256;
-        const long its = (cps + cls_per_step - 1) / cls_per_step;
-        const long cost = rounds * (its + fixed_steps);
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ns; }
-    }
-    return best;
+// class splits: one block = (split, token tile).  The split count is a function of the DICTIONARY only (about 1280 classes = 20 / 10
+// steps per split: 15 splits for PP-OCRv6's 18710 classes), never of the token count M: a token's sum of exponentials is formed split by
+// split and merged in split order (ctc_merge_kernel), so a split count that followed M (rounds 1-5 minimised rounds x steps per launch)
+// made the last bits of a line's probabilities - and with them its mean confidence - depend on how many lines shared its launch.  The
+// price is one partly filled last round of ~23 steps per launch (a launch of the bench runs 9-16 rounds).  Every split owns at least
+// one class (classes per split are rounded up to a multiple of 4).
+static int ctc_pick_nsplit(int C) {
+    int ns = (C + 1279) / 1280;
+    if (ns > 64) ns = 64;
+    while (ns > 1 && (long)(((C + ns - 1) / ns + 3) / 4 * 4) * (ns - 1) >= C) --ns;
+    return ns < 1 ? 1 : ns;
 }
 int ctc_head_nsplit(int M, int C, bool split_fp16) {
-    return split_fp16 ? ctc_pick_nsplit(M, C, CH_TOK, CH_CLS, 3) : ctc_pick_nsplit(M, C, CT_TOK, CT_CLS, 2);
+    (void)M; (void)split_fp16;
+    return ctc_pick_nsplit(C);
 }
 
 void launch_ctc_head(const CtcParams& p, hipStream_t s) {

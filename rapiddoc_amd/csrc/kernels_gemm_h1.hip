@@ -483,7 +483,7 @@ bool gemm_h1_shape_ok(int K, int cout) { return K % HK == 0 && K >= 2 * HK && co
 bool gemm_h1_applies(const ConvParams& p) {
     static const bool off = [] { const char* e = getenv("RD_GEMM_H1"); return e && e[0] == '0'; }();
     return !off && p.w1 && p.w1_inv > 0.f && p.KH == 1 && p.KW == 1 && p.SH == 1 && p.SW == 1 && p.PT == 0 && p.PL == 0 && p.OH == p.H && p.OW == p.W &&
-           p.out_mode == OUT_NHWC && !p.ascale && gemm_h1_shape_ok(p.K, p.Ng) && p.M >= 2048 && (p.xld % 4) == 0 &&
+           p.out_mode == OUT_NHWC && !p.ascale && gemm_h1_shape_ok(p.K, p.Ng) && (p.xld % 4) == 0 &&
            (unsigned long long)HM * (unsigned long long)p.xld * 4ull + (unsigned long long)p.K * 4ull < (1ull << 31);
 }
 

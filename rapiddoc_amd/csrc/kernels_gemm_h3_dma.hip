@@ -516,7 +516,7 @@ __global__ void __launch_bounds__(1024) gemm_h3_dma16_kernel(ConvParams p, int n
 bool gemm_h3_dma_applies(const ConvParams& p) {
     static const bool off = [] { const char* e = getenv("RD_H3_DMA"); return e && e[0] == '0'; }();
     return !off && p.wh && p.KH == 1 && p.KW == 1 && p.SH == 1 && p.SW == 1 && p.PT == 0 && p.PL == 0 && p.OH == p.H && p.OW == p.W &&
-           p.out_mode == OUT_NHWC && !p.ascale && p.K % 4 == 0 && p.K >= 2 * DK && p.Ng >= 96 && p.M >= 2048 && (p.xld % 4) == 0;
+           p.out_mode == OUT_NHWC && !p.ascale && p.K % 4 == 0 && p.K >= 2 * DK && p.Ng >= 96 && (p.xld % 4) == 0;
 }
 
 // which of the two kernels launch_gemm_h3_dma runs for p (the per-op profile names it)

@@ -736,7 +736,7 @@ void launch_layernorm(const float* x, int xld, float* y, int yld, const float* g
 // --------------------------------------------------------------------------------------------------
 template <int HD>
 __global__ void __launch_bounds__(256) attention_kernel(const float* qkv, float* o, int T, int heads, float scale, const int32_t* seg,
-                                                        int tk_cap) {
+                                                        int tk_cap, int skip_upto) {
     // K / V rows are padded to HDP = 16 / 32 floats in LDS so that a key costs HDP / 4 ds_read_b128 (every lane reads the same
     // address: a broadcast) instead of HD ds_read_b32 - round 1's 15 scalar reads per dot product made this kernel LDS-issue
     // bound (51 us per launch for 0.4 GFLOP); same two-pass max-subtracted softmax, same operation order per element.
@@ -754,6 +754,7 @@ __global__ void __launch_bounds__(256) attention_kernel(const float* qkv, float*
     if (seg) {                 // ragged batch: this sequence's own offset and length (T was the longest: it sized the LDS)
         tok0 = (size_t)seg[2 * b];
         T = seg[2 * b + 1];
+        if (T <= skip_upto) return;      // (lines the matrix-core kernel serves: launch_attention)
     }
     const float* base = qkv + tok0 * 3 * C;
     auto stage = [&](int k0, int kn, bool with_v) {         // keys [k0, k0 + kn) -> LDS rows [0, kn)
@@ -849,21 +850,26 @@ __global__ void __launch_bounds__(256) attention_kernel(const float* qkv, float*
 // kernels of other streams that share the CU)
 int attention_lds_keys(int hd) { return (144 * 1024) / (2 * ((hd + 3) / 4 * 4) * (int)sizeof(float)); }
 template <int HD>
-static void launch_attention_t(const float* qkv, float* o, int B, int T, int heads, float scale, hipStream_t s, const int32_t* seg) {
+static void launch_attention_t(const float* qkv, float* o, int B, int T, int heads, float scale, hipStream_t s, const int32_t* seg, int skip_upto) {
     const int cap = attention_lds_keys(HD);
     const size_t sh = (size_t)2 * std::min(T, cap) * ((HD + 3) / 4 * 4) * sizeof(float);
     static unsigned long long lds_ok = 0;
     if (sh > 64 * 1024) rd_allow_dynamic_lds((const void*)attention_kernel<HD>, (size_t)144 * 1024, lds_ok);
-    hipLaunchKernelGGL(attention_kernel<HD>, dim3(B, heads), dim3(256), sh, s, qkv, o, T, heads, scale, seg, cap);
+    hipLaunchKernelGGL(attention_kernel<HD>, dim3(B, heads), dim3(256), sh, s, qkv, o, T, heads, scale, seg, cap, skip_upto);
 }
 void launch_attention(const float* qkv, float* o, int B, int T, int heads, int hd, float scale, hipStream_t s, const int32_t* seg) {
-    if (attention_h3_applies(T, hd)) {
-        launch_attention_h3(qkv, o, B, T, heads, hd, scale, s, seg);
-        return;
+    // The kernel that serves a line follows from the LINE's length (matrix cores up to attention_h3_max_t() tokens, the VALU kernel beyond),
+    // not from the longest line of its launch: a ragged launch (seg) that holds lines of both kinds runs both kernels over the same line
+    // table, each skipping the other's lines, so a line's bits do not depend on its neighbours in the launch.
+    int skip_upto = 0;
+    if (attention_h3_applies(1, hd)) {
+        if (attention_h3_applies(T, hd) || seg) launch_attention_h3(qkv, o, B, T, heads, hd, scale, s, seg);
+        if (attention_h3_applies(T, hd)) return;
+        if (seg) skip_upto = attention_h3_max_t();
     }
-    if (hd == 15) launch_attention_t<15>(qkv, o, B, T, heads, scale, s, seg);
-    else if (hd == 16) launch_attention_t<16>(qkv, o, B, T, heads, scale, s, seg);
-    else if (hd == 32) launch_attention_t<32>(qkv, o, B, T, heads, scale, s, seg);
+    if (hd == 15) launch_attention_t<15>(qkv, o, B, T, heads, scale, s, seg, skip_upto);
+    else if (hd == 16) launch_attention_t<16>(qkv, o, B, T, heads, scale, s, seg, skip_upto);
+    else if (hd == 32) launch_attention_t<32>(qkv, o, B, T, heads, scale, s, seg, skip_upto);
 }
 
 // --------------------------------------------------------------------------------------------------

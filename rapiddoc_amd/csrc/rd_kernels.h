@@ -46,6 +46,9 @@ struct ConvParams {
     // inverse of that scale (prepare_gemm_h1_weights), or nullptr / 0
     const uint16_t* w1 = nullptr;
     float w1_inv = 0.f;
+    // the small-M (<= 32 rows) fp32 path of launch_conv_igemm: only for layers whose M is a batch size BY CONSTRUCTION (the formula decoder's
+    // linears); image layers never set it - their kernel is picked by the layer, not by how many rows a launch happens to hold
+    int allow_skinny = 0;
     int fast_epi = 1;               // interior tiles of the split implicit-GEMM kernels store through buffer accesses (round 5; RD_CONV_FAST_EPI=0: A/B)
 };
 void launch_conv_igemm(const ConvParams& p, hipStream_t s);
@@ -167,6 +170,7 @@ void launch_layernorm(const float* x, int xld, float* y, int yld, const float* g
                       float eps, hipStream_t s);
 // qkv: [B*T][3*heads*hd] (q|k|v, head-major) -> o: [B*T][heads*hd]
 // seg != nullptr: ragged batch - sequence b is seg[2b+1] tokens starting at token seg[2b]; T is then the longest one
+int attention_h3_max_t();                     // lines up to this many tokens run on the matrix-core kernel, longer ones on the VALU kernel
 bool attention_h3_applies(int T, int hd);     // kernels_attention_h3.hip: the same attention on the split-fp16 matrix cores
 void launch_attention_h3(const float* qkv, float* o, int B, int T, int heads, int hd, float scale, hipStream_t s, const int32_t* seg);
 void launch_attention(const float* qkv, float* o, int B, int T, int heads, int hd, float scale, hipStream_t s, const int32_t* seg = nullptr);

@@ -75,6 +75,19 @@ def test_bare_gpus_2_starts_two_ranks_itself_and_equals_one_rank_in_the_default_
     assert a["config"]["result_crc32"] == b["config"]["result_crc32"]
 
 
+def test_four_pages_over_four_ranks_one_page_each_equal_one_rank():
+    """The smallest shards there are: one page per rank, so every rank's launches hold a quarter of the lines -
+    and the gathered, page-ordered strings and confidences are still the single-process run's, byte for byte, in the default precision
+    mode (kernels are picked by the layer, not by the launch size: tests/test_gpu_launch_invariance.py)."""
+    env = _clean_env()
+    a = _last_json(_run([sys.executable, str(ROOT / "bench.py"), *COMMON], env))
+    b = _last_json(_run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", *COMMON], dict(env, RD_BENCH_BACKEND="gloo"), timeout=600))
+    assert b["n_gpus"] == 4 and b["config"]["world_size"] == 4 and b["config"]["pages_per_gpu"] == 1
+    assert "auto" in b["config"]["precision"] and b["config"]["range_fallbacks"] == 0
+    assert a["config"]["pages_gathered"] == b["config"]["pages_gathered"] == 4
+    assert a["config"]["result_crc32"] == b["config"]["result_crc32"]
+
+
 def test_more_ranks_than_devices_over_rccl_fails_loudly():
     """A bare `--gpus 8` on a box with fewer devices must not print an N = 1 number: one rank per GPU over RCCL needs eight devices."""
     import torch
