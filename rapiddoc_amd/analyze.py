@@ -364,6 +364,8 @@ class TableOcr:
     `rec_fn(canvas [1,h,w,3], quads [n,4,2]) -> [(text, score)]` (with `use_word_box`: `[(text, score, [(word, conf, box) ...])]`, what
     rapidocr's cal_rec_boxes leaves per line) replace them (tests replaying traces of the reference)."""
 
+    _warned_line_level = False       # the use_word_box downgrade is reported once per process
+
     def __init__(self, pipeline, det_raw_fn=None, rec_fn=None, skip_text_in_image: bool = True, use_img2table: bool = False,
                  table_formula_enable: bool = True, lang: str = "ch", use_word_box: bool = True):
         self.pipe, self.rec_fn, self.use_word_box = pipeline, rec_fn, use_word_box
@@ -397,14 +399,19 @@ class TableOcr:
         quads = np.asarray(boxes, dtype=np.float32).reshape(-1, 4, 2)
         # word boxes come from the strict two-stage recogniser (per-line kept time steps); a pipeline built in another batching mode
         # serves the table model line-level entries (the reference's use_word_box=False shape) instead of failing in the table stage
-        pipe = self.det._pipe_for(lang or self.det.lang)
-        words_ok = self.rec_fn is not None or (getattr(pipe, "rec_mode", None) == "strict" and getattr(pipe, "rec_two_stage", False))
+        pipe = None if self.rec_fn is not None else self.det._pipe_for(lang or self.det.lang)     # (a custom rec_fn needs no pipeline of that language)
+        words_ok = pipe is None or (getattr(pipe, "rec_mode", None) == "strict" and getattr(pipe, "rec_two_stage", False))
         if self.use_word_box and words_ok:
             return self._word_level(canvas, quads, h, w, lang)
+        if self.use_word_box and not TableOcr._warned_line_level:
+            TableOcr._warned_line_level = True
+            import warnings
+            warnings.warn("TableOcr: use_word_box=True needs the strict two-stage recogniser (rec_mode='strict'); this pipeline serves the "
+                          "table model LINE-level entries (the reference's use_word_box=False input shape)", RuntimeWarning, stacklevel=2)
         if self.rec_fn is not None:
             lines = self.rec_fn(canvas, quads)
         else:
-            lines = self.det._pipe_for(lang or self.det.lang).rec_forward_sources([(canvas.contiguous(), [quads])], image_keys=[[0]], pooled=False)[0][0]
+            lines = pipe.rec_forward_sources([(canvas.contiguous(), [quads])], image_keys=[[0]], pooled=False)[0][0]
         return [[q for q in quads], [table_host.normalize_table_ocr_text(t) for t, _s in lines], [s for _t, s in lines]]
 
     def _word_level(self, canvas: torch.Tensor, quads: np.ndarray, h: int, w: int, lang: Optional[str]) -> list:

@@ -15,7 +15,10 @@
 // Round 5 (RS): the tile is read ONCE.  W1's input channels are permuted in the image so that the 8 k-slots a lane feeds to k-step ks
 // of GEMM1 are the 2 x 4 channels it owns in the C/D layout of Y^T (blocks 2 ks, 2 ks + 1: channels 16 ob + 4 kg .. + 4, the ws
 // kernel's arrangement): the tile load uses the epilogue's float4 addresses and the residual is re-formed from the split fragments
-// already in registers, x = hi + lo * 2^-11 (exact sum, 2^-24 |x| from x) instead of a second fetch of the tile and the gate
+// already in registers, x ~ hi + lo (the sum is exact in fp32; it differs from x by lo's rounding: lo = fp16(x - hi) rounds a 13-bit
+// remainder to 11 bits, <= 2^-22 |x|, and where lo is an fp16 subnormal - |x| < 2^-3 - by an ABSOLUTE 2^-25; the residual stream therefore
+// picks up to ~4 fp32 ulps per block instead of none: tests/test_gpu_parity.py::test_mixer_residual_from_split_fragments_small_inputs)
+// instead of a second fetch of the tile and the gate
 // (counters, round 4: 361 MB moved per launch against 255 MB algorithmic).  The fragments must stay live through the hidden loop for
 // that, which the two accumulator sets of the round-2 arithmetic leave no room for at 128 registers (four wavefronts per SIMD) - so
 // the kernel moves to the ONE-accumulator split of kernels_gemm_h1.hip / kernels_mixer_ws.hip: low planes unscaled (x = hi + lo;

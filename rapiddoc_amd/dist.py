@@ -264,6 +264,11 @@ class GlobalLineWidths:
         self.dist, self.device, self.rec_batch_num = dist, device, rec_batch_num
         self.calls = 0
 
+    @property
+    def world_size(self) -> int:
+        d = self.dist
+        return 1 if d is None or not d.is_initialized() else int(d.get_world_size())
+
     def __call__(self, keys, ratios):
         import numpy as np
         from . import ocr_host

@@ -707,6 +707,9 @@ class PagePipeline:
             pages = src.to(self.tdev, non_blocking=src.is_pinned())
         self._page_keys = None if page_keys is None else [int(k) for k in page_keys]
         assert self._page_keys is None or len(self._page_keys) == pages.shape[0]
+        if self.rec_width_sync is not None and page_keys is None and getattr(self.rec_width_sync, "world_size", 1) > 1:
+            # local page indices would interleave the ranks' pages in the pooled order (every rank has a page 0)
+            raise ValueError("rec_width_sync over more than one rank needs page_keys: the pages' positions in the GLOBAL page list")
         self._width_sync_epoch += 1
         self._in_run_batch = True
         try:
@@ -772,6 +775,15 @@ class PagePipeline:
         else:
             self.stats["front_prefetched"] = 1.0
         cur.wait_event(h["det_done"])
+        if self.rec_width_sync is not None and self.det.precision != "fp32" and os.environ.get("RD_DEV_SKIP_RANGE_CHECK") != "1":
+            # page-sharded strict mode: the det maps decide which (key, ratio) list this rank hands to the width collective, so the det
+            # range guard is settled BEFORE the recogniser stage - an overflowed map must neither feed the peers' widths nor make this rank
+            # repeat a collective its peers make once (without the exchange the deferred check of _run_batch_guarded is enough)
+            if self.det.check_range_and_fallback():
+                self.stats["range_fallbacks"] = self.stats.get("range_fallbacks", 0) + 1
+                h = self._front(pages, P)             # det (and layout) again, the det engine now on fp32 MFMA
+                self.stats["front_prefetched"] = 0.0
+                cur.wait_event(h["det_done"])
         prob_maps, det_hw = h["prob_maps"], h["det_hw"]
         self.last_det = (prob_maps, det_hw)         # a VIEW of the engine's output buffer: valid until the next det forward of this shape
         if quads_per_page is None:

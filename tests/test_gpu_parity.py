@@ -362,6 +362,37 @@ def test_fused_mixer_kernels_match_fp64(C_, M, variant):
     assert float((y[M:] - 555.0).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("C_,variant", [(96, 300), (192, 400), (96, 200), (192, 200)])
+@pytest.mark.parametrize("xs", [1.0, 1e-3, 1e-5])
+def test_mixer_residual_from_split_fragments_small_inputs(C_, variant, xs):
+    """The resident-weights (300) and weight-streaming (200 / 400) mixers re-form the residual x from the (hi, lo) fragments they already
+    hold instead of reading the tile again (round 5).  hi + lo differs from x by lo's rounding: <= 2^-22 |x| where lo is a normal fp16,
+    an ABSOLUTE 2^-25 (res kernel; ws: 2^-25 / the pixel's scale) where it is subnormal - so the output's error against fp64 stays
+    bounded by that plus the products' own 2^-21-relative error, for activations of ordinary and of small magnitude."""
+    import ctypes as C
+    from rapiddoc_amd import _lib
+    lib = _lib.load()
+    lib.rd_debug_time_mixer.restype = C.c_float
+    lib.rd_debug_time_mixer.argtypes = [C.c_int] * 4 + [C.c_void_p] * 6
+    M = 4099
+    g = torch.Generator(device="cuda").manual_seed(C_ + variant)
+    x = (torch.rand((M, C_), device="cuda", generator=g) - 0.5) * 2 * xs
+    x[:, ::7] *= 1e-3                                        # channels far below their pixel's largest
+    w1 = (torch.rand((2 * C_, C_), device="cuda", generator=g) - 0.5) * 0.2
+    w2 = (torch.rand((C_, 2 * C_), device="cuda", generator=g) - 0.5) * 0.2
+    b1 = (torch.rand(2 * C_, device="cuda", generator=g) - 0.5) * xs
+    b2 = (torch.rand(C_, device="cuda", generator=g) - 0.5) * xs
+    y = torch.zeros((M, C_), device="cuda")
+    lib.rd_debug_time_mixer(C_, M, variant, 1, x.data_ptr(), y.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr())
+    torch.cuda.synchronize()
+    xd = x.double()
+    ref = xd + torch.nn.functional.gelu(xd @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+    err = (y.double() - ref).abs()
+    # per element: 2^-22 |x| (residual) + 2^-25 (subnormal low plane) + the mixer's own product error, 1e-6 of the output scale
+    bound = 2.0 ** -22 * xd.abs() + 2.0 ** -25 + 1e-6 * float(ref.abs().max())
+    assert bool((err <= bound).all()), (float(err.max()), float((err - bound).max()))
+
+
 def test_forward_is_deterministic(engines, golden_dir):
     """Same input, same handle, twice: bit-identical outputs (no atomics or run-to-run scheduling in the arithmetic; the SE
     pooling is a fixed two-stage reduction, the split-fp16 kernels only use an atomic for the range flag)."""

@@ -426,3 +426,37 @@ def test_region_ocr_of_a_page_shard_reads_what_the_whole_batch_reads(golden_dir,
     assert ocr(pages[:1], [[]], page_keys=[9]) == [[]]
     assert len(ex.contrib) == n_before + 1 and len(ex.contrib[7][0]) == 0
     pipe.rec_width_sync = None
+
+
+def test_det_range_trip_under_the_width_exchange_makes_one_collective_call(golden_dir, monkeypatch):
+    """with `rec_width_sync` set, a det engine that leaves the fp16 range is caught BEFORE the recogniser stage - the
+    det forward is repeated on fp32 MFMA, the (key, ratio) list this rank hands to the exchange comes from the repeated maps, and the
+    exchange is called exactly ONCE for the batch (a second call would pair with the peers' next collective)."""
+    from rapiddoc_amd.pages import synth_batch
+    from rapiddoc_amd.pipeline import PagePipeline
+    from rapiddoc_amd import ocr_host
+    monkeypatch.setenv("RD_PRECISION", "auto")
+    states = {k: _state(golden_dir, k) for k in ("ppocrv6_det", "ppocrv6_rec")}
+    big = dict(states["ppocrv6_det"])
+    stem = [k for k in big if k.endswith("weight") and big[k].ndim == 4 and big[k].shape[1] == 3][0]
+    big[stem] = big[stem] * 3.0e5                          # every later det activation ~1e5 x larger: the split kernels flag it
+    pipe = PagePipeline({"ppocrv6_det": big, "ppocrv6_rec": states["ppocrv6_rec"]}, rec_mode="strict", n_rec_streams=2)
+    pages_np, boxes = synth_batch(5, 2)
+    pages = torch.from_numpy(pages_np).cuda()
+    quads = [np.asarray([[x0, y0, x1, y0, x1, y1, x0, y1] for x0, y0, x1, y1 in np.asarray(b).reshape(-1, 4)[:7]], np.float32).reshape(-1, 4, 2)
+             for b in boxes]
+    calls = []
+
+    def exchange(keys, ratios):
+        calls.append((np.array(keys), np.array(ratios)))
+        return ocr_host.rec_reference_widths(list(ratios))
+    pipe.rec_width_sync = exchange
+    assert pipe.det.precision == "auto"
+    res = pipe.run_batch(pages, quads, page_keys=[4, 9])
+    assert pipe.det.precision == "fp32" and pipe.det.range_fallbacks == 1          # tripped, and settled before the recogniser ran
+    assert len(calls) == 1 and sorted(set(calls[0][0].tolist())) == [4, 9]
+    assert [len(r.lines) for r in res] == [7, 7]
+    res2 = pipe.run_batch(pages, quads, page_keys=[4, 9])                           # the next batch: one more call, no new trip
+    assert len(calls) == 2 and pipe.det.range_fallbacks == 1
+    assert [[t for _q, t, _s in r.lines] for r in res] == [[t for _q, t, _s in r.lines] for r in res2]
+    pipe.rec_width_sync = None
