@@ -1096,15 +1096,18 @@ void Builder::ctc_stats(const TView& logits, const TView& idx_ext, const TView& 
     emit(std::move(r));
 }
 
-void Builder::softmax_rows(const TView& logits, const TView& out_ext) {
+void Builder::softmax_rows(const TView& logits, const TView& out_ext, const TView* idx_ext, const TView* prob_ext) {
     if (!planning()) return;
     OpRecord r;
     r.name = "softmax";
     r.kind = "softmax";
     r.bytes = 12.0 * logits.pixels() * logits.c;
     const TView lv = logits, ov = out_ext;
-    r.run = [lv, ov](const Plan& pl, const RunCtx& c) {
-        launch_row_softmax(pl.vptr(lv, c), pl.ld(lv), pl.vptr(ov, c), (int)lv.pixels(), lv.c, c.stream);
+    const bool stats = idx_ext != nullptr && prob_ext != nullptr;
+    const TView iv = stats ? *idx_ext : TView{}, pv = stats ? *prob_ext : TView{};
+    r.run = [lv, ov, stats, iv, pv](const Plan& pl, const RunCtx& c) {
+        launch_row_softmax(pl.vptr(lv, c), pl.ld(lv), pl.vptr(ov, c), (int)lv.pixels(), lv.c, c.stream,
+                           stats ? (int32_t*)pl.vptr(iv, c) : nullptr, stats ? pl.vptr(pv, c) : nullptr);
     };
     emit(std::move(r));
 }

@@ -202,7 +202,7 @@ class Builder {
     void to_nchw(const TView& x, const TView& out_ext);
     void copy(const TView& x, const TView& out);   // same geometry, possibly different channel strides
     void ctc_stats(const TView& logits, const TView& idx_ext, const TView& prob_ext);
-    void softmax_rows(const TView& logits, const TView& out_ext);
+    void softmax_rows(const TView& logits, const TView& out_ext, const TView* idx_ext = nullptr, const TView* prob_ext = nullptr);
     void ctc_head(const std::string& prefix, const TView& x, const TView& idx_ext, const TView& prob_ext);
 
     const HostTensor& weight(const std::string& name) const { return ws_->get(name); }

@@ -918,7 +918,11 @@ void launch_rowmax_softmax(const float* logits, int ld, int M, int C, int32_t* i
     if (M > 0) hipLaunchKernelGGL(rowmax_softmax_kernel, dim3(M), dim3(256), 0, s, logits, ld, M, C, idx, prob);
 }
 
-__global__ void __launch_bounds__(256) row_softmax_kernel(const float* z, int ld, float* out, int C) {
+// With `idx` / `prob`: the two reductions rapidocr's CTCLabelDecode performs on this very tensor (`preds.argmax(axis=2)`, `preds.max(axis=2)`,
+// rapid_ocr.py:443-449), computed from the VALUES WRITTEN - prob = the row's largest softmax value (exp(0) * inv = inv), idx = the lowest class
+// whose written value equals it, which is what numpy's argmax returns when two logits round to the same probability - so a host that asks the
+// lazy S2 result (session.LazySoftmax) for argmax / max gets bit for bit what it would get from the materialised array.
+__global__ void __launch_bounds__(256) row_softmax_kernel(const float* z, int ld, float* out, int C, int32_t* idx, float* prob) {
     const int row = blockIdx.x;
     const float* zr = z + (size_t)row * ld;
     float mx = -INFINITY;
@@ -936,10 +940,25 @@ __global__ void __launch_bounds__(256) row_softmax_kernel(const float* z, int ld
     __syncthreads();
     const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
     float* orow = out + (size_t)row * C;
-    for (int c = threadIdx.x; c < C; c += 256) orow[c] = __expf(zr[c] - mx) * inv;
+    int first = 0x7fffffff;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float pv = __expf(zr[c] - mx) * inv;
+        orow[c] = pv;
+        if (pv == inv && c < first) first = c;          // (the row's maximum is written as exactly `inv`: __expf(0) = 1)
+    }
+    if (idx == nullptr) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
+    __shared__ int redi[4];
+    if ((threadIdx.x & 63) == 0) redi[threadIdx.x >> 6] = first;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        idx[row] = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+        prob[row] = inv;
+    }
 }
-void launch_row_softmax(const float* logits, int ld, float* out, int M, int C, hipStream_t s) {
-    if (M > 0) hipLaunchKernelGGL(row_softmax_kernel, dim3(M), dim3(256), 0, s, logits, ld, out, C);
+void launch_row_softmax(const float* logits, int ld, float* out, int M, int C, hipStream_t s, int32_t* idx, float* prob) {
+    if (M > 0) hipLaunchKernelGGL(row_softmax_kernel, dim3(M), dim3(256), 0, s, logits, ld, out, C, idx, prob);
 }
 
 // --------------------------------------------------------------------------------------------------

@@ -271,10 +271,12 @@ void build_ppocrv6_rec(Builder& b, int B, int H, int W, int flags) {
             b.ctc_stats(lg, idx, prob);
         } else {
             TView lg = b.linear("head.head", seq, ACT_NONE);
-            b.ctc_stats(lg, idx, prob);
             if (flags & REC_WANT_SOFTMAX) {
+                // (idx, prob) = numpy's argmax / max of the softmax tensor as written: what the host's CTC decode would compute from it
                 TView sm = b.external(3, B, 1, T, ncls);
-                b.softmax_rows(lg, sm);
+                b.softmax_rows(lg, sm, &idx, &prob);
+            } else {
+                b.ctc_stats(lg, idx, prob);
             }
             b.release(lg);
         }

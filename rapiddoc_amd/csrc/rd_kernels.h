@@ -181,7 +181,8 @@ void launch_add(const float* a, int ald, const float* b, int bld, float* y, int 
 // CTC head statistics from logits: idx[m] = argmax_c z[m][c], prob[m] = 1 / sum_c exp(z[m][c]-max)
 void launch_rowmax_softmax(const float* logits, int ld, int M, int C, int32_t* idx, float* prob, hipStream_t s);
 // full softmax (only when the caller asks for the reference-shaped [B,T,C] probabilities)
-void launch_row_softmax(const float* logits, int ld, float* out, int M, int C, hipStream_t s);
+// softmax rows; with idx / prob also numpy's argmax / max of the rows WRITTEN (lowest class among equal values)
+void launch_row_softmax(const float* logits, int ld, float* out, int M, int C, hipStream_t s, int32_t* idx = nullptr, float* prob = nullptr);
 // Fused CTC head: logits are never materialised.
 struct CtcParams {
     const float* x; int xld;   // [M][K]

@@ -153,35 +153,56 @@ class RdEngine:
             x = x.contiguous().float()
         return x
 
-    def det_forward(self, x: torch.Tensor) -> torch.Tensor:
+    def det_forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, after_launch=None) -> torch.Tensor:
+        """`out` / `after_launch`: as in `rec_forward` (a caller-owned [B,1,H,W] float32 result tensor; work enqueued behind the launch)."""
         x = self._prep(x)
         B, Cc, H, W_ = x.shape
-        out = self._out("det", (B, 1, H, W_), torch.float32, x.device)
+        if out is None:
+            out = self._out("det", (B, 1, H, W_), torch.float32, x.device)
+        elif out.shape != (B, 1, H, W_) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise EngineError("det_forward: `out` does not match the forward's shape")
 
         def launch():
             self._chk(self._l.rd_det_forward(self._h, x.data_ptr(), B, H, W_, out.data_ptr(), None, 0, _stream_ptr()))
             self._log()
+            if after_launch is not None:
+                after_launch()
         self._guarded(launch)
         return out
 
-    def rec_forward(self, x: torch.Tensor, flags: int = 0) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+    def rec_forward(self, x: torch.Tensor, flags: int = 0, out: Optional[tuple] = None,
+                    after_launch=None) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+        """`out`: (idx int32 [B,T], prob float32 [B,T], full float32 [B,T,C] or None) contiguous device tensors to write into - a caller
+        that hands over the SAME addresses call after call (session.Mi355RecSession) lets the library replay the forward as one
+        hipGraph launch.  `after_launch()`: enqueued behind every (re)launch, in front of the range guard's synchronisation (e.g. the
+        caller's device -> host copies, so that one synchronisation serves both)."""
         x = self._prep(x)
         B, Cc, H, W_ = x.shape
         if H != 48:
             raise EngineError("rec input height must be 48")
         T = self._l.rd_rec_seq_len(W_)
-        idx = torch.empty((B, T), dtype=torch.int32, device=x.device)
-        prob = torch.empty((B, T), dtype=torch.float32, device=x.device)
-        full = None
-        if flags & (REC_WANT_SOFTMAX | REC_WANT_LOGITS):
-            full = torch.empty((B, T, self.num_classes), dtype=torch.float32, device=x.device)
+        want_full = bool(flags & (REC_WANT_SOFTMAX | REC_WANT_LOGITS))
+        if out is not None:
+            idx, prob, full = out
+            ok = (idx.shape == (B, T) and idx.dtype == torch.int32 and idx.is_contiguous() and prob.shape == (B, T)
+                  and prob.dtype == torch.float32 and prob.is_contiguous()
+                  and (not want_full or (full is not None and full.shape == (B, T, self.num_classes) and full.dtype == torch.float32
+                                         and full.is_contiguous())))
+            if not ok:
+                raise EngineError("rec_forward: `out` tensors do not match the forward's shapes")
+        else:
+            idx = torch.empty((B, T), dtype=torch.int32, device=x.device)
+            prob = torch.empty((B, T), dtype=torch.float32, device=x.device)
+            full = torch.empty((B, T, self.num_classes), dtype=torch.float32, device=x.device) if want_full else None
 
         def launch():
             self._chk(self._l.rd_rec_forward(self._h, x.data_ptr(), B, W_, idx.data_ptr(), prob.data_ptr(),
-                                             full.data_ptr() if full is not None else None, flags, None, 0, _stream_ptr()))
+                                             full.data_ptr() if want_full else None, flags, None, 0, _stream_ptr()))
             self._log()
+            if after_launch is not None:
+                after_launch()
         self._guarded(launch)
-        return idx, prob, full
+        return idx, prob, (full if want_full else None)
 
     # two-stage form of the recogniser (include/rapiddoc_mi355.h: rd_rec_backbone_forward / rd_rec_tail_forward)
     @property

@@ -46,6 +46,7 @@ def test_rec_session_from_cfg_returns_the_reference_softmax(tmp_path, golden_dir
     st = _state(golden_dir, "ppocrv6_rec")
     sess = Mi355RecSession.from_cfg({"model_path": str(_write(tmp_path, "ppocrv6_rec", st))})
     x = np.random.default_rng(width).uniform(-1, 1, (6, 3, 48, width)).astype(np.float32)       # a chunk of six, as rapid_ocr.py:443 hands it over
+    sess.lazy_softmax = False                                                                   # the plain-ndarray form of the seam
     got = sess(x)
     with torch.no_grad():
         ref = torch.softmax(O.rec_forward(O.as_torch_state(st), torch.from_numpy(x)), dim=2).numpy()
@@ -80,6 +81,8 @@ def test_the_reference_chunk_loop_through_the_session_gives_the_fast_path_string
     cw, ch, rot, _keep = pipe.last_rec_crop_sizes
     crop_hw = [(int(cw[i]), int(ch[i])) if rot[i] else (int(ch[i]), int(cw[i])) for i in range(n)]
     sess = Mi355RecSession.from_cfg({"model_path": str(_write(tmp_path, "ppocrv6_rec", states["ppocrv6_rec"]))})
+    from rapiddoc_amd.session import LazySoftmax
+    assert sess.lazy_softmax                                               # the default: preds stay in HBM, argmax / max come from the device
     # the reference's loop
     ratios = np.array([w / float(h) for h, w in crop_hw])
     indices = np.argsort(ratios)
@@ -96,10 +99,43 @@ def test_the_reference_chunk_loop_through_the_session_gives_the_fast_path_string
             batch[r] = src[:, :, :img_w]
         preds = sess(batch)                                                # numpy [B, T, C] softmax, as torch.py:186-192 returns it
         n_calls += 1
-        assert preds.shape[:2] == (len(idxs), ocr_host.rec_seq_len(img_w))
+        assert isinstance(preds, LazySoftmax) and preds.shape[:2] == (len(idxs), ocr_host.rec_seq_len(img_w))
         for r, (t, s) in enumerate(ocr_host.ctc_decode(preds.argmax(axis=2), preds.max(axis=2), pipe.characters)):
             out[idxs[r]] = (t, s)
-    assert n_calls == -(-n // 6)
+    assert n_calls == -(-n // 6) and sess.softmax_materialized == 0       # not one softmax tensor crossed PCIe
     assert [t for t, _s in out] == [t for _q, t, _s in flat]
     # (scores printed to three places: at most one unit of the third place apart)
     assert max(abs(ocr_host.format_score(s) - fs) for (_t, s), (_q, _t2, fs) in zip(out, flat)) <= 1e-3 + 1e-9
+
+
+@pytest.mark.parametrize("width", [320, 481, 1056])
+def test_lazy_softmax_is_the_eager_array_bit_for_bit(tmp_path, golden_dir, width):
+    """VERDICT r5 next #5.  One session, the same chunk twice: `lazy_softmax=False` returns the ndarray of rounds 1-5; the default returns a
+    LazySoftmax whose argmax(axis=2) / max(axis=2) - answered from the device's reductions, nothing materialised - equal numpy's on that
+    ndarray EXACTLY (values and dtypes; ties resolved like numpy: the lowest class among equal written values), and which turns into
+    that very ndarray (np.asarray, indexing, arithmetic, other reductions) on any other access."""
+    from rapiddoc_amd.session import LazySoftmax, Mi355RecSession
+    st = _state(golden_dir, "ppocrv6_rec")
+    sess = Mi355RecSession.from_cfg({"model_path": str(_write(tmp_path, "ppocrv6_rec", st))})
+    x = np.random.default_rng(width).uniform(-1, 1, (6, 3, 48, width)).astype(np.float32)
+    sess.lazy_softmax = False
+    eager = sess(x)
+    assert type(eager) is np.ndarray
+    sess.lazy_softmax = True
+    lazy = sess(x)
+    assert isinstance(lazy, LazySoftmax) and lazy.shape == eager.shape and lazy.dtype == eager.dtype and len(lazy) == 6
+    am, mx = lazy.argmax(axis=2), lazy.max(axis=2)
+    assert am.dtype == eager.argmax(axis=2).dtype and mx.dtype == np.float32
+    assert np.array_equal(am, eager.argmax(axis=2)) and np.array_equal(mx, eager.max(axis=2))
+    assert np.array_equal(np.argmax(lazy, axis=-1), am) and np.array_equal(np.max(lazy, axis=2), mx)
+    assert not lazy.materialized and sess.softmax_materialized == 0
+    assert np.array_equal(np.asarray(lazy), eager) and lazy.materialized and sess.softmax_materialized == 1
+    lazy2 = sess(x)
+    assert np.array_equal(lazy2[3, 5:9], eager[3, 5:9]) and lazy2.materialized                  # indexing materialises
+    lazy3 = sess(x)
+    assert np.array_equal(lazy3 * 2.0, eager * 2.0) and np.array_equal(lazy3.sum(axis=2), eager.sum(axis=2))
+    assert np.array_equal(lazy3.argmax(axis=1), eager.argmax(axis=1))                           # another axis: from the materialised array
+    # a constructed tie: two classes with the same logit row-wise cannot be forced from outside, but equal WRITTEN values can be checked
+    # against numpy's rule directly on the eager tensor: the device's argmax is the first index holding the row maximum
+    first = (eager == eager.max(axis=2, keepdims=True)).argmax(axis=2)
+    assert np.array_equal(am, first)
