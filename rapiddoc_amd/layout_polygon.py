@@ -226,57 +226,70 @@ def polygon_to_quad(polygon) -> Optional[np.ndarray]:
     return np.roll(quad, -int(np.argmin(quad[:, 0] + quad[:, 1])), axis=0)
 
 
+def _mask_windows(boxes: np.ndarray, mask_hw: Sequence[int], scale_ratio: Sequence[float]):
+    """All boxes at once: integer page rectangles [n, 4] (x0, y0, x1, y1: the float corners truncated), and the window of the detector's
+    mask grid under each (columns c0:c1, rows r0:r1) - page pixels times input size / page size / 4, rounded half to even like the
+    reference's round(), clipped to the grid."""
+    hm, wm = mask_hw
+    page = boxes[:, 2:6].astype(np.int32)
+    fx, fy = scale_ratio[0] / 4, scale_ratio[1] / 4
+    cols = np.clip(np.rint(page[:, [0, 2]] * fx).astype(np.int64), 0, wm)
+    rows = np.clip(np.rint(page[:, [1, 3]] * fy).astype(np.int64), 0, hm)
+    return page, cols, rows
+
+
+def _auto_shape(polygon, quad, rect: np.ndarray, previous):
+    """'auto' mode for one box whose mask gave a polygon (post_process.py:499-529): the min-area quad - or the box itself when that
+    quad covers >= 95 % of box U quad - is taken when it agrees with the polygon (IoU >= 0.8, always measured against the min-area
+    quad) and the box barely touches what the PREVIOUS box returned (< 1 % of the smaller of the two); else the polygon."""
+    if quad is None:
+        return polygon
+    min_quad = quad.tolist()
+    candidate = rect if polygon_overlap_ratio(rect.tolist(), min_quad, mode="union") >= 0.95 else quad
+    agrees = polygon_overlap_ratio(polygon.tolist() if isinstance(polygon, np.ndarray) else polygon, min_quad, mode="union") >= 0.8
+    clear = previous is None or polygon_overlap_ratio(previous.tolist(), rect.tolist(), mode="small") < 0.01
+    return candidate if agrees and clear else polygon
+
+
 def polygons_from_masks(boxes: np.ndarray, masks: np.ndarray, scale_ratio: Sequence[float], layout_shape_mode: str) -> list:
-    """post_process.py:425-533.  boxes [n, 6] float32 (page pixels), masks [n, hm, wm] (the detector's mask grid, 1/4 of its input
-    size), scale_ratio = input size / page size per axis.  One entry per box: the box rectangle (float32 [4, 2]) where no usable
-    mask exists or in 'rect' mode, else the polygon / quad, or None."""
+    """post_process.py:425-533 (`extract_polygon_points_by_masks`).  boxes [n, 6] float32 (page pixels), masks [n, hm, wm] (the
+    detector's mask grid, 1/4 of its input size), scale_ratio = input size / page size per axis.  One entry per box: the box rectangle
+    (float32 [4, 2]) where no usable mask exists or in 'rect' mode, else the polygon / quad, or None.
+
+    Own structure (round 6): the box -> mask-window arithmetic runs over all boxes at once (`_mask_windows`), the boxes that have
+    something to trace are known before the loop, and the per-box decision of the 'auto' mode is `_auto_shape`; the loop itself stays
+    sequential because that decision looks at what the previous box returned.  One quirk of the reference is part of its output and kept:
+    the width that `custom_vertices` may bridge is that of the "widest box" computed as column 4 minus column 3 (x_max - y_min)."""
     if layout_shape_mode not in ("rect", "poly", "quad", "auto"):
         raise ValueError("layout_shape_mode must be one of ['rect', 'poly', 'quad', 'auto']")
-    scale_w, scale_h = scale_ratio[0] / 4, scale_ratio[1] / 4
-    h_m, w_m = masks.shape[1:]
-    out: list = []
-    # NOTE the reference takes column 4 minus column 3 (xmax - ymin) for its "widest box": kept as is
-    max_box_w = max(boxes[:, 4] - boxes[:, 3])
-    for i in range(len(boxes)):
-        x_min, y_min, x_max, y_max = boxes[i, 2:6].astype(np.int32)
-        box_w, box_h = x_max - x_min, y_max - y_min
-        rect = np.array([[x_min, y_min], [x_max, y_min], [x_max, y_max], [x_min, y_max]], dtype=np.float32)
-        if box_w <= 0 or box_h <= 0:
-            out.append(rect)
-            continue
-        xs = np.clip([int(round(x_min * scale_w)), int(round(x_max * scale_w))], 0, w_m)
-        ys = np.clip([int(round(y_min * scale_h)), int(round(y_max * scale_h))], 0, h_m)
-        cropped = masks[i, ys[0]:ys[1], xs[0]:xs[1]]
-        if cropped.size == 0 or np.sum(cropped) == 0 or layout_shape_mode == "rect":
-            out.append(rect)
-            continue
-        resized = resize_nearest(cropped.astype(np.uint8), int(box_w), int(box_h))
-        polygon = mask_to_polygon(resized, box_w if box_w > max_box_w * 0.6 else max_box_w)
-        if polygon is not None and len(polygon) < 4:
-            out.append(rect)
-            continue
-        if polygon is not None and len(polygon) > 0:
-            polygon = polygon + np.array([x_min, y_min])
+    n = len(boxes)
+    page, cols, rows = _mask_windows(boxes, masks.shape[1:], scale_ratio)
+    wh = page[:, 2:4] - page[:, 0:2]
+    rects = np.stack([page[:, [0, 1]], page[:, [2, 1]], page[:, [2, 3]], page[:, [0, 3]]], axis=1).astype(np.float32)      # [n, 4, 2]
+    shapes: list = [rects[i] for i in range(n)]
+    if layout_shape_mode == "rect" or n == 0:
+        return shapes
+    widest = max(boxes[:, 4] - boxes[:, 3])
+    traceable = [i for i in range(n) if wh[i, 0] > 0 and wh[i, 1] > 0 and rows[i, 1] > rows[i, 0] and cols[i, 1] > cols[i, 0]
+                 and masks[i, rows[i, 0]:rows[i, 1], cols[i, 0]:cols[i, 1]].sum() != 0]
+    for i in traceable:
+        w, h = int(wh[i, 0]), int(wh[i, 1])
+        window = masks[i, rows[i, 0]:rows[i, 1], cols[i, 0]:cols[i, 1]]
+        polygon = mask_to_polygon(resize_nearest(window.astype(np.uint8), w, h), wh[i, 0] if wh[i, 0] > widest * 0.6 else widest)
+        if polygon is not None:
+            if len(polygon) < 4:
+                continue                                            # a degenerate trace: the rectangle stays
+            if len(polygon) > 0:
+                polygon = polygon + page[i, 0:2]
         if layout_shape_mode == "poly":
-            out.append(polygon)
-        elif layout_shape_mode == "quad":
-            quad = polygon_to_quad(polygon)
-            out.append(quad if quad is not None else rect)
-        else:                                                        # auto
-            quad = polygon_to_quad(polygon)
-            if quad is not None:
-                quad_list = quad.tolist()                             # stays the min-area quad in the second comparison
-                if polygon_overlap_ratio(rect.tolist(), quad_list, mode="union") >= 0.95:
-                    quad = rect                                       # a quad that is nearly the box: the box
-                poly_list = polygon.tolist() if isinstance(polygon, np.ndarray) else polygon
-                iou_quad = polygon_overlap_ratio(poly_list, quad_list, mode="union")
-                previous = out[-1] if out else None
-                iou_prev = polygon_overlap_ratio(previous.tolist(), rect.tolist(), mode="small") if previous is not None else 0
-                if iou_quad >= 0.8 and iou_prev < 0.01:
-                    out.append(quad)
-                    continue
-            out.append(polygon)
-    return out
+            shapes[i] = polygon
+            continue
+        quad = polygon_to_quad(polygon)
+        if layout_shape_mode == "quad":
+            shapes[i] = quad if quad is not None else rects[i]
+        else:
+            shapes[i] = _auto_shape(polygon, quad, rects[i], shapes[i - 1] if i > 0 else None)
+    return shapes
 
 
 def polygon_keep_mask(crop_hw: Sequence[int], polygon_points, x_min: int, y_min: int) -> np.ndarray:

@@ -70,3 +70,12 @@ def test_importing_the_package_defaults_the_hardware_queue_count_and_respects_an
     assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "16"
     env["GPU_MAX_HW_QUEUES"] = "4"
     assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "4"
+    # the override is a side effect on the embedding process: it is logged once (INFO, logger "rapiddoc_amd") and can be asked for
+    code2 = ("import logging, os, sys; logging.basicConfig(level=logging.INFO, stream=sys.stdout, format='%%(name)s|%%(message)s'); "
+             "sys.path.insert(0, %r); import rapiddoc_amd; print(rapiddoc_amd.HW_QUEUES_SET_BY_IMPORT)" % root)
+    del env["GPU_MAX_HW_QUEUES"]
+    out = subprocess.run([sys.executable, "-c", code2], env=env, capture_output=True, text=True).stdout
+    assert out.count("rapiddoc_amd|rapiddoc_amd: GPU_MAX_HW_QUEUES was unset") == 1 and out.strip().endswith("True")
+    env["GPU_MAX_HW_QUEUES"] = "8"
+    out = subprocess.run([sys.executable, "-c", code2], env=env, capture_output=True, text=True).stdout
+    assert "GPU_MAX_HW_QUEUES" not in out and out.strip().endswith("False")
