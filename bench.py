@@ -636,6 +636,8 @@ def main():
                         name = "conv_stream_h3_kernel"
                     if op["cfg"].startswith("direct"):
                         name = "conv_direct_h3_kernel"
+                    if op["cfg"].startswith("c3h1"):     # round 6: the one-accumulator direct 3x3 (kernels_conv3x3_h1.hip)
+                        name = "conv3x3_h1_kernel"
                     if op["cfg"].startswith("dma"):   # LDS-DMA GEMM: 8-wavefront kernel, 16-wavefront one for K <= 384
                         name = "gemm_h3_dma16_kernel" if op["cfg"].startswith("dma16w") else "gemm_h3_dma_kernel"
                     if op["cfg"].startswith("h1w"):   # round 5: the single-accumulator split GEMM (kernels_gemm_h1.hip)
@@ -658,7 +660,7 @@ def main():
                 a[0] += op["flops"]; a[1] += op["bytes"]; a[2] += op["ms"]; a[3] += 1
                 tot_ms += op["ms"]
             e.set_profiling(False)
-        mfma = {k: v for k, v in agg.items() if k.startswith(("conv_igemm", "gemm_h3", "gemm_h1", "lc_mixer", "ctc_head", "conv_direct", "conv_stream", "stem_fused"))}
+        mfma = {k: v for k, v in agg.items() if k.startswith(("conv_igemm", "gemm_h3", "gemm_h1", "lc_mixer", "ctc_head", "conv_direct", "conv3x3_h1", "conv_stream", "stem_fused"))}
         dom = max(mfma, key=lambda k: mfma[k][2])
         fl, by, ms, n = mfma[dom]
         ach = fl / (ms * 1e-3) / 1e12

@@ -439,9 +439,25 @@ float rd_debug_conv(int N, int H, int W, int Cin, int Cout, int KH, int KW, int 
     p.KH = KH; p.KW = KW; p.SH = p.SW = S; p.PT = PT; p.PL = PL; p.act = act; p.out_mode = rd::OUT_NHWC;
     p.res = res; p.rld = Cout;
     p.M = N * p.OH * p.OW; p.K = KH * KW * Cin; p.Ng = Cout;
+    // the one-accumulator 3x3 kernel needs its own weight image, prepared here the way the engine prepares it (RD_CONV3X3_H1=0 or
+    // *used_direct = 1 / 2 on entry: the older kernels).  Reported as *used_direct = 3.
+    void* img3 = nullptr;
+    if (wh && !(used_direct && *used_direct) && rd::conv3x3_h1_shape_ok(KH, KW, Cin, Cout)) {
+        std::vector<float> hw((size_t)Cout * p.K);
+        if (hipMemcpy(hw.data(), w, hw.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+            std::vector<uint16_t> img;
+            const float inv = rd::prepare_conv3x3_h1_weights(hw.data(), Cout, Cin, img);
+            if (hipMalloc(&img3, img.size() * 2) == hipSuccess) {
+                (void)hipMemcpy(img3, img.data(), img.size() * 2, hipMemcpyHostToDevice);
+                p.w3 = (const uint16_t*)img3;
+                p.w3_inv = inv;
+            }
+        }
+    }
+    const bool c3 = wh && rd::conv3x3_h1_applies(p);
     const bool force = used_direct && *used_direct == 1 && wh && rd::conv_direct_h3_supported(p);
     const bool force_stream = used_direct && *used_direct == 2 && wh && rd::conv_stream_h3_supported(p);
-    if (used_direct) *used_direct = force_stream ? 2 : (force || (wh && !rd::conv_stream_h3_applies(p) && rd::conv_direct_h3_applies(p))) ? 1
+    if (used_direct) *used_direct = c3 ? 3 : force_stream ? 2 : (force || (wh && !rd::conv_stream_h3_applies(p) && rd::conv_direct_h3_applies(p))) ? 1
                                     : (wh && rd::conv_stream_h3_applies(p)) ? 2 : 0;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -459,6 +475,7 @@ float rd_debug_conv(int N, int H, int W, int Cin, int Cout, int KH, int KW, int 
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (img3) (void)hipFree(img3);
     return iters > 0 ? ms / iters : 0.f;
 }
 

@@ -371,8 +371,12 @@ TView Builder::conv(const std::string& wname, const std::string& bname, const st
             p.w1 = reinterpret_cast<const uint16_t*>(pb_->ptr(key + "#w1"));
             p.w1_inv = *pb_->host_ptr(key + "#w1s");
         }
+        if (pb_->has(key + "#w3")) {
+            p.w3 = reinterpret_cast<const uint16_t*>(pb_->ptr(key + "#w3"));
+            p.w3_inv = *pb_->host_ptr(key + "#w3s");
+        }
         p.range_flag = range_flag_;
-        r.cfg = std::string(conv_stream_h3_applies(p) ? "stream" : conv_direct_h3_applies(p) ? "direct" : gemm_h1_applies(p) ? "h1w256x128" : gemm_h3_dma_applies(p) ? (gemm_h3_dma_uses16(p) ? "dma16w256x128" : "dma256x128") : cout > 96 ? "256x128" : cout > 64 ? "128x96"
+        r.cfg = std::string(conv_stream_h3_applies(p) ? "stream" : conv3x3_h1_applies(p) ? "c3h1" : conv_direct_h3_applies(p) ? "direct" : gemm_h1_applies(p) ? "h1w256x128" : gemm_h3_dma_applies(p) ? (gemm_h3_dma_uses16(p) ? "dma16w256x128" : "dma256x128") : cout > 96 ? "256x128" : cout > 64 ? "128x96"
                             : (cout > 32 && p.M >= 65536) ? "256x64" : K <= 256 || cout <= 32 ? "128x32" : "128x64") + "/h3";
     }
     r.run = [p, xv, yv, rv, av, has_res, has_as, h3](const Plan& pl, const RunCtx& c) mutable {
@@ -419,6 +423,12 @@ void Builder::fold_conv(const std::string& wname, const std::string& bname, cons
         split_weights_h3(wf.data(), cout, K, hi, lo);
         pb_->add_u16(key + "#wh", hi);
         pb_->add_u16(key + "#wl", lo);
+        if (conv3x3_h1_shape_ok(kh, kw, cin, cout)) {               // one-accumulator direct 3x3: slab-ordered fragment image
+            std::vector<uint16_t> img;
+            const float inv = prepare_conv3x3_h1_weights(wf.data(), cout, cin, img);
+            pb_->add_u16(key + "#w3", img);
+            pb_->add(key + "#w3s", std::vector<float>{inv});
+        }
         if (kh == 1 && kw == 1 && gemm_h1_shape_ok(K, cout)) {      // single-accumulator GEMM: fragment-ordered, per-channel pre-scaled image
             std::vector<uint16_t> img;
             const float inv = prepare_gemm_h1_weights(wf.data(), cout, K, img);

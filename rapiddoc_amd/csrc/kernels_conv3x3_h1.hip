@@ -1,0 +1,408 @@
+// Direct 3x3 / stride-1 / pad-1 convolution on the fp16 matrix cores with ONE fp32 accumulator set (round 6) - PPHGNetV2's 3x3 stacks
+// (stages.0 / stages.1 of the PP-DocLayout backbone and of the formula encoder, rec_pphgnetv2.py:1001-1071) and the DB head's conv_down
+// (det_db_head.py:52-149).  Successor of conv_direct_h3_kernel (kernels_conv_direct_h3.hip) for these layers; that kernel's ablations
+// ADD UP (patch loads + fragment reads + weight slabs + MFMAs + stores, one 119-KB workgroup per CU, every phase exposed)
+// and VERDICT r5 #7 / next #3 asked for the arithmetic and the occupancy the pointwise GEMM got in round 5 (kernels_gemm_h1.hip):
+//   * ONE accumulator: x = hi + lo with hi = fp16(x), lo = fp16(x - hi) UNSCALED (gfx950's matrix cores keep fp16 subnormals: an
+//     absolute error of 2^-25 below |x| = 2^-3), the weights pre-scaled per matrix by a power of two (max |w| in [2^13, 2^14)), the three
+//     products hi.hi + hi.lo + lo.hi go into the same fp32 accumulator and the sum is multiplied by the exact inverse scale in the
+//     epilogue.  Half the accumulator registers of the two-set arithmetic, no 2^-11 fold;
+//   * with the registers freed a wavefront owns TWO rows of 32 output pixels x all output channels (<= 96): the weight fragments of a
+//     k-step are read once for 64 pixels - 8 (10) ds_read_b128 per 12 (18) MFMAs at two (three) channel blocks, where the old kernel
+//     paid 6 (8) per 6 (9): the LDS port is no longer as busy as the matrix pipe;
+//   * a workgroup is FOUR wavefronts on an 8 x 32 tile with <= 79 KB of LDS, so TWO workgroups share a CU (__launch_bounds__(256, 2))
+//     with independent barriers: while one stages its patch (global -> split -> LDS), runs its epilogue or waits, the other one's
+//     MFMAs own the matrix pipes;
+//   * LDS: the input patch (10 x 34 pixels, 32 input channels per pass) split ONCE into two fp16 planes (80-byte pixel stride = 16 x
+//     odd: conflict-free ds_read_b128; the nine taps are address offsets), and a ring of FOUR weight slabs.  A slab is one k-step (16
+//     input channels of one tap): NB x {hi, lo} MFMA fragments of 1 KB, stored by the host in consumption order
+//     (prepare_conv3x3_h1_weights), so a slab is filled by LINEAR `global_load_lds` copies - no staging registers, no ds_write - three
+//     steps ahead of its use, and a fragment read is ds_read_b128 at fragment + 16 * lane.  The slab sequence is cyclic: the DMA stream
+//     keeps running across tiles of the persistent workgroups;
+//   * one barrier per k-step (12-18 MFMAs per wavefront); fragments are read one step ahead of their MFMAs.
+// Everything else (bias, activation, residual, range guard, NHWC views with row strides) as the other split kernels.  Results do not
+// depend on the launch size (one kernel for every M).
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
+#include "rd_device.h"
+
+namespace rd {
+
+static constexpr int C3_TR = 8, C3_TC = 32;                   // output tile (rows x columns)
+static constexpr int C3_PW = C3_TC + 2, C3_PH = C3_TR + 2;    // patch
+static constexpr int C3_PP = C3_PW * C3_PH;                   // 340 patch pixels
+static constexpr int C3_CC = 32;                              // input channels per pass
+static constexpr int C3_S = C3_CC * 2 + 16;                   // bytes per patch pixel in one fp16 plane
+static constexpr int C3_PLANE = C3_PP * C3_S;                 // 27 200 bytes
+static constexpr int C3_D = 4;                                // weight slabs in the ring
+#ifndef RD_C3_PIN
+#define RD_C3_PIN 0      // developer A/B: 0 = the scheduler places the fragment reads, 1 = pinned in front of the MFMAs, 2 = pinned for NB < 3
+#endif
+
+// x = hi + lo, hi = fp16(x), lo = fp16(x - hi) (kernels_gemm_h1.hip h1_split8): one packed conversion per pair + one v_fma_mix per element.
+// `neg1` is -1.0f in a register the compiler cannot see through (a literal folds the fma into sub + extra conversions).
+typedef _Float16 c3_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void c3_split4(const f32x4 v, float neg1, f16x4& hi, f16x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+        const c3_f16x2 h = __builtin_convertvector(f32x2{v[e], v[e + 1]}, c3_f16x2);
+        hi[e] = h[0];
+        hi[e + 1] = h[1];
+        lo[e] = (_Float16)__builtin_fmaf((float)h[0], neg1, v[e]);
+        lo[e + 1] = (_Float16)__builtin_fmaf((float)h[1], neg1, v[e + 1]);
+    }
+}
+
+template <int NB>
+struct C3Frag { f16x8 ah[2], al[2], bh[NB], bl[NB]; };
+
+// "my pieces of the slab about to be read have landed" - a wavefront issues one (NB == 3: wavefronts 0, 1 two; NB == 1: wavefronts 2, 3
+// none) DMA instruction per slab and C3_D - 2 younger slabs may still be in flight; the DMA loads retire in issue order, and younger STORES
+// (an epilogue's) cannot satisfy the count in their place: with at most n operations left of which the loads form a suffix of the issue
+// order, the oldest load is among the completed ones - then the workgroup barrier: everybody's pieces have landed, and everybody has
+// read its fragments of the slab whose buffer is refilled next.
+// Measured and dropped (profiles/r6_conv3x3_h1.txt): the NEXT patch prefetched into registers under a pass's MFMAs (eleven buffer loads
+// younger than the slab waited for, the count raised by eleven for the three steps they are in flight): no gain (294 -> 310 us on B4
+// stages.0; 44 more live registers), and ONE run in ~100 returned a wrong element - register loads (MUBUF) and LDS-DMA loads (GLOBAL) in
+// flight together are evidently not retired in one common order, which the count relies on.  The patch loads of this kernel are therefore
+// always consumed (a full drain) before the next step barrier counts anything.
+template <int NB>
+__device__ __forceinline__ void c3_wait_slab_barrier(int wave) {
+    if (NB == 3 && wave < 2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else if (NB == 1 && wave >= 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+}
+
+template <int NB>
+__global__ void __launch_bounds__(256, 2) conv3x3_h1_kernel(ConvParams p, int tiles_r, int tiles_c, int ntiles, int nstep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int SLAB = NB * 2 * 1024;                     // bytes of one weight slab
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    unsigned char* Ph = smem;
+    unsigned char* Pl = smem + C3_PLANE;
+    unsigned char* Wb = smem + 2 * C3_PLANE;
+    const _Float16* wimg = reinterpret_cast<const _Float16*>(p.w3);
+    float neg1 = -1.f;
+    asm volatile("" : "+s"(neg1));
+
+    // ---- weight stream: slab j of the global step sequence = slab (j mod nstep) of the image -> ring buffer j mod C3_D
+    int w_issue = 0, w_pos = 0;                             // next slab to request: global index, position in the weight cycle
+    auto dma_slab = [&]() {
+        const _Float16* src = wimg + (size_t)w_pos * (SLAB / 2) + lane * 8;
+        unsigned char* dst = Wb + (unsigned)(w_issue & (C3_D - 1)) * SLAB;
+        auto piece = [&](int f) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 512),
+                                             (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+        };
+        if constexpr (NB == 2) {
+            piece(wave);
+        } else if constexpr (NB == 3) {
+            piece(wave);
+            if (wave < 2) piece(wave + 4);
+        } else {
+            if (wave < 2) piece(wave);
+        }
+        ++w_issue;
+        if (++w_pos == nstep) w_pos = 0;
+    };
+
+    // ---- patch staging: the patch has 10 rows x 34 columns x 8 channel groups (of 4) = 2720 slots; thread t owns slots t, t + 256, ...
+    // (eleven, the last one only for t < 160), fixed for the whole kernel: row / column / group are decoded once
+    constexpr int NSLOT = 11, ROWSLOTS = C3_PW * 8;
+    // slot i of thread t is q = t + 256 i = 272 i + (t - 16 i): row i, remainder t - 16 i - or, where that is negative, row i - 1 and
+    // remainder + 272; the channel group q & 7 = t & 7 is the same for all of a thread's slots (decoded on the fly: no slot tables)
+    // (decoded from a copy of the thread id the compiler cannot see through, made inside stage_patch: otherwise every slot's row / column /
+    //  clamped offsets are hoisted out of the tile loop and live - ~40 registers - through the MFMA steps)
+    int stid = tid;
+    auto slot_row = [&](int i) { return stid - 16 * i < 0 ? i - 1 : i; };
+    auto slot_col = [&](int i) { const int rem = stid - 16 * i; return (rem < 0 ? rem + ROWSLOTS : rem) >> 3; };
+    float amax = 0.f;
+    int img = 0, oh0 = 0, ow0 = 0;
+    u32x4 pre[NSLOT];                                       // the patch in flight: raw fp32, one 16-byte load per slot
+    unsigned pre_ok = 0;                                    // bit i: slot i lies inside the image (else it is written as zeros)
+    // request input channels [c0, c0 + 4 * groups) of the patch of tile (im, oh, ow): every load unconditional (clamped row / column, the
+    // slot's own channel group or group 0), all eleven in flight together; masked when written
+    auto load_patch = [&](int im, int oh, int ow, int c0, int groups) {
+        // 32-bit byte offsets inside the image through a buffer descriptor (launcher: an image has < 2^30 elements): the per-slot address
+        // is four integer operations, where 64-bit pointer arithmetic cost a dozen and was hoisted into ~30 live registers
+        typedef __amdgpu_buffer_rsrc_t rsrc_t;
+        const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)im * p.H * p.W * p.xld + c0), 0, 0x7fffffff, 0x00020000);
+        stid = tid;
+        asm volatile("" : "+v"(stid));
+        const int s_grp = stid & 7;
+        const unsigned gsel = s_grp < groups ? 16u * (unsigned)s_grp : 0u;
+        pre_ok = 0;
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const int ih = oh - 1 + slot_row(i), iw = ow - 1 + slot_col(i);
+            if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) pre_ok |= 1u << i;
+            const unsigned off = ((unsigned)min(max(ih, 0), p.H - 1) * (unsigned)p.W + (unsigned)min(max(iw, 0), p.W - 1)) * (unsigned)p.xld * 4u + gsel;
+            pre[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, 0, 0);
+        }
+    };
+    // split the patch in flight and write its two fp16 planes
+    auto write_patch = [&](int groups) {
+        stid = tid;
+        asm volatile("" : "+v"(stid));
+        const int s_grp = stid & 7;
+        if (s_grp >= groups) return;                        // (this pass's channel groups only: the others are never read)
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            if (i + 1 == NSLOT && stid + 256 * (NSLOT - 1) >= C3_PH * ROWSLOTS) continue;
+            const f32x4 x4 = (pre_ok >> i) & 1u ? __builtin_bit_cast(f32x4, pre[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            f16x4 hi, lo;
+            c3_split4(x4, neg1, hi, lo);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) amax = (x4[e] != x4[e]) ? INFINITY : fmaxf(amax, fabsf(x4[e]));
+            const unsigned o = (unsigned)(slot_row(i) * C3_PW + slot_col(i)) * C3_S + (unsigned)s_grp * 8;
+            *reinterpret_cast<f16x4*>(Ph + o) = hi;
+            *reinterpret_cast<f16x4*>(Pl + o) = lo;
+        }
+    };
+
+    // ---- fragments of one step: A = this wavefront's two pixel rows at tap (kh, kw), k-step ks of the pass; B = the slab's fragments
+    const unsigned a_lane = (unsigned)((2 * wave) * C3_PW + l31) * C3_S + (unsigned)lhi * 16u;
+    const unsigned b_lane = (unsigned)lane * 16u;
+    auto read_frag = [&](C3Frag<NB>& f, int tap, int ks, int slab) {
+        const int kh = tap / 3, kw = tap - 3 * kh;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const unsigned a = a_lane + (unsigned)((r + kh) * C3_PW + kw) * C3_S + (unsigned)ks * 32u;
+            f.ah[r] = *reinterpret_cast<const f16x8*>(Ph + a);
+            f.al[r] = *reinterpret_cast<const f16x8*>(Pl + a);
+        }
+        const unsigned char* wb = Wb + (unsigned)(slab & (C3_D - 1)) * SLAB + b_lane;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            f.bh[nb] = *reinterpret_cast<const f16x8*>(wb + (2 * nb) * 1024);
+            f.bl[nb] = *reinterpret_cast<const f16x8*>(wb + (2 * nb + 1) * 1024);
+        }
+    };
+
+    f32x16 acc[2][NB];
+    C3Frag<NB> fr[2];
+    int g = 0;                                              // global step counter (slab index of the step being computed)
+    // one pass of KSN k-steps per tap over the staged patch: 9 * KSN steps, fully unrolled (taps and k-steps are compile-time offsets)
+    auto run_pass = [&](auto ksn_c) {
+        constexpr int KSN = decltype(ksn_c)::value;
+        constexpr int NS = 9 * KSN;
+        read_frag(fr[0], 0, 0, g);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            // slab g + 1 (read below) has landed everywhere, and every wavefront has read its fragments of slab g: its buffer is free
+            c3_wait_slab_barrier<NB>(wave);
+            dma_slab();                                     // slab g + C3_D -> the buffer of slab g
+            C3Frag<NB>& cur = fr[s & 1];
+            // the next step's fragments are requested BEFORE this step's MFMAs (pinned: left alone the scheduler sinks the reads behind
+            // most of the MFMAs, and the next step then opens with a wait for the LDS)
+            if (s + 1 < NS) read_frag(fr[(s + 1) & 1], (s + 1) / KSN, (s + 1) % KSN, g + 1);
+            if constexpr (RD_C3_PIN == 1 || (RD_C3_PIN == 2 && NB < 3)) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[r][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.ah[r], cur.bh[nb], acc[r][nb], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[r][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.ah[r], cur.bl[nb], acc[r][nb], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[r][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.al[r], cur.bh[nb], acc[r][nb], 0, 0, 0);
+            ++g;
+        }
+    };
+
+    const int full_passes = p.Cin / C3_CC, tail16 = (p.Cin % C3_CC) / 16;
+    auto decode = [&](int v, int& im, int& oh, int& ow) {
+        // XCD-contiguous tile order (workgroup b sits on XCD b % 8): an XCD's workgroups walk ONE contiguous run of the tile list, so
+        // the halo rows / columns neighbouring tiles share are served by that XCD's own L2
+        const int xcd = v & 7, jj = v >> 3, q = ntiles >> 3, rm = ntiles & 7;
+        int t = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + jj;
+        const int tc = t % tiles_c;
+        t /= tiles_c;
+        const int tr = t % tiles_r;
+        im = t / tiles_r;
+        oh = tr * C3_TR;
+        ow = tc * C3_TC;
+    };
+#pragma unroll 1
+    for (int i = 0; i < C3_D; ++i) dma_slab();              // slabs 0 .. 3 of the stream
+    unsigned emax = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (once: from here on a step's barrier has always waited for the next step's slab)
+#pragma unroll 1
+    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+        decode(v, img, oh0, ow0);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[r][nb][i] = 0.f;
+        // full passes of 32 input channels, then - Cin % 32 == 16 - the 16-channel tail pass.  Two loops one behind the other, not one
+        // loop that branches between the two unrolled bodies: with the branch inside, the register allocator gave each body its own copy
+        // of the accumulators (192 registers at three output blocks, an accumulator block spilled and reloaded every step)
+#pragma unroll 1
+        for (int pass = 0; pass < full_passes; ++pass) {
+            load_patch(img, oh0, ow0, pass * C3_CC, 8);     // (requested before the barrier: in flight while the stragglers arrive)
+            asm volatile("s_barrier" ::: "memory");         // every wavefront is done with the previous patch
+            write_patch(8);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the patch is in LDS
+            run_pass(std::integral_constant<int, 2>{});
+        }
+        if (tail16) {
+            load_patch(img, oh0, ow0, full_passes * C3_CC, 4);
+            asm volatile("s_barrier" ::: "memory");
+            write_patch(4);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            run_pass(std::integral_constant<int, 1>{});
+        }
+
+        // ---- epilogue: lane = output channel, registers = 16 of the 32 pixels of a row.  One path for interior and edge tiles: every
+        // access goes through a buffer descriptor that ENDS behind the row's last valid pixel, so the hardware's range check drops the
+        // stores (and zeroes the residual loads) of pixels past the image's right edge - no per-pixel compare / branch.
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int oh = oh0 + 2 * wave + r;
+            if (oh >= p.OH) continue;
+            const size_t pix0 = ((size_t)img * p.OH + oh) * p.OW + ow0;
+            const unsigned npix = (unsigned)min(C3_TC, p.OW - ow0);
+            typedef __amdgpu_buffer_rsrc_t rsrc_t;
+            const rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y + pix0 * p.yld, 0, (int)(npix * (unsigned)p.yld * 4u), 0x00020000);
+            const rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res + pix0 * p.rld : p.y), 0,
+                                                                (int)(npix * (unsigned)(p.res ? p.rld : p.yld) * 4u), 0x00020000);
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));                 // (keeps the epilogue's offsets out of the registers that live through the steps)
+            const int l31e = lane_e & 31, lhie = lane_e >> 5;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int n = nb * 32 + l31e;
+                if (n < p.Ng) {
+                    const float bv = p.bias ? p.bias[n] : 0.f;
+                    float o[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        o[i] = fmaf(acc[r][nb][i], p.w3_inv, bv);
+                        emax = max(emax, __float_as_uint(o[i]) & 0x7fffffffu);
+                    }
+                    if (p.act == ACT_RELU) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) o[i] = fmaxf(o[i], 0.f);
+                    } else if (p.act != ACT_NONE) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) o[i] = rd_act(o[i], p.act);
+                    }
+                    const unsigned yoff = ((unsigned)(4 * lhie) * (unsigned)p.yld + (unsigned)n) * 4u;
+                    if (p.res) {
+                        const unsigned roff = ((unsigned)(4 * lhie) * (unsigned)p.rld + (unsigned)n) * 4u;
+                        float rs[16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            rs[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, (int)roff, (int)((unsigned)((i & 3) + 8 * (i >> 2)) * (unsigned)p.rld * 4u), 0));
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) o[i] += rs[i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[i]), ry, (int)yoff, (int)((unsigned)((i & 3) + 8 * (i >> 2)) * (unsigned)p.yld * 4u), 2);
+                }
+                __builtin_amdgcn_sched_barrier(0);          // (one block at a time: the blocks' temporaries do not pile up)
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (DMA pieces still in flight target this workgroup's LDS)
+    if ((emax >= 0x7f800000u || !(amax < 65504.f)) && p.range_flag) rd_raise_flag(p.range_flag);
+}
+
+// geometry the kernel can run (and the host prepares a weight image for)
+bool conv3x3_h1_shape_ok(int kh, int kw, int cin, int cout) {
+    return kh == 3 && kw == 3 && cin % 16 == 0 && cin >= 32 && cin <= 512 && cout >= 8 && cout <= 96;
+}
+
+bool conv3x3_h1_applies(const ConvParams& p) {
+    static const bool off = [] { const char* e = getenv("RD_CONV3X3_H1"); return e && e[0] == '0'; }();
+    return !off && p.w3 && p.w3_inv > 0.f && conv3x3_h1_shape_ok(p.KH, p.KW, p.Cin, p.Ng) && p.SH == 1 && p.SW == 1 && p.PT == 1 && p.PL == 1 &&
+           p.OH == p.H && p.OW == p.W && p.out_mode == OUT_NHWC && !p.ascale && !p.ln_g && (p.xld % 4) == 0;
+}
+
+void launch_conv3x3_h1(const ConvParams& p, hipStream_t s) {
+    if (p.M <= 0) return;
+    const int tiles_r = (p.OH + C3_TR - 1) / C3_TR, tiles_c = (p.OW + C3_TC - 1) / C3_TC;
+    const int ntiles = p.N * tiles_r * tiles_c;
+    const int nstep = 9 * (p.Cin / 16);
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    const int nb = (p.Ng + 31) / 32;
+    const size_t lds = (size_t)2 * C3_PLANE + (size_t)C3_D * nb * 2048;
+    const dim3 grid((unsigned)std::min(ntiles, 2 * n_cu)), block(256);
+    static unsigned long long ok1 = 0, ok2 = 0, ok3 = 0;
+    switch (nb) {
+        case 1:
+            rd_allow_dynamic_lds((const void*)conv3x3_h1_kernel<1>, lds, ok1);
+            hipLaunchKernelGGL(conv3x3_h1_kernel<1>, grid, block, lds, s, p, tiles_r, tiles_c, ntiles, nstep);
+            break;
+        case 2:
+            rd_allow_dynamic_lds((const void*)conv3x3_h1_kernel<2>, lds, ok2);
+            hipLaunchKernelGGL(conv3x3_h1_kernel<2>, grid, block, lds, s, p, tiles_r, tiles_c, ntiles, nstep);
+            break;
+        default:
+            rd_allow_dynamic_lds((const void*)conv3x3_h1_kernel<3>, lds, ok3);
+            hipLaunchKernelGGL(conv3x3_h1_kernel<3>, grid, block, lds, s, p, tiles_r, tiles_c, ntiles, nstep);
+            break;
+    }
+}
+
+// Host: the weight image.  w = folded weights [N][K], k = (kh * 3 + kw) * Cin + ci.  Slab order = the kernel's step order: full passes
+// of 32 input channels (tap-major, two k-steps per tap), then - Cin % 32 == 16 - one pass of 16 (one k-step per tap).  A slab holds,
+// for every 32-wide output block nb, the hi and the lo fragment (1 KB each): lane (l31, lhi) carries w[nb * 32 + l31][k .. k + 8) of its
+// k-half.  Weights are scaled by 2^ex so that max |w| lands in [2^13, 2^14); returns 2^-ex.
+float prepare_conv3x3_h1_weights(const float* w, int N, int Cin, std::vector<uint16_t>& img) {
+    const int K = 9 * Cin, nb_n = (N + 31) / 32, nstep = 9 * (Cin / 16);
+    img.assign((size_t)nstep * nb_n * 2 * 512, 0);
+    float mx = 0.f;
+    for (size_t i = 0; i < (size_t)N * K; ++i) mx = std::fmax(mx, std::fabs(w[i]));
+    int ex = 0;
+    if (mx > 0.f && std::isfinite(mx)) {
+        int x = 0;
+        (void)std::frexp(mx, &x);
+        ex = 14 - x;
+        ex = ex > 100 ? 100 : ex < -100 ? -100 : ex;
+    }
+    const int full = Cin / 32, tail16 = (Cin % 32) / 16;
+    size_t slab = 0;
+    for (int pass = 0; pass < full + tail16; ++pass) {
+        const int ksn = pass < full ? 2 : 1;
+        for (int tap = 0; tap < 9; ++tap)
+            for (int ks = 0; ks < ksn; ++ks, ++slab)
+                for (int nb = 0; nb < nb_n; ++nb)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int n = nb * 32 + (lane & 31);
+                        if (n >= N) continue;
+                        for (int e = 0; e < 8; ++e) {
+                            const int k = tap * Cin + pass * 32 + ks * 16 + 8 * (lane >> 5) + e;
+                            const float vs = std::ldexp(w[(size_t)n * K + k], ex);
+                            const _Float16 hh = (_Float16)vs;
+                            const _Float16 ll = (_Float16)(vs - (float)hh);
+                            uint16_t hb, lb;
+                            __builtin_memcpy(&hb, &hh, 2);
+                            __builtin_memcpy(&lb, &ll, 2);
+                            const size_t base = ((slab * nb_n + nb) * 2) * 512 + (size_t)lane * 8 + e;
+                            img[base] = hb;
+                            img[base + 512] = lb;
+                        }
+                    }
+    }
+    return std::ldexp(1.f, -ex);
+}
+
+}  // namespace rd

@@ -417,6 +417,10 @@ void launch_conv_igemm_h3(const ConvParams& p, hipStream_t s) {
         launch_conv_stream_h3(p, s);
         return;
     }
+    if (conv3x3_h1_applies(p)) {       // 3x3 stride 1 pad 1, <= 96 output channels: one accumulator set, two workgroups per CU (round 6)
+        launch_conv3x3_h1(p, s);
+        return;
+    }
     if (conv_direct_h3_applies(p)) {   // 2x2 / 3x3 stride 1, <= 96 output channels: patch in LDS, taps as address offsets
         launch_conv_direct_h3(p, s);
         return;

@@ -49,6 +49,9 @@ struct ConvParams {
     // the small-M (<= 32 rows) fp32 path of launch_conv_igemm: only for layers whose M is a batch size BY CONSTRUCTION (the formula decoder's
     // linears); image layers never set it - their kernel is picked by the layer, not by how many rows a launch happens to hold
     int allow_skinny = 0;
+    // one-accumulator direct 3x3 (kernels_conv3x3_h1.hip): slab-ordered fragment image of the pre-scaled weights + the inverse scale
+    const uint16_t* w3 = nullptr;
+    float w3_inv = 0.f;
     int fast_epi = 1;               // interior tiles of the split implicit-GEMM kernels store through buffer accesses (round 5; RD_CONV_FAST_EPI=0: A/B)
 };
 void launch_conv_igemm(const ConvParams& p, hipStream_t s);
@@ -63,6 +66,11 @@ bool gemm_h1_applies(const ConvParams& p);
 void launch_gemm_h1(const ConvParams& p, hipStream_t s);
 float prepare_gemm_h1_weights(const float* w, int N, int K, std::vector<uint16_t>& img);   // returns the inverse scale
 void launch_conv_igemm_h3(const ConvParams& p, hipStream_t s);
+// direct 3x3 / stride 1 / pad 1, <= 96 output channels, one accumulator set, two workgroups per CU (kernels_conv3x3_h1.hip, round 6)
+bool conv3x3_h1_shape_ok(int kh, int kw, int cin, int cout);   // host-side: which layers get a weight image
+bool conv3x3_h1_applies(const ConvParams& p);
+void launch_conv3x3_h1(const ConvParams& p, hipStream_t s);
+float prepare_conv3x3_h1_weights(const float* w, int N, int Cin, std::vector<uint16_t>& img);   // returns the inverse scale
 // direct 2x2 / 3x3 stride-1 convolution for narrow outputs (kernels_conv_direct_h3.hip); launch_conv_igemm_h3 dispatches to it
 bool conv_direct_h3_supported(const ConvParams& p);   // geometry
 bool conv_direct_h3_applies(const ConvParams& p);     // geometry + routing policy
