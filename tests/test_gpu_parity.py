@@ -388,9 +388,17 @@ def test_mixer_residual_from_split_fragments_small_inputs(C_, variant, xs):
     xd = x.double()
     ref = xd + torch.nn.functional.gelu(xd @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
     err = (y.double() - ref).abs()
-    # per element: 2^-22 |x| (residual) + 2^-25 (subnormal low plane) + the mixer's own product error, 1e-6 of the output scale
-    bound = 2.0 ** -22 * xd.abs() + 2.0 ** -25 + 1e-6 * float(ref.abs().max())
-    assert bool((err <= bound).all()), (float(err.max()), float((err - bound).max()))
+    # per element: 2^-22 |x| (residual) + 2^-25 (subnormal low plane of the residual) + the mixer's own product error, 1e-6 of the
+    # output scale + what the SAME subnormal low planes do to the two products: every operand element whose low plane is an fp16
+    # subnormal (|x| < 2^-3 in the unscaled res kernel; the small channels of a pixel in ws) enters its product with an absolute
+    # rounding error uniform in +-2^-25, which reaches the output through one row of W1, GELU' (<= 1.13) and one row of W2, and the
+    # hidden activation's own low plane through one row of W2: 6 sigma of that sum (an absolute 1e-7..2e-7 at these weights - fp32's
+    # own eps at |y| ~ 1, whatever the tensor's scale: the guard's range flag covers overflow, underflow costs this much)
+    sig = 2.0 ** -25 / 3 ** 0.5
+    r1 = float(w1.double().norm(dim=1).max()); r2 = float(w2.double().norm(dim=1).max())
+    bound = 2.0 ** -22 * xd.abs() + 2.0 ** -25 + 1e-6 * float(ref.abs().max()) + 6 * sig * r2 * (1.0 + 1.13 * r1)
+    assert bool((err <= bound).all()), (float(err.max()), float((err - bound).max()), float(bound.min()))
+    print(f"mixer small-input error C={C_} variant={variant} xs={xs}: max err {float(err.max()):.3e}, min bound {float(bound.min()):.3e}")
 
 
 def test_forward_is_deterministic(engines, golden_dir):
