@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "engine.h"
+#include "rd_device.h"
 
 namespace rd {
 
@@ -284,10 +285,299 @@ __global__ void __launch_bounds__(256) dec_attn_fused_kernel(AttnFusedParams p) 
     if (tid < 32) p.out[(size_t)b * p.ldo + h * HD + tid] = (red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid]) * inv;
 }
 
+// Round 6: dec_attn_fused_kernel with its latency chain folded.  The round-4 kernel ran LayerNorm -> barrier -> (q, then k, then v: three
+// serial rounds of sixteen 16-byte weight loads per thread) -> barrier -> K rows -> scores: 9.6 us (self) / 7.0 us (cross) per launch, twelve
+// launches per token.  Nothing in the weight rows or in the cached K rows depends on x, so here
+//   * every thread requests its weight row FIRST (self: 768 threads, one of q | k | v each, so the three projections are one round), and
+//     the thread's first cached K row right behind it; LayerNorm of the row runs under those loads;
+//   * the attention itself is the first 256 threads, unchanged.
+// Per output the same eight lanes read the same float4s and sum in the same order, LayerNorm and the softmax are the same code on the same
+// 256 threads: results are bit-identical to dec_attn_fused_kernel (RD_DEC_ATTN2=0 selects it for A/B).
+template <bool SELF>
+__global__ void __launch_bounds__(SELF ? 768 : 256) dec_attn_fused2_kernel(AttnFusedParams p) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    float* xn = smf;                   // [512] normalised row
+    float* qs = smf + D;               // [32] q | [32] k | [32] v of this step
+    float* red = qs + 3 * HD;          // [256]
+    float* sc = red + 256;             // [T] scores
+    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    static_assert(D == 512 && HD == 32, "two values per thread, eight float4 per head row");
+    const bool att = !SELF || tid < 256;                  // the 256 threads of LayerNorm and of the attention
+    const int t256 = SELF ? (tid & 255) : tid, pm = SELF ? (tid >> 8) : 0;       // projection: matrix pm, output o, part
+    const int o = t256 >> 3, part = t256 & 7;
+    // ---- requested first: this thread's weight row (its eighth of it), its first cached K row
+    const int row = pm * D + h * HD + o;
+    f4 wv[16];
+    {
+        const f4* wr = reinterpret_cast<const f4*>(p.w + (size_t)row * D);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wv[i] = wr[8 * i + part];
+    }
+    const int Tc = SELF ? p.st->step : p.fixed_T;
+    const bool kpre = att && tid < Tc;
+    f4 k0[8];
+    {
+        const f4* kr = reinterpret_cast<const f4*>(p.kc + (size_t)b * p.seq_stride + (size_t)(kpre ? tid : 0) * p.ldkv + h * HD);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) k0[d] = kr[d];       // (row 0 of the cache buffer exists for every step; unused when !kpre)
+    }
+    // ---- LayerNorm of row b (threads 0 .. 255)
+    {
+        float v0 = 0.f, v1 = 0.f;
+        if (att) { v0 = p.x[(size_t)b * D + tid]; v1 = p.x[(size_t)b * D + 256 + tid]; }
+        float s = wsum(v0 + v1);
+        if (att && lane == 0) red[wave] = s;
+        __syncthreads();
+        const float mean = (red[0] + red[1] + red[2] + red[3]) / D;
+        const float d0 = v0 - mean, d1 = v1 - mean;
+        float q = wsum(d0 * d0 + d1 * d1);
+        if (att && lane == 0) red[4 + wave] = q;
+        __syncthreads();
+        const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / D + 1e-5f);
+        if (att) {
+            xn[tid] = d0 * rstd * p.ln_g[tid] + p.ln_b[tid];
+            xn[256 + tid] = d1 * rstd * p.ln_g[256 + tid] + p.ln_b[256 + tid];
+        }
+    }
+    __syncthreads();
+    // ---- this head's projections
+    {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const f4 xr = reinterpret_cast<const f4*>(xn)[8 * i + part];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = fmaf(xr[e], wv[i][e], acc);
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (part == 0) {
+            const float v = acc + p.bias[row];
+            qs[pm * HD + o] = v;
+            if (SELF && pm == 1) p.kw[(size_t)b * p.seq_stride + (size_t)Tc * p.ldkv + h * HD + o] = v;
+            if (SELF && pm == 2) p.vw[(size_t)b * p.seq_stride + (size_t)Tc * p.ldkv + h * HD + o] = v;
+        }
+    }
+    __syncthreads();
+    // ---- single-query attention (threads 0 .. 255; this step's k, v come from LDS)
+    const int T = Tc + (SELF ? 1 : 0);
+    f4 q[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) q[d] = reinterpret_cast<const f4*>(qs)[d];
+    auto krow = [&](int j) -> const float* { return (!SELF || j < Tc) ? p.kc + (size_t)b * p.seq_stride + (size_t)j * p.ldkv + h * HD : qs + HD; };
+    auto vrow = [&](int j) -> const float* { return (!SELF || j < Tc) ? p.vc + (size_t)b * p.seq_stride + (size_t)j * p.ldkv + h * HD : qs + 2 * HD; };
+    float mx = -INFINITY;
+    if (att) {
+        for (int j = tid; j < T; j += 256) {
+            f4 k[8];
+            if (j == tid && kpre) {
+#pragma unroll
+                for (int d = 0; d < 8; ++d) k[d] = k0[d];
+            } else {
+                const f4* kr = reinterpret_cast<const f4*>(krow(j));
+#pragma unroll
+                for (int d = 0; d < 8; ++d) k[d] = kr[d];
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = fmaf(q[d][e], k[d][e], s);
+            sc[j] = s;
+            mx = fmaxf(mx, s);
+        }
+    }
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o2, 64));
+    if (att && lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    if (att) {
+        for (int j = tid; j < T; j += 256) {
+            const float e = __expf(sc[j] - mx);
+            sc[j] = e;
+            sum += e;
+        }
+    }
+    sum = wsum(sum);
+    __syncthreads();                       // (red[0..3] read by everybody; sc[] complete)
+    if (att && lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+    // output: thread (g = tid / 8: one of 32 key groups, dq = tid % 8: dims 4 dq .. + 3), four rows in flight
+    const int dq = tid & 7, g = tid >> 3;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (att) {
+        int j = g;
+        for (; j + 96 < T; j += 128) {
+            const f4 v0 = reinterpret_cast<const f4*>(vrow(j))[dq], v1 = reinterpret_cast<const f4*>(vrow(j + 32))[dq];
+            const f4 v2 = reinterpret_cast<const f4*>(vrow(j + 64))[dq], v3 = reinterpret_cast<const f4*>(vrow(j + 96))[dq];
+            acc += v0 * sc[j];
+            acc += v1 * sc[j + 32];
+            acc += v2 * sc[j + 64];
+            acc += v3 * sc[j + 96];
+        }
+        for (; j < T; j += 32) acc += reinterpret_cast<const f4*>(vrow(j))[dq] * sc[j];
+    }
+    __syncthreads();                       // red[] is reused below
+#pragma unroll
+    for (int o2 = 8; o2 < 64; o2 <<= 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], o2, 64);
+    }
+    if (att && lane < 8) *reinterpret_cast<f4*>(&red[wave * 32 + 4 * lane]) = acc;
+    __syncthreads();
+    if (tid < 32) p.out[(size_t)b * p.ldo + h * HD + tid] = (red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid]) * inv;
+}
+
+// Round 6: the decode step's linears (M = the decode batch, K = 512 / 2048) as weight-streaming GEMVs.  profiles/r4_formula_decode.txt: 25 of a
+// step's 39 launches were skinny2_gemm_kernel at 5 - 35 us each for 1 - 4 MB of weights (fc2: 4 MB in 15 us = 0.28 TB/s) - 32 workgroups of
+// four wavefronts, every wavefront four columns x two serial K passes.  The guide's price list puts a dependent kernel boundary at 1.2 - 1.9 us
+// and a 256-workgroup grid barrier at 4 - 5 us, so folding the step into ONE persistent kernel trades every boundary for
+// something dearer; what a launch costs here is its own latency chain, and that is what this kernel shortens:
+//   * ONE column group (CW columns x all of K) per wavefront and pass, K in a single pass (KPL float4 per lane and column): every byte of a
+//     wavefront's weights is requested by its first instructions, before X is staged and normalised, and N = 512 fills 128 workgroups
+//     instead of 32;
+//   * wide layers (lm_head: 50 000 columns, 102 MB) loop over column groups with the NEXT group's weights requested before this group's
+//     arithmetic (register double buffer): the stream never drains, X is staged (and normalised: the final LayerNorm rides here instead of
+//     in a launch of its own) once per workgroup;
+//   * arithmetic identical to skinny2_gemm_kernel (kernels_conv.hip), bit for bit: a lane owns k = 4 lane + 256 h, h ascending, the same
+//     product expression, the same halving butterfly (sums over lanes in the order xor 32, 16, .. 1), the same LayerNorm - the decoded ids
+//     cannot move (tests/test_gpu_round3.py::test_formula_decoder_300_tokens_equals_reference; RD_DEC_GEMV=0 keeps the old launches for A/B).
+struct GemvParams {
+    const float* x; int M, K, N;      // x [M][K]
+    const float* w; const float* bias; // w [N][K]
+    const float* ln_g; const float* ln_b;
+    const float* res;                 // [M][N] or nullptr, added after the activation
+    float* y;                         // [M][N]
+    int act;
+};
+template <int MT, int CW, int KPL, bool DB>
+__global__ void __launch_bounds__(256) dec_gemv_kernel(GemvParams p, int n_groups) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int NV = MT * CW, KP = 256 * KPL;       // K == KP (host)
+    extern __shared__ __attribute__((aligned(16))) float gx[];          // [MT][KP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gw = (int)blockIdx.x * 4 + wave, GW = (int)gridDim.x * 4;
+    f4 wa[CW][KPL], wb[DB ? CW : 1][DB ? KPL : 1];      // DB: two register sets alternate (wide layers)
+    auto load_w = [&](f4 (&wr)[CW][KPL], int g) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            const int n = min(g * CW + c, p.N - 1);            // clamped: columns past N are computed on the last column and never stored
+            const f4* wp = reinterpret_cast<const f4*>(p.w + (size_t)n * KP) + lane;
+#pragma unroll
+            for (int h = 0; h < KPL; ++h) wr[c][h] = wp[64 * h];
+        }
+    };
+    if (gw < n_groups) load_w(wa, gw);
+    // X -> LDS, fused pre-LayerNorm (wave w normalises rows w, w + 4, ...): skinny2_gemm_kernel's code
+    for (int i = tid; i < MT * (KP / 4); i += 256) {
+        const int m = i / (KP / 4), k = 4 * (i - m * (KP / 4));
+        *reinterpret_cast<f4*>(&gx[m * KP + k]) = m < p.M ? *reinterpret_cast<const f4*>(p.x + (size_t)m * KP + k) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    if (p.ln_g) {
+        if constexpr (KP == 512) {
+            for (int m = wave; m < MT; m += 4) {
+                float v[8], s1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    v[i] = gx[m * KP + lane + 64 * i];
+                    s1 += v[i];
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+                const float mean = s1 / KP;
+                float s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float d = v[i] - mean;
+                    s2 += d * d;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+                const float rstd = rsqrtf(s2 / KP + 1e-5f);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int k = lane + 64 * i;
+                    gx[m * KP + k] = (v[i] - mean) * rstd * p.ln_g[k] + p.ln_b[k];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    auto finish = [&](const f4 (&wr)[CW][KPL], int g) {
+        float acc[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int h = 0; h < KPL; ++h) {
+            const int kq = h * 256 + 4 * lane;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const f4 xv = *reinterpret_cast<const f4*>(&gx[m * KP + kq]);
+#pragma unroll
+                for (int c = 0; c < CW; ++c)
+                    acc[c * MT + m] += xv[0] * wr[c][h][0] + xv[1] * wr[c][h][1] + xv[2] * wr[c][h][2] + xv[3] * wr[c][h][3];
+            }
+            if constexpr (KPL > 2) __builtin_amdgcn_sched_barrier(0);      // keeps the X reads of later h out of this one's registers
+        }
+        // halving butterfly (skinny2_gemm_kernel): a lane whose bit o is set keeps the upper half of what it carries
+        int cnt = NV, idx = 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            if (cnt > 1) {
+                cnt >>= 1;
+                const bool up = (lane & o) != 0;
+#pragma unroll
+                for (int j = 0; j < NV / 2; ++j) {
+                    if (j < cnt) {
+                        const float lo = acc[j], hi = acc[j + cnt];
+                        const float send = up ? lo : hi, keep = up ? hi : lo;
+                        acc[j] = keep + __shfl_xor(send, o, 64);
+                    }
+                }
+                if (up) idx += cnt;
+            } else {
+                acc[0] += __shfl_xor(acc[0], o, 64);
+            }
+        }
+        constexpr int LOW = NV >= 64 ? 0 : (64 / NV - 1);
+        const int c = idx / MT, m = idx - c * MT, n = g * CW + c;
+        if ((lane & LOW) == 0 && m < p.M && n < p.N) {
+            float v = rd_act(acc[0] + (p.bias ? p.bias[n] : 0.f), p.act);
+            if (p.res) v += p.res[(size_t)m * p.N + n];
+            p.y[(size_t)m * p.N + n] = v;
+        }
+    };
+    // column groups gw, gw + GW, ...: neighbouring wavefronts stream neighbouring rows of W
+    if constexpr (DB) {
+        for (int g = gw; g < n_groups; g += 2 * GW) {
+            if (g + GW < n_groups) load_w(wb, g + GW);
+            finish(wa, g);
+            if (g + GW < n_groups) {
+                if (g + 2 * GW < n_groups) load_w(wa, g + 2 * GW);
+                finish(wb, g + GW);
+            }
+        }
+    } else {
+        for (int g = gw; g < n_groups; g += GW) {
+            if (g != gw) load_w(wa, g);
+            finish(wa, g);
+        }
+    }
+}
+
 // next token: argmax of the logits row (forced EOS at the length limit), pad for finished sequences, append.  The last
 // block to finish advances the step counter (arrival ticket), so no separate launch is needed.
+// Round 6: the NEXT step's embedding + LayerNorm (dec_embed_ln_kernel's arithmetic, one wavefront) rides at the end of this kernel when
+// `emb` is given: one launch fewer per token.
+struct NextEmbed { const float* emb; const float* pos; const float* g; const float* b; float* x; int max_new; };
 __global__ void __launch_bounds__(1024) dec_select_kernel(const float* logits, int V, long long* ids, int ids_ld, int* unfinished,
-                                                          DecState* st, int B) {
+                                                          DecState* st, int B, NextEmbed ne) {
     const int b = blockIdx.x, tid = threadIdx.x, t = st->step;
     const float* z = logits + (size_t)b * V;
     float mx = -INFINITY;
@@ -328,12 +618,14 @@ __global__ void __launch_bounds__(1024) dec_select_kernel(const float* logits, i
         }
         __syncthreads();
     }
+    __shared__ int s_tok;
     if (tid == 0) {
         int tok = smi[0];
         if (t + 1 == FORCED_EOS_LEN - 1) tok = EOS_ID;          // input length == max_length - 1 -> only EOS survives
         const int unf = unfinished[b];
         tok = unf ? tok : PAD_ID;
         ids[(size_t)b * ids_ld + t + 1] = tok;
+        s_tok = tok;
         if (unf && tok == EOS_ID) {
             unfinished[b] = 0;
             atomicSub(&st->n_unfinished, 1);
@@ -342,6 +634,30 @@ __global__ void __launch_bounds__(1024) dec_select_kernel(const float* logits, i
         if (atomicAdd(&st->arrived, 1) == B - 1) {   // every block has read `step` (t) before its ticket: safe to advance
             st->arrived = 0;
             st->step = t + 1;
+        }
+    }
+    if (!ne.emb || t + 1 >= ne.max_new) return;      // (uniform over the block)
+    __syncthreads();
+    if (tid < 64) {    // x[b] = LayerNorm(emb[tok] + pos[(t + 1) + 2]): the input row of the next step
+        const long long tok = s_tok;
+        const int lane = tid;
+        float v[8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = ne.emb[(size_t)tok * D + c] + ne.pos[(size_t)(t + 1 + 2) * D + c];
+            s += v[i];
+        }
+        const float mean = wsum(s) / D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q += (v[i] - mean) * (v[i] - mean);
+        const float rstd = rsqrtf(wsum(q) / D + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            ne.x[(size_t)b * D + c] = (v[i] - mean) * rstd * ne.g[c] + ne.b[c];
         }
     }
 }
@@ -369,6 +685,9 @@ class FormulaDecoder {
    private:
     void gemm(const float* x, int M, int K, const std::string& key, int N, float* y, int act, const float* res, hipStream_t s,
               const std::string& ln_key = "", float* ln_tmp = nullptr);
+    // the decode step's linears (M <= 32 rows, K = 512 / 2048) through dec_gemv_kernel; false = shape not covered, nothing launched
+    bool gemv(const float* x, int M, int K, const std::string& key, int N, float* y, int act, const float* res, hipStream_t s,
+              const std::string& ln_key = "");
     void ln(const float* x, const std::string& key, float* y, int M, hipStream_t s) {
         launch_layernorm(x, D, y, D, params_.ptr(key + ".weight"), params_.ptr(key + ".bias"), M, D, 1e-5f, s);
     }
@@ -482,6 +801,48 @@ void FormulaDecoder::gemm(const float* x, int M, int K, const std::string& key, 
     launch_conv_igemm(p, s);
 }
 
+template <int MT, int CW, int KPL, bool DB>
+static void launch_gemv(const GemvParams& p, int max_wgs, hipStream_t s) {
+    const int n_groups = (p.N + CW - 1) / CW;
+    const size_t lds = (size_t)MT * 256 * KPL * sizeof(float);
+    static unsigned long long lds_ok = 0;
+    rd_allow_dynamic_lds((const void*)dec_gemv_kernel<MT, CW, KPL, DB>, lds, lds_ok);
+    const int grid = std::min((n_groups + 3) / 4, max_wgs);
+    hipLaunchKernelGGL((dec_gemv_kernel<MT, CW, KPL, DB>), dim3(grid), dim3(256), lds, s, p, n_groups);
+}
+
+bool FormulaDecoder::gemv(const float* x, int M, int K, const std::string& key, int N, float* y, int act, const float* res, hipStream_t s,
+                          const std::string& ln_key) {
+    static const bool on = [] { const char* e = getenv("RD_DEC_GEMV"); return !(e && e[0] == '0'); }();
+    // developer knobs (tools/bench_formula.py sweeps): workgroups of a wide layer's loop, columns per wavefront of a wide layer
+    static const int wide_wgs = [] { const char* e = getenv("RD_DEC_GEMV_WGS"); return e ? atoi(e) : 512; }();
+    if (!on || M > 32 || (K != 512 && K != 2048) || (K == 2048 && (M > 16 || !ln_key.empty()))) return false;
+    GemvParams p{};
+    p.x = x; p.M = M; p.K = K; p.N = N;
+    p.w = params_.ptr(key + "#w");
+    p.bias = params_.has(key + "#b") ? params_.ptr(key + "#b") : nullptr;
+    if (!ln_key.empty()) {
+        p.ln_g = params_.ptr(ln_key + ".weight");
+        p.ln_b = params_.ptr(ln_key + ".bias");
+    }
+    p.res = res; p.y = y; p.act = act;
+    const bool wide = N > 4096;          // loops over column groups with the next group's weights in flight
+    if (K == 2048) {
+        if (M <= 8) launch_gemv<8, 1, 8, false>(p, 1024, s);
+        else launch_gemv<16, 1, 8, false>(p, 1024, s);
+    } else if (M <= 8) {
+        if (wide) launch_gemv<8, 4, 2, true>(p, wide_wgs, s);
+        else launch_gemv<8, 1, 2, false>(p, 1024, s);
+    } else if (M <= 16) {
+        if (wide) launch_gemv<16, 2, 2, true>(p, wide_wgs, s);
+        else launch_gemv<16, 1, 2, false>(p, 1024, s);
+    } else {
+        if (wide) launch_gemv<32, 1, 2, true>(p, wide_wgs, s);
+        else launch_gemv<32, 1, 2, false>(p, 1024, s);
+    }
+    return true;
+}
+
 int FormulaDecoder::decode(const float* enc, int B, int S, int max_new, long long* ids_out, hipStream_t s) {
     RD_HIP(hipSetDevice(device_));
     RD_CHECK(B > 0 && S > 0 && max_new > 0, "formula decode: empty batch");
@@ -533,12 +894,24 @@ int FormulaDecoder::decode(const float* enc, int B, int S, int max_new, long lon
     // fused projection + attention launches (dec_attn_fused_kernel): RD_DEC_FUSED=0 keeps the round-3 form (A/B, parity tests)
     static const bool fused_env = [] { const char* e = getenv("RD_DEC_FUSED"); return !(e && e[0] == '0'); }();
     const bool fused = fused_env && B <= 32;
+    static const bool attn2 = [] { const char* e = getenv("RD_DEC_ATTN2"); return !(e && e[0] == '0'); }();
     const size_t fsh_self = (size_t)(D + 3 * HD + 256 + ((Tmax + 3) & ~3)) * f, fsh_cross = (size_t)(D + 3 * HD + 256 + ((S + 3) & ~3)) * f;
     // One decode step = ~70 dependent launches whose arguments never change (the step index lives in device memory), so
     // the step is captured once into a hipGraph and replayed: the host cost per step drops from ~70 launches to one.
-    auto enqueue_step = [&]() {
+    // a linear of the step: the weight-streaming GEMV where it covers the shape, the round-3 skinny GEMM otherwise
+    auto lin = [&](const float* xin, int K, const std::string& key, int N, float* y, int act, const float* res, const std::string& ln_key = "",
+                   float* ln_tmp = nullptr) {
+        if (!gemv(xin, B, K, key, N, y, act, res, s, ln_key)) gemm(xin, B, K, key, N, y, act, res, s, ln_key, ln_tmp);
+    };
+    // the embedding of step t + 1 rides in step t's select launch (RD_DEC_EMBED_IN_SELECT=0: its own launch, as rounds 1-5); the first
+    // step's is enqueued once, ahead of the loop
+    static const bool embed_in_select = [] { const char* e = getenv("RD_DEC_EMBED_IN_SELECT"); return !(e && e[0] == '0'); }();
+    auto enqueue_embed = [&]() {
         hipLaunchKernelGGL(dec_embed_ln_kernel, dim3(B), dim3(64), 0, s, params_.ptr("emb"), params_.ptr("pos"), ids_out, ids_ld, st,
                            params_.ptr("ln_emb.weight"), params_.ptr("ln_emb.bias"), x);
+    };
+    auto enqueue_step = [&]() {
+        if (!embed_in_select) enqueue_embed();
         float* cur = x;
         float* nxt = x2;
         for (int l = 0; l < n_layers_; ++l) {
@@ -550,19 +923,21 @@ int FormulaDecoder::decode(const float* enc, int B, int S, int max_new, long lon
                 sp.kc = kc + (size_t)l * B * Tmax * D; sp.vc = vc + (size_t)l * B * Tmax * D; sp.ldkv = D; sp.seq_stride = (long long)Tmax * D;
                 sp.kw = kc + (size_t)l * B * Tmax * D; sp.vw = vc + (size_t)l * B * Tmax * D;
                 sp.st = st; sp.fixed_T = 0; sp.out = a; sp.ldo = D;
-                hipLaunchKernelGGL((dec_attn_fused_kernel<true>), dim3(B, HEADS), dim3(256), fsh_self, s, sp);
-                gemm(a, B, D, K + "so", D, nxt, ACT_NONE, cur, s);
+                if (attn2) hipLaunchKernelGGL((dec_attn_fused2_kernel<true>), dim3(B, HEADS), dim3(768), fsh_self, s, sp);
+                else hipLaunchKernelGGL((dec_attn_fused_kernel<true>), dim3(B, HEADS), dim3(256), fsh_self, s, sp);
+                lin(a, D, K + "so", D, nxt, ACT_NONE, cur);
                 std::swap(cur, nxt);
                 AttnFusedParams xp{};
                 xp.x = cur; xp.ln_g = params_.ptr(K + "ln2.weight"); xp.ln_b = params_.ptr(K + "ln2.bias");
                 xp.w = params_.ptr(K + "cq#w"); xp.bias = params_.ptr(K + "cq#b");
                 xp.kc = ckv + (size_t)l * B * S * 2 * D; xp.vc = xp.kc + D; xp.ldkv = 2 * D; xp.seq_stride = (long long)S * 2 * D;
                 xp.st = st; xp.fixed_T = S; xp.out = a; xp.ldo = D;
-                hipLaunchKernelGGL((dec_attn_fused_kernel<false>), dim3(B, HEADS), dim3(256), fsh_cross, s, xp);
-                gemm(a, B, D, K + "co", D, nxt, ACT_NONE, cur, s);
+                if (attn2) hipLaunchKernelGGL((dec_attn_fused2_kernel<false>), dim3(B, HEADS), dim3(256), fsh_cross, s, xp);
+                else hipLaunchKernelGGL((dec_attn_fused_kernel<false>), dim3(B, HEADS), dim3(256), fsh_cross, s, xp);
+                lin(a, D, K + "co", D, nxt, ACT_NONE, cur);
                 std::swap(cur, nxt);
-                gemm(cur, B, D, K + "fc1", FFN, ff, ACT_GELU, nullptr, s, K + "ln3", h);
-                gemm(ff, B, FFN, K + "fc2", D, nxt, ACT_NONE, cur, s);
+                lin(cur, D, K + "fc1", FFN, ff, ACT_GELU, nullptr, K + "ln3", h);
+                lin(ff, FFN, K + "fc2", D, nxt, ACT_NONE, cur);
                 std::swap(cur, nxt);
                 continue;
             }
@@ -591,9 +966,13 @@ int FormulaDecoder::decode(const float* enc, int B, int S, int max_new, long lon
             gemm(ff, B, FFN, K + "fc2", D, nxt, ACT_NONE, cur, s);
             std::swap(cur, nxt);
         }
-        gemm(cur, B, D, "lm", vocab_, lg, ACT_NONE, nullptr, s, "ln_out", h);
-        hipLaunchKernelGGL(dec_select_kernel, dim3(B), dim3(1024), 0, s, lg, vocab_, ids_out, ids_ld, unf, st, B);
+        lin(cur, D, "lm", vocab_, lg, ACT_NONE, nullptr, "ln_out", h);
+        RD_CHECK(cur == x, "formula decode: the layer stack must end in the buffer the next embedding is written to");
+        NextEmbed ne{};
+        if (embed_in_select) ne = NextEmbed{params_.ptr("emb"), params_.ptr("pos"), params_.ptr("ln_emb.weight"), params_.ptr("ln_emb.bias"), x, max_new};
+        hipLaunchKernelGGL(dec_select_kernel, dim3(B), dim3(1024), 0, s, lg, vocab_, ids_out, ids_ld, unf, st, B, ne);
     };
+    if (embed_in_select) enqueue_embed();
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     static const bool use_graph = [] { const char* e = getenv("RD_DECODE_GRAPH"); return !(e && e[0] == '0'); }();

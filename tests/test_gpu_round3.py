@@ -366,3 +366,44 @@ def test_fused_stem_equals_separate_kernels(golden_dir, kind, shape, monkeypatch
     for u, v in zip(a, b):
         scale = max(1.0, float(v.abs().max()))
         assert float((u - v).abs().max()) < 2e-5 * scale
+
+
+_DECODE_AB = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from pathlib import Path
+from rapiddoc_amd.engine import RdEngine
+from test_oracle_golden import formula_long_case
+st, enc, g = formula_long_case(Path(sys.argv[1]) / "tests" / "golden")
+eng = RdEngine("ppformulanet_head").load_weights(st)
+e = torch.from_numpy(enc).cuda()
+e8 = torch.cat([e, e.flip(0) * 0.5, e * 1.5, e.flip(1)], 0)          # B = 8: the batch the bench quotes
+ids2 = eng.formula_decode(e, 300).cpu().numpy()
+ids8 = eng.formula_decode(e8, 120).cpu().numpy()
+np.savez(sys.argv[2], ids2=ids2, ids8=ids8)
+'''
+
+
+def test_formula_decode_round6_launches_are_bit_identical_to_round5(tmp_path):
+    """Round 6 replaced the decode step's skinny GEMMs by weight-streaming GEMVs (dec_gemv_kernel), folded the attention launches' latency
+    chain (dec_attn_fused2_kernel) and moved the next step's embedding into the select launch.  Each keeps the arithmetic of the launch
+    it replaces (same lane -> k assignment, same product expression, same reduction trees), so the ids of a 300-token decode (B = 2) and
+    of a 120-token decode at the bench's B = 8 must equal the round-5 launches' ids exactly (env switches are read once per process:
+    two child processes)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = str(Path(__file__).resolve().parents[1])
+    script = tmp_path / "ab.py"
+    script.write_text(_DECODE_AB)
+    outs = []
+    for tag, extra in (("new", {}), ("old", {"RD_DEC_GEMV": "0", "RD_DEC_ATTN2": "0", "RD_DEC_EMBED_IN_SELECT": "0"})):
+        out = tmp_path / f"{tag}.npz"
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, str(script), root, str(out)], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert (outs[0]["ids2"] == outs[1]["ids2"]).all()
+    assert (outs[0]["ids8"] == outs[1]["ids8"]).all()
+    assert outs[0]["ids8"].shape[0] == 8 and outs[0]["ids8"].shape[1] > 20
