@@ -479,6 +479,44 @@ float rd_debug_conv(int N, int H, int W, int Cin, int Cout, int KH, int KW, int 
     return iters > 0 ? ms / iters : 0.f;
 }
 
+// developer entry: the fused stem tail (kernels_stem34.hip).  x NHWC fp32 [N][H][W][xld >= Cin]; w3 [N1][9 Cin] with k = (kh * 3 + kw) * Cin + ci,
+// w4 [N2][N1], biases [N1] / [N2] (device pointers); y NHWC [N][OH][OW][yld >= N2].  Images are prepared here the way the engine prepares them.
+// Returns ms per launch, -1 when the shape is not covered.
+float rd_debug_stem34(int N, int H, int W, int Cin, int xld, int N1, int N2, int yld, int act3, int act4, int iters, float* x, float* w3, float* b3,
+                      float* w4, float* b4, float* y, unsigned* range_flag) {
+    if (!rd::stem34_shape_ok(Cin, N1, N2)) return -1.f;
+    std::vector<float> h3((size_t)N1 * 9 * Cin), h4((size_t)N2 * N1), hb3((size_t)((N1 + 31) / 32) * 32, 0.f);
+    if (hipMemcpy(h3.data(), w3, h3.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1.f;
+    if (hipMemcpy(h4.data(), w4, h4.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1.f;
+    if (hipMemcpy(hb3.data(), b3, (size_t)N1 * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1.f;
+    std::vector<uint16_t> i3, i4;
+    float inv[2];
+    rd::prepare_stem34_weights(h3.data(), h4.data(), Cin, N1, N2, i3, i4, inv);
+    void *d3 = nullptr, *d4 = nullptr, *db3 = nullptr;
+    if (hipMalloc(&d3, i3.size() * 2) != hipSuccess || hipMalloc(&d4, i4.size() * 2) != hipSuccess || hipMalloc(&db3, hb3.size() * 4) != hipSuccess) return -1.f;
+    (void)hipMemcpy(d3, i3.data(), i3.size() * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d4, i4.data(), i4.size() * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db3, hb3.data(), hb3.size() * 4, hipMemcpyHostToDevice);
+    rd::Stem34Params p{};
+    p.x = x; p.xld = xld; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.y = y; p.yld = yld;
+    p.OH = (H - 1) / 2 + 1; p.OW = (W - 1) / 2 + 1; p.N1 = N1; p.N2 = N2;
+    p.w3 = (const uint16_t*)d3; p.w3_inv = inv[0]; p.b3 = (const float*)db3;
+    p.w4 = (const uint16_t*)d4; p.w4_inv = inv[1]; p.b4 = b4;
+    p.act3 = act3; p.act4 = act4; p.range_flag = range_flag;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    rd::launch_stem34(p, nullptr);
+    (void)hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters; ++i) rd::launch_stem34(p, nullptr);
+    (void)hipEventRecord(e1, nullptr);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(d3); (void)hipFree(d4); (void)hipFree(db3);
+    return iters > 0 ? ms / iters : 0.f;
+}
+
 // developer entry: one depthwise convolution through launch_dwconv (x NHWC fp32 [N][H][W][C], w [KH*KW][C], bias [C] or null,
 // res NHWC or null, line_w int32 [N] valid widths or null, gap = [N][chunks][C] partial sums of the output or null).
 // *gap_chunks receives the chunk count the launcher uses for this geometry.  Returns ms per launch.

@@ -779,6 +779,79 @@ TView Builder::stem_front(const std::string& w1, const std::string& bn1, const s
     return cat;
 }
 
+TView Builder::stem_tail(const std::string& w3, const std::string& bn3, const std::string& w4, const std::string& bn4, const TView& x, int act3,
+                         int act4, const TView* out) {
+    const int n1 = weight_dim(w3, 0), cin = weight_dim(w3, 1), n2 = weight_dim(w4, 0);
+    ConvGeom g3;
+    g3.kh = g3.kw = 3;
+    g3.sh = g3.sw = 2;
+    g3.pt = g3.pl = g3.pb = g3.pr = 1;
+    ConvGeom g1;
+    const std::string fkey = w3 + "|" + bn3 + "|" + w4 + "|" + bn4 + "|stemtail";
+    const int oh = out_dim(x.h, 3, 2, 1, 1), ow = out_dim(x.w, 3, 2, 1, 1);
+    // (fused: 16-byte float4 accesses on both sides - channel strides and the output view's channel offset are multiples of four floats;
+    //  an image of < 2^30 elements for the 32-bit buffer offsets of the patch loads)
+    const bool fused = planning() && stem34_enabled() && (h3_ || mixer_h3_) && pb_->has(fkey + "#w3") && plan_->ld(x) % 4 == 0 &&
+                       (size_t)x.h * x.w * plan_->ld(x) < ((size_t)1 << 30) && (!out || (plan_->ld(*out) % 4 == 0 && out->coff % 4 == 0)) &&
+                       (size_t)oh * ow * (out ? plan_->ld(*out) : n2) < ((size_t)1 << 29);
+    if (!fused) {
+        TView s3 = conv(w3, "", bn3, x, g3, act3);
+        TView s4 = conv(w4, "", bn4, s3, g1, act4, out);
+        release(s3);
+        if (!planning() && stem34_enabled() && !pb_->has(fkey + "#w3") && stem34_shape_ok(cin, n1, n2) && weight_dim(w3, 2) == 3 && weight_dim(w3, 3) == 3 &&
+            weight_dim(w4, 1) == n1) {
+            const std::string k3 = w3 + "|" + bn3, k4 = w4 + "|" + bn4;
+            const float* f3 = pb_->host_ptr(k3 + "#w");
+            const float* f4 = pb_->host_ptr(k4 + "#w");
+            if (fits_fp16_range(std::vector<float>(f3, f3 + (size_t)n1 * 9 * cin)) && fits_fp16_range(std::vector<float>(f4, f4 + (size_t)n2 * n1))) {
+                std::vector<uint16_t> img3, img4;
+                float inv[2];
+                prepare_stem34_weights(f3, f4, cin, n1, n2, img3, img4, inv);
+                pb_->add_u16(fkey + "#w3", img3);
+                pb_->add_u16(fkey + "#w4", img4);
+                std::vector<float> b3((size_t)((n1 + 31) / 32) * 32, 0.f), b4((size_t)n2, 0.f);
+                if (pb_->has(k3 + "#b")) std::copy(pb_->host_ptr(k3 + "#b"), pb_->host_ptr(k3 + "#b") + n1, b3.begin());
+                if (pb_->has(k4 + "#b")) std::copy(pb_->host_ptr(k4 + "#b"), pb_->host_ptr(k4 + "#b") + n2, b4.begin());
+                pb_->add(fkey + "#b3", b3);
+                pb_->add(fkey + "#b4", b4);
+                pb_->add(fkey + "#inv", std::vector<float>{inv[0], inv[1]});
+            }
+        }
+        return s4;
+    }
+    TView y = out ? *out : alloc(x.n, oh, ow, n2);
+    RD_CHECK(y.n == x.n && y.h == oh && y.w == ow && y.c == n2, "stem_tail output view mismatch: " + w4);
+    Stem34Params p{};
+    p.xld = plan_->ld(x);
+    p.N = x.n; p.H = x.h; p.W = x.w; p.Cin = cin;
+    p.yld = plan_->ld(y);
+    p.OH = oh; p.OW = ow; p.N1 = n1; p.N2 = n2;
+    p.w3 = reinterpret_cast<const uint16_t*>(pb_->ptr(fkey + "#w3"));
+    p.w4 = reinterpret_cast<const uint16_t*>(pb_->ptr(fkey + "#w4"));
+    p.b3 = pb_->ptr(fkey + "#b3");
+    p.b4 = pb_->ptr(fkey + "#b4");
+    p.w3_inv = pb_->host_ptr(fkey + "#inv")[0];
+    p.w4_inv = pb_->host_ptr(fkey + "#inv")[1];
+    p.act3 = act3; p.act4 = act4;
+    p.range_flag = range_flag_;
+    OpRecord r;
+    r.name = w3 + ":tail";
+    r.kind = "stem_tail";
+    r.cfg = "C" + std::to_string(cin) + "_" + std::to_string(n1) + "_" + std::to_string(n2);
+    r.shape = "M" + std::to_string(x.n * oh * ow) + "_K" + std::to_string(9 * cin) + "_N" + std::to_string(n1) + "_N" + std::to_string(n2);
+    r.flops = 2.0 * x.n * oh * ow * (9.0 * cin * n1 + (double)n1 * n2);
+    r.bytes = 4.0 * ((double)x.pixels() * cin + (double)x.n * oh * ow * n2 + 9.0 * cin * n1 + (double)n1 * n2);
+    const TView xv = x, yv = y;
+    r.run = [p, xv, yv](const Plan& pl, const RunCtx& c) mutable {
+        Stem34Params q = p;
+        q.x = pl.vptr(xv, c);
+        q.y = pl.vptr(yv, c);
+        launch_stem34(q, c.stream);
+    };
+    emit(std::move(r));
+    return y;
+}
+
 void Builder::mask_cols(const TView& v, int col) {
     if (!has_lt_ || !planning()) return;
     OpRecord r;

@@ -184,6 +184,10 @@ class Builder {
     // kernel in the split-fp16 precision modes (kernels_stem_fused.hip), the four separate kernels otherwise.
     TView stem_front(const std::string& w1, const std::string& bn1, const std::string& w2a, const std::string& bn2a,
                      const std::string& w2b, const std::string& bn2b, const TView& x_nchw);
+    // stem3 (3x3 / stride 2 / pad 1 + BN + act) -> stem4 (1x1 + BN + act): one fused kernel in the split-fp16 precision modes
+    // (kernels_stem34.hip, round 6), the two convolutions otherwise.  `out`: where stem4's output goes (a channel slot of a concat buffer)
+    TView stem_tail(const std::string& w3, const std::string& bn3, const std::string& w4, const std::string& bn4, const TView& x, int act3,
+                    int act4, const TView* out = nullptr);
     struct GapOut { TView partial; int chunks = 0; };  // per-image partial sums of a layer's output (SE pooling)
     TView dwconv(const std::string& wname, const std::string& bname, const std::string& bn, const TView& x,
                  const ConvGeom& g, int act, const TView* out = nullptr, const TView* res = nullptr, GapOut* gap = nullptr,

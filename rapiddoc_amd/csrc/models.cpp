@@ -39,10 +39,8 @@ static TView lc_stem(Builder& b, const std::string& p, const TView& x_nchw, int 
     // stem1 (H/2, c1) -> [max-pool | stem2a (c1/2) -> stem2b (c1)] -> cat (2 c1): one fused kernel in the split-fp16 modes
     (void)c1;
     TView cat = b.stem_front(cw("stem1"), bn("stem1"), cw("stem2a"), bn("stem2a"), cw("stem2b"), bn("stem2b"), x_nchw);
-    TView s3 = b.conv(cw("stem3"), "", bn("stem3"), cat, geom(3, 2), ACT_RELU);
+    TView s4 = b.stem_tail(cw("stem3"), bn("stem3"), cw("stem4"), bn("stem4"), cat, ACT_RELU, ACT_RELU);
     b.release(cat);
-    TView s4 = b.conv(cw("stem4"), "", bn("stem4"), s3, geom(1), ACT_RELU);
-    b.release(s3);
     (void)c2;
     return s4;
 }
@@ -315,8 +313,6 @@ static void build_pphgnetv2(Builder& b, const TView& x, const HgStageCfg (&cfg)[
     // stem (StemBlock, rec_pphgnetv2.py:979-1056)
     TView cat = b.stem_front(cw("stem.stem1"), bn("stem.stem1"), cw("stem.stem2a"), bn("stem.stem2a"), cw("stem.stem2b"),
                              bn("stem.stem2b"), x);
-    TView s3 = b.conv(cw("stem.stem3"), "", bn("stem.stem3"), cat, geom(3, 2), ACT_RELU);
-    b.release(cat);
 
     // stage inputs are produced straight into channel slot 0 of the stage's dense-concat buffer
     TView cur, cur_cat;
@@ -324,10 +320,11 @@ static void build_pphgnetv2(Builder& b, const TView& x, const HgStageCfg (&cfg)[
     {
         const HgStageCfg& c = cfg[0];
         RD_CHECK(!c.down, "PPHGNetV2: the first stage does not downsample");
-        cur_cat = new_cat(B, s3.h, s3.w, c, c.cin);
+        const int s3h = (cat.h + 2 - 3) / 2 + 1, s3w = (cat.w + 2 - 3) / 2 + 1;      // stem3: 3x3 / stride 2 / pad 1
+        cur_cat = new_cat(B, s3h, s3w, c, c.cin);
         cur = b.slice(cur_cat, 0, c.cin);
-        b.conv(cw("stem.stem4"), "", bn("stem.stem4"), s3, geom(1), ACT_RELU, &cur);
-        b.release(s3);
+        b.stem_tail(cw("stem.stem3"), bn("stem.stem3"), cw("stem.stem4"), bn("stem.stem4"), cat, ACT_RELU, ACT_RELU, &cur);
+        b.release(cat);
     }
     for (int si = 0; si < 4; ++si) {
         const HgStageCfg& c = cfg[si];

@@ -66,6 +66,24 @@ bool gemm_h1_applies(const ConvParams& p);
 void launch_gemm_h1(const ConvParams& p, hipStream_t s);
 float prepare_gemm_h1_weights(const float* w, int N, int K, std::vector<uint16_t>& img);   // returns the inverse scale
 void launch_conv_igemm_h3(const ConvParams& p, hipStream_t s);
+// stem tail: 3x3 / stride 2 / pad 1 conv (+ bias + act3) -> 1x1 conv (+ bias + act4) in one kernel (kernels_stem34.hip, round 6).
+// x NHWC [N][H][W][xld >= Cin]; y NHWC [N][OH][OW][yld >= N2], OH = (H - 1) / 2 + 1, OW likewise; pointers and row strides 16-byte aligned.
+struct Stem34Params {
+    const float* x; int xld;
+    int N, H, W, Cin;
+    float* y; int yld;
+    int OH, OW, N1, N2;
+    const uint16_t* w3; float w3_inv; const float* b3;     // slab-ordered image of the 3x3, bias padded with zeros to 32-wide blocks
+    const uint16_t* w4; float w4_inv; const float* b4;     // fragment image of the 1x1 (input channels in the 3x3's C/D register order), bias [N2]
+    int act3, act4;
+    unsigned* range_flag = nullptr;
+    int abl = 0;     // developer ablation bits (results are garbage): 1 no fragment reads / MFMAs, 2 no patch split / write, 4 no patch loads, 8 no epilogue, 16 no weight DMA
+};
+bool stem34_shape_ok(int cin, int n1, int n2);
+bool stem34_enabled();                        // RD_STEM34=1 (default off: measured level with the two-kernel path, profiles/r6_stem34.txt)
+void launch_stem34(const Stem34Params& p, hipStream_t s);
+void prepare_stem34_weights(const float* w3, const float* w4, int Cin, int N1, int N2, std::vector<uint16_t>& img3, std::vector<uint16_t>& img4,
+                            float inv[2]);
 // direct 3x3 / stride 1 / pad 1, <= 96 output channels, one accumulator set, two workgroups per CU (kernels_conv3x3_h1.hip, round 6)
 bool conv3x3_h1_shape_ok(int kh, int kw, int cin, int cout);   // host-side: which layers get a weight image
 bool conv3x3_h1_applies(const ConvParams& p);

@@ -17,6 +17,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/p_${c}_$TAG -o a -- $B > /tmp/p.log 2>&1
   python $R/tools/pmc_summary.py $(find /tmp/p_${c}_$TAG -name "*counter_collection.csv" | head -1) $O/${TAG}_pmc_$c.csv > /dev/null
 done
+# effective clock per kernel: GRBM_GUI_ACTIVE in a pass of its own, joined with the same pass's kernel trace
+timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d /tmp/p_clk_$TAG -o a -- $B > /tmp/pclk.log 2>&1
+python $R/tools/pmc_clock.py $(find /tmp/p_clk_$TAG -name "*counter_collection.csv" | head -1) $(find /tmp/p_clk_$TAG -name "*kernel_trace.csv" | head -1) $O/${TAG}_pmc_clock.csv > /dev/null 2>$O/${TAG}_pmc_clock.err
 python $R/tools/pmc_traffic.py $O/${TAG}_pmc_FETCH_SIZE.csv $O/${TAG}_pmc_WRITE_SIZE.csv $O/${TAG}_pmc_traffic.json "collection ${TAG}, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bench.py --steps 1 --warmup 0 --setup-steps 0 (8 rec streams, the bench's launch mix)" 1 > /dev/null
 cp $O/${TAG}_pmc_traffic.json $R/profiles/pmc_traffic.json          # what bench.py reads (committed from gpurun_out afterwards)
 unset RD_BENCH_STOP_AFTER_TIMED
