@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
 """Effective clock per kernel from a rocprofv3 `--kernel-trace --pmc GRBM_GUI_ACTIVE` pass (the power-bound reading of the
-matrix kernels was an inference from s_memtime stamps): GRBM_GUI_ACTIVE counts the graphics clock's cycles while the GPU is busy, a counter
-pass runs the dispatches one at a time, so  sum(GRBM_GUI_ACTIVE) / sum(kernel duration)  over a kernel's dispatches is the clock that kernel
-gets when it has the chip to itself.  The counter is reported summed over the XCDs on some stacks: the table carries the raw ratio and the
-ratio divided by the XCD count that makes the bandwidth-bound kernels (which do not throttle) land at the chip's peak clock.
-Usage: pmc_clock.py <counter_collection.csv> <kernel_trace.csv> <out.csv>"""
+matrix kernels was an inference from s_memtime stamps).  GRBM_GUI_ACTIVE counts graphics-clock cycles while the GPU is busy; a counter pass
+runs the dispatches one at a time.  Per dispatch the counter covers the kernel PLUS a fixed window around it (counter start / stop), and it is
+reported summed over the chip's XCDs, so a plain  cycles / duration  over-reads short kernels (se_fc, 11 us: 34 cycles/ns).  A kernel family
+whose dispatches differ in length gives both numbers: the least-squares line  cycles = slope * duration + intercept  over its dispatches has
+slope = XCDs * clock and intercept = XCDs * clock * window.  Families with too little spread in duration get the window of the best-fitted
+family instead.  Usage: pmc_clock.py <counter_collection.csv> <kernel_trace.csv> <out.csv>"""
 import csv
 import sys
 from collections import defaultdict
 
 cc, kt, out = sys.argv[1], sys.argv[2], sys.argv[3]
+XCDS = 8
 dur = {}
 with open(kt) as f:
     for r in csv.DictReader(f):
@@ -22,25 +24,47 @@ with open(cc) as f:
             continue
         did = r.get("Dispatch_Id") or r.get("Correlation_Id")
         cyc[did] += float(r["Counter_Value"])
-agg = defaultdict(lambda: [0, 0.0, 0.0])
+pts = defaultdict(list)
 for did, c in cyc.items():
-    if did not in dur:
-        continue
-    ns, name = dur[did]
-    k = name.split("(")[0].replace("void ", "")
-    a = agg[k]
-    a[0] += 1
-    a[1] += c
-    a[2] += ns
-rows = sorted(agg.items(), key=lambda kv: -kv[1][2])
-# XCD normalisation: the highest raw ratio among kernels with >= 1 ms of total time is taken to be a kernel running at the peak clock
-raw = {k: (v[1] / v[2] if v[2] else 0.0) for k, v in rows}
-top = max([r for k, r in raw.items() if agg[k][2] > 1e6] or [1.0])
-PEAK = 2.4
-nx = max(1, round(top / PEAK))
+    if did in dur:
+        ns, name = dur[did]
+        pts[name.split("(")[0].replace("void ", "")].append((float(ns), c))
+
+
+def fit(p):
+    n = len(p)
+    sx = sum(a for a, _ in p); sy = sum(b for _, b in p)
+    sxx = sum(a * a for a, _ in p); sxy = sum(a * b for a, b in p)
+    den = n * sxx - sx * sx
+    if n < 8 or den <= 0:
+        return None
+    slope = (n * sxy - sx * sy) / den
+    icpt = (sy - slope * sx) / n
+    lo, hi = min(a for a, _ in p), max(a for a, _ in p)
+    if hi < 2.0 * lo or slope <= 0:
+        return None
+    ss_res = sum((b - slope * a - icpt) ** 2 for a, b in p)
+    ss_tot = sum((b - sy / n) ** 2 for _, b in p) or 1.0
+    return slope, icpt, 1.0 - ss_res / ss_tot
+
+
+fits = {k: fit(p) for k, p in pts.items()}
+good = {k: v for k, v in fits.items() if v and v[2] > 0.98}
+# window (ns) of the family with the most time among the well-fitted ones
+ref = max(good, key=lambda k: sum(a for a, _ in pts[k])) if good else None
+window_ns = good[ref][1] / good[ref][0] if ref else 0.0
+rows = sorted(pts.items(), key=lambda kv: -sum(a for a, _ in kv[1]))
 with open(out, "w") as f:
-    f.write(f"# GRBM_GUI_ACTIVE / duration per kernel; divided by {nx} (counter summed over {nx} XCDs: highest raw ratio {top:.2f} cycles/ns)\n")
-    f.write("kernel,dispatches,total_ms,gui_active_cycles,cycles_per_ns_raw,effective_GHz\n")
-    for k, v in rows:
-        f.write(f"{k.replace(',', ';')},{v[0]},{v[2] / 1e6:.3f},{v[1]:.6g},{raw[k]:.4f},{raw[k] / nx:.3f}\n")
-print(open(out).read()[:4000])
+    f.write(f"# GRBM_GUI_ACTIVE (summed over {XCDS} XCDs) vs kernel duration, one counter pass of the bench's step, dispatches serialised by the profiler.\n")
+    f.write(f"# fit: cycles = slope * ns + intercept per family (>= 8 dispatches, durations spread >= 2x, R^2 > 0.98); clock = slope / {XCDS}.\n")
+    f.write(f"# no fit: clock = cycles / (ns + window) / {XCDS} with the window of {ref}: {window_ns:.0f} ns.\n")
+    f.write("kernel,dispatches,total_ms,avg_us,raw_cycles_per_ns,fit_R2,effective_GHz,method\n")
+    for k, p in rows:
+        tns = sum(a for a, _ in p); tc = sum(b for _, b in p)
+        v = good.get(k)
+        if v:
+            ghz, r2, how = v[0] / XCDS, f"{v[2]:.4f}", "fit"
+        else:
+            ghz, r2, how = tc / (tns + window_ns * len(p)) / XCDS, "", "window"
+        f.write(f"{k.replace(',', ';')},{len(p)},{tns / 1e6:.3f},{tns / len(p) / 1e3:.1f},{tc / tns:.3f},{r2},{ghz:.3f},{how}\n")
+print(open(out).read()[:5000])
