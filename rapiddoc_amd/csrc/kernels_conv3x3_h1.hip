@@ -340,7 +340,7 @@ void launch_conv3x3_h1(const ConvParams& p, hipStream_t s) {
         int dev = 0, n = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n > 0 ? n : 256;
+        return rd_cu_budget(n > 0 ? n : 256);
     }();
     const int nb = (p.Ng + 31) / 32;
     const size_t lds = (size_t)2 * C3_PLANE + (size_t)C3_D * nb * 2048;

@@ -493,7 +493,7 @@ void launch_gemm_h1(const ConvParams& p, hipStream_t s) {
         int dev = 0, n = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n > 0 ? n : 256;
+        return rd_cu_budget(n > 0 ? n : 256);
     }();
     static const int per_cu = [] { const char* e = getenv("RD_GEMM1_WGS"); return e ? atoi(e) : 2; }();     // developer A/B: 1 = one workgroup per CU
     static const int dbg = [] { const char* e = getenv("RD_GEMM1_DBG"); return e ? atoi(e) : 0; }();

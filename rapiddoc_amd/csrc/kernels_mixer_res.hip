@@ -249,7 +249,7 @@ static void launch_res(const MixerParams& p, hipStream_t s) {
         int dev = 0, n = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n > 0 ? n : 256;
+        return rd_cu_budget(n > 0 ? n : 256);
     }();
     const int n_tiles = (p.M + 15) / 16;
     const int n_wg = (n_tiles + MR_WAVES - 1) / MR_WAVES;

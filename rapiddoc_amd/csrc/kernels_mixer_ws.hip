@@ -835,7 +835,7 @@ void launch_mixer_fused_ws(const MixerParams& p, hipStream_t s) {
         int dev = 0;
         hipDeviceProp_t prop;
         (void)hipGetDevice(&dev);
-        n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        n_cu = rd_cu_budget((hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256);
     }
     const int n_tiles = (p.M + WS_PX - 1) / WS_PX;
     const int n_wg = (n_tiles + WS_WAVES - 1) / WS_WAVES;

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 namespace rd {
@@ -18,6 +19,15 @@ inline void rd_allow_dynamic_lds(const void* kernel, size_t bytes, unsigned long
         (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         mask |= bit;
     }
+}
+
+// CUs the persistent matrix kernels size their grids for.  Their workgroups book a CU's LDS and registers completely (gemm_h1 2 x 80 KB,
+// the mixers 146 - 148 KB), so while one of them covers all 256 CUs nothing of another stream - not even a bandwidth-bound depthwise
+// launch that needs no matrix pipe - can start: RD_PERSISTENT_CUS=n leaves 256 - n CUs (spread over the XCDs by the dispatcher's round robin)
+// to whatever else is in flight.  Default: all of them.
+inline int rd_cu_budget(int n_cu) {
+    static const int env = [] { const char* e = std::getenv("RD_PERSISTENT_CUS"); return e ? std::atoi(e) : 0; }();
+    return env > 0 && env < n_cu ? env : n_cu;
 }
 
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_SIGMOID = 4, ACT_HSIG = 5, ACT_HSIG_PADDLE = 6 };
