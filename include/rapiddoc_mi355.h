@@ -231,6 +231,27 @@ int rd_layout_postprocess(const float* boxes, int n, int ncol, int img_w, int im
 int rd_layout_postprocess_select(const float* boxes, int n, int ncol, int img_w, int img_h, const rd_layout_post_cfg* cfg,
                                  float* sel_boxes, int32_t* sel_src, int32_t* n_sel);
 
+/* RT-DETR-family head operators - PREPARATION ONLY, PARITY UNPINNED (rapiddoc_amd/csrc/kernels_rtdetr.hip).  PP-DocLayout's neck / decoder
+ * are ONNX files that are not part of the offline reference tree (rapid_layout_self/inference_engine/onnxruntime/main.py:61-78 only loads
+ * them), so the graph cannot be read: these three entries implement operators whose definition does not depend on it, are tested against
+ * fp64 restatements of their published definitions (tests/test_gpu_rtdetr_ops.py), and are wired into nothing.  Device pointers.
+ *   rd_msdeform_attn   multi-scale deformable attention sampling (Deformable DETR eq. 3): value [B][S][H][D], shapes int32 [L][2] = (h, w),
+ *                      level_start int32 [L], loc [B][Q][H][L][P][2] = (x, y) in [0, 1], attn [B][Q][H][L][P] -> out [B][Q][H * D];
+ *                      bilinear samples as grid_sample(align_corners = False, zero padding); H * D <= 1024
+ *   rd_topk_rows       per row of n scores: the k <= 1024 largest, descending, equal values in ascending index order, NaN above +inf
+ *                      (the (queries x classes) selection in front of PPPostProcess, pp_doclayout/main.py:88-139)
+ *   rd_encoder_layer   one post-norm transformer encoder layer (AIFI): MHA(q = k = x + pos, v = x) + residual + LayerNorm, FFN + residual +
+ *                      LayerNorm over B sequences of T tokens; in_w [3 Dm][Dm] packed q | k | v; head_dim 16 or 32; `act` = rd activation
+ *                      code (2 = GELU, 1 = ReLU); workspace of rd_encoder_layer_workspace(B * T, Dm, F) bytes */
+int rd_msdeform_attn(int device_id, const float* value, const int32_t* shapes, const int32_t* level_start, const float* loc, const float* attn,
+                     float* out, int B, int S, int H, int D, int Q, int L, int P, void* stream);
+int rd_topk_rows(int device_id, const float* scores, int rows, int n, int k, float* out_vals, int32_t* out_idx, void* stream);
+size_t rd_encoder_layer_workspace(int M, int Dm, int F);
+int rd_encoder_layer(int device_id, const float* x, const float* pos, int B, int T, int Dm, int heads, int F, int act, const float* in_w,
+                     const float* in_b, const float* out_w, const float* out_b, const float* ln1_g, const float* ln1_b, const float* w1,
+                     const float* b1, const float* w2, const float* b2, const float* ln2_g, const float* ln2_b, float eps, float* out, void* ws,
+                     size_t ws_bytes, void* stream);
+
 /* Raster / polygon primitives of the polygon branch (HOST pointers; rapiddoc_amd/csrc/polygon_ops.cpp).  Each replaces one
  * OpenCV / shapely call of the reference (PARITY UNPINNED: neither library is available offline; restated from their published
  * algorithms):

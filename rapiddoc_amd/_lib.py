@@ -55,6 +55,10 @@ SYMBOLS = {
     "rd_polygon_area": (C.c_double, [C.c_void_p, C.c_int]),
     "rd_polygon_intersection_area": (C.c_double, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "rd_fill_poly": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
+    "rd_msdeform_attn": (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_void_p]),
+    "rd_topk_rows": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rd_encoder_layer_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "rd_encoder_layer": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 12 + [C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rd_set_precision": (C.c_int, [C.c_void_p, C.c_char_p]),
     "rd_range_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rd_plan_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

@@ -11,7 +11,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 OUT = PKG / "librapiddoc_mi355.so"
-SOURCES = ["kernels_conv.hip", "kernels_conv_h3.hip", "kernels_conv_direct_h3.hip", "kernels_conv3x3_h1.hip", "kernels_stem34.hip", "kernels_conv_stream_h3.hip", "kernels_gemm_h3_dma.hip", "kernels_gemm_h1.hip", "kernels_misc.hip", "kernels_dw_lds.hip", "kernels_stem_fused.hip", "kernels_image.hip", "kernels_dbpost.hip", "kernels_attention_h3.hip", "kernels_ctc.hip", "kernels_mixer.hip", "kernels_mixer_h3.hip", "kernels_mixer_ws.hip", "kernels_mixer_res.hip", "formula_decoder.hip", "engine.cpp", "models.cpp", "api.cpp", "db_postprocess.cpp", "layout_postprocess.cpp", "polygon_ops.cpp", "rec_chunks.cpp"]
+SOURCES = ["kernels_conv.hip", "kernels_conv_h3.hip", "kernels_conv_direct_h3.hip", "kernels_conv3x3_h1.hip", "kernels_stem34.hip", "kernels_rtdetr.hip", "kernels_conv_stream_h3.hip", "kernels_gemm_h3_dma.hip", "kernels_gemm_h1.hip", "kernels_misc.hip", "kernels_dw_lds.hip", "kernels_stem_fused.hip", "kernels_image.hip", "kernels_dbpost.hip", "kernels_attention_h3.hip", "kernels_ctc.hip", "kernels_mixer.hip", "kernels_mixer_h3.hip", "kernels_mixer_ws.hip", "kernels_mixer_res.hip", "formula_decoder.hip", "engine.cpp", "models.cpp", "api.cpp", "db_postprocess.cpp", "layout_postprocess.cpp", "polygon_ops.cpp", "rec_chunks.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-x", "hip"]
 # Per-file code-generation flags (tests/test_isa_resources.py and tools/isa_mix.py compile with the same ones: `extra_flags_for`).
 # kernels_mixer_ws.hip: hipcc -O3 SLP-packs adjacent scalar fp32 chains into v_pk_*_f32, and packed fp32 VALU does NOT issue under another

@@ -270,6 +270,79 @@ int rd_ctc_collapse_lines(int device_id, const int32_t* idx, const float* prob, 
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// ---- RT-DETR-family head operators (preparation only, parity unpinned: include/rapiddoc_mi355.h) ----------------------------------
+int rd_msdeform_attn(int device_id, const float* value, const int32_t* shapes, const int32_t* level_start, const float* loc, const float* attn,
+                     float* out, int B, int S, int H, int D, int Q, int L, int P, void* stream) {
+    if (!value || !shapes || !level_start || !loc || !attn || !out || B < 0 || S <= 0 || H <= 0 || D <= 0 || Q < 0 || L <= 0 || P <= 0 || H * D > 1024)
+        return 1;
+    if (hipSetDevice(device_id) != hipSuccess) return 1;
+    rd::launch_msdeform_attn(value, shapes, level_start, loc, attn, out, B, S, H, D, Q, L, P, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int rd_topk_rows(int device_id, const float* scores, int rows, int n, int k, float* out_vals, int32_t* out_idx, void* stream) {
+    if (!scores || !out_vals || !out_idx || rows < 0 || n <= 0 || k <= 0 || k > 1024 || k > n) return 1;
+    if (hipSetDevice(device_id) != hipSuccess) return 1;
+    rd::launch_topk_rows(scores, rows, n, k, out_vals, out_idx, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+size_t rd_encoder_layer_workspace(int M, int Dm, int F) {
+    if (M <= 0 || Dm <= 0 || F <= 0) return 0;
+    return ((size_t)M * Dm * 3 /* x + pos, attention output, post-norm-1 */ + (size_t)M * 3 * Dm /* q | k | v */ + (size_t)M * F) * sizeof(float);
+}
+
+// One post-norm transformer encoder layer over B sequences of T tokens (M = B * T rows of Dm):
+//   a = MHA(q = k = x + pos, v = x);  y1 = LN1(x + a Wo^T + bo);  out = LN2(y1 + W2 act(W1 y1 + b1) + b2)
+// in_w [3 Dm][Dm] / in_b [3 Dm] = the packed q | k | v projection (nn.MultiheadAttention's in_proj), head_dim = Dm / heads in {16, 32}.
+// Composed from the engine's kernels: fp32-MFMA GEMMs (launch_conv_igemm on raw [N][K] weights), launch_attention, launch_layernorm.
+int rd_encoder_layer(int device_id, const float* x, const float* pos, int B, int T, int Dm, int heads, int F, int act, const float* in_w,
+                     const float* in_b, const float* out_w, const float* out_b, const float* ln1_g, const float* ln1_b, const float* w1,
+                     const float* b1, const float* w2, const float* b2, const float* ln2_g, const float* ln2_b, float eps, float* out, void* ws,
+                     size_t ws_bytes, void* stream) {
+    const int M = B * T;
+    if (!x || !in_w || !out_w || !w1 || !w2 || !ln1_g || !ln1_b || !ln2_g || !ln2_b || !out || !ws || B <= 0 || T <= 0 || heads <= 0 ||
+        Dm % heads != 0 || Dm % 4 != 0 || F % 4 != 0 || ws_bytes < rd_encoder_layer_workspace(M, Dm, F))
+        return 1;
+    const int hd = Dm / heads;
+    if (hd != 16 && hd != 32) return 1;
+    if (hipSetDevice(device_id) != hipSuccess) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    float* xp = (float*)ws;
+    float* att = xp + (size_t)M * Dm;
+    float* y1 = att + (size_t)M * Dm;
+    float* qkv = y1 + (size_t)M * Dm;
+    float* ff = qkv + (size_t)M * 3 * Dm;
+    auto gemm = [&](const float* a, int K, const float* w, const float* b, int N, float* y, int yld, int a_act, const float* res) {
+        rd::ConvParams p{};
+        p.x = a; p.xld = K; p.N = 1; p.H = 1; p.W = M; p.Cin = K;
+        p.w = w; p.bias = b; p.y = y; p.yld = yld; p.OH = 1; p.OW = M; p.Cout = N;
+        p.KH = p.KW = p.SH = p.SW = 1;
+        p.res = res; p.rld = N;
+        p.act = a_act; p.out_mode = rd::OUT_NHWC;
+        p.M = M; p.K = K; p.Ng = N;
+        rd::launch_conv_igemm(p, s);
+    };
+    try {
+        const float* qk_in = x;
+        if (pos) {
+            rd::launch_add(x, Dm, pos, Dm, xp, Dm, M, Dm, s);
+            qk_in = xp;
+        }
+        gemm(qk_in, Dm, in_w, in_b, 2 * Dm, qkv, 3 * Dm, rd::ACT_NONE, nullptr);                                   // q | k from x + pos
+        gemm(x, Dm, in_w + (size_t)2 * Dm * Dm, in_b ? in_b + 2 * Dm : nullptr, Dm, qkv + 2 * Dm, 3 * Dm, rd::ACT_NONE, nullptr);   // v from x
+        rd::launch_attention(qkv, att, B, T, heads, hd, 1.0f / std::sqrt((float)hd), s);
+        gemm(att, Dm, out_w, out_b, Dm, xp, Dm, rd::ACT_NONE, x);                                                   // x + a Wo^T + bo
+        rd::launch_layernorm(xp, Dm, y1, Dm, ln1_g, ln1_b, M, Dm, eps, s);
+        gemm(y1, Dm, w1, b1, F, ff, F, act, nullptr);
+        gemm(ff, F, w2, b2, Dm, xp, Dm, rd::ACT_NONE, y1);
+        rd::launch_layernorm(xp, Dm, out, Dm, ln2_g, ln2_b, M, Dm, eps, s);
+    } catch (...) {
+        return 1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 size_t rd_db_boxes_workspace(int B, int H, int W, int max_runs, int max_candidates) {
     (void)W;
     if (B <= 0 || H <= 0 || max_runs <= 0 || max_candidates <= 0) return 0;

@@ -76,6 +76,10 @@ bool gemm_h1_applies(const ConvParams& p);
 void launch_gemm_h1(const ConvParams& p, hipStream_t s);
 float prepare_gemm_h1_weights(const float* w, int N, int K, std::vector<uint16_t>& img);   // returns the inverse scale
 void launch_conv_igemm_h3(const ConvParams& p, hipStream_t s);
+// RT-DETR-family head operators, preparation only (kernels_rtdetr.hip; nothing in the engine calls them)
+void launch_msdeform_attn(const float* value, const int32_t* shapes, const int32_t* start, const float* loc, const float* attn, float* out, int B,
+                          int S, int H, int D, int Q, int L, int P, hipStream_t s);
+void launch_topk_rows(const float* scores, int rows, int n, int k, float* out_vals, int32_t* out_idx, hipStream_t s);
 // stem tail: 3x3 / stride 2 / pad 1 conv (+ bias + act3) -> 1x1 conv (+ bias + act4) in one kernel (kernels_stem34.hip, round 6).
 // x NHWC [N][H][W][xld >= Cin]; y NHWC [N][OH][OW][yld >= N2], OH = (H - 1) / 2 + 1, OW likewise; pointers and row strides 16-byte aligned.
 struct Stem34Params {
