@@ -438,7 +438,16 @@ void Builder::fold_conv(const std::string& wname, const std::string& bname, cons
     }
 }
 
-TView Builder::mixer_fused(const std::string& prefix, const TView& x, const TView* gate) {
+bool Builder::mixer_takes_dw(const std::string& prefix, int C) const {
+    if (!planning() || !(h3_ || mixer_h3_) || !mixer_res_fuses_dw(C)) return false;
+    const std::string hkey = prefix + ".mixer#h3";
+    static const bool ws_off = std::getenv("RD_MIXER_WS") && std::string(std::getenv("RD_MIXER_WS")) == "0";
+    const bool split = pb_->has(hkey + ".w1h");
+    const bool ws = split && !ws_off && pb_->has(hkey + ".ws");
+    return split && !ws && pb_->has(hkey + ".res");       // the route Builder::mixer_fused takes to the resident-weights kernel
+}
+
+TView Builder::mixer_fused(const std::string& prefix, const TView& x, const TView* gate, const std::string* dw_key) {
     // prefix.channel_conv1 / channel_conv2 (+ normalization), residual block: out channels == in channels
     const std::string w1 = prefix + ".channel_conv1.convolution.weight", bn1 = prefix + ".channel_conv1.normalization";
     const std::string w2 = prefix + ".channel_conv2.convolution.weight", bn2 = prefix + ".channel_conv2.normalization";
@@ -500,23 +509,37 @@ TView Builder::mixer_fused(const std::string& prefix, const TView& x, const TVie
     p.xld = plan_->ld(x);
     p.yld = plan_->ld(y);
     p.M = (int)x.pixels(); p.HW = x.h * x.w; p.C = C;
+    const bool with_dw = dw_key != nullptr;
+    if (with_dw) {
+        RD_CHECK(res_k && !gate, "mixer_fused: the depthwise conv only rides in the resident-weights kernel, without a gate: " + prefix);
+        RD_CHECK((size_t)x.pixels() * plan_->ld(x) < ((size_t)1 << 29), "mixer_fused + depthwise: the input tensor exceeds the 32-bit tap offsets");
+        p.dw_w = pb_->ptr(*dw_key + "#w");
+        p.dw_b = pb_->ptr(*dw_key + "#b");
+        p.dwH = x.h; p.dwW = x.w;
+    }
     p.w1 = pb_->ptr(w1 + "|" + bn1 + "#w"); p.b1 = pb_->ptr(w1 + "|" + bn1 + "#b");
     p.w2 = pb_->ptr(w2 + "|" + bn2 + "#w"); p.b2 = pb_->ptr(w2 + "|" + bn2 + "#b");
     OpRecord r;
     r.name = prefix + ".mixer";
-    r.kind = res_k ? "mixer_fused_res" : ws ? "mixer_fused_ws" : split ? "mixer_fused_h3" : "mixer_fused";
+    r.kind = res_k ? (with_dw ? "mixer_fused_res_dw" : "mixer_fused_res") : ws ? "mixer_fused_ws" : split ? "mixer_fused_h3" : "mixer_fused";
     r.cfg = "C" + std::to_string(C);
     r.shape = "M" + std::to_string(p.M) + "_C" + std::to_string(C);
-    r.flops = 8.0 * p.M * (double)C * C;
+    r.flops = 8.0 * p.M * (double)C * C + (with_dw ? 18.0 * p.M * C : 0.0);
     r.bytes = 8.0 * p.M * C;
     const TView xv = x, yv = y;
     const bool has_gate = gate != nullptr;
     const TView gv = gate ? *gate : TView{};
-    r.run = [p, xv, yv, gv, has_gate, split, ws, res_k](const Plan& pl, const RunCtx& c) {
+    const bool has_lt = with_dw && has_lt_;
+    const TView ltv = lt_;
+    r.run = [p, xv, yv, gv, has_gate, split, ws, res_k, has_lt, ltv](const Plan& pl, const RunCtx& c) {
         MixerParams q = p;
         q.x = pl.vptr(xv, c);
         q.y = pl.vptr(yv, c);
         q.gate = has_gate ? pl.vptr(gv, c) : nullptr;
+        if (has_lt) {        // (as Builder::dwconv: column 2 of the line table = the line's width at this resolution)
+            q.dw_line_w = reinterpret_cast<const int32_t*>(pl.vptr(ltv, c)) + 2;
+            q.dw_line_w_stride = kLineTabStride;
+        }
         if (res_k) launch_mixer_fused_res(q, c.stream);
         else if (ws) launch_mixer_fused_ws(q, c.stream);
         else if (split) launch_mixer_fused_h3(q, c.stream);

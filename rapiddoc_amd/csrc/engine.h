@@ -170,7 +170,12 @@ class Builder {
                const ConvGeom& g, int act, const TView* out = nullptr, const TView* res = nullptr,
                const TView* ascale = nullptr);
     // fused PPLCNetV4 residual channel mixer (prefix.channel_conv1/2); gate = optional SE gate [N,1,1,C]
-    TView mixer_fused(const std::string& prefix, const TView& x, const TView* gate);
+    // `dw_key`: (round 6) x is the block's INPUT and the mixer computes the block's depthwise 3x3 / stride 1 itself from the weights
+    // Builder::dwconv folded under that key (only where mixer_takes_dw says so)
+    TView mixer_fused(const std::string& prefix, const TView& x, const TView* gate, const std::string* dw_key = nullptr);
+    // true when, in THIS plan, the channel mixer of `prefix` will run on the kernel that can take the block's depthwise conv along
+    bool mixer_takes_dw(const std::string& prefix, int C) const;
+    static std::string dw_key(const std::string& wname, const std::string& bn) { return wname + "|" + bn + "|dw"; }
     void fold_conv(const std::string& wname, const std::string& bname, const std::string& bn);
     TView linear(const std::string& prefix, const TView& x, int act, const TView* out = nullptr,
                  const TView* res = nullptr);

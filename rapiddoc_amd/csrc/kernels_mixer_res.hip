@@ -26,6 +26,7 @@
 // sums multiplied by the exact inverse scales (p.ws_inv1 / ws_inv2) where they leave the accumulators.
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "rd_device.h"
@@ -52,11 +53,20 @@ struct ResGeom {
     static constexpr int F2 = OB * NQ;          // W2 fragments per plane
     static constexpr size_t IMG_BYTES = (size_t)2 * (F1 + F2) * 1024;
     static constexpr size_t LDS_BYTES = IMG_BYTES + (size_t)(H2 + C) * sizeof(float);
+    static constexpr size_t LDS_BYTES_DW = LDS_BYTES + (size_t)10 * C * sizeof(float);      // + the depthwise taps [9][C] and bias [C]
 };
 
 // image layout: [W1 hi: F1 fragments][W1 lo][W2 hi: F2][W2 lo]; W1 fragment (hb, ks), W2 fragment (ob, q)
-template <int C, bool GATED, bool RS>
+// DW (round 6): the block's depthwise 3x3 / stride 1 / pad 1 (rec_lcnetv4.py:187-206, the token mixer of a no-SE block) is computed in the
+// tile load: p.x is the block's INPUT, a lane forms the six float4 of ITS pixel's depthwise output from nine float4 taps each (clamped
+// addresses, masked values: rows outside the map and columns outside the line's own width read as the conv's zero padding) with the taps'
+// weights from LDS - bias first, then taps in (kh, kw) order, one fma per tap (the accumulation order of dwconv3x3_lds_kernel, whose
+// compiled form mixes fused and unfused multiply-adds: the two routes agree to a few ulps, tests/test_gpu_mixer_dw.py) - and goes on to
+// the split exactly as the loaded tile did.  The depthwise output is
+// never written: one write + one read of the activation less per block; the taps' re-reads are L1 / L2 hits.
+template <int C, bool GATED, bool RS, bool DW = false>
 __global__ void __launch_bounds__(1024) lc_mixer_res_kernel(MixerParams p, const unsigned char* __restrict__ wimg, int n_tiles) {
+    static_assert(!DW || (!GATED && RS), "the fused depthwise form: no gate, residual from the fragments");
     using G = ResGeom<C>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float* B1s = reinterpret_cast<float*>(lds + G::IMG_BYTES);
@@ -69,6 +79,11 @@ __global__ void __launch_bounds__(1024) lc_mixer_res_kernel(MixerParams p, const
         for (int i = tid; i < (int)(G::IMG_BYTES / 16); i += 1024) dst[i] = src[i];
         for (int i = tid; i < G::H2; i += 1024) B1s[i] = p.b1[i];
         for (int i = tid; i < C; i += 1024) B2s[i] = p.b2[i];
+        if constexpr (DW) {
+            float* DWs = B2s + C;
+            for (int i = tid; i < 9 * C; i += 1024) DWs[i] = p.dw_w[i];
+            for (int i = tid; i < C; i += 1024) DWs[9 * C + i] = p.dw_b[i];
+        }
     }
     __syncthreads();
     const unsigned char* W1h = lds;
@@ -81,6 +96,8 @@ __global__ void __launch_bounds__(1024) lc_mixer_res_kernel(MixerParams p, const
     float neg1 = -1.f;
     asm volatile("" : "+s"(neg1));
     const float inv1 = p.ws_inv1, inv2 = p.ws_inv2;
+    typedef __amdgpu_buffer_rsrc_t rsrc_t;
+    const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, 0x7fffffff, 0x00020000);      // (DW: the tap loads)
 
     for (int tile = (int)blockIdx.x * MR_WAVES + wave; tile < n_tiles; tile += (int)gridDim.x * MR_WAVES) {
         const int mm = tile * 16 + px;
@@ -90,10 +107,68 @@ __global__ void __launch_bounds__(1024) lc_mixer_res_kernel(MixerParams p, const
         // ---- X^T as B fragments: k-step ks, lane (px, kg) = channels 16 (2 ks) + 4 kg .. + 4 and 16 (2 ks + 1) + 4 kg .. + 4 (W1's
         // columns are permuted to this order in the image): the lane's own channels of output blocks 2 ks and 2 ks + 1
         f16x8 xh[G::KS1], xl[G::KS1];
+        // DW: the nine taps of this lane's pixel = three row offsets + three column offsets (clamped into the map) and their validity
+        // (byte offsets into a buffer descriptor over the input tensor: the launcher checks that it is smaller than 2^31 bytes)
+        unsigned roff[3] = {0, 0, 0}, coff[3] = {0, 0, 0};
+        unsigned tap_ok = 0;
+        if constexpr (DW) {
+            const int n = m / p.HW, rem = m - n * p.HW;
+            const int h = rem / p.dwW, w = rem - h * p.dwW;
+            const int wlim = p.dw_line_w ? min(p.dwW, p.dw_line_w[n * p.dw_line_w_stride]) : p.dwW;
+            const unsigned xb = ((unsigned)n * (unsigned)p.HW * (unsigned)p.xld + 4u * (unsigned)kg) * 4u;
+            unsigned rok = 0, cok = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int ih = h - 1 + k, iw = w - 1 + k;
+                if ((unsigned)ih < (unsigned)p.dwH) rok |= 1u << k;
+                if ((unsigned)iw < (unsigned)wlim) cok |= 1u << k;
+                roff[k] = xb + (unsigned)(min(max(ih, 0), p.dwH - 1) * p.dwW) * (unsigned)p.xld * 4u;
+                coff[k] = (unsigned)min(max(iw, 0), p.dwW - 1) * (unsigned)p.xld * 4u;
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                if (((rok >> (k / 3)) & 1u) && ((cok >> (k % 3)) & 1u)) tap_ok |= 1u << k;
+        }
 #pragma unroll
         for (int ks = 0; ks < G::KS1; ++ks) {
-            f32x4 v0 = *reinterpret_cast<const f32x4*>(xp + 32 * ks);
-            f32x4 v1 = *reinterpret_cast<const f32x4*>(xp + 32 * ks + 16);
+            f32x4 v0, v1;
+            if constexpr (DW) {
+                const float* DWs = B2s + C;
+                v0 = *reinterpret_cast<const f32x4*>(&DWs[9 * C + 32 * ks + 4 * kg]);
+                v1 = *reinterpret_cast<const f32x4*>(&DWs[9 * C + 32 * ks + 16 + 4 * kg]);
+                // one kernel row at a time: six unconditional float4 loads in flight (all eighteen at once do not fit 128 registers)
+                auto taps = [&](auto k0c, auto k1c) {
+                    constexpr int K0 = decltype(k0c)::value, K1 = decltype(k1c)::value;
+                    f32x4 t0[K1 - K0], t1[K1 - K0];
+#pragma unroll
+                    for (int k = K0; k < K1; ++k) {
+                        const unsigned off = roff[k / 3] + coff[k % 3];
+                        t0[k - K0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, 128 * ks, 0));
+                        t1[k - K0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, 128 * ks + 64, 0));
+                    }
+#pragma unroll
+                    for (int k = K0; k < K1; ++k) {
+                        const bool ok = (tap_ok >> k) & 1u;
+                        const f32x4 w0 = *reinterpret_cast<const f32x4*>(&DWs[k * C + 32 * ks + 4 * kg]);
+                        const f32x4 w1 = *reinterpret_cast<const f32x4*>(&DWs[k * C + 32 * ks + 16 + 4 * kg]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v0[e] = __builtin_fmaf(ok ? t0[k - K0][e] : 0.f, w0[e], v0[e]);
+                            v1[e] = __builtin_fmaf(ok ? t1[k - K0][e] : 0.f, w1[e], v1[e]);
+                        }
+                    }
+                };
+                __builtin_amdgcn_sched_barrier(0);           // (keeps the next group's loads out of this group's registers)
+                taps(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+                __builtin_amdgcn_sched_barrier(0);
+                taps(std::integral_constant<int, 3>{}, std::integral_constant<int, 6>{});
+                __builtin_amdgcn_sched_barrier(0);
+                taps(std::integral_constant<int, 6>{}, std::integral_constant<int, 9>{});
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                v0 = *reinterpret_cast<const f32x4*>(xp + 32 * ks);
+                v1 = *reinterpret_cast<const f32x4*>(xp + 32 * ks + 16);
+            }
             if (GATED) {
                 v0 *= *reinterpret_cast<const f32x4*>(gp + 32 * ks);
                 v1 *= *reinterpret_cast<const f32x4*>(gp + 32 * ks + 16);
@@ -184,6 +259,14 @@ __global__ void __launch_bounds__(1024) lc_mixer_res_kernel(MixerParams p, const
     if (!(amax < 65504.f) && p.range_flag) rd_raise_flag(p.range_flag);   // (NaN: through the output check in the epilogue)
 }
 
+// the depthwise 3x3 of a no-SE block rides in this kernel's tile load - only with RD_MIXER_DW=1: measured, the 54 tap loads + 216 fmas per
+// lane and tile cost the mixer more (31 launches: 3.36 -> 5.44 ms per 32-page step) than the depthwise launches they replace (1.59 ms);
+// profiles/r6_mixer_dw.txt
+bool mixer_res_fuses_dw(int C) {
+    static const bool on = [] { const char* e = getenv("RD_MIXER_DW"); return e && e[0] == '1'; }();
+    return on && mixer_res_supported(C);
+}
+
 bool mixer_res_supported(int C) {
     static const bool off = [] { const char* e = getenv("RD_MIXER_RES"); return e && e[0] == '0'; }();
     return !off && (C == 64 || C == 96);       // multiples of 32 whose image fits in LDS (C = 128: 256 KB)
@@ -257,7 +340,11 @@ static void launch_res(const MixerParams& p, hipStream_t s) {
     const unsigned char* img = reinterpret_cast<const unsigned char*>(p.w1h);
     static unsigned long long ok0 = 0, ok1 = 0, ok2 = 0, ok3 = 0;
     static const bool rs = [] { const char* e = getenv("RD_RES_RS"); return !(e && e[0] == '0'); }();     // A/B switch: RD_RES_RS=0 = residual re-read (round 2-4)
-    if (p.gate && rs) {
+    if (p.dw_w) {            // (the builder only asks for it without a gate; the residual then always comes from the fragments)
+        static unsigned long long okd = 0;
+        rd_allow_dynamic_lds((const void*)lc_mixer_res_kernel<C, false, true, true>, G::LDS_BYTES_DW, okd);
+        hipLaunchKernelGGL((lc_mixer_res_kernel<C, false, true, true>), dim3(grid), dim3(1024), G::LDS_BYTES_DW, s, p, img, n_tiles);
+    } else if (p.gate && rs) {
         rd_allow_dynamic_lds((const void*)lc_mixer_res_kernel<C, true, true>, G::LDS_BYTES, ok3);
         hipLaunchKernelGGL((lc_mixer_res_kernel<C, true, true>), dim3(grid), dim3(1024), G::LDS_BYTES, s, p, img, n_tiles);
     } else if (rs) {

@@ -53,6 +53,13 @@ static TView lc_block(Builder& b, const std::string& p, const TView& x, const Lc
     TView t;
     Builder::GapOut gap;  // the depthwise kernel also emits the SE pooling partial sums of its output
     Builder::GapOut* gp = c.se ? &gap : nullptr;
+    // (round 6) a no-SE 3x3 block whose mixer runs on the resident-weights kernel: the depthwise conv is computed in that kernel's tile load
+    // and its output never written (the PREPARE pass still folds the depthwise weights through dwconv)
+    const bool fuse_dw = rep && !c.se && c.k == 3 && mixer_fused_supported(c.cin) && !g_disable_fused_mixer && b.mixer_takes_dw(p, c.cin);
+    if (fuse_dw) {
+        const std::string key = Builder::dw_key(p + ".token_conv.weight", "");
+        return b.mixer_fused(p, x, nullptr, &key);
+    }
     if (rep) t = b.dwconv(p + ".token_conv.weight", p + ".token_conv.bias", "", x, g, ACT_NONE, nullptr, nullptr, gp);
     else t = b.dwconv(p + ".token_conv.convolution.weight", "", p + ".token_conv.normalization", x, g, ACT_NONE, nullptr, nullptr, gp);
     TView gate;

@@ -329,8 +329,15 @@ struct MixerParams {
     int dbg = 0;   // microbenchmark ablation bits (h3 kernel): 1 no GELU, 2 no weight streaming, 4 skip GEMM1, 8 skip GEMM2
     float ws_inv1 = 1.f, ws_inv2 = 1.f;   // ws kernel: inverse power-of-two scales of its weight stream image
     bool ws_pf = false;                   // ws kernel (C = 192): tile prefetch into the X registers, residual folded into the accumulator
+    // resident-weights kernel (kernels_mixer_res.hip) only: the block's depthwise 3x3 / stride 1 / pad 1 computed in the tile load (round 6).
+    // x is then the block's INPUT [N][dwH][dwW][xld]; dw_w [9][C] (tap-major) and dw_b [C] as Builder::dwconv folds them; dw_line_w as
+    // DwParams::line_w (per-image valid width, or nullptr)
+    const float* dw_w = nullptr; const float* dw_b = nullptr;
+    int dwH = 0, dwW = 0;
+    const int32_t* dw_line_w = nullptr; int dw_line_w_stride = 0;
 };
 bool mixer_fused_supported(int C);
+bool mixer_res_fuses_dw(int C);      // kernels_mixer_res.hip: the block's depthwise 3x3 computed in the tile load (round 6)
 void launch_mixer_fused_h3(const MixerParams& p, hipStream_t s);
 void prepare_mixer_weights_h3(const float* w1, const float* w2, int C, std::vector<uint16_t>& w1h, std::vector<uint16_t>& w1l,
                               std::vector<uint16_t>& w2h, std::vector<uint16_t>& w2l);
