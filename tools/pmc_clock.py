@@ -49,10 +49,12 @@ def fit(p):
 
 
 fits = {k: fit(p) for k, p in pts.items()}
-good = {k: v for k, v in fits.items() if v and v[2] > 0.98}
-# window (ns) of the family with the most time among the well-fitted ones
-ref = max(good, key=lambda k: sum(a for a, _ in pts[k])) if good else None
-window_ns = good[ref][1] / good[ref][0] if ref else 0.0
+# a usable fit: tight (R^2 > 0.97) with a positive intercept (the window around a dispatch cannot be negative)
+good = {k: v for k, v in fits.items() if v and v[2] > 0.97 and v[1] > 0}
+# the window (ns) for families without a usable fit: the median over the usable fits' own windows
+wins = sorted(v[1] / v[0] for v in good.values())
+window_ns = wins[len(wins) // 2] if wins else 0.0
+ref = "the median of %d fitted families" % len(wins)
 rows = sorted(pts.items(), key=lambda kv: -sum(a for a, _ in kv[1]))
 with open(out, "w") as f:
     f.write(f"# GRBM_GUI_ACTIVE (summed over {XCDS} XCDs) vs kernel duration, one counter pass of the bench's step, dispatches serialised by the profiler.\n")
@@ -65,6 +67,12 @@ with open(out, "w") as f:
         if v:
             ghz, r2, how = v[0] / XCDS, f"{v[2]:.4f}", "fit"
         else:
-            ghz, r2, how = tc / (tns + window_ns * len(p)) / XCDS, "", "window"
+            fv = fits.get(k)
+            ghz, r2, how = tc / (tns + window_ns * len(p)) / XCDS, (f"{fv[2]:.4f}" if fv else ""), "window"
         f.write(f"{k.replace(',', ';')},{len(p)},{tns / 1e6:.3f},{tns / len(p) / 1e3:.1f},{tc / tns:.3f},{r2},{ghz:.3f},{how}\n")
+with open(out.replace(".csv", "_points.csv"), "w") as f:
+    f.write("kernel,duration_ns,gui_active_cycles\n")
+    for k, p in rows[:10]:
+        for a, b in p:
+            f.write(f"{k.replace(',', ';')},{a:.0f},{b:.0f}\n")
 print(open(out).read()[:5000])
