@@ -455,8 +455,12 @@ struct GemvParams {
     float* y;                         // [M][N]
     int act;
 };
-template <int MT, int CW, int KPL, bool DB>
+// DX (so / co: no LayerNorm, K = 512, M <= 8): X is not staged at all - a lane only ever multiplies the X values of ITS k positions, so
+// it reads those sixteen float4 (L2 hits: the same 16 KB for every workgroup) straight into registers next to its weight loads: no LDS
+// write, no barrier, one memory round trip.  Same products in the same order.
+template <int MT, int CW, int KPL, bool DB, bool DX = false>
 __global__ void __launch_bounds__(256) dec_gemv_kernel(GemvParams p, int n_groups) {
+    static_assert(!DX || (MT * KPL <= 16 && !DB), "direct X: sixteen float4 per lane at most, one column group per wavefront");
     typedef float f4 __attribute__((ext_vector_type(4)));
     constexpr int NV = MT * CW, KP = 256 * KPL;       // K == KP (host)
     extern __shared__ __attribute__((aligned(16))) float gx[];          // [MT][KP]
@@ -473,13 +477,22 @@ __global__ void __launch_bounds__(256) dec_gemv_kernel(GemvParams p, int n_group
         }
     };
     if (gw < n_groups) load_w(wa, gw);
+    f4 xd[DX ? MT : 1][DX ? KPL : 1];
+    if constexpr (DX) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int h = 0; h < KPL; ++h)
+                xd[m][h] = m < p.M ? reinterpret_cast<const f4*>(p.x + (size_t)m * KP)[lane + 64 * h] : f4{0.f, 0.f, 0.f, 0.f};
+    }
     // X -> LDS, fused pre-LayerNorm (wave w normalises rows w, w + 4, ...): skinny2_gemm_kernel's code
+    if constexpr (!DX)
     for (int i = tid; i < MT * (KP / 4); i += 256) {
         const int m = i / (KP / 4), k = 4 * (i - m * (KP / 4));
         *reinterpret_cast<f4*>(&gx[m * KP + k]) = m < p.M ? *reinterpret_cast<const f4*>(p.x + (size_t)m * KP + k) : f4{0.f, 0.f, 0.f, 0.f};
     }
-    __syncthreads();
-    if (p.ln_g) {
+    if constexpr (!DX) __syncthreads();
+    if (!DX && p.ln_g) {
         if constexpr (KP == 512) {
             for (int m = wave; m < MT; m += 4) {
                 float v[8], s1 = 0.f;
@@ -518,7 +531,9 @@ __global__ void __launch_bounds__(256) dec_gemv_kernel(GemvParams p, int n_group
             const int kq = h * 256 + 4 * lane;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const f4 xv = *reinterpret_cast<const f4*>(&gx[m * KP + kq]);
+                f4 xv;
+                if constexpr (DX) xv = xd[m][h];
+                else xv = *reinterpret_cast<const f4*>(&gx[m * KP + kq]);
 #pragma unroll
                 for (int c = 0; c < CW; ++c)
                     acc[c * MT + m] += xv[0] * wr[c][h][0] + xv[1] * wr[c][h][1] + xv[2] * wr[c][h][2] + xv[3] * wr[c][h][3];
@@ -801,14 +816,14 @@ void FormulaDecoder::gemm(const float* x, int M, int K, const std::string& key, 
     launch_conv_igemm(p, s);
 }
 
-template <int MT, int CW, int KPL, bool DB>
+template <int MT, int CW, int KPL, bool DB, bool DX = false>
 static void launch_gemv(const GemvParams& p, int max_wgs, hipStream_t s) {
     const int n_groups = (p.N + CW - 1) / CW;
-    const size_t lds = (size_t)MT * 256 * KPL * sizeof(float);
+    const size_t lds = DX ? 0 : (size_t)MT * 256 * KPL * sizeof(float);
     static unsigned long long lds_ok = 0;
-    rd_allow_dynamic_lds((const void*)dec_gemv_kernel<MT, CW, KPL, DB>, lds, lds_ok);
+    rd_allow_dynamic_lds((const void*)dec_gemv_kernel<MT, CW, KPL, DB, DX>, lds, lds_ok);
     const int grid = std::min((n_groups + 3) / 4, max_wgs);
-    hipLaunchKernelGGL((dec_gemv_kernel<MT, CW, KPL, DB>), dim3(grid), dim3(256), lds, s, p, n_groups);
+    hipLaunchKernelGGL((dec_gemv_kernel<MT, CW, KPL, DB, DX>), dim3(grid), dim3(256), lds, s, p, n_groups);
 }
 
 bool FormulaDecoder::gemv(const float* x, int M, int K, const std::string& key, int N, float* y, int act, const float* res, hipStream_t s,
@@ -831,7 +846,9 @@ bool FormulaDecoder::gemv(const float* x, int M, int K, const std::string& key, 
         if (M <= 8) launch_gemv<8, 1, 8, false>(p, 1024, s);
         else launch_gemv<16, 1, 8, false>(p, 1024, s);
     } else if (M <= 8) {
+        static const bool dx = [] { const char* e = getenv("RD_DEC_GEMV_DX"); return !(e && e[0] == '0'); }();     // A/B
         if (wide) launch_gemv<8, 4, 2, true>(p, wide_wgs, s);
+        else if (dx && ln_key.empty()) launch_gemv<8, 1, 2, false, true>(p, 1024, s);
         else launch_gemv<8, 1, 2, false>(p, 1024, s);
     } else if (M <= 16) {
         if (wide) launch_gemv<16, 2, 2, true>(p, wide_wgs, s);
