@@ -455,12 +455,14 @@ struct GemvParams {
     float* y;                         // [M][N]
     int act;
 };
-// DX (so / co: no LayerNorm, K = 512, M <= 8): X is not staged at all - a lane only ever multiplies the X values of ITS k positions, so
-// it reads those sixteen float4 (L2 hits: the same 16 KB for every workgroup) straight into registers next to its weight loads: no LDS
-// write, no barrier, one memory round trip.  Same products in the same order.
+// DX (so / co / fc2: no LayerNorm in front, M <= 8): X is not staged at all - a lane only ever multiplies the X values of ITS k positions,
+// so it reads those float4 (L2 hits: the same 16 / 64 KB for every workgroup) straight into registers next to its weight loads - at most 32
+// at a time, i.e. fc2 (K = 2048) in two batches of four rows: no LDS write, no barrier.  Same products in the same order per output.
 template <int MT, int CW, int KPL, bool DB, bool DX = false>
 __global__ void __launch_bounds__(256) dec_gemv_kernel(GemvParams p, int n_groups) {
-    static_assert(!DX || (MT * KPL <= 16 && !DB), "direct X: sixteen float4 per lane at most, one column group per wavefront");
+    static_assert(!DX || !DB, "direct X: one column group per wavefront");
+    constexpr int XR = !DX ? 1 : (MT * KPL <= 16 ? MT : 32 / KPL);     // DX: rows whose X values sit in registers at a time (<= 32 float4)
+    static_assert(!DX || (MT % XR == 0 && CW == 1), "direct X: whole row batches, one column per wavefront");
     typedef float f4 __attribute__((ext_vector_type(4)));
     constexpr int NV = MT * CW, KP = 256 * KPL;       // K == KP (host)
     extern __shared__ __attribute__((aligned(16))) float gx[];          // [MT][KP]
@@ -477,14 +479,17 @@ __global__ void __launch_bounds__(256) dec_gemv_kernel(GemvParams p, int n_group
         }
     };
     if (gw < n_groups) load_w(wa, gw);
-    f4 xd[DX ? MT : 1][DX ? KPL : 1];
-    if constexpr (DX) {
+    f4 xd[DX ? XR : 1][DX ? KPL : 1];
+    auto load_x = [&](int m0) {       // rows m0 .. m0 + XR of X, this lane's k positions
+        if constexpr (DX) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < XR; ++m)
 #pragma unroll
-            for (int h = 0; h < KPL; ++h)
-                xd[m][h] = m < p.M ? reinterpret_cast<const f4*>(p.x + (size_t)m * KP)[lane + 64 * h] : f4{0.f, 0.f, 0.f, 0.f};
-    }
+                for (int h = 0; h < KPL; ++h)
+                    xd[m][h] = m0 + m < p.M ? reinterpret_cast<const f4*>(p.x + (size_t)(m0 + m) * KP)[lane + 64 * h] : f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    load_x(0);
     // X -> LDS, fused pre-LayerNorm (wave w normalises rows w, w + 4, ...): skinny2_gemm_kernel's code
     if constexpr (!DX)
     for (int i = tid; i < MT * (KP / 4); i += 256) {
@@ -526,19 +531,32 @@ __global__ void __launch_bounds__(256) dec_gemv_kernel(GemvParams p, int n_group
         float acc[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+        if constexpr (DX) {
+            // row batch by row batch (a value acc[m] only ever sees its own row: per (column, row) the products still arrive in h order)
+#pragma unroll
+            for (int m0 = 0; m0 < MT; m0 += XR) {
+                if (m0) load_x(m0);
+#pragma unroll
+                for (int h = 0; h < KPL; ++h)
+#pragma unroll
+                    for (int m = 0; m < XR; ++m) {
+                        const f4 xv = xd[m][h];
+                        acc[m0 + m] += xv[0] * wr[0][h][0] + xv[1] * wr[0][h][1] + xv[2] * wr[0][h][2] + xv[3] * wr[0][h][3];
+                    }
+            }
+        } else {
 #pragma unroll
         for (int h = 0; h < KPL; ++h) {
             const int kq = h * 256 + 4 * lane;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                f4 xv;
-                if constexpr (DX) xv = xd[m][h];
-                else xv = *reinterpret_cast<const f4*>(&gx[m * KP + kq]);
+                const f4 xv = *reinterpret_cast<const f4*>(&gx[m * KP + kq]);
 #pragma unroll
                 for (int c = 0; c < CW; ++c)
                     acc[c * MT + m] += xv[0] * wr[c][h][0] + xv[1] * wr[c][h][1] + xv[2] * wr[c][h][2] + xv[3] * wr[c][h][3];
             }
             if constexpr (KPL > 2) __builtin_amdgcn_sched_barrier(0);      // keeps the X reads of later h out of this one's registers
+        }
         }
         // halving butterfly (skinny2_gemm_kernel): a lane whose bit o is set keeps the upper half of what it carries
         int cnt = NV, idx = 0;
@@ -620,22 +638,26 @@ __global__ void __launch_bounds__(1024) dec_select_kernel(const float* logits, i
         const float v = z[c];
         if (v > mx) { mx = v; mi = c; }
     }
-    __shared__ float smx[1024];
-    __shared__ int smi[1024];
-    smx[tid] = mx;
-    smi[tid] = mi;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if (tid < o) {
-            const float a = smx[tid], c = smx[tid + o];
-            const int ia = smi[tid], ic = smi[tid + o];
-            if (c > a || (c == a && ic < ia)) { smx[tid] = c; smi[tid] = ic; }
-        }
-        __syncthreads();
+    // (value, index) pairs are totally ordered - larger value first, then smaller index - so any reduction tree gives the pair the ten-level
+    // LDS tree of rounds 1-5 gave: butterfly inside the wavefront, one exchange between the sixteen (round 6: two barriers instead of eleven)
+    __shared__ float smx[16];
+    __shared__ int smi[16];
+    auto better = [](float c, int ic, float a, int ia) { return c > a || (c == a && ic < ia); };
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float c = __shfl_xor(mx, o, 64);
+        const int ic = __shfl_xor(mi, o, 64);
+        if (better(c, ic, mx, mi)) { mx = c; mi = ic; }
     }
+    if ((tid & 63) == 0) { smx[tid >> 6] = mx; smi[tid >> 6] = mi; }
+    __syncthreads();
     __shared__ int s_tok;
     if (tid == 0) {
-        int tok = smi[0];
+        float a = smx[0];
+        int ia = smi[0];
+        for (int w = 1; w < 16; ++w)
+            if (better(smx[w], smi[w], a, ia)) { a = smx[w]; ia = smi[w]; }
+        int tok = ia;
         if (t + 1 == FORCED_EOS_LEN - 1) tok = EOS_ID;          // input length == max_length - 1 -> only EOS survives
         const int unf = unfinished[b];
         tok = unf ? tok : PAD_ID;
@@ -843,7 +865,9 @@ bool FormulaDecoder::gemv(const float* x, int M, int K, const std::string& key, 
     p.res = res; p.y = y; p.act = act;
     const bool wide = N > 4096;          // loops over column groups with the next group's weights in flight
     if (K == 2048) {
-        if (M <= 8) launch_gemv<8, 1, 8, false>(p, 1024, s);
+        static const bool dx8 = [] { const char* e = getenv("RD_DEC_GEMV_DX"); return !(e && e[0] == '0'); }();     // A/B
+        if (M <= 8 && dx8) launch_gemv<8, 1, 8, false, true>(p, 1024, s);
+        else if (M <= 8) launch_gemv<8, 1, 8, false>(p, 1024, s);
         else launch_gemv<16, 1, 8, false>(p, 1024, s);
     } else if (M <= 8) {
         static const bool dx = [] { const char* e = getenv("RD_DEC_GEMV_DX"); return !(e && e[0] == '0'); }();     // A/B
