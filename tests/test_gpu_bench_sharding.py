@@ -13,7 +13,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parents[1]
-COMMON = ["--scaling", "strong", "--global-pages", "4", "--rec-streams", "2", "--steps", "1", "--warmup", "0", "--setup-steps", "0", "--no-cpu-baseline",
+COMMON = ["--scaling", "strong", "--global-pages", "4", "--rec-streams", "2", "--steps", "1", "--warmup", "0", "--setup-steps", "0", "--setup-passes", "0", "--no-cpu-baseline",
           "--no-extra-passes", "--vary-pages", "1"]
 # rounds 3-4 needed this to get equal strings: one line per rec batch in the throughput mode (still covered below)
 THROUGHPUT_1 = ["--rec-mode", "throughput", "--rec-chunking", "fixed", "--rec-batch", "1"]
@@ -123,7 +123,7 @@ def test_two_ranks_weak_scaling_cover_the_same_global_list():
     """--scaling weak: 2 pages per rank x 2 ranks = the same 4-page global list (rank r takes pages r, r + 2): same crc as the
     single-process run over 4 pages."""
     env = _clean_env()
-    base = ["--rec-streams", "2", "--steps", "1", "--warmup", "0", "--setup-steps", "0", "--no-cpu-baseline", "--no-extra-passes", "--vary-pages", "1"]
+    base = ["--rec-streams", "2", "--steps", "1", "--warmup", "0", "--setup-steps", "0", "--setup-passes", "0", "--no-cpu-baseline", "--no-extra-passes", "--vary-pages", "1"]
     a = _last_json(_run([sys.executable, str(ROOT / "bench.py"), "--scaling", "weak", "--pages", "4", *base], env))
     b = _last_json(_run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                          "--master-port", "29743", str(ROOT / "bench.py"), "--gpus", "2", "--scaling", "weak", "--pages", "2", *base],

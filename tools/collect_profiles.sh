@@ -22,7 +22,7 @@ cp /tmp/rq_$TAG/s_kernel_stats.csv $O/${TAG}_rocprofv3_kernel_stats_1stream.csv
 # exactly one step per pass, so that dispatches = launches per step
 # RD_BENCH_STOP_AFTER_TIMED=1: no per-op profiling pass behind the timed step (it would launch every kernel a second time)
 export RD_BENCH_STOP_AFTER_TIMED=1
-B="python $R/bench.py --steps 1 --warmup 0 --setup-steps 0 --no-cpu-baseline --no-extra-passes $ONE"
+B="python $R/bench.py --steps 1 --warmup 0 --setup-steps 0 --setup-passes 0 --no-cpu-baseline --no-extra-passes $ONE"
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d /tmp/p1_$TAG -o a -- $B > /tmp/p1.log 2>&1
 python $R/tools/pmc_summary.py $(find /tmp/p1_$TAG -name "*counter_collection.csv" | head -1) $O/${TAG}_pmc_sq.csv > /dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
